@@ -1,0 +1,120 @@
+"""Seeded synthetic weights for the copenet two-view network.
+
+There is no network access for checkpoints, so tests and bench use random-init
+weights of the reference architecture.  The generator is pure numpy
+(`RandomState` streams are bit-stable across machines) and yields a
+``state_dict`` whose keys/shapes are exactly those of the reference module
+(reference: copenet/src/copenet/models/model_copenet.py:53-92, torchvision
+ResNet-50 naming; 331 entries incl. BN ``num_batches_tracked``).
+
+Distributions follow the reference init (model_copenet.py:74-84) except that
+BN statistics are randomised so that the BN scale/shift epilogue is actually
+exercised (the reference defaults 0/1/1/0 would hide folding bugs):
+  conv      N(0, sqrt(2 / (k*k*C_out)))
+  bn        gamma~U(.5,1.5) (last BN of a block: U(.25,.75)), beta~N(0,.1),
+            running_mean~N(0,.1), running_var~U(.5,1.5)
+  fc1, fc2  U(-1/sqrt(in), 1/sqrt(in)) weight and bias (nn.Linear default)
+  dec*      xavier_uniform(gain=0.01) weight, Linear-default bias
+"""
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+LAYERS = (3, 4, 6, 3)            # model_copenet.py:234
+PLANES = (64, 128, 256, 512)
+EXPANSION = 4                    # model_copenet.py:12
+NPOSE = 21 * 6                   # model_copenet.py:56
+FC1_IN = 512 * EXPANSION + 3 + 3 + 6 + NPOSE + 10 + NPOSE + 10   # 2332, :67
+HMR_FC1_IN = 512 * EXPANSION + 22 * 6 + 10 + 3                  # 2193, model_hmr.py
+
+
+def _conv(rs, cout, cin, k):
+    std = math.sqrt(2.0 / (k * k * cout))
+    return rs.normal(0.0, std, size=(cout, cin, k, k)).astype(np.float32)
+
+
+def _bn(rs, sd, prefix, c, last=False):
+    lo, hi = (0.25, 0.75) if last else (0.5, 1.5)
+    sd[prefix + ".weight"] = rs.uniform(lo, hi, size=c).astype(np.float32)
+    sd[prefix + ".bias"] = rs.normal(0.0, 0.1, size=c).astype(np.float32)
+    sd[prefix + ".running_mean"] = rs.normal(0.0, 0.1, size=c).astype(np.float32)
+    sd[prefix + ".running_var"] = rs.uniform(0.5, 1.5, size=c).astype(np.float32)
+    sd[prefix + ".num_batches_tracked"] = np.zeros((), dtype=np.int64)
+
+
+def _linear(rs, sd, prefix, cout, cin, xavier_gain=None):
+    if xavier_gain is None:
+        b = 1.0 / math.sqrt(cin)
+    else:
+        b = xavier_gain * math.sqrt(6.0 / (cin + cout))
+    sd[prefix + ".weight"] = rs.uniform(-b, b, size=(cout, cin)).astype(np.float32)
+    bb = 1.0 / math.sqrt(cin)
+    sd[prefix + ".bias"] = rs.uniform(-bb, bb, size=cout).astype(np.float32)
+
+
+def trunk_state_dict(rs):
+    """ResNet-50 v1.5 trunk entries (conv1/bn1/layer1..4), reference order."""
+    sd = OrderedDict()
+    sd["conv1.weight"] = _conv(rs, 64, 3, 7)
+    _bn(rs, sd, "bn1", 64)
+    inplanes = 64
+    for li, (planes, nblocks) in enumerate(zip(PLANES, LAYERS), start=1):
+        for bi in range(nblocks):
+            p = "layer%d.%d" % (li, bi)
+            sd[p + ".conv1.weight"] = _conv(rs, planes, inplanes, 1)
+            _bn(rs, sd, p + ".bn1", planes)
+            sd[p + ".conv2.weight"] = _conv(rs, planes, planes, 3)
+            _bn(rs, sd, p + ".bn2", planes)
+            sd[p + ".conv3.weight"] = _conv(rs, planes * EXPANSION, planes, 1)
+            _bn(rs, sd, p + ".bn3", planes * EXPANSION, last=True)
+            if bi == 0:
+                sd[p + ".downsample.0.weight"] = _conv(rs, planes * EXPANSION, inplanes, 1)
+                _bn(rs, sd, p + ".downsample.1", planes * EXPANSION, last=True)
+            inplanes = planes * EXPANSION
+    return sd
+
+
+def load_mean_params(path):
+    d = np.load(path)
+    return (d["pose"].astype(np.float32)[None], d["shape"].astype(np.float32)[None],
+            d["cam"].astype(np.float32)[None])
+
+
+def copenet_state_dict(seed, mean_params_path, variant="copenet"):
+    """Full state_dict (numpy arrays) for the two-view ``copenet`` (or ``hmr``) module."""
+    rs = np.random.RandomState(seed)
+    sd = trunk_state_dict(rs)
+    fc1_in = FC1_IN if variant == "copenet" else HMR_FC1_IN
+    npose_out = 3 + 6 + NPOSE if variant == "copenet" else 22 * 6
+    _linear(rs, sd, "fc1", 1024, fc1_in)
+    _linear(rs, sd, "fc2", 1024, 1024)
+    _linear(rs, sd, "decpose", npose_out, 1024, xavier_gain=0.01)
+    _linear(rs, sd, "decshape", 10, 1024, xavier_gain=0.01)
+    _linear(rs, sd, "deccam", 3, 1024, xavier_gain=0.01)
+    pose, shape, cam = load_mean_params(mean_params_path)
+    sd["init_pose"], sd["init_shape"], sd["init_cam"] = pose, shape, cam
+    return sd
+
+
+def to_torch(sd):
+    import torch
+    return OrderedDict((k, torch.from_numpy(np.ascontiguousarray(v))) for k, v in sd.items())
+
+
+def synthetic_inputs(seed, batch, img=224):
+    """Synthetic two-view batch: normalised crops, bb, init position, intrinsics."""
+    rs = np.random.RandomState(seed)
+    out = {}
+    for v in (0, 1):
+        out["im%d" % v] = rs.standard_normal((batch, 3, img, img)).astype(np.float32)
+    for v in (0, 1):
+        bb = np.empty((batch, 3), np.float32)
+        bb[:, 0:2] = rs.uniform(-0.5, 0.5, size=(batch, 2))
+        bb[:, 2] = rs.uniform(0.2, 1.0, size=batch)
+        out["bb%d" % v] = bb
+    intr = np.zeros((batch, 3, 3), np.float32)
+    intr[:, 0, 0] = intr[:, 1, 1] = 1475.0
+    intr[:, 0, 2], intr[:, 1, 2], intr[:, 2, 2] = 960.0, 540.0, 1.0
+    out["intr0"], out["intr1"] = intr, intr.copy()
+    return out

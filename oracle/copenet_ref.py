@@ -1,0 +1,130 @@
+"""ORACLE (test infrastructure, never shipped, never measured as the product).
+
+CPU restatement, in plain torch functional ops on fp32 (or fp64) tensors, of the
+reference network on the hot path:
+
+  trunk       copenet.forward_feat_ext   copenet/src/copenet/models/model_copenet.py:161-176
+  bottleneck  Bottleneck.forward         model_copenet.py:27-47
+  regressor   copenet.forward_reg        model_copenet.py:178-204
+  IEF driver  copenet.forward            model_copenet.py:112-159
+  hmr head    model_hmr.copenet.forward  copenet/src/copenet/models/model_hmr.py:112-172
+
+Parity pinning: tests/test_oracle_golden.py checks every function here against
+tests/golden/*.npz, which tools/make_golden.py produced by importing the real
+reference modules from /root/reference in the build container (PINNED).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+Weights come in as a state_dict with the reference's key names.
+"""
+import torch
+import torch.nn.functional as F
+
+LAYERS = (3, 4, 6, 3)
+BN_EPS = 1e-5  # nn.BatchNorm2d default, used by model_copenet.py:17,20,22,60
+
+
+def _bn(x, sd, p):
+    # eval-mode BatchNorm2d: (x - mean) / sqrt(var + eps) * gamma + beta
+    return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
+                        sd[p + ".weight"], sd[p + ".bias"], False, 0.0, BN_EPS)
+
+
+def bottleneck(x, sd, p, stride, has_down):
+    """model_copenet.py:27-47 (stride on the 3x3: line 18)."""
+    out = F.relu(_bn(F.conv2d(x, sd[p + ".conv1.weight"]), sd, p + ".bn1"))
+    out = F.relu(_bn(F.conv2d(out, sd[p + ".conv2.weight"], stride=stride, padding=1), sd, p + ".bn2"))
+    out = _bn(F.conv2d(out, sd[p + ".conv3.weight"]), sd, p + ".bn3")
+    if has_down:
+        residual = _bn(F.conv2d(x, sd[p + ".downsample.0.weight"], stride=stride), sd, p + ".downsample.1")
+    else:
+        residual = x
+    return F.relu(out + residual)
+
+
+def stem(x, sd):
+    """model_copenet.py:163-166: conv7x7/2 p3 -> BN -> ReLU -> maxpool3/2 p1."""
+    x = F.relu(_bn(F.conv2d(x, sd["conv1.weight"], stride=2, padding=3), sd, "bn1"))
+    return F.max_pool2d(x, kernel_size=3, stride=2, padding=1)
+
+
+def forward_feat_ext(x, sd, taps=None):
+    """model_copenet.py:161-176.  `taps` (dict) optionally receives per-stage activations."""
+    x = stem(x, sd)
+    if taps is not None:
+        taps["stem"] = x
+    for li, nblocks in enumerate(LAYERS, start=1):
+        for bi in range(nblocks):
+            stride = 2 if (bi == 0 and li > 1) else 1
+            x = bottleneck(x, sd, "layer%d.%d" % (li, bi), stride, bi == 0)
+        if taps is not None:
+            taps["layer%d" % li] = x
+    x = F.avg_pool2d(x, 7, stride=1)           # AvgPool2d(7, stride=1), :173
+    return x.view(x.size(0), -1)
+
+
+def _lin(x, sd, p):
+    return F.linear(x, sd[p + ".weight"], sd[p + ".bias"])
+
+
+def forward_reg(sd, xf0, xf1, bb0, bb1, pos0, pos1, orient0, orient1, art0, art1, shape0, shape1):
+    """model_copenet.py:178-204.  Concat order from :185 and :192; dropout is identity in eval."""
+    xc0 = torch.cat([xf0, bb0, pos0, orient0, art0, shape0, art1, shape1], 1)
+    xc0 = _lin(_lin(xc0, sd, "fc1"), sd, "fc2")
+    xc1 = torch.cat([xf1, bb1, pos1, orient1, art1, shape1, art0, shape0], 1)
+    xc1 = _lin(_lin(xc1, sd, "fc1"), sd, "fc2")
+    pshape0 = shape0 + _lin(xc0, sd, "decshape")
+    ppose0 = torch.cat([pos0, orient0, art0], 1) + _lin(xc0, sd, "decpose")
+    pshape1 = shape1 + _lin(xc1, sd, "decshape")
+    ppose1 = torch.cat([pos1, orient1, art1], 1) + _lin(xc1, sd, "decpose")
+    return ppose0, pshape0, ppose1, pshape1
+
+
+def ief(sd, xf0, xf1, bb0, bb1, init_position0, init_position1,
+        init_theta0=None, init_theta1=None, init_shape0=None, init_shape1=None, iters=3):
+    """IEF loop of model_copenet.py:119-159 starting from trunk features."""
+    B = xf0.shape[0]
+    ip = sd["init_pose"]
+
+    def _init(theta):
+        t = ip if theta is None else theta
+        return t[:, :6].expand(B, -1), t[:, 6:22 * 6].expand(B, -1)
+
+    o0, a0 = _init(init_theta0)
+    o1, a1 = _init(init_theta1)
+    s0 = sd["init_shape"].expand(B, -1) if init_shape0 is None else init_shape0
+    s1 = sd["init_shape"].expand(B, -1) if init_shape1 is None else init_shape1
+    p0, b0, p1, b1 = forward_reg(sd, xf0, xf1, bb0, bb1, init_position0, init_position1,
+                                 o0, o1, a0, a1, s0, s1)
+    for _ in range(int(iters) - 1):
+        p0, b0, p1, b1 = forward_reg(sd, xf0, xf1, bb0, bb1, p0[:, :3], p1[:, :3],
+                                     p0[:, 3:9], p1[:, 3:9], p0[:, 9:], p1[:, 9:], b0, b1)
+    return p0, b0, p1, b1
+
+
+def copenet_forward(sd, x0, x1, bb0, bb1, init_position0, init_position1,
+                    init_theta0=None, init_theta1=None, init_shape0=None, init_shape1=None, iters=3):
+    """model_copenet.py:112-159."""
+    xf0 = forward_feat_ext(x0, sd)
+    xf1 = forward_feat_ext(x1, sd)
+    return ief(sd, xf0, xf1, bb0, bb1, init_position0, init_position1,
+               init_theta0, init_theta1, init_shape0, init_shape1, iters)
+
+
+# ------------------------------------------------------------------ hmr (Config 1, CPU plumbing)
+def hmr_forward_reg(sd, xf, pose, shape, cam):
+    """model_hmr.py:160-172."""
+    xc = _lin(_lin(torch.cat([xf, pose, shape, cam], 1), sd, "fc1"), sd, "fc2")
+    return _lin(xc, sd, "decpose") + pose, _lin(xc, sd, "decshape") + shape, _lin(xc, sd, "deccam") + cam
+
+
+def hmr_forward(sd, x, iters=3):
+    """model_hmr.py:112-141; returns (rotmat (B,22,3,3), betas, cam)."""
+    from .geometry_ref import rot6d_to_rotmat
+    B = x.shape[0]
+    pose = sd["init_pose"][:, :22 * 6].expand(B, -1)
+    shape = sd["init_shape"].expand(B, -1)
+    cam = sd["init_cam"].expand(B, -1)
+    xf = forward_feat_ext(x, sd)
+    for _ in range(int(iters)):
+        pose, shape, cam = hmr_forward_reg(sd, xf, pose, shape, cam)
+    return rot6d_to_rotmat(pose).view(B, 22, 3, 3), shape, cam

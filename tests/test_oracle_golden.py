@@ -1,0 +1,120 @@
+"""Pin the oracle to the reference: every function in oracle/ vs tests/golden (made by
+tools/make_golden.py from the imported reference modules).  CPU only."""
+import numpy as np
+import torch
+
+from conftest import MEAN_PARAMS, rel_err
+from oracle import copenet_ref, geometry_ref
+
+TOL = 2e-6   # same torch kernels on the same CPU arithmetic; only op fusion order may differ
+
+
+def test_generators_reproduce_golden_inputs(golden, copenet_inputs):
+    g = golden["copenet_b2"]
+    assert abs(copenet_inputs["im0"].double().sum().item() - float(g["im0_sum"])) < 1e-6
+    assert abs(copenet_inputs["im1"].double().sum().item() - float(g["im1_sum"])) < 1e-6
+    flat = copenet_inputs["im0"].reshape(-1)[torch.from_numpy(g["im_sample_idx"])]
+    assert np.array_equal(flat.numpy(), g["im0_sample"])
+    assert np.array_equal(copenet_inputs["bb0"].numpy(), g["bb0"])
+
+
+def test_state_dict_keys_match_reference(golden, copenet_sd):
+    ref_keys = [str(k) for k in golden["copenet_b2"]["state_dict_keys"]]
+    assert sorted(copenet_sd.keys()) == sorted(ref_keys)
+    assert len(ref_keys) == 331
+
+
+def test_trunk_matches_reference(golden, copenet_sd, copenet_inputs):
+    g = golden["copenet_b2"]
+    with torch.no_grad():
+        taps = {}
+        xf0 = copenet_ref.forward_feat_ext(copenet_inputs["im0"], copenet_sd, taps)
+        xf1 = copenet_ref.forward_feat_ext(copenet_inputs["im1"], copenet_sd)
+    assert rel_err(xf0.numpy(), g["xf0"]) < TOL
+    assert rel_err(xf1.numpy(), g["xf1"]) < TOL
+    for k, v in taps.items():
+        s = v.reshape(-1)[torch.from_numpy(g["act_idx_%s" % k])].numpy()
+        assert rel_err(s, g["act0_%s" % k]) < TOL, k
+
+
+def test_ief_matches_reference(golden, copenet_sd, copenet_inputs):
+    g = golden["copenet_b2"]
+    xf0, xf1 = torch.from_numpy(g["xf0"]), torch.from_numpy(g["xf1"])
+    pos = torch.from_numpy(g["init_position"])
+    with torch.no_grad():
+        for it in (1, 2, 3):
+            p0, b0, p1, b1 = copenet_ref.ief(copenet_sd, xf0, xf1, copenet_inputs["bb0"], copenet_inputs["bb1"],
+                                             pos, pos, iters=it)
+            assert rel_err(p0.numpy(), g["pose0_it%d" % it]) < TOL
+            assert rel_err(p1.numpy(), g["pose1_it%d" % it]) < TOL
+            assert rel_err(b0.numpy(), g["betas0_it%d" % it]) < TOL
+            assert rel_err(b1.numpy(), g["betas1_it%d" % it]) < TOL
+        p0, b0, p1, b1 = copenet_ref.ief(
+            copenet_sd, xf0, xf1, copenet_inputs["bb0"], copenet_inputs["bb1"], pos, pos,
+            init_theta0=torch.from_numpy(g["ci_theta0"]), init_theta1=torch.from_numpy(g["ci_theta1"]),
+            init_shape0=torch.from_numpy(g["ci_shape0"]), init_shape1=torch.from_numpy(g["ci_shape1"]), iters=2)
+    assert rel_err(p0.numpy(), g["ci_pose0"]) < TOL and rel_err(p1.numpy(), g["ci_pose1"]) < TOL
+    assert rel_err(b0.numpy(), g["ci_betas0"]) < TOL and rel_err(b1.numpy(), g["ci_betas1"]) < TOL
+
+
+def test_full_forward_matches_reference(golden, copenet_sd, copenet_inputs):
+    g = golden["copenet_b2"]
+    pos = torch.from_numpy(g["init_position"])
+    with torch.no_grad():
+        p0, b0, p1, b1 = copenet_ref.copenet_forward(copenet_sd, copenet_inputs["im0"], copenet_inputs["im1"],
+                                                     copenet_inputs["bb0"], copenet_inputs["bb1"], pos, pos, iters=3)
+    assert rel_err(p0.numpy(), g["pose0_it3"]) < TOL and rel_err(b1.numpy(), g["betas1_it3"]) < TOL
+
+
+def test_hmr_config1_matches_reference(golden):
+    """BASELINE config 0: hmr single view, batch 1, CPU."""
+    from airpose_amd import weights as W
+    g = golden["hmr_b1"]
+    sd = W.to_torch(W.copenet_state_dict(int(g["weights_seed"]), MEAN_PARAMS, variant="hmr"))
+    x = torch.from_numpy(W.synthetic_inputs(int(g["inputs_seed"]), 1)["im0"])
+    assert abs(x.double().sum().item() - float(g["im_sum"])) < 1e-6
+    with torch.no_grad():
+        rotmat, betas, cam = copenet_ref.hmr_forward(sd, x, iters=3)
+    assert rel_err(rotmat.numpy(), g["rotmat"]) < 1e-5
+    assert rel_err(betas.numpy(), g["betas"]) < TOL and rel_err(cam.numpy(), g["cam"]) < TOL
+
+
+def test_geometry_matches_reference(golden):
+    g = golden["geometry"]
+    R = geometry_ref.rot6d_to_rotmat(torch.from_numpy(g["rot6d_in"]))
+    assert np.allclose(R.numpy(), g["rot6d_out"], rtol=0, atol=1e-6)
+    assert np.allclose(R[0].numpy(), np.eye(3), atol=1e-7)            # [1,0,0,1,0,0] -> I
+    pts = torch.from_numpy(g["proj_points"])
+    out = geometry_ref.perspective_projection(pts, torch.eye(3).expand(3, 3, 3), torch.zeros(3, 3),
+                                              [1475, 1475], torch.from_numpy(g["proj_center"]).unsqueeze(0))
+    assert rel_err(out.numpy(), g["proj_out"]) < TOL
+    out = geometry_ref.perspective_projection(pts, torch.from_numpy(g["proj_rt_R"]),
+                                              torch.from_numpy(g["proj_rt_t"]) + torch.tensor([0, 0, 5.0]),
+                                              [1000.0, 1100.0], torch.from_numpy(g["proj_center"]))
+    assert rel_err(out.numpy(), g["proj_rt_out"]) < TOL
+    v, j = geometry_ref.transform_smpl(torch.from_numpy(g["tf_mat"]), torch.from_numpy(g["tf_verts"]),
+                                       torch.from_numpy(g["tf_joints"]))
+    assert rel_err(v.numpy(), g["tf_verts_out"]) < TOL and rel_err(j.numpy(), g["tf_joints_out"]) < TOL
+    rr = geometry_ref.batch_rodrigues_quat(torch.from_numpy(g["rodrigues_in"]))
+    assert np.allclose(rr.numpy(), g["rodrigues_out"], atol=1e-6)
+
+
+def test_ief_known_answers(copenet_sd):
+    """zeroed decoders return the init; swapping the views swaps the outputs."""
+    torch.manual_seed(3)
+    B = 3
+    xf0, xf1 = torch.randn(B, 2048), torch.randn(B, 2048)
+    bb0, bb1 = torch.rand(B, 3), torch.rand(B, 3)
+    pos0, pos1 = torch.randn(B, 3), torch.randn(B, 3)
+    with torch.no_grad():
+        a = copenet_ref.ief(copenet_sd, xf0, xf1, bb0, bb1, pos0, pos1, iters=3)
+        b = copenet_ref.ief(copenet_sd, xf1, xf0, bb1, bb0, pos1, pos0, iters=3)
+        for x, y in zip(a, (b[2], b[3], b[0], b[1])):
+            assert torch.equal(x, y)
+        sdz = dict(copenet_sd)
+        for k in ("decpose", "decshape"):
+            sdz[k + ".weight"] = torch.zeros_like(sdz[k + ".weight"])
+            sdz[k + ".bias"] = torch.zeros_like(sdz[k + ".bias"])
+        p0, s0, p1, s1 = copenet_ref.ief(sdz, xf0, xf1, bb0, bb1, pos0, pos1, iters=3)
+    assert torch.allclose(p0[:, :3], pos0) and torch.allclose(s1, copenet_sd["init_shape"].expand(B, -1))
+    assert torch.allclose(p0[:, 3:], copenet_sd["init_pose"][:, :132].expand(B, -1))
