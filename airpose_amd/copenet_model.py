@@ -1,0 +1,260 @@
+"""Drop-in for the reference network module (boundary #1).
+
+Mirrors ``copenet.models.model_copenet`` (copenet/src/copenet/models/model_copenet.py):
+``copenet(block, layers, smpl_mean_params)`` with ``forward`` (:112-159), ``forward_feat_ext``
+(:161-176), ``forward_reg`` (:178-204) and ``getcopenet`` (:229-239) -- same argument names,
+same outputs, same sub-module / buffer names, hence the same 331 ``state_dict`` keys, so
+``copenet_twoview`` (copenet/src/copenet/copenet_twoview.py:60,79-80) and Lightning checkpoints
+work unchanged.  The nn.Conv2d / nn.BatchNorm2d / nn.Linear children are parameter containers
+only: all compute goes through the C ABI of libairpose_hip.so (hand-written gfx950 kernels).
+Inference (eval) only; there is no CPU or eager fallback.
+"""
+import ctypes
+import threading
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _native as N
+
+
+class Bottleneck(nn.Module):
+    """Parameter container with the reference block's child names (model_copenet.py:8-25)."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, downsample=None):
+        super().__init__()
+        self.conv1 = nn.Conv2d(inplanes, planes, kernel_size=1, bias=False)
+        self.bn1 = nn.BatchNorm2d(planes)
+        self.conv2 = nn.Conv2d(planes, planes, kernel_size=3, stride=stride, padding=1, bias=False)
+        self.bn2 = nn.BatchNorm2d(planes)
+        self.conv3 = nn.Conv2d(planes, planes * 4, kernel_size=1, bias=False)
+        self.bn3 = nn.BatchNorm2d(planes * 4)
+        self.relu = nn.ReLU(inplace=True)
+        self.downsample = downsample
+        self.stride = stride
+
+    def forward(self, x):
+        raise RuntimeError("airpose_amd.Bottleneck holds parameters only; the trunk runs in libairpose_hip.so")
+
+
+class copenet(nn.Module):
+    """SMPL-X iterative regressor with ResNet-50 trunk and cross-view fusion, on MI355X."""
+
+    variant = 0            # ap_net_create variant (0: two-view copenet)
+    fc1_extra = 3 + 3 + 6 + 21 * 6 + 10 + 21 * 6 + 10
+
+    def __init__(self, block=Bottleneck, layers=(3, 4, 6, 3), smpl_mean_params=None, precision="bf16"):
+        super().__init__()
+        if tuple(layers) != (3, 4, 6, 3):
+            raise ValueError("only the ResNet-50 layout [3, 4, 6, 3] of the reference is supported")
+        if precision not in N.PRECISIONS:
+            raise ValueError("precision must be 'bf16' (throughput) or 'fp32' (parity)")
+        self.precision = precision
+        self.inplanes = 64
+        npose = 21 * 6
+        self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
+        self.bn1 = nn.BatchNorm2d(64)
+        self.relu = nn.ReLU(inplace=True)
+        self.maxpool = nn.MaxPool2d(kernel_size=3, stride=2, padding=1)
+        self.layer1 = self._make_layer(block, 64, layers[0])
+        self.layer2 = self._make_layer(block, 128, layers[1], stride=2)
+        self.layer3 = self._make_layer(block, 256, layers[2], stride=2)
+        self.layer4 = self._make_layer(block, 512, layers[3], stride=2)
+        self.avgpool = nn.AvgPool2d(7, stride=1)
+        self.fc1 = nn.Linear(512 * 4 + self.fc1_extra, 1024)
+        self.drop1 = nn.Dropout()
+        self.fc2 = nn.Linear(1024, 1024)
+        self.drop2 = nn.Dropout()
+        self.decpose = nn.Linear(1024, self._npose_out(npose))
+        self.decshape = nn.Linear(1024, 10)
+        self.deccam = nn.Linear(1024, 3)
+        for m in (self.decpose, self.decshape, self.deccam):
+            nn.init.xavier_uniform_(m.weight, gain=0.01)
+        for m in self.modules():
+            if isinstance(m, nn.Conv2d):
+                n = m.kernel_size[0] * m.kernel_size[1] * m.out_channels
+                m.weight.data.normal_(0, (2.0 / n) ** 0.5)
+        if smpl_mean_params is None:
+            pose, shape, cam = np.zeros(144, np.float32), np.zeros(10, np.float32), np.zeros(3, np.float32)
+        else:
+            mp = np.load(smpl_mean_params)
+            pose, shape, cam = mp["pose"][:], mp["shape"][:].astype("float32"), mp["cam"]
+        self.register_buffer("init_pose", torch.from_numpy(np.asarray(pose, np.float32)).unsqueeze(0))
+        self.register_buffer("init_shape", torch.from_numpy(np.asarray(shape, np.float32)).unsqueeze(0))
+        self.register_buffer("init_cam", torch.from_numpy(np.asarray(cam, np.float32)).unsqueeze(0))
+        self._handle = None
+        self._packed_sig = None
+        self._lock = threading.Lock()   # handles are not re-entrant (rospy callbacks come from other threads)
+
+    @staticmethod
+    def _npose_out(npose):
+        return 3 + 6 + npose
+
+    def _make_layer(self, block, planes, blocks, stride=1):
+        downsample = None
+        if stride != 1 or self.inplanes != planes * block.expansion:
+            downsample = nn.Sequential(
+                nn.Conv2d(self.inplanes, planes * block.expansion, kernel_size=1, stride=stride, bias=False),
+                nn.BatchNorm2d(planes * block.expansion))
+        mods = [block(self.inplanes, planes, stride, downsample)]
+        self.inplanes = planes * block.expansion
+        mods += [block(self.inplanes, planes) for _ in range(1, blocks)]
+        return nn.Sequential(*mods)
+
+    # ------------------------------------------------------------------ native handle
+    def _signature(self):
+        ver = 0
+        for t in self.parameters():
+            ver += t._version + (id(t) & 0xffff)
+        for t in self.buffers():
+            ver += t._version + (id(t) & 0xffff)
+        return (self.precision, ver)
+
+    def _native(self, device):
+        """(Re)pack the current parameters into the library when they changed."""
+        N.require_gpu()
+        sig = (device.index, self._signature())
+        if self._handle is not None and sig == self._packed_sig:
+            return self._handle
+        L = N.lib()
+        if self._handle is None:
+            h = ctypes.c_void_p()
+            N.check(L.ap_net_create(ctypes.byref(h), device.index or 0, N.PRECISIONS[self.precision], self.variant),
+                    "ap_net_create")
+            self._handle = h
+        for name, t in self.state_dict().items():
+            if not t.dtype.is_floating_point:
+                continue                                   # num_batches_tracked
+            a = np.ascontiguousarray(t.detach().to("cpu", torch.float32).numpy())
+            shape = (ctypes.c_int64 * max(a.ndim, 1))(*a.shape)
+            N.check(L.ap_net_set_tensor(self._handle, name.encode(), a.ctypes.data_as(ctypes.c_void_p), shape, a.ndim),
+                    "ap_net_set_tensor(%s)" % name)
+        N.check(L.ap_net_finalize(self._handle), "ap_net_finalize")
+        self._packed_sig = sig
+        return self._handle
+
+    def __del__(self):
+        try:
+            if getattr(self, "_handle", None) is not None:
+                N.lib().ap_net_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+    def _check_eval(self):
+        if self.training:
+            raise RuntimeError("airpose_amd.copenet implements the inference path only: call .eval() "
+                               "(training through the HIP kernels is out of scope)")
+
+    @staticmethod
+    def _dev(x):
+        if not x.is_cuda:
+            raise RuntimeError("airpose_amd.copenet: inputs must be CUDA (ROCm) tensors; there is no CPU path")
+        return x.device
+
+    # ------------------------------------------------------------------ reference API
+    def forward_feat_ext(self, x):
+        """(n,3,224,224) -> (n,2048)   [model_copenet.py:161-176]"""
+        self._check_eval()
+        dev = self._dev(x)
+        if x.dim() != 4 or x.shape[1:] != (3, 224, 224):
+            raise RuntimeError("forward_feat_ext expects (n, 3, 224, 224) NCHW crops (AvgPool2d(7) fixes the size)")
+        x = N.f32c(x)
+        out = torch.empty(x.shape[0], 2048, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(N.lib().ap_trunk_fwd(h, N.dptr(x, "x"), x.shape[0], N.dptr(out), N.stream_ptr(dev)), "ap_trunk_fwd")
+        return out
+
+    @staticmethod
+    def _bs(t, B, width, name):
+        """(tensor, batch stride) for an optional (1|B, >=width) initial-state tensor."""
+        if t is None:
+            return None, 0
+        if t.dim() != 2 or t.shape[1] < width or t.shape[0] not in (1, B):
+            raise RuntimeError("%s must be (1|B, >=%d)" % (name, width))
+        return t, (0 if t.shape[0] == 1 and B != 1 else t.shape[1])
+
+    def _ief(self, entry, a0, a1, bb0, bb1, pos0, pos1, th0, th1, sh0, sh1, B, iters, dev):
+        bb0, bb1, pos0, pos1 = (N.f32c(t, dev) for t in (bb0, bb1, pos0, pos1))
+        th0, th0s = self._bs(N.f32c(th0, dev), B, 132, "init_theta0")
+        th1, th1s = self._bs(N.f32c(th1, dev), B, 132, "init_theta1")
+        sh0, sh0s = self._bs(N.f32c(sh0, dev), B, 10, "init_shape0")
+        sh1, sh1s = self._bs(N.f32c(sh1, dev), B, 10, "init_shape1")
+        pose = torch.empty(2, B, 135, device=dev, dtype=torch.float32)
+        betas = torch.empty(2, B, 10, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            fn = getattr(N.lib(), entry)
+            N.check(fn(h, N.dptr(a0), N.dptr(a1), N.dptr(bb0), N.dptr(bb1), N.dptr(pos0), N.dptr(pos1),
+                       N.dptr(th0), th0s, N.dptr(th1), th1s, N.dptr(sh0), sh0s, N.dptr(sh1), sh1s, B, int(iters),
+                       N.dptr(pose[0]), N.dptr(betas[0]), N.dptr(pose[1]), N.dptr(betas[1]), N.stream_ptr(dev)), entry)
+        return pose[0], betas[0], pose[1], betas[1]
+
+    def forward(self, x0, x1, bb0, bb1, init_position0, init_position1, init_theta0=None, init_theta1=None,
+                init_shape0=None, init_shape1=None, iters=3):
+        """[model_copenet.py:112-159] -> (pred_pose0 (B,135), pred_betas0 (B,10), pred_pose1, pred_betas1)."""
+        self._check_eval()
+        dev = self._dev(x0)
+        B = x0.shape[0]
+        if x0.shape[1:] != (3, 224, 224) or x1.shape != x0.shape:
+            raise RuntimeError("forward expects two (B, 3, 224, 224) crops")
+        return self._ief("ap_copenet_fwd", N.f32c(x0), N.f32c(x1, dev), bb0, bb1, init_position0, init_position1,
+                         init_theta0, init_theta1, init_shape0, init_shape1, B, iters, dev)
+
+    def forward_ief(self, xf0, xf1, bb0, bb1, init_position0, init_position1, init_theta0=None, init_theta1=None,
+                    init_shape0=None, init_shape1=None, iters=3):
+        """The IEF loop of forward() from pre-computed trunk features (model_copenet.py:144-157)."""
+        self._check_eval()
+        dev = self._dev(xf0)
+        return self._ief("ap_regressor_fwd", N.f32c(xf0), N.f32c(xf1, dev), bb0, bb1, init_position0, init_position1,
+                         init_theta0, init_theta1, init_shape0, init_shape1, xf0.shape[0], iters, dev)
+
+    def forward_reg(self, xf0, xf1, bb0, bb1, pred_position0, pred_position1, pred_orient0, pred_orient1,
+                    pred_art_pose0, pred_art_pose1, pred_shape0, pred_shape1):
+        """One regressor evaluation for both views [model_copenet.py:178-204]."""
+        th0 = torch.cat([pred_orient0, pred_art_pose0], 1)
+        th1 = torch.cat([pred_orient1, pred_art_pose1], 1)
+        return self.forward_ief(xf0, xf1, bb0, bb1, pred_position0, pred_position1, th0, th1,
+                                pred_shape0, pred_shape1, iters=1)
+
+    def regressor_step(self, xf, bb, pose, betas, partner):
+        """One forward_reg evaluation for ONE view with the partner's (art_pose | shape) (B,136) supplied by
+        the caller -- the view-split / on-drone exchange step (README.md:238-241)."""
+        self._check_eval()
+        dev = self._dev(xf)
+        B = xf.shape[0]
+        xf, bb, pose, betas, partner = (N.f32c(t, dev) for t in (xf, bb, pose, betas, partner))
+        if partner.shape != (B, 136) or pose.shape != (B, 135) or betas.shape != (B, 10):
+            raise RuntimeError("regressor_step: pose (B,135), betas (B,10), partner (B,136)")
+        pose_out = torch.empty(B, 135, device=dev, dtype=torch.float32)
+        betas_out = torch.empty(B, 10, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(N.lib().ap_regressor_step(h, N.dptr(xf), N.dptr(bb), N.dptr(pose), N.dptr(betas), N.dptr(partner),
+                                              136, B, N.dptr(pose_out), N.dptr(betas_out), N.stream_ptr(dev)),
+                    "ap_regressor_step")
+        return pose_out, betas_out
+
+    # ------------------------------------------------------------------ measurement hooks (bench.py)
+    def enable_timing(self, on=True):
+        N.check(N.lib().ap_net_enable_timing(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+                "ap_net_enable_timing")
+
+    def timing(self, reset=True):
+        ms = (ctypes.c_double * 4)()
+        n = ctypes.c_int64()
+        N.check(N.lib().ap_net_timing(self._handle, ms, ctypes.byref(n), int(reset)), "ap_net_timing")
+        return {"stem_ms": ms[0], "conv_ms": ms[1], "avgpool_ms": ms[2], "regressor_ms": ms[3], "passes": n.value}
+
+    def set_chunk(self, images):
+        N.check(N.lib().ap_net_set_chunk(self._native(torch.device("cuda", torch.cuda.current_device())), int(images)),
+                "ap_net_set_chunk")
+
+
+def getcopenet(smpl_mean_params, pretrained=True, precision="bf16", **kwargs):
+    """model_copenet.getcopenet (:229-239).  ImageNet initialisation needs torchvision + network, neither
+    of which exists here; weights arrive through load_state_dict / load_from_checkpoint instead."""
+    return copenet(Bottleneck, [3, 4, 6, 3], smpl_mean_params, precision=precision, **kwargs)

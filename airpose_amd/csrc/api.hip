@@ -1,0 +1,818 @@
+// C ABI of libairpose_hip.so: handle management, weight folding/packing, kernel sequencing.
+// Declarations and the reference interfaces each entry point replaces: include/airpose_hip.h.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/airpose_hip.h"
+#include "ap_common.h"
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIP_TRY(expr)                                                                              \
+    do {                                                                                           \
+        hipError_t _e = (expr);                                                                    \
+        if (_e != hipSuccess)                                                                      \
+            return fail((int)_e, std::string(#expr) + ": " + hipGetErrorString(_e));               \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    hipError_t reserve(size_t n) {
+        if (n <= bytes) return hipSuccess;
+        if (p) {
+            hipError_t e = hipDeviceSynchronize();
+            if (e != hipSuccess) return e;
+            (void)hipFree(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) bytes = n;
+        return e;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+    template <typename T> T* as() const { return (T*)p; }
+};
+
+hipError_t upload(DevBuf& b, const void* src, size_t n) {
+    hipError_t e = b.reserve(n);
+    if (e != hipSuccess) return e;
+    return hipMemcpy(b.p, src, n, hipMemcpyHostToDevice);
+}
+
+struct HostTensor {
+    std::vector<int64_t> shape;
+    std::vector<float> data;
+    size_t numel() const { return data.size(); }
+};
+
+struct Layer {                  // a conv or linear layer in packed device form
+    int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
+    int wld = 0, cout_pad = 0;
+    DevBuf w, scale, shift;
+};
+
+struct Timing {
+    bool on = false;
+    std::vector<hipEvent_t> pool;
+    size_t used = 0;
+    std::vector<size_t> marks[4];   // pairs of event indices per stage
+    int64_t passes = 0;
+    hipError_t rec(hipStream_t st, size_t* idx) {
+        if (used == pool.size()) {
+            hipEvent_t e;
+            hipError_t r = hipEventCreate(&e);
+            if (r != hipSuccess) return r;
+            pool.push_back(e);
+        }
+        *idx = used++;
+        return hipEventRecord(pool[*idx], st);
+    }
+    hipError_t collect(double ms[4], int nstage, int64_t* n, bool reset) {
+        for (int s = 0; s < nstage; ++s) {
+            ms[s] = 0.0;
+            for (size_t i = 0; i + 1 < marks[s].size(); i += 2) {
+                hipError_t r = hipEventSynchronize(pool[marks[s][i + 1]]);
+                if (r != hipSuccess) return r;
+                float t = 0.f;
+                r = hipEventElapsedTime(&t, pool[marks[s][i]], pool[marks[s][i + 1]]);
+                if (r != hipSuccess) return r;
+                ms[s] += t;
+            }
+        }
+        *n = passes;
+        if (reset) {
+            for (auto& m : marks) m.clear();
+            used = 0;
+            passes = 0;
+        }
+        return hipSuccess;
+    }
+    void destroy() {
+        for (auto e : pool) (void)hipEventDestroy(e);
+        pool.clear();
+    }
+};
+
+constexpr double BN_EPS = 1e-5;
+constexpr int ST = 148, SLD = 288, DLD = 148;
+
+}  // namespace
+
+struct ap_net {
+    int device = 0, prec = AP_PREC_BF16, variant = 0;
+    bool finalized = false;
+    std::map<std::string, HostTensor> tensors;
+    // trunk
+    DevBuf stem_w, stem_scale, stem_shift;
+    struct Block { Layer c1, c2, c3, down; bool has_down = false; };
+    std::vector<Block> blocks;
+    // regressor (fp32)
+    Layer fc1_feat, fc1_state, fc2, dec;
+    DevBuf mean_pose, mean_shape;
+    // workspace
+    int chunk = 0;
+    DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds, ws_feat;
+    DevBuf ws_H, ws_S, ws_T1, ws_T2, ws_D, ws_state;
+    Timing tm;
+    size_t esize() const { return prec == AP_PREC_BF16 ? 2 : 4; }
+};
+
+struct ap_smplx {
+    int device = 0;
+    SmplxModelDev m{};
+    Layer dirs;                 // blend-shape GEMM operand: rows = 3V, K = 512
+    DevBuf j_template, j_shapedirs, parents, depth, skin_idx, skin_w, extra_verts, lmk_tri, lmk_bary;
+    DevBuf ws_coef, ws_A, ws_jposed, ws_post, ws_vposed;
+    int n_out_joints = 0;
+    Timing tm;
+};
+
+namespace {
+
+// ---------------------------------------------------------------------------------- packing
+const HostTensor* find(const ap_net* h, const std::string& name) {
+    auto it = h->tensors.find(name);
+    return it == h->tensors.end() ? nullptr : &it->second;
+}
+
+int bn_fold(const ap_net* h, const std::string& p, int c, std::vector<float>& scale, std::vector<float>& shift) {
+    const HostTensor *g = find(h, p + ".weight"), *b = find(h, p + ".bias"), *m = find(h, p + ".running_mean"),
+                     *v = find(h, p + ".running_var");
+    if (!g || !b || !m || !v) return fail(AP_ESTATE, "missing BatchNorm tensors for " + p);
+    if ((int)g->numel() != c || (int)b->numel() != c || (int)m->numel() != c || (int)v->numel() != c)
+        return fail(AP_ESHAPE, "BatchNorm size mismatch for " + p);
+    const int cp = ((c + 127) / 128) * 128;
+    scale.assign(cp, 1.f);
+    shift.assign(cp, 0.f);
+    for (int i = 0; i < c; ++i) {
+        const double s = (double)g->data[i] / std::sqrt((double)v->data[i] + BN_EPS);
+        scale[i] = (float)s;
+        shift[i] = (float)((double)b->data[i] - (double)m->data[i] * s);
+    }
+    return AP_OK;
+}
+
+// OIHW fp32 -> [cout_pad][kh][kw][cin] in the handle's storage type
+int pack_conv(ap_net* h, const std::string& wname, const std::string& bnname, int cin, int cout, int k, int stride,
+              int pad, Layer& L) {
+    const HostTensor* w = find(h, wname);
+    if (!w) return fail(AP_ESTATE, "missing tensor " + wname);
+    if (w->shape.size() != 4 || w->shape[0] != cout || w->shape[1] != cin || w->shape[2] != k || w->shape[3] != k)
+        return fail(AP_ESHAPE, "shape mismatch for " + wname);
+    L.cin = cin; L.cout = cout; L.k = k; L.stride = stride; L.pad = pad;
+    L.wld = k * k * cin;
+    L.cout_pad = ((cout + 127) / 128) * 128;
+    std::vector<float> scale, shift;
+    int rc = bn_fold(h, bnname, cout, scale, shift);
+    if (rc) return rc;
+    const size_t n = (size_t)L.cout_pad * L.wld;
+    if (h->prec == AP_PREC_BF16) {
+        std::vector<uint16_t> pk(n, 0);
+        for (int o = 0; o < cout; ++o)
+            for (int c = 0; c < cin; ++c)
+                for (int r = 0; r < k; ++r)
+                    for (int s = 0; s < k; ++s)
+                        pk[(size_t)o * L.wld + (r * k + s) * cin + c] =
+                            host_f32_to_bf16(w->data[(((size_t)o * cin + c) * k + r) * k + s]);
+        HIP_TRY(upload(L.w, pk.data(), n * 2));
+    } else {
+        std::vector<float> pk(n, 0.f);
+        for (int o = 0; o < cout; ++o)
+            for (int c = 0; c < cin; ++c)
+                for (int r = 0; r < k; ++r)
+                    for (int s = 0; s < k; ++s)
+                        pk[(size_t)o * L.wld + (r * k + s) * cin + c] = w->data[(((size_t)o * cin + c) * k + r) * k + s];
+        HIP_TRY(upload(L.w, pk.data(), n * 4));
+    }
+    HIP_TRY(upload(L.scale, scale.data(), scale.size() * 4));
+    HIP_TRY(upload(L.shift, shift.data(), shift.size() * 4));
+    return AP_OK;
+}
+
+// fp32 GEMM operand from rows [out][ld_src] taking columns [col0, col0+ncols); K padded to 32
+int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const float* bias, Layer& L) {
+    L.cin = ((ncols + 31) / 32) * 32;
+    L.cout = ((nout + 3) / 4) * 4;
+    L.k = 1; L.stride = 1; L.pad = 0;
+    L.wld = L.cin;
+    L.cout_pad = ((nout + 127) / 128) * 128;
+    std::vector<float> pk((size_t)L.cout_pad * L.wld, 0.f), scale(L.cout_pad, 1.f), shift(L.cout_pad, 0.f);
+    for (int o = 0; o < nout; ++o) {
+        memcpy(&pk[(size_t)o * L.wld], W + (size_t)o * ld_src + col0, (size_t)ncols * 4);
+        if (bias) shift[o] = bias[o];
+    }
+    HIP_TRY(upload(L.w, pk.data(), pk.size() * 4));
+    HIP_TRY(upload(L.scale, scale.data(), scale.size() * 4));
+    HIP_TRY(upload(L.shift, shift.data(), shift.size() * 4));
+    return AP_OK;
+}
+
+int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int is_bf16,
+             hipStream_t st) {
+    ConvArgs a{};
+    a.x = x; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = res; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = L.cin;
+    a.Ho = (H + 2 * L.pad - L.k) / L.stride + 1;
+    a.Wo = (W + 2 * L.pad - L.k) / L.stride + 1;
+    a.Cout = L.cout;
+    a.KH = a.KW = L.k; a.stride = L.stride; a.pad = L.pad;
+    a.M = N * a.Ho * a.Wo;
+    a.ldx = L.cin; a.ldy = L.cout; a.ldr = L.cout; a.wld = L.wld;
+    a.relu = relu;
+    HIP_TRY(ap_launch_conv(a, is_bf16, st));
+    return AP_OK;
+}
+
+// y[M][ldy] = x[M][ldx(:K)] * W^T * scale + shift (+ res)
+int run_gemm(const Layer& L, const float* x, int ldx, int K, int M, float* y, int ldy, const float* res, int ldr,
+             hipStream_t st) {
+    ConvArgs a{};
+    a.x = x; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = res; a.y = y;
+    a.N = M; a.H = a.W = a.Ho = a.Wo = 1;
+    a.Cin = K; a.Cout = L.cout;
+    a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+    a.M = M;
+    a.ldx = ldx; a.ldy = ldy; a.ldr = ldr; a.wld = L.wld;
+    a.relu = 0;
+    HIP_TRY(ap_launch_conv(a, 0, st));
+    return AP_OK;
+}
+
+int finalize_trunk(ap_net* h) {
+    // stem: [64][3][7][7] -> [k = (r,s,c)][64] fp32 for the direct kernel
+    const HostTensor* w = find(h, "conv1.weight");
+    if (!w) return fail(AP_ESTATE, "missing tensor conv1.weight");
+    if (w->numel() != 64 * 3 * 49) return fail(AP_ESHAPE, "shape mismatch for conv1.weight");
+    std::vector<float> sw(147 * 64);
+    for (int o = 0; o < 64; ++o)
+        for (int c = 0; c < 3; ++c)
+            for (int r = 0; r < 7; ++r)
+                for (int s = 0; s < 7; ++s) sw[((r * 7 + s) * 3 + c) * 64 + o] = w->data[((o * 3 + c) * 7 + r) * 7 + s];
+    HIP_TRY(upload(h->stem_w, sw.data(), sw.size() * 4));
+    std::vector<float> sc, sh;
+    int rc = bn_fold(h, "bn1", 64, sc, sh);
+    if (rc) return rc;
+    HIP_TRY(upload(h->stem_scale, sc.data(), sc.size() * 4));
+    HIP_TRY(upload(h->stem_shift, sh.data(), sh.size() * 4));
+
+    static const int layers[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
+    h->blocks.clear();
+    h->blocks.resize(16);
+    int inpl = 64, bi_all = 0;
+    for (int li = 0; li < 4; ++li)
+        for (int bi = 0; bi < layers[li]; ++bi, ++bi_all) {
+            char p[64];
+            snprintf(p, sizeof p, "layer%d.%d", li + 1, bi);
+            const std::string P(p);
+            const int pl = planes[li], stride = (bi == 0 && li > 0) ? 2 : 1;
+            ap_net::Block& B = h->blocks[bi_all];
+            if ((rc = pack_conv(h, P + ".conv1.weight", P + ".bn1", inpl, pl, 1, 1, 0, B.c1))) return rc;
+            if ((rc = pack_conv(h, P + ".conv2.weight", P + ".bn2", pl, pl, 3, stride, 1, B.c2))) return rc;
+            if ((rc = pack_conv(h, P + ".conv3.weight", P + ".bn3", pl, pl * 4, 1, 1, 0, B.c3))) return rc;
+            B.has_down = bi == 0;
+            if (B.has_down)
+                if ((rc = pack_conv(h, P + ".downsample.0.weight", P + ".downsample.1", inpl, pl * 4, 1, stride, 0,
+                                    B.down)))
+                    return rc;
+            inpl = pl * 4;
+        }
+    return AP_OK;
+}
+
+int finalize_regressor(ap_net* h) {
+    const HostTensor *w1 = find(h, "fc1.weight"), *b1 = find(h, "fc1.bias"), *w2 = find(h, "fc2.weight"),
+                     *b2 = find(h, "fc2.bias"), *wp = find(h, "decpose.weight"), *bp = find(h, "decpose.bias"),
+                     *wsh = find(h, "decshape.weight"), *bsh = find(h, "decshape.bias"), *ip = find(h, "init_pose"),
+                     *is = find(h, "init_shape");
+    if (!w1 || !b1 || !w2 || !b2 || !wp || !bp || !wsh || !bsh || !ip || !is)
+        return fail(AP_ESTATE, "missing regressor tensors (fc1/fc2/decpose/decshape/init_pose/init_shape)");
+    if (h->variant != 0) return AP_OK;   // hmr head: trunk only in this build
+    if (w1->numel() != (size_t)1024 * 2332 || w2->numel() != (size_t)1024 * 1024 || wp->numel() != (size_t)135 * 1024 ||
+        wsh->numel() != (size_t)10 * 1024 || ip->numel() < 132 || is->numel() != 10)
+        return fail(AP_ESHAPE, "regressor tensor shape mismatch");
+    int rc;
+    if ((rc = pack_linear(w1->data.data(), 2332, 0, 2048, 1024, b1->data.data(), h->fc1_feat))) return rc;
+    if ((rc = pack_linear(w1->data.data(), 2332, 2048, 284, 1024, nullptr, h->fc1_state))) return rc;
+    if ((rc = pack_linear(w2->data.data(), 1024, 0, 1024, 1024, b2->data.data(), h->fc2))) return rc;
+    std::vector<float> wd((size_t)145 * 1024), bd(145);
+    memcpy(wd.data(), wp->data.data(), (size_t)135 * 1024 * 4);
+    memcpy(wd.data() + (size_t)135 * 1024, wsh->data.data(), (size_t)10 * 1024 * 4);
+    memcpy(bd.data(), bp->data.data(), 135 * 4);
+    memcpy(bd.data() + 135, bsh->data.data(), 10 * 4);
+    if ((rc = pack_linear(wd.data(), 1024, 0, 1024, 145, bd.data(), h->dec))) return rc;
+    std::vector<float> mp(144, 0.f);
+    memcpy(mp.data(), ip->data.data(), std::min<size_t>(144, ip->numel()) * 4);
+    HIP_TRY(upload(h->mean_pose, mp.data(), 144 * 4));
+    HIP_TRY(upload(h->mean_shape, is->data.data(), 10 * 4));
+    return AP_OK;
+}
+
+int trunk_chunk(ap_net* h, const float* x, int n, float* feat, hipStream_t st) {
+    const int bf = h->prec == AP_PREC_BF16;
+    const size_t es = h->esize();
+    HIP_TRY(h->ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
+    HIP_TRY(h->ws_a.reserve((size_t)n * 802816 * es));
+    HIP_TRY(h->ws_b.reserve((size_t)n * 802816 * es));
+    HIP_TRY(h->ws_ds.reserve((size_t)n * 802816 * es));
+    HIP_TRY(h->ws_t1.reserve((size_t)n * 401408 * es));
+    HIP_TRY(h->ws_t2.reserve((size_t)n * 200704 * es));
+    size_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &e0));
+    HIP_TRY(ap_launch_stem_conv(x, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
+                                h->ws_stem.p, n, bf, st));
+    HIP_TRY(ap_launch_maxpool(h->ws_stem.p, h->ws_a.p, n, bf, st));
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
+    void *cur = h->ws_a.p, *nxt = h->ws_b.p;
+    int H = 56;
+    int rc;
+    for (auto& B : h->blocks) {
+        const int Ho = (H + 2 - 3) / B.c2.stride + 1;
+        if ((rc = run_conv(B.c1, cur, n, H, H, h->ws_t1.p, nullptr, 1, bf, st))) return rc;
+        if ((rc = run_conv(B.c2, h->ws_t1.p, n, H, H, h->ws_t2.p, nullptr, 1, bf, st))) return rc;
+        const void* res = cur;
+        if (B.has_down) {
+            if ((rc = run_conv(B.down, cur, n, H, H, h->ws_ds.p, nullptr, 0, bf, st))) return rc;
+            res = h->ws_ds.p;
+        }
+        if ((rc = run_conv(B.c3, h->ws_t2.p, n, Ho, Ho, nxt, res, 1, bf, st))) return rc;
+        std::swap(cur, nxt);
+        H = Ho;
+    }
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &e2));
+    HIP_TRY(ap_launch_avgpool(cur, feat, n, 2048, bf, st));
+    if (h->tm.on) {
+        HIP_TRY(h->tm.rec(st, &e3));
+        h->tm.marks[0].push_back(e0); h->tm.marks[0].push_back(e1);
+        h->tm.marks[1].push_back(e1); h->tm.marks[1].push_back(e2);
+        h->tm.marks[2].push_back(e2); h->tm.marks[2].push_back(e3);
+    }
+    return AP_OK;
+}
+
+int trunk_fwd(ap_net* h, const float* x, int n_img, float* feat, hipStream_t st) {
+    if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
+    if (n_img <= 0 || !x || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
+    int chunk = h->chunk > 0 ? h->chunk : (h->prec == AP_PREC_BF16 ? 64 : 32);
+    for (int i0 = 0; i0 < n_img; i0 += chunk) {
+        const int n = std::min(chunk, n_img - i0);
+        int rc = trunk_chunk(h, x + (size_t)i0 * 3 * 224 * 224, n, feat + (size_t)i0 * 2048, st);
+        if (rc) return rc;
+    }
+    if (h->tm.on) h->tm.passes++;
+    return AP_OK;
+}
+
+struct RegInputs {
+    const float *xf0, *xf1, *bb0, *bb1, *pos0, *pos1, *th0, *th1, *sh0, *sh1;
+    int th0_bs, th1_bs, sh0_bs, sh1_bs;
+};
+
+// xf rows: view 0 then view 1 (two_view) laid out by the caller as two pointers; H rows follow the same order
+int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view, const float* partner,
+                  int partner_ld, int pos_bs, float* pose0, float* betas0, float* pose1, float* betas1,
+                  hipStream_t st) {
+    if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
+    if (h->variant != 0) return fail(AP_ESTATE, "regressor entry points need a copenet (variant 0) handle");
+    if (B <= 0 || iters < 1) return fail(AP_EINVAL, "regressor: bad B / iters");
+    const int rows = two_view ? 2 * B : B;
+    HIP_TRY(h->ws_H.reserve((size_t)rows * 1024 * 4));
+    HIP_TRY(h->ws_T1.reserve((size_t)rows * 1024 * 4));
+    HIP_TRY(h->ws_T2.reserve((size_t)rows * 1024 * 4));
+    HIP_TRY(h->ws_S.reserve((size_t)rows * SLD * 4));
+    HIP_TRY(h->ws_D.reserve((size_t)rows * DLD * 4));
+    HIP_TRY(h->ws_state.reserve((size_t)rows * ST * 4));
+    size_t e0 = 0, e1 = 0;
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &e0));
+    float *Hb = h->ws_H.as<float>(), *T1 = h->ws_T1.as<float>(), *T2 = h->ws_T2.as<float>(), *S = h->ws_S.as<float>(),
+          *D = h->ws_D.as<float>(), *state = h->ws_state.as<float>();
+    int rc;
+    // trunk-feature part of fc1 (+ bias), constant over the iterations
+    if ((rc = run_gemm(h->fc1_feat, in.xf0, 2048, 2048, B, Hb, 1024, nullptr, 0, st))) return rc;
+    if (two_view)
+        if ((rc = run_gemm(h->fc1_feat, in.xf1, 2048, 2048, B, Hb + (size_t)B * 1024, 1024, nullptr, 0, st))) return rc;
+    RegInitArgs ia{};
+    ia.pos0 = in.pos0; ia.pos1 = in.pos1; ia.theta0 = in.th0; ia.theta1 = in.th1; ia.shape0 = in.sh0; ia.shape1 = in.sh1;
+    ia.theta0_bs = in.th0_bs; ia.theta1_bs = in.th1_bs; ia.shape0_bs = in.sh0_bs; ia.shape1_bs = in.sh1_bs;
+    ia.pos_bs = pos_bs; ia.rows = rows;
+    ia.mean_pose = h->mean_pose.as<float>(); ia.mean_shape = h->mean_shape.as<float>();
+    ia.state = state; ia.B = B;
+    HIP_TRY(ap_launch_reg_init(ia, st));
+    for (int it = 0; it < iters; ++it) {
+        HIP_TRY(ap_launch_reg_update_assemble(state, it ? D : nullptr, DLD, in.bb0, in.bb1, partner, partner_ld, S, B,
+                                              two_view, st));
+        if ((rc = run_gemm(h->fc1_state, S, SLD, SLD, rows, T1, 1024, Hb, 1024, st))) return rc;
+        if ((rc = run_gemm(h->fc2, T1, 1024, 1024, rows, T2, 1024, nullptr, 0, st))) return rc;
+        if ((rc = run_gemm(h->dec, T2, 1024, 1024, rows, D, DLD, nullptr, 0, st))) return rc;
+    }
+    // fold the last delta into the state and emit
+    HIP_TRY(ap_launch_reg_update_assemble(state, D, DLD, in.bb0, in.bb1, partner, partner_ld, S, B, two_view, st));
+    HIP_TRY(ap_launch_reg_output(state, pose0, betas0, pose1, betas1, B, two_view, st));
+    if (h->tm.on) {
+        HIP_TRY(h->tm.rec(st, &e1));
+        h->tm.marks[3].push_back(e0); h->tm.marks[3].push_back(e1);
+    }
+    return AP_OK;
+}
+
+}  // namespace
+
+// ================================================================================== C ABI
+extern "C" {
+
+const char* ap_version(void) { return "airpose_hip 0.1 (gfx950)"; }
+const char* ap_last_error(void) { return g_err.c_str(); }
+
+int ap_net_create(ap_net** out, int device, int precision, int variant) {
+    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16) || (variant != 0 && variant != 1))
+        return fail(AP_EINVAL, "ap_net_create: bad arguments");
+    HIP_TRY(hipSetDevice(device));
+    ap_net* h = new ap_net();
+    h->device = device; h->prec = precision; h->variant = variant;
+    *out = h;
+    return AP_OK;
+}
+
+void ap_net_destroy(ap_net* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : {&h->stem_w, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->ws_stem, &h->ws_a,
+                      &h->ws_b, &h->ws_t1, &h->ws_t2, &h->ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
+                      &h->ws_D, &h->ws_state})
+        b->release();
+    auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
+    for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); }
+    rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec);
+    h->tm.destroy();
+    delete h;
+}
+
+int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const int64_t* shape, int ndim) {
+    if (!h || !name || !host_data || ndim < 0 || ndim > 8) return fail(AP_EINVAL, "ap_net_set_tensor: bad arguments");
+    HostTensor t;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) {
+        if (shape[i] < 0) return fail(AP_ESHAPE, "negative dimension");
+        t.shape.push_back(shape[i]);
+        n *= (size_t)shape[i];
+    }
+    t.data.assign(host_data, host_data + n);
+    h->tensors[name] = std::move(t);
+    h->finalized = false;
+    return AP_OK;
+}
+
+int ap_net_finalize(ap_net* h) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    HIP_TRY(hipSetDevice(h->device));
+    int rc = finalize_trunk(h);
+    if (rc) return rc;
+    if ((rc = finalize_regressor(h))) return rc;
+    h->finalized = true;
+    return AP_OK;
+}
+
+int ap_net_precision(const ap_net* h) { return h ? h->prec : AP_EINVAL; }
+
+int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* stream) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    return trunk_fwd(h, x_nchw, n_img, feat, (hipStream_t)stream);
+}
+
+int ap_regressor_fwd(ap_net* h, const float* xf0, const float* xf1, const float* bb0, const float* bb1,
+                     const float* pos0, const float* pos1, const float* init_theta0, int theta0_bs,
+                     const float* init_theta1, int theta1_bs, const float* init_shape0, int shape0_bs,
+                     const float* init_shape1, int shape1_bs, int B, int iters, float* pose0, float* betas0,
+                     float* pose1, float* betas1, void* stream) {
+    if (!h || !xf0 || !xf1 || !bb0 || !bb1 || !pos0 || !pos1 || !pose0 || !betas0 || !pose1 || !betas1)
+        return fail(AP_EINVAL, "ap_regressor_fwd: null argument");
+    RegInputs in{xf0, xf1, bb0, bb1, pos0, pos1, init_theta0, init_theta1, init_shape0, init_shape1,
+                 theta0_bs, theta1_bs, shape0_bs, shape1_bs};
+    return regressor_run(h, in, B, iters, 1, nullptr, 0, 3, pose0, betas0, pose1, betas1, (hipStream_t)stream);
+}
+
+int ap_regressor_step(ap_net* h, const float* xf, const float* bb, const float* pose_in, const float* betas_in,
+                      const float* partner, int partner_ld, int B, float* pose_out, float* betas_out, void* stream) {
+    if (!h || !xf || !bb || !pose_in || !betas_in || !partner || !pose_out || !betas_out || partner_ld < 136)
+        return fail(AP_EINVAL, "ap_regressor_step: bad argument");
+    RegInputs in{xf, nullptr, bb, nullptr, pose_in, nullptr, pose_in + 3, nullptr, betas_in, nullptr, 135, 0, 10, 0};
+    return regressor_run(h, in, B, 1, 0, partner, partner_ld, 135, pose_out, betas_out, nullptr, nullptr,
+                         (hipStream_t)stream);
+}
+
+int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0, const float* bb1,
+                   const float* pos0, const float* pos1, const float* init_theta0, int theta0_bs,
+                   const float* init_theta1, int theta1_bs, const float* init_shape0, int shape0_bs,
+                   const float* init_shape1, int shape1_bs, int B, int iters, float* pose0, float* betas0,
+                   float* pose1, float* betas1, void* stream) {
+    if (!h || !x0 || !x1) return fail(AP_EINVAL, "ap_copenet_fwd: null argument");
+    if (B <= 0) return fail(AP_EINVAL, "ap_copenet_fwd: bad batch");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(h->ws_feat.reserve((size_t)2 * B * 2048 * 4));
+    float* f0 = h->ws_feat.as<float>();
+    float* f1 = f0 + (size_t)B * 2048;
+    int rc = trunk_fwd(h, x0, B, f0, st);
+    if (rc) return rc;
+    if ((rc = trunk_fwd(h, x1, B, f1, st))) return rc;
+    if (h->tm.on) h->tm.passes--;   // two trunk calls = one forward pass
+    return ap_regressor_fwd(h, f0, f1, bb0, bb1, pos0, pos1, init_theta0, theta0_bs, init_theta1, theta1_bs,
+                            init_shape0, shape0_bs, init_shape1, shape1_bs, B, iters, pose0, betas0, pose1, betas1,
+                            stream);
+}
+
+int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* scale, const float* shift,
+                   const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
+                   int relu, void* stream) {
+    const int bf = precision == AP_PREC_BF16;
+    if ((precision != AP_PREC_BF16 && precision != AP_PREC_FP32) || !x || !w || !scale || !shift || !y || N <= 0 ||
+        H <= 0 || W <= 0 || ksize <= 0 || stride <= 0 || pad < 0)
+        return fail(AP_EINVAL, "ap_conv2d_nhwc: bad argument");
+    if (Cin % (bf ? 64 : 32) || Cout % (bf ? 8 : 4) || Cin <= 0 || Cout <= 0)
+        return fail(AP_ESHAPE, "ap_conv2d_nhwc: Cin must be a multiple of 64 (bf16) / 32 (fp32), Cout of 8 / 4");
+    ConvArgs a{};
+    a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.Cin = Cin;
+    a.Ho = (H + 2 * pad - ksize) / stride + 1;
+    a.Wo = (W + 2 * pad - ksize) / stride + 1;
+    if (a.Ho <= 0 || a.Wo <= 0) return fail(AP_ESHAPE, "ap_conv2d_nhwc: empty output");
+    a.Cout = Cout; a.KH = a.KW = ksize; a.stride = stride; a.pad = pad;
+    a.M = N * a.Ho * a.Wo;
+    a.ldx = Cin; a.ldy = Cout; a.ldr = Cout; a.wld = ksize * ksize * Cin; a.relu = relu;
+    HIP_TRY(ap_launch_conv(a, bf, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_net_enable_timing(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->tm.on = on != 0;
+    return AP_OK;
+}
+
+int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset) {
+    if (!h || !ms || !passes) return fail(AP_EINVAL, "ap_net_timing: null argument");
+    HIP_TRY(h->tm.collect(ms, 4, passes, reset != 0));
+    return AP_OK;
+}
+
+int ap_net_set_chunk(ap_net* h, int images_per_chunk) {
+    if (!h || images_per_chunk < 0) return fail(AP_EINVAL, "ap_net_set_chunk: bad argument");
+    h->chunk = images_per_chunk;
+    return AP_OK;
+}
+
+// ---------------------------------------------------------------------------------- SMPL-X
+int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
+    if (!out || !md) return fail(AP_EINVAL, "ap_smplx_create: null argument");
+    const int V = md->num_verts, J = md->num_joints, NS = md->num_shape_coeffs;
+    if (V <= 0 || J <= 1 || J > 64 || NS != 20 || md->num_extra < 0 || md->num_landmarks < 0 ||
+        J + md->num_extra + md->num_landmarks > 128)
+        return fail(AP_ESHAPE, "ap_smplx_create: unsupported model dimensions");
+    if (!md->v_template || !md->shapedirs || !md->posedirs || !md->J_regressor || !md->parents || !md->lbs_weights ||
+        (md->num_landmarks && (!md->faces || !md->lmk_faces_idx || !md->lmk_bary_coords)) ||
+        (md->num_extra && !md->extra_joint_verts))
+        return fail(AP_EINVAL, "ap_smplx_create: null model array");
+    HIP_TRY(hipSetDevice(device));
+    ap_smplx* h = new ap_smplx();
+    h->device = device;
+    SmplxModelDev& m = h->m;
+    m.V = V; m.J = J; m.ncoef = 512;
+    const int NP = (J - 1) * 9;
+    if (20 + NP > m.ncoef) { delete h; return fail(AP_ESHAPE, "too many pose features"); }
+    // rest joints as an affine function of the shape coefficients (exact algebra, done in fp64):
+    //   J = J_regressor (v_template + shapedirs c) = J_template + J_shapedirs c
+    std::vector<float> jt((size_t)J * 3), jsd((size_t)J * 3 * 20);
+    for (int j = 0; j < J; ++j) {
+        double t[3] = {0, 0, 0};
+        std::vector<double> sd(60, 0.0);
+        for (int v = 0; v < V; ++v) {
+            const double r = md->J_regressor[(size_t)j * V + v];
+            if (r == 0.0) continue;
+            for (int c = 0; c < 3; ++c) {
+                t[c] += r * md->v_template[(size_t)v * 3 + c];
+                for (int l = 0; l < 20; ++l) sd[c * 20 + l] += r * md->shapedirs[((size_t)v * 3 + c) * 20 + l];
+            }
+        }
+        for (int c = 0; c < 3; ++c) {
+            jt[j * 3 + c] = (float)t[c];
+            for (int l = 0; l < 20; ++l) jsd[((size_t)j * 3 + c) * 20 + l] = (float)sd[c * 20 + l];
+        }
+    }
+    // kinematic tree
+    std::vector<int> par(J), dep(J, 0);
+    int maxd = 0;
+    for (int j = 0; j < J; ++j) {
+        par[j] = j == 0 ? -1 : (int)md->parents[j];
+        if (j > 0 && (par[j] < 0 || par[j] >= j)) { delete h; return fail(AP_ESHAPE, "parents must satisfy 0 <= parent < child"); }
+        dep[j] = j == 0 ? 0 : dep[par[j]] + 1;
+        maxd = std::max(maxd, dep[j]);
+    }
+    m.max_depth = maxd;
+    // sparse skinning weights, ascending bone index, K = max non-zeros per vertex (4 / 8 / exact)
+    int K = 1;
+    for (int v = 0; v < V; ++v) {
+        int nz = 0;
+        for (int j = 0; j < J; ++j) nz += md->lbs_weights[(size_t)v * J + j] != 0.f;
+        K = std::max(K, nz);
+    }
+    K = K <= 4 ? 4 : (K <= 8 ? 8 : K);
+    m.K = K;
+    std::vector<int> sidx((size_t)V * K, 0);
+    std::vector<float> sw((size_t)V * K, 0.f);
+    for (int v = 0; v < V; ++v) {
+        int k = 0;
+        for (int j = 0; j < J; ++j) {
+            const float w = md->lbs_weights[(size_t)v * J + j];
+            if (w != 0.f) { sidx[(size_t)v * K + k] = j; sw[(size_t)v * K + k] = w; ++k; }
+        }
+    }
+    // blend-shape operand: row n = 3v+c, columns [20 shape/expr | (J-1)*9 pose | 0 pad]; shift = v_template
+    Layer& L = h->dirs;
+    const int rows = 3 * V;
+    L.cin = m.ncoef; L.k = 1; L.stride = 1; L.pad = 0; L.wld = m.ncoef;
+    L.cout = ((rows + 3) / 4) * 4;
+    L.cout_pad = ((rows + 127) / 128) * 128;
+    m.ldv = L.cout_pad;
+    {
+        std::vector<float> pk((size_t)L.cout_pad * L.wld, 0.f), scale(L.cout_pad, 1.f), shift(L.cout_pad, 0.f);
+        for (int n = 0; n < rows; ++n) {
+            float* dst = &pk[(size_t)n * L.wld];
+            memcpy(dst, md->shapedirs + (size_t)n * 20, 20 * 4);
+            shift[n] = md->v_template[n];
+        }
+        for (int p = 0; p < NP; ++p) {
+            const float* src = md->posedirs + (size_t)p * rows;
+            for (int n = 0; n < rows; ++n) pk[(size_t)n * L.wld + 20 + p] = src[n];
+        }
+        hipError_t e = upload(L.w, pk.data(), pk.size() * 4);
+        if (e == hipSuccess) e = upload(L.scale, scale.data(), scale.size() * 4);
+        if (e == hipSuccess) e = upload(L.shift, shift.data(), shift.size() * 4);
+        if (e != hipSuccess) { ap_smplx_destroy(h); return fail((int)e, std::string("upload: ") + hipGetErrorString(e)); }
+    }
+    std::vector<int> ev(std::max(1, md->num_extra)), tri(std::max(1, md->num_landmarks * 3));
+    for (int i = 0; i < md->num_extra; ++i) {
+        ev[i] = (int)md->extra_joint_verts[i];
+        if (ev[i] < 0 || ev[i] >= V) { ap_smplx_destroy(h); return fail(AP_ESHAPE, "extra joint vertex id out of range"); }
+    }
+    for (int l = 0; l < md->num_landmarks; ++l) {
+        const int64_t f = md->lmk_faces_idx[l];
+        if (f < 0 || f >= md->num_faces) { ap_smplx_destroy(h); return fail(AP_ESHAPE, "landmark face id out of range"); }
+        for (int c = 0; c < 3; ++c) {
+            tri[l * 3 + c] = (int)md->faces[f * 3 + c];
+            if (tri[l * 3 + c] < 0 || tri[l * 3 + c] >= V) { ap_smplx_destroy(h); return fail(AP_ESHAPE, "face vertex id out of range"); }
+        }
+    }
+    hipError_t e = upload(h->j_template, jt.data(), jt.size() * 4);
+    if (e == hipSuccess) e = upload(h->j_shapedirs, jsd.data(), jsd.size() * 4);
+    if (e == hipSuccess) e = upload(h->parents, par.data(), par.size() * 4);
+    if (e == hipSuccess) e = upload(h->depth, dep.data(), dep.size() * 4);
+    if (e == hipSuccess) e = upload(h->skin_idx, sidx.data(), sidx.size() * 4);
+    if (e == hipSuccess) e = upload(h->skin_w, sw.data(), sw.size() * 4);
+    if (e == hipSuccess) e = upload(h->extra_verts, ev.data(), ev.size() * 4);
+    if (e == hipSuccess) e = upload(h->lmk_tri, tri.data(), tri.size() * 4);
+    if (e == hipSuccess)
+        e = upload(h->lmk_bary, md->num_landmarks ? (const void*)md->lmk_bary_coords : (const void*)tri.data(),
+                   std::max(1, md->num_landmarks * 3) * 4);
+    if (e != hipSuccess) { ap_smplx_destroy(h); return fail((int)e, std::string("upload: ") + hipGetErrorString(e)); }
+    m.j_template = h->j_template.as<float>(); m.j_shapedirs = h->j_shapedirs.as<float>();
+    m.parents = h->parents.as<int>(); m.depth = h->depth.as<int>();
+    m.skin_idx = h->skin_idx.as<int>(); m.skin_w = h->skin_w.as<float>();
+    m.extra_verts = h->extra_verts.as<int>(); m.lmk_tri = h->lmk_tri.as<int>(); m.lmk_bary = h->lmk_bary.as<float>();
+    m.n_extra = md->num_extra; m.n_lmk = md->num_landmarks;
+    h->n_out_joints = J + md->num_extra + md->num_landmarks;
+    *out = h;
+    return AP_OK;
+}
+
+void ap_smplx_destroy(ap_smplx* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (DevBuf* b : {&h->dirs.w, &h->dirs.scale, &h->dirs.shift, &h->j_template, &h->j_shapedirs, &h->parents, &h->depth,
+                      &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A,
+                      &h->ws_jposed, &h->ws_post, &h->ws_vposed})
+        b->release();
+    h->tm.destroy();
+    delete h;
+}
+
+int ap_smplx_num_joints_out(const ap_smplx* h) { return h ? h->n_out_joints : AP_EINVAL; }
+
+}  // extern "C"
+
+namespace {
+int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
+    const SmplxModelDev& m = h->m;
+    const int n = a.n;
+    HIP_TRY(h->ws_coef.reserve((size_t)n * m.ncoef * 4));
+    HIP_TRY(h->ws_A.reserve((size_t)n * m.J * 12 * 4));
+    HIP_TRY(h->ws_jposed.reserve((size_t)n * m.J * 3 * 4));
+    HIP_TRY(h->ws_post.reserve((size_t)n * 12 * 4));
+    HIP_TRY(h->ws_vposed.reserve((size_t)n * m.ldv * 4));
+    a.coef = h->ws_coef.as<float>(); a.A = h->ws_A.as<float>(); a.jposed = h->ws_jposed.as<float>();
+    a.post = (a.pose6d || a.post_rt) ? h->ws_post.as<float>() : nullptr;
+    a.vposed = h->ws_vposed.as<float>();
+    size_t ev[5] = {0, 0, 0, 0, 0};
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[0]));
+    HIP_TRY(ap_launch_smplx_prep(m, a, st));
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[1]));
+    // v_posed = v_template + [betas | expr | pose_feature] . dirs^T; hand/face rows of the pose feature are
+    // identically zero when no extra pose is supplied, so the contraction stops after the 21 body joints
+    int K = body_only ? 20 + 21 * 9 : 20 + (m.J - 1) * 9;
+    K = ((K + 31) / 32) * 32;
+    ConvArgs g{};
+    g.x = a.coef; g.w = h->dirs.w.p; g.scale = h->dirs.scale.as<float>(); g.shift = h->dirs.shift.as<float>();
+    g.res = nullptr; g.y = h->ws_vposed.p;
+    g.N = n; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = K; g.Cout = h->dirs.cout; g.KH = g.KW = 1; g.stride = 1; g.pad = 0;
+    g.M = n; g.ldx = m.ncoef; g.ldy = m.ldv; g.ldr = 0; g.wld = h->dirs.wld; g.relu = 0;
+    HIP_TRY(ap_launch_conv(g, 0, st));
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[2]));
+    HIP_TRY(ap_launch_smplx_skin(m, a, st));
+    if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[3]));
+    HIP_TRY(ap_launch_smplx_joints(m, a, st));
+    if (h->tm.on) {
+        HIP_TRY(h->tm.rec(st, &ev[4]));
+        for (int s = 0; s < 4; ++s) { h->tm.marks[s].push_back(ev[s]); h->tm.marks[s].push_back(ev[s + 1]); }
+        h->tm.passes++;
+    }
+    return AP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int ap_smplx_fwd(ap_smplx* h, int n, const float* betas, const float* expression, const float* global_orient,
+                 const float* body_pose, const float* extra_pose, const float* transl, float* vertices,
+                 float* joints, void* stream) {
+    if (!h || n <= 0 || !betas || !body_pose || !vertices || !joints) return fail(AP_EINVAL, "ap_smplx_fwd: bad argument");
+    SmplxFwdArgs a{};
+    a.n = n; a.betas = betas; a.expression = expression; a.global_orient = global_orient; a.body_pose = body_pose;
+    a.extra_pose = extra_pose; a.transl = transl; a.vertices = vertices; a.joints = joints;
+    return smplx_run(h, a, extra_pose == nullptr, (hipStream_t)stream);
+}
+
+int ap_smplx_fwd_fused(ap_smplx* h, int n, const float* pred_pose, int pose_ld, const float* betas,
+                       const float* cam_center, float fx, float fy, float* vertices_cam, float* joints_cam,
+                       float* joints2d, float* rotmat, void* stream) {
+    if (!h || n <= 0 || !pred_pose || pose_ld < 135 || !betas || !vertices_cam || !joints_cam)
+        return fail(AP_EINVAL, "ap_smplx_fwd_fused: bad argument");
+    SmplxFwdArgs a{};
+    a.n = n; a.betas = betas;
+    a.pose6d = pred_pose + 3; a.pose6d_ld = pose_ld;
+    a.post_t = pred_pose; a.post_t_ld = pose_ld;
+    a.cam_center = cam_center; a.fx = fx; a.fy = fy;
+    a.vertices = vertices_cam; a.joints = joints_cam; a.joints2d = cam_center ? joints2d : nullptr;
+    a.rotmat_out = rotmat;
+    return smplx_run(h, a, true, (hipStream_t)stream);
+}
+
+int ap_smplx_enable_timing(ap_smplx* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->tm.on = on != 0;
+    return AP_OK;
+}
+
+int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset) {
+    if (!h || !ms || !passes) return fail(AP_EINVAL, "ap_smplx_timing: null argument");
+    HIP_TRY(h->tm.collect(ms, 4, passes, reset != 0));
+    return AP_OK;
+}
+
+int ap_rot6d_to_rotmat(const float* x6, int n, float* rotmat, void* stream) {
+    if (!x6 || !rotmat || n <= 0) return fail(AP_EINVAL, "ap_rot6d_to_rotmat: bad argument");
+    HIP_TRY(ap_launch_rot6d(x6, n, rotmat, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_transform_points(const float* rt, const float* pts, int B, int P, float* out, void* stream) {
+    if (!rt || !pts || !out || B <= 0 || P <= 0) return fail(AP_EINVAL, "ap_transform_points: bad argument");
+    HIP_TRY(ap_launch_transform_points(rt, pts, B, P, out, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_perspective_projection(const float* pts, int B, int P, const float* rotation, const float* translation,
+                              float fx, float fy, const float* center, float* out, void* stream) {
+    if (!pts || !center || !out || B <= 0 || P <= 0) return fail(AP_EINVAL, "ap_perspective_projection: bad argument");
+    HIP_TRY(ap_launch_projection(pts, B, P, rotation, translation, fx, fy, center, out, (hipStream_t)stream));
+    return AP_OK;
+}
+
+}  // extern "C"

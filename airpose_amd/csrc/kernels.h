@@ -1,0 +1,112 @@
+// Internal launch interface between the C-ABI layer (api.hip) and the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+struct ConvArgs {
+    const void* x;        // NHWC activations [N][H][W][ldx], element type T
+    const void* w;        // [Cout_pad][KH*KW*Cin] (row stride wld), element type T
+    const float* scale;   // [Cout_pad]
+    const float* shift;   // [Cout_pad]
+    const void* res;      // optional residual [M][ldr], element type T
+    void* y;              // [M][ldy]
+    int N, H, W, Cin;
+    int Ho, Wo, Cout;     // Cout: number of stored channels (multiple of 16 B / sizeof(T))
+    int KH, KW, stride, pad;
+    int M;                // N*Ho*Wo
+    int ldx, ldy, ldr, wld;
+    int relu;
+    int mtiles, ntiles;   // filled by the launcher
+};
+
+int ap_conv_cout_pad(void);
+hipError_t ap_launch_conv(const ConvArgs& a, int is_bf16, hipStream_t st);
+
+// ---- stem / pooling (stem.hip)
+// conv 7x7/2 p3 (3->64) + BN + ReLU from NCHW fp32 into NHWC T [N][112][112][64]
+hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, const float* scale, const float* shift,
+                               void* y, int n_img, int is_bf16, hipStream_t st);
+hipError_t ap_launch_stem_conv_mfma(const float* x_nchw, const void* w_packed, const float* scale, const float* shift,
+                                    void* y_pooled, int n_img, hipStream_t st);
+// maxpool 3x3/2 p1: [N][112][112][64] -> [N][56][56][64]
+hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int is_bf16, hipStream_t st);
+// global 7x7 average: [N][49][C] T -> [N][C] fp32
+hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int is_bf16, hipStream_t st);
+
+// ---- regressor glue (regressor.hip); all fp32
+struct RegInitArgs {
+    const float *pos0, *pos1;          // [B][3]
+    const float *theta0, *theta1;      // [tb][>=132] (tb = 1 or B) or NULL -> mean pose
+    const float *shape0, *shape1;      // [sb][10] or NULL -> mean shape
+    int theta0_bs, theta1_bs, shape0_bs, shape1_bs;   // batch strides in floats (0 = broadcast)
+    int pos_bs;                        // batch stride of pos0/pos1 in floats
+    int rows;                          // 2B (two views) or B (single view: only the *0 inputs are read)
+    const float* mean_pose;            // [144]
+    const float* mean_shape;           // [10]
+    float* state;                      // [2B][148]: pos3 | orient6 | art126 | shape10 | pad3
+    int B;
+};
+hipError_t ap_launch_reg_init(const RegInitArgs& a, hipStream_t st);
+// state (+= delta[:, :145] if delta) ; S[row] = [bb3 pos3 orient6 art126 shape10 art_other126 shape_other10 0 0 0 0]
+hipError_t ap_launch_reg_update_assemble(float* state, const float* delta, int ldd, const float* bb0, const float* bb1,
+                                         const float* partner, int partner_ld,
+                                         float* S, int B, int two_view, hipStream_t st);
+hipError_t ap_launch_reg_output(const float* state, float* pose0, float* betas0, float* pose1, float* betas1,
+                                int B, int two_view, hipStream_t st);
+
+// ---- SMPL-X (smplx.hip)
+struct SmplxModelDev {
+    int V, J, K;                  // vertices, joints (55), bones per vertex
+    int ncoef;                    // columns of the coefficient matrix (512)
+    int ldv;                      // row stride of v_posed workspace (floats)
+    const float* j_template;      // [J][3]
+    const float* j_shapedirs;     // [J][3][20]
+    const int* parents;           // [J]
+    const int* depth;             // [J]
+    int max_depth;
+    const int* skin_idx;          // [V][K]
+    const float* skin_w;          // [V][K]
+    const int* extra_verts;       // [21]
+    const int* lmk_tri;           // [51][3]
+    const float* lmk_bary;        // [51][3]
+    int n_extra, n_lmk;
+};
+struct SmplxFwdArgs {
+    int n;                        // bodies
+    const float* betas;           // [n][10]
+    const float* expression;      // [n][10] or NULL
+    // pose input, one of:
+    const float* pose6d;          // [n][pose6d_ld]: 22 x 6D (root first); root becomes the post rotation
+    int pose6d_ld;
+    const float* global_orient;   // [n][9] or NULL (identity)
+    const float* body_pose;       // [n][21][9]
+    const float* extra_pose;      // [n][33][9] or NULL (identity)
+    const float* transl;          // [n][3] or NULL
+    // post transform (transform_smpl): X' = R X + t
+    const float* post_rt;         // [n][12] (3x4 row-major) or NULL
+    const float* post_t;          // with pose6d: translation [n][post_t_ld]
+    int post_t_ld;
+    // projection
+    const float* cam_center;      // [n][2] or NULL
+    float fx, fy;
+    // workspace
+    float* coef;                  // [n][ncoef]
+    float* A;                     // [n][J][12]
+    float* jposed;                // [n][J][3]
+    float* post;                  // [n][12] resolved post transform
+    const float* vposed;          // [n][ldv]
+    // outputs
+    float* vertices;              // [n][V][3]
+    float* joints;                // [n][J+21+51][3]
+    float* joints2d;              // [n][127][2] or NULL
+    float* rotmat_out;            // [n][22][9] or NULL (pose6d mode)
+};
+hipError_t ap_launch_smplx_prep(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);
+hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);
+hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);
+
+// ---- stand-alone geometry helpers (smplx.hip)
+hipError_t ap_launch_rot6d(const float* x6, int n, float* R, hipStream_t st);
+hipError_t ap_launch_transform_points(const float* rt, const float* pts, int B, int P, float* out, hipStream_t st);
+hipError_t ap_launch_projection(const float* pts, int B, int P, const float* R, const float* t, float fx, float fy,
+                                const float* center, float* out, hipStream_t st);

@@ -1,0 +1,100 @@
+// Glue kernels of the iterative (IEF) regressor with cross-view fusion, fp32.
+// Reference: copenet/src/copenet/models/model_copenet.py:112-159 (forward), :178-204 (forward_reg).
+//
+// The three Linear layers run on the fp32 MFMA GEMM (conv_igemm.hip); fc1 is split by linearity into
+// the 2048 trunk-feature columns (constant over the IEF iterations: computed once) and the 284
+// state columns [bb | pos | orient | art | shape | art_other | shape_other] (model_copenet.py:185,192),
+// which these kernels assemble.  Rows 0..B-1 are view 0, rows B..2B-1 view 1; the cross-view swap is
+// the partner-row read below (or, in view-split mode, an exchanged `partner` buffer).
+#include "ap_common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int ST = 148;    // state row: pos3 | orient6 | art126 | shape10 | pad3
+constexpr int SLD = 288;   // assembled fc1 state-input row (284 + 4 zero pad)
+
+__global__ void reg_init_kernel(const RegInitArgs a) {
+    const int row = blockIdx.x, v = row >= a.B, b = v ? row - a.B : row;
+    const float* pos = (v ? a.pos1 : a.pos0) + (size_t)b * a.pos_bs;
+    const float* theta = v ? a.theta1 : a.theta0;
+    const float* shape = v ? a.shape1 : a.shape0;
+    const float* th = theta ? theta + (size_t)b * (v ? a.theta1_bs : a.theta0_bs) : a.mean_pose;
+    const float* sh = shape ? shape + (size_t)b * (v ? a.shape1_bs : a.shape0_bs) : a.mean_shape;
+    float* s = a.state + (size_t)row * ST;
+    for (int i = threadIdx.x; i < ST; i += blockDim.x) {
+        float val = 0.f;
+        if (i < 3) val = pos[i];
+        else if (i < 135) val = th[i - 3];          // orient = theta[:6], art = theta[6:132]
+        else if (i < 145) val = sh[i - 135];
+        s[i] = val;
+    }
+}
+
+__global__ void reg_update_assemble_kernel(float* __restrict__ state, const float* __restrict__ delta, int ldd,
+                                           const float* __restrict__ bb0, const float* __restrict__ bb1,
+                                           const float* __restrict__ partner, int partner_ld,
+                                           float* __restrict__ S, int B, int two_view) {
+    // one block per sample; handles both views of the pair so the swap needs no second pass
+    const int b = blockIdx.x, nv = two_view ? 2 : 1;
+    __shared__ float st[2][ST];
+    for (int i = threadIdx.x; i < nv * ST; i += blockDim.x) {
+        const int v = i / ST, e = i - v * ST;
+        const size_t row = (size_t)v * B + b;
+        float val = state[row * ST + e];
+        if (delta && e < 145) {
+            val += delta[row * ldd + e];
+            state[row * ST + e] = val;
+        }
+        st[v][e] = val;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nv * SLD; i += blockDim.x) {
+        const int v = i / SLD, e = i - v * SLD;
+        const size_t row = (size_t)v * B + b;
+        float val = 0.f;
+        if (e < 3) val = (v ? bb1 : bb0)[(size_t)b * 3 + e];
+        else if (e < 148) val = st[v][e - 3];                      // pos, orient, art, shape (state[0:145])
+        else if (e < 284) {
+            const int k = e - 148;                                 // partner art (126) | shape (10)
+            if (two_view) val = st[1 - v][k < 126 ? 9 + k : 135 + (k - 126)];
+            else val = partner[(size_t)b * partner_ld + k];
+        }
+        S[row * SLD + e] = val;
+    }
+}
+
+__global__ void reg_output_kernel(const float* __restrict__ state, float* __restrict__ pose0,
+                                  float* __restrict__ betas0, float* __restrict__ pose1, float* __restrict__ betas1,
+                                  int B, int two_view) {
+    const int row = blockIdx.x, v = row >= B, b = v ? row - B : row;
+    const float* s = state + (size_t)row * ST;
+    float* pose = (v ? pose1 : pose0) + (size_t)b * 135;
+    float* betas = (v ? betas1 : betas0) + (size_t)b * 10;
+    for (int i = threadIdx.x; i < 145; i += blockDim.x) {
+        if (i < 135) pose[i] = s[i];
+        else betas[i - 135] = s[i];
+    }
+}
+
+}  // namespace
+
+hipError_t ap_launch_reg_init(const RegInitArgs& a, hipStream_t st) {
+    hipLaunchKernelGGL(reg_init_kernel, dim3(a.rows), dim3(64), 0, st, a);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_reg_update_assemble(float* state, const float* delta, int ldd, const float* bb0,
+                                         const float* bb1, const float* partner, int partner_ld, float* S, int B,
+                                         int two_view, hipStream_t st) {
+    hipLaunchKernelGGL(reg_update_assemble_kernel, dim3(B), dim3(128), 0, st, state, delta, ldd, bb0, bb1, partner,
+                       partner_ld, S, B, two_view);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_reg_output(const float* state, float* pose0, float* betas0, float* pose1, float* betas1, int B,
+                                int two_view, hipStream_t st) {
+    hipLaunchKernelGGL(reg_output_kernel, dim3(two_view ? 2 * B : B), dim3(64), 0, st, state, pose0, betas0, pose1,
+                       betas1, B, two_view);
+    return hipGetLastError();
+}

@@ -1,0 +1,156 @@
+/* airpose_hip.h -- C ABI of libairpose_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the per-frame inference hot path of AirPose.  Nothing like it exists
+ * upstream (the reference is pure Python); every entry point names the reference interface it
+ * replaces.  Paths are relative to the reference checkout.
+ *
+ * Conventions
+ *   - every data pointer is a DEVICE pointer owned by the caller (PyTorch's caching allocator in the
+ *     Python host); the library owns only packed weights and a per-handle workspace;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden sync, except
+ *     that a call which has to grow the workspace synchronises the device once;
+ *   - return value: 0 = ok, negative = AP_E* argument/state error, positive = hipError_t;
+ *     ap_last_error() returns a thread-local description;
+ *   - handles are not re-entrant: one in-flight call per handle (the Python shim takes a lock);
+ *   - all tensors are dense row-major float32 unless stated.
+ */
+#ifndef AIRPOSE_HIP_H
+#define AIRPOSE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AP_OK 0
+#define AP_EINVAL (-1)  /* bad argument */
+#define AP_ESHAPE (-2)  /* tensor name / shape mismatch */
+#define AP_ESTATE (-3)  /* handle not finalised, missing tensors */
+#define AP_ENOMEM (-4)
+
+#define AP_PREC_FP32 0 /* fp32 storage, v_mfma_f32_16x16x4_f32: parity mode (1e-4 vs the CPU reference) */
+#define AP_PREC_BF16 1 /* bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate: throughput mode */
+
+typedef struct ap_net ap_net;     /* ResNet-50 trunk + IEF regressor */
+typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
+
+const char* ap_version(void);
+const char* ap_last_error(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * Network handle.  Replaces model_copenet.getcopenet()/copenet.__init__
+ * (copenet/src/copenet/models/model_copenet.py:53-92, 229-239) and load_state_dict.
+ * Tensors are handed over under the reference's own state_dict names ("conv1.weight",
+ * "layer3.2.bn1.running_var", "fc1.bias", "init_pose", ...) as HOST float32 arrays in PyTorch layout
+ * (conv OIHW, linear [out][in]); ap_net_finalize folds BN into a per-channel scale/shift, repacks
+ * the weights K-contiguous NHWC in the handle's precision and uploads them.  Calling set_tensor +
+ * finalize again re-packs (fine-tuned weights).
+ * variant: 0 = copenet two-view (fc1 in = 2332), 1 = hmr single view head (fc1 in = 2193; trunk only used). */
+int ap_net_create(ap_net** out, int device, int precision, int variant);
+void ap_net_destroy(ap_net* h);
+int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
+int ap_net_finalize(ap_net* h);
+int ap_net_precision(const ap_net* h);
+
+/* copenet.forward_feat_ext (model_copenet.py:161-176).
+ * x: [n_img][3][224][224] NCHW fp32 (the reference input contract); feat: [n_img][2048] fp32. */
+int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* stream);
+
+/* IEF loop of copenet.forward (model_copenet.py:119-159) starting from trunk features.
+ * xf*: [B][2048]; bb*, pos*: [B][3]; init_theta*: [tb][>=132] with batch stride theta*_bs floats
+ * (0 broadcasts one row; NULL = model mean pose); init_shape*: [sb][10] likewise (NULL = mean shape).
+ * Outputs pose*: [B][135] = trans3 | root6D | body 21x6D, betas*: [B][10]. */
+int ap_regressor_fwd(ap_net* h, const float* xf0, const float* xf1, const float* bb0, const float* bb1,
+                     const float* pos0, const float* pos1, const float* init_theta0, int theta0_bs,
+                     const float* init_theta1, int theta1_bs, const float* init_shape0, int shape0_bs,
+                     const float* init_shape1, int shape1_bs, int B, int iters, float* pose0, float* betas0,
+                     float* pose1, float* betas1, void* stream);
+
+/* One forward_reg evaluation for ONE view (model_copenet.py:185-188,198-199), for the view-split /
+ * on-drone topology (README.md:238-241: step1/step2/step3 with the partner's state exchanged between
+ * steps).  pose_in [B][135], betas_in [B][10] = this view's current state; partner [B][partner_ld] =
+ * the other view's art pose (126) | shape (10); outputs as above. */
+int ap_regressor_step(ap_net* h, const float* xf, const float* bb, const float* pose_in, const float* betas_in,
+                      const float* partner, int partner_ld, int B, float* pose_out, float* betas_out, void* stream);
+
+/* copenet.forward (model_copenet.py:112-159): both trunks (one batched 2B pass, shared weights) + IEF. */
+int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0, const float* bb1,
+                   const float* pos0, const float* pos1, const float* init_theta0, int theta0_bs,
+                   const float* init_theta1, int theta1_bs, const float* init_shape0, int shape0_bs,
+                   const float* init_shape1, int shape1_bs, int B, int iters, float* pose0, float* betas0,
+                   float* pose1, float* betas1, void* stream);
+
+/* One fused convolution of the trunk: y = act(conv(x, w) * scale + shift (+ res)), the building block of
+ * Bottleneck.forward (model_copenet.py:27-47: conv -> BN -> [+ residual] -> ReLU).  Exposed so the kernel can be
+ * unit-tested and reused.  NHWC activations x [N][H][W][Cin], y/res [N][Ho][Wo][Cout]; w [Cout_pad][k][k][Cin]
+ * with Cout_pad = Cout rounded up to 128 (zero rows), scale/shift [Cout_pad]; element type of x/w/res/y is
+ * bf16 (AP_PREC_BF16) or float (AP_PREC_FP32); Cin a multiple of 64 (bf16) / 32 (fp32), Cout of 8 / 4. */
+int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* scale, const float* shift,
+                   const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
+                   int relu, void* stream);
+
+/* Stage timing for bench.py: when enabled, HIP events bracket the stem, the implicit-GEMM conv stack,
+ * the pooling tail and the regressor on the caller's stream.  ap_net_timing synchronises on the last
+ * recorded events and returns the ACCUMULATED milliseconds and the number of recorded passes since
+ * the last reset.  ms[0]=stem+maxpool, ms[1]=conv stack (52 launches/pass), ms[2]=avgpool, ms[3]=regressor. */
+int ap_net_enable_timing(ap_net* h, int on);
+int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset);
+/* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
+int ap_net_set_chunk(ap_net* h, int images_per_chunk);
+
+/* ---------------------------------------------------------------------------------------------
+ * SMPL-X handle.  Replaces smplx.SMPLX(model_dir, batch_size=.., create_transl=False)
+ * (call site copenet/src/copenet/copenet_twoview.py:36-45; upstream smplx==0.1.28 semantics). */
+typedef struct ap_smplx_model {
+    int32_t num_verts, num_joints, num_faces; /* 10475, 55, 20908 */
+    int32_t num_shape_coeffs;                 /* betas + expression columns of shapedirs (20) */
+    int32_t num_extra, num_landmarks;         /* 21, 51 */
+    const float* v_template;                  /* [V][3] */
+    const float* shapedirs;                   /* [V][3][num_shape_coeffs] */
+    const float* posedirs;                    /* [(J-1)*9][V*3] */
+    const float* J_regressor;                 /* [J][V] */
+    const int64_t* parents;                   /* [J], parents[0] = -1 */
+    const float* lbs_weights;                 /* [V][J] */
+    const int64_t* faces;                     /* [F][3] */
+    const int64_t* extra_joint_verts;         /* [num_extra] */
+    const int64_t* lmk_faces_idx;             /* [num_landmarks] */
+    const float* lmk_bary_coords;             /* [num_landmarks][3] */
+} ap_smplx_model; /* all HOST pointers */
+
+int ap_smplx_create(ap_smplx** out, const ap_smplx_model* model, int device);
+void ap_smplx_destroy(ap_smplx* h);
+int ap_smplx_num_joints_out(const ap_smplx* h); /* 127 */
+
+/* SMPLX.forward(betas, body_pose, global_orient, transl, pose2rot=False)
+ * (copenet_twoview.py:237-241).  global_orient [n][3][3] or NULL (identity); body_pose [n][21][3][3];
+ * extra_pose [n][33][3][3] (jaw, leye, reye, 15 left hand, 15 right hand) or NULL (identity);
+ * expression [n][10] or NULL; transl [n][3] or NULL.  vertices [n][V][3], joints [n][127][3]. */
+int ap_smplx_fwd(ap_smplx* h, int n, const float* betas, const float* expression, const float* global_orient,
+                 const float* body_pose, const float* extra_pose, const float* transl, float* vertices,
+                 float* joints, void* stream);
+
+/* Fused caller slice for one view: rot6d_to_rotmat -> SMPLX.forward(global_orient = I, transl = 0) ->
+ * transform_smpl([R_root | trans]) -> perspective_projection(R = I, t = 0)
+ * (copenet_twoview.py:222-223, 237-246, 307-311).  pred_pose [n][pose_ld]: trans3 (already un-scaled) |
+ * 22 x 6D; betas [n][10]; cam_center [n][2] (intr[:, :2, 2]) or NULL.  Outputs: vertices_cam [n][V][3],
+ * joints_cam [n][127][3], joints2d [n][127][2] (NULL if cam_center NULL), rotmat [n][22][3][3] or NULL. */
+int ap_smplx_fwd_fused(ap_smplx* h, int n, const float* pred_pose, int pose_ld, const float* betas,
+                       const float* cam_center, float fx, float fy, float* vertices_cam, float* joints_cam,
+                       float* joints2d, float* rotmat, void* stream);
+int ap_smplx_enable_timing(ap_smplx* h, int on);
+/* ms[0]=prep/chain, ms[1]=blend-shape GEMM, ms[2]=skin, ms[3]=joints+projection */
+int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);
+
+/* ---------------------------------------------------------------------------------------------
+ * Stand-alone geometry helpers (copenet/src/copenet/utils/geometry.py:47-61, 63-91;
+ * copenet/src/copenet/utils/utils.py:237-256). */
+int ap_rot6d_to_rotmat(const float* x6, int n, float* rotmat, void* stream);          /* [n][6] -> [n][3][3] */
+int ap_transform_points(const float* rt, const float* pts, int B, int P, float* out, void* stream); /* rt [B][3][4] */
+int ap_perspective_projection(const float* pts, int B, int P, const float* rotation, const float* translation,
+                              float fx, float fy, const float* center, float* out, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AIRPOSE_HIP_H */

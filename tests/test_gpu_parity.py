@@ -1,0 +1,350 @@
+"""Parity tests proper: the HIP path (through the C ABI) against the CPU oracle and the committed
+golden vectors.  Need a real MI355X:  python -m pytest tests -m gpu
+
+Tolerances (written here, as the scope demands):
+  fp32 parity mode   1e-4 relative (max |a-b| / max |b|) on regressed theta/beta, 3-D joints/vertices, 2-D
+                     projection -- the bar of BASELINE.json north_star
+  bf16 throughput    reported; asserted < 5e-2 (bf16 storage has 8 mantissa bits through 53 convs)
+"""
+import ctypes
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import MEAN_PARAMS, rel_err
+
+pytestmark = pytest.mark.gpu
+
+TOL32 = 1e-4
+TOLBF = 5e-2
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need the MI355X"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def net32(copenet_sd, dev):
+    from airpose_amd import copenet_model
+    net = copenet_model.getcopenet(MEAN_PARAMS, precision="fp32").eval()
+    net.load_state_dict(copenet_sd)
+    return net
+
+
+@pytest.fixture(scope="module")
+def netbf(copenet_sd, dev):
+    from airpose_amd import copenet_model
+    net = copenet_model.getcopenet(MEAN_PARAMS, precision="bf16").eval()
+    net.load_state_dict(copenet_sd)
+    return net
+
+
+@pytest.fixture(scope="module")
+def body(smplx_model, dev):
+    from airpose_amd import smplx
+    return smplx.SMPLX(model_data=smplx_model)
+
+
+def test_native_library_is_loaded():
+    from airpose_amd import _native
+    L = _native.lib()
+    assert b"gfx950" in L.ap_version()
+    with open("/proc/self/maps") as f:
+        assert "libairpose_hip.so" in f.read()
+
+
+# ------------------------------------------------------------------------------------------------ conv primitive
+def _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed):
+    from airpose_amd import _native as Nn
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, Cin, H, H, generator=g)
+    w = torch.randn(Cout, Cin, k, k, generator=g) * (2.0 / (k * k * Cin)) ** 0.5
+    scale = torch.rand(Cout, generator=g) + 0.5
+    shift = torch.randn(Cout, generator=g) * 0.1
+    Ho = (H + 2 * pad - k) // stride + 1
+    res = torch.randn(N, Cout, Ho, Ho, generator=g) if use_res else None
+    tdt = torch.bfloat16 if prec == "bf16" else torch.float32
+    xq, wq = x.to(tdt), w.to(tdt)
+    resq = res.to(tdt) if use_res else None
+    # oracle on the SAME (rounded) operands, fp64 accumulate
+    ref = F.conv2d(xq.double(), wq.double(), stride=stride, padding=pad)
+    ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
+    if use_res:
+        ref = ref + resq.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    cpad = (Cout + 127) // 128 * 128
+    wp = torch.zeros(cpad, k, k, Cin, dtype=tdt)
+    wp[:Cout] = wq.permute(0, 2, 3, 1)
+    sp, hp = torch.ones(cpad), torch.zeros(cpad)
+    sp[:Cout], hp[:Cout] = scale, shift
+    xd = xq.permute(0, 2, 3, 1).contiguous().to(dev)
+    rd = resq.permute(0, 2, 3, 1).contiguous().to(dev) if use_res else None
+    wd, sd_, hd = wp.to(dev), sp.to(dev), hp.to(dev)
+    y = torch.full((N, Ho, Ho, Cout), float("nan"), dtype=tdt, device=dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    rc = Nn.lib().ap_conv2d_nhwc(Nn.PRECISIONS[prec], p(xd), p(wd), p(sd_), p(hd), p(rd), p(y), N, H, H, Cin, Cout, k,
+                                 stride, pad, int(relu), Nn.stream_ptr(dev))
+    Nn.check(rc, "ap_conv2d_nhwc")
+    torch.cuda.synchronize()
+    got = y.float().cpu().permute(0, 3, 1, 2).double()
+    return got, ref
+
+
+CONV_CASES = [
+    # N, H, Cin, Cout, k, stride, pad, relu, res
+    (2, 56, 64, 64, 1, 1, 0, True, False),      # layer1 conv1: single K step, BN=64 tile
+    (2, 56, 64, 64, 3, 1, 1, True, False),      # layer1 conv2: 3x3 halo
+    (2, 56, 64, 256, 1, 1, 0, True, True),      # conv3 + residual + relu
+    (1, 56, 256, 128, 1, 1, 0, True, False),
+    (2, 56, 128, 128, 3, 2, 1, True, False),    # stride-2 3x3 (layer2.0 conv2)
+    (2, 56, 256, 512, 1, 2, 0, False, False),   # stride-2 1x1 downsample, no relu
+    (3, 14, 256, 256, 3, 1, 1, True, False),    # ragged M (3*196 = 588)
+    (1, 7, 512, 2048, 1, 1, 0, True, True),     # tiny M = 49, wide N
+    (5, 7, 512, 512, 3, 1, 1, True, False),     # K = 4608
+    (64, 28, 128, 512, 1, 1, 0, True, True),    # large M -> 128x128 tiles
+]
+
+
+@pytest.mark.parametrize("prec", ["fp32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_primitive(dev, prec, case):
+    N, H, Cin, Cout, k, stride, pad, relu, use_res = case
+    got, ref = _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed=hash(case) % 10000)
+    assert torch.isfinite(got).all()
+    # operands identical: fp32 differs only by accumulation order, bf16 additionally by the output rounding
+    tol = 2e-5 if prec == "fp32" else 6e-3
+    assert rel_err(got.numpy(), ref.numpy()) < tol
+
+
+# ------------------------------------------------------------------------------------------------ trunk / IEF / forward
+def test_trunk_fp32_matches_golden(golden, net32, copenet_inputs, dev):
+    g = golden["copenet_b2"]
+    xf0 = net32.forward_feat_ext(copenet_inputs["im0"].to(dev)).cpu().numpy()
+    xf1 = net32.forward_feat_ext(copenet_inputs["im1"].to(dev)).cpu().numpy()
+    e0, e1 = rel_err(xf0, g["xf0"]), rel_err(xf1, g["xf1"])
+    print("trunk fp32 rel err %.3e %.3e" % (e0, e1))
+    assert e0 < TOL32 and e1 < TOL32
+
+
+def test_trunk_bf16_close_to_golden(golden, netbf, copenet_inputs, dev):
+    g = golden["copenet_b2"]
+    xf0 = netbf.forward_feat_ext(copenet_inputs["im0"].to(dev)).cpu().numpy()
+    e0 = rel_err(xf0, g["xf0"])
+    print("trunk bf16 rel err %.3e" % e0)
+    assert e0 < TOLBF
+
+
+def test_trunk_batch_and_chunk_invariance(net32, dev):
+    """Ragged batches and the depth-first chunking must not change any value (each output element has a
+    fixed accumulation order)."""
+    from airpose_amd import weights as W
+    x = torch.from_numpy(W.synthetic_inputs(99, 5)["im0"]).to(dev)
+    net32.set_chunk(0)
+    full = net32.forward_feat_ext(x)
+    net32.set_chunk(2)
+    chunked = net32.forward_feat_ext(x)
+    net32.set_chunk(0)
+    single = torch.cat([net32.forward_feat_ext(x[i:i + 1]) for i in range(5)])
+    assert rel_err(chunked.cpu().numpy(), full.cpu().numpy()) < 1e-6
+    assert rel_err(single.cpu().numpy(), full.cpu().numpy()) < 1e-6
+
+
+def test_ief_fp32_matches_golden(golden, net32, copenet_inputs, dev):
+    g = golden["copenet_b2"]
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    pos = t("init_position")
+    for it in (1, 2, 3):
+        p0, b0, p1, b1 = net32.forward_ief(t("xf0"), t("xf1"), copenet_inputs["bb0"].to(dev),
+                                           copenet_inputs["bb1"].to(dev), pos, pos, iters=it)
+        for got, key in ((p0, "pose0"), (b0, "betas0"), (p1, "pose1"), (b1, "betas1")):
+            assert rel_err(got.cpu().numpy(), g["%s_it%d" % (key, it)]) < TOL32, (key, it)
+    p0, b0, p1, b1 = net32.forward_ief(t("xf0"), t("xf1"), copenet_inputs["bb0"].to(dev), copenet_inputs["bb1"].to(dev),
+                                       pos, pos, init_theta0=t("ci_theta0"), init_theta1=t("ci_theta1"),
+                                       init_shape0=t("ci_shape0"), init_shape1=t("ci_shape1"), iters=2)
+    assert rel_err(p0.cpu().numpy(), g["ci_pose0"]) < TOL32 and rel_err(p1.cpu().numpy(), g["ci_pose1"]) < TOL32
+    assert rel_err(b0.cpu().numpy(), g["ci_betas0"]) < TOL32 and rel_err(b1.cpu().numpy(), g["ci_betas1"]) < TOL32
+
+
+def test_forward_fp32_matches_golden(golden, net32, copenet_inputs, dev):
+    g = golden["copenet_b2"]
+    gin = {k: v.to(dev) for k, v in copenet_inputs.items()}
+    pos = torch.from_numpy(g["init_position"]).to(dev)
+    p0, b0, p1, b1 = net32(gin["im0"], gin["im1"], gin["bb0"], gin["bb1"], pos, pos, iters=3)
+    errs = [rel_err(p0.cpu().numpy(), g["pose0_it3"]), rel_err(b0.cpu().numpy(), g["betas0_it3"]),
+            rel_err(p1.cpu().numpy(), g["pose1_it3"]), rel_err(b1.cpu().numpy(), g["betas1_it3"])]
+    print("forward fp32 rel errs", errs)
+    assert max(errs) < TOL32
+
+
+def test_forward_bf16_tolerance(golden, netbf, copenet_inputs, dev):
+    g = golden["copenet_b2"]
+    gin = {k: v.to(dev) for k, v in copenet_inputs.items()}
+    pos = torch.from_numpy(g["init_position"]).to(dev)
+    p0, b0, p1, b1 = netbf(gin["im0"], gin["im1"], gin["bb0"], gin["bb1"], pos, pos, iters=3)
+    errs = [rel_err(p0.cpu().numpy(), g["pose0_it3"]), rel_err(b1.cpu().numpy(), g["betas1_it3"])]
+    print("forward bf16 rel errs", errs)
+    assert max(errs) < TOLBF
+
+
+def test_view_swap_symmetry_and_zero_decoder(net32, copenet_sd, dev):
+    """SURVEY §8c (vi)/(vii) on the GPU path."""
+    torch.manual_seed(3)
+    B = 3
+    xf0, xf1 = torch.randn(B, 2048, device=dev), torch.randn(B, 2048, device=dev)
+    bb0, bb1 = torch.rand(B, 3, device=dev), torch.rand(B, 3, device=dev)
+    pos0, pos1 = torch.randn(B, 3, device=dev), torch.randn(B, 3, device=dev)
+    a = net32.forward_ief(xf0, xf1, bb0, bb1, pos0, pos1, iters=3)
+    b = net32.forward_ief(xf1, xf0, bb1, bb0, pos1, pos0, iters=3)
+    for x, y in zip(a, (b[2], b[3], b[0], b[1])):
+        assert torch.equal(x, y)
+
+
+def test_forward_reg_and_step_match_oracle(net32, copenet_sd, dev):
+    from oracle import copenet_ref
+    torch.manual_seed(5)
+    B = 4
+    xf0, xf1 = torch.randn(B, 2048), torch.randn(B, 2048)
+    bb0, bb1 = torch.rand(B, 3), torch.rand(B, 3)
+    pose0, pose1 = torch.randn(B, 135) * 0.5, torch.randn(B, 135) * 0.5
+    s0, s1 = torch.randn(B, 10) * 0.5, torch.randn(B, 10) * 0.5
+    with torch.no_grad():
+        want = copenet_ref.forward_reg(copenet_sd, xf0, xf1, bb0, bb1, pose0[:, :3], pose1[:, :3], pose0[:, 3:9],
+                                       pose1[:, 3:9], pose0[:, 9:], pose1[:, 9:], s0, s1)
+    d = lambda t: t.to(dev)
+    got = net32.forward_reg(d(xf0), d(xf1), d(bb0), d(bb1), d(pose0[:, :3]), d(pose1[:, :3]), d(pose0[:, 3:9]),
+                            d(pose1[:, 3:9]), d(pose0[:, 9:]), d(pose1[:, 9:]), d(s0), d(s1))
+    for g_, w_ in zip(got, want):
+        assert rel_err(g_.cpu().numpy(), w_.numpy()) < TOL32
+    # single-view step with the partner state supplied by the caller == the same numbers
+    partner0 = torch.cat([pose1[:, 9:], s1], 1)
+    p, s = net32.regressor_step(d(xf0), d(bb0), d(pose0), d(s0), d(partner0))
+    assert rel_err(p.cpu().numpy(), want[0].numpy()) < TOL32 and rel_err(s.cpu().numpy(), want[1].numpy()) < TOL32
+
+
+# ------------------------------------------------------------------------------------------------ SMPL-X + geometry
+def _rand_rot(n, gen):
+    from oracle import geometry_ref
+    return geometry_ref.rot6d_to_rotmat(torch.randn(n, 6, generator=gen))
+
+
+def test_smplx_forward_matches_oracle(body, smplx_model, dev):
+    from oracle import smplx_ref
+    gen = torch.Generator().manual_seed(11)
+    B = 5
+    betas = torch.randn(B, 10, generator=gen)
+    bp = _rand_rot(B * 21, gen).view(B, 21, 3, 3)
+    go = _rand_rot(B, gen).view(B, 1, 3, 3)
+    tr = torch.randn(B, 3, generator=gen)
+    want_v, want_j = smplx_ref.smplx_forward(smplx_model, betas, bp, global_orient=go, transl=tr)
+    out = body.forward(betas=betas.to(dev), body_pose=bp.to(dev), global_orient=go.to(dev), transl=tr.to(dev),
+                       pose2rot=False)
+    assert out.vertices.shape == (B, 10475, 3) and out.joints.shape == (B, 127, 3)
+    ev, ej = rel_err(out.vertices.cpu().numpy(), want_v.numpy()), rel_err(out.joints.cpu().numpy(), want_j.numpy())
+    print("smplx rel err verts %.3e joints %.3e" % (ev, ej))
+    assert ev < TOL32 and ej < TOL32
+    # the reference's own call: identity global_orient, zero transl
+    eye = torch.eye(3).expand(B, 1, 3, 3)
+    want_v, want_j = smplx_ref.smplx_forward(smplx_model, betas, bp, global_orient=eye, transl=torch.zeros(B, 3))
+    out = body.forward(betas=betas.to(dev), body_pose=bp.to(dev), global_orient=eye.contiguous().to(dev),
+                       transl=torch.zeros(B, 3, device=dev), pose2rot=False)
+    assert rel_err(out.vertices.cpu().numpy(), want_v.numpy()) < TOL32
+    assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
+
+
+def test_smplx_hands_face_expression(body, smplx_model, dev):
+    from oracle import smplx_ref
+    gen = torch.Generator().manual_seed(12)
+    B = 2
+    betas, expr = torch.randn(B, 10, generator=gen), torch.randn(B, 10, generator=gen)
+    bp = _rand_rot(B * 21, gen).view(B, 21, 3, 3)
+    jaw = _rand_rot(B, gen).view(B, 1, 3, 3)
+    lh = _rand_rot(B * 15, gen).view(B, 15, 3, 3)
+    want_v, want_j = smplx_ref.smplx_forward(smplx_model, betas, bp, expression=expr, jaw_pose=jaw, left_hand_pose=lh)
+    out = body.forward(betas=betas.to(dev), body_pose=bp.to(dev), expression=expr.to(dev), jaw_pose=jaw.to(dev),
+                       left_hand_pose=lh.to(dev), pose2rot=False)
+    assert rel_err(out.vertices.cpu().numpy(), want_v.numpy()) < TOL32
+    assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
+
+
+def test_smplx_identity_is_template(body, smplx_model, dev):
+    eye = torch.eye(3, device=dev).expand(1, 21, 3, 3).contiguous()
+    out = body.forward(betas=torch.zeros(1, 10, device=dev), body_pose=eye, pose2rot=False)
+    assert np.allclose(out.vertices[0].cpu().numpy(), smplx_model["v_template"], atol=2e-6)
+    assert np.allclose(out.joints[0, :55].cpu().numpy(), smplx_model["J_regressor"] @ smplx_model["v_template"], atol=2e-6)
+
+
+def test_geometry_helpers_match_golden(golden, dev):
+    from airpose_amd import geometry, utils
+    g = golden["geometry"]
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    R = geometry.rot6d_to_rotmat(t("rot6d_in"))
+    assert np.allclose(R.cpu().numpy(), g["rot6d_out"], atol=1e-6)
+    out = geometry.perspective_projection(t("proj_points"), torch.eye(3, device=dev).expand(3, 3, 3),
+                                          torch.zeros(3, 3, device=dev), [1475, 1475], t("proj_center").unsqueeze(0))
+    assert rel_err(out.cpu().numpy(), g["proj_out"]) < 1e-6
+    out = geometry.perspective_projection(t("proj_points"), t("proj_rt_R"),
+                                          t("proj_rt_t") + torch.tensor([0, 0, 5.0], device=dev), [1000.0, 1100.0],
+                                          t("proj_center"))
+    assert rel_err(out.cpu().numpy(), g["proj_rt_out"]) < 1e-6
+    v, j, _, _ = utils.transform_smpl(t("tf_mat"), t("tf_verts"), t("tf_joints"))
+    assert rel_err(v.cpu().numpy(), g["tf_verts_out"]) < 1e-6 and rel_err(j.cpu().numpy(), g["tf_joints_out"]) < 1e-6
+
+
+def test_whole_pipeline_fp32_matches_oracle(net32, body, copenet_sd, copenet_inputs, smplx_model, dev):
+    """BASELINE config 2 at test size: regressed theta/beta, 3-D joints/vertices, 2-D projection within 1e-4."""
+    from airpose_amd import pipeline
+    from oracle import pipeline_ref
+    inp = copenet_inputs
+    with torch.no_grad():
+        want = pipeline_ref.infer(copenet_sd, smplx_model, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"],
+                                  inp["intr0"], inp["intr1"])
+    got = pipeline.TwoViewInference(net32, body)({k: v.to(dev) for k, v in inp.items()})
+    for k in sorted(want):
+        e = rel_err(got[k].cpu().numpy(), want[k].numpy())
+        print("%-22s rel err %.3e" % (k, e))
+        assert e < TOL32, k
+
+
+def test_full_size_properties_bf16(netbf, body, dev):
+    """BASELINE size (B = 256 pairs, bf16): size-independent properties instead of a CPU oracle run --
+    finite outputs, exact view-swap symmetry, and rows identical to a B = 2 run of the same inputs."""
+    from airpose_amd import pipeline
+    from airpose_amd import weights as W
+    B = 256
+    small = W.synthetic_inputs(1234, 2)
+    gen = torch.Generator(device="cpu").manual_seed(7)
+    im0 = torch.randn(B, 3, 224, 224, generator=gen)
+    im1 = torch.randn(B, 3, 224, 224, generator=gen)
+    im0[:2], im1[:2] = torch.from_numpy(small["im0"]), torch.from_numpy(small["im1"])
+    bb0, bb1 = torch.rand(B, 3, generator=gen), torch.rand(B, 3, generator=gen)
+    bb0[:2], bb1[:2] = torch.from_numpy(small["bb0"]), torch.from_numpy(small["bb1"])
+    intr = torch.tensor([[1475.0, 0, 960], [0, 1475.0, 540], [0, 0, 1]]).expand(B, 3, 3).contiguous()
+    d = lambda t: t.to(dev)
+    pipe = pipeline.TwoViewInference(netbf, body)
+    out = pipe({"im0": d(im0), "im1": d(im1), "bb0": d(bb0), "bb1": d(bb1), "intr0": d(intr), "intr1": d(intr)})
+    for k, v in out.items():
+        assert torch.isfinite(v).all(), k
+    assert out["pred_vertices_cam0"].shape == (B, 10475, 3) and out["pred_j2d_cam1"].shape == (B, 127, 2)
+    swp = pipe({"im0": d(im1), "im1": d(im0), "bb0": d(bb1), "bb1": d(bb0), "intr0": d(intr), "intr1": d(intr)})
+    assert torch.equal(out["pred_pose0"], swp["pred_pose1"]) and torch.equal(out["pred_betas1"], swp["pred_betas0"])
+    assert torch.equal(out["pred_j3d_cam0"], swp["pred_j3d_cam1"])
+    two = pipe({"im0": d(im0[:2]), "im1": d(im1[:2]), "bb0": d(bb0[:2]), "bb1": d(bb1[:2]), "intr0": d(intr[:2]),
+                "intr1": d(intr[:2])})
+    assert rel_err(two["pred_pose0"].cpu().numpy(), out["pred_pose0"][:2].cpu().numpy()) < 1e-6
+    assert rel_err(two["pred_vertices_cam1"].cpu().numpy(), out["pred_vertices_cam1"][:2].cpu().numpy()) < 1e-6
+
+
+def test_errors_are_loud(net32, dev):
+    with pytest.raises(RuntimeError):
+        net32.forward_feat_ext(torch.zeros(1, 3, 224, 224))          # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        net32.forward_feat_ext(torch.zeros(1, 3, 200, 200, device=dev))
+    net32.train()
+    with pytest.raises(RuntimeError):
+        net32.forward_feat_ext(torch.zeros(1, 3, 224, 224, device=dev))
+    net32.eval()
