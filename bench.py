@@ -1,0 +1,201 @@
+#!/usr/bin/env python
+"""Headline benchmark: two-view frames (pairs) per second of the AirPose inference hot path on MI355X.
+
+  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+One step = one pass of the whole hot path over one batch of synthetic input resident in HBM:
+copenet_twoview forward (ResNet-50 trunk on both views, 3 IEF iterations with cross-view fusion)
+-> in-place translation un-scale -> rot6d -> SMPL-X LBS (10475 verts) -> root transform -> 2-D
+projection, at 256 pairs per GPU in bf16 (BASELINE.json metric: "two-view frames/sec at batch 256").
+Pairs are independent units: every rank owns its own 256 pairs, no data-path collective (weak scaling).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel = the bf16 implicit-GEMM conv (52 launches per trunk chunk); algorithmic
+                FLOPs of those launches / their HIP-event time measured live in the timed region
+  cpu_baseline  the CPU oracle (a torch restatement pinned to the reference) timed on this box's host
+                cores on a bounded sample -- a reported baseline, not the target
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+if REPO not in sys.path:
+    sys.path.insert(0, REPO)
+MEAN = os.path.join(REPO, "airpose_amd", "data", "smpl_mean_params.npz")
+
+PEAK_BF16_DENSE_TFLOPS = 2500.0      # MI355X_MICROARCH.md: ~2.5 PF dense bf16 MFMA
+PEAK_FP32_TFLOPS = 157.3
+PEAK_HBM_GBS = 8000.0
+
+
+def conv_stack_flops_per_image():
+    """2*MAC of the 52 implicit-GEMM convolutions (everything in the trunk but the 7x7 stem)."""
+    layers, planes = (3, 4, 6, 3), (64, 128, 256, 512)
+    macs, inpl, H = 0, 64, 56
+    for li, (pl, nb) in enumerate(zip(planes, layers)):
+        for bi in range(nb):
+            stride = 2 if (bi == 0 and li > 0) else 1
+            Ho = H // stride
+            macs += H * H * inpl * pl                      # conv1 1x1
+            macs += Ho * Ho * pl * pl * 9                  # conv2 3x3 (stride here)
+            macs += Ho * Ho * pl * pl * 4                  # conv3 1x1
+            if bi == 0:
+                macs += Ho * Ho * inpl * pl * 4            # downsample 1x1
+            inpl, H = pl * 4, Ho
+    return 2 * macs
+
+
+STEM_FLOPS_PER_IMAGE = 2 * 112 * 112 * 64 * 147
+REG_FLOPS_PER_PAIR = 2 * 3 * 2 * (2332 * 1024 + 1024 * 1024 + 1024 * 145)
+
+
+def cpu_baseline(sd, md, sample_pairs):
+    """Time the oracle (pure torch CPU restatement of the reference path) on a bounded sample."""
+    import torch
+    from airpose_amd import weights as W
+    from oracle import pipeline_ref
+    inp = {k: torch.from_numpy(v) for k, v in W.synthetic_inputs(4321, sample_pairs).items()}
+    best = None
+    with torch.no_grad():
+        for i in range(3):                                 # 1 warm-up + best of 2
+            t0 = time.perf_counter()
+            pipeline_ref.infer(sd, md, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], inp["intr0"], inp["intr1"])
+            dt = time.perf_counter() - t0
+            if i and (best is None or dt < best):
+                best = dt
+    return {"value": sample_pairs / best, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d pairs (224x224, 3 IEF iterations, SMPL-X tail), fp32 torch CPU oracle, best of 2 after 1 warm-up"
+                      % sample_pairs}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
+    ap.add_argument("--precision", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--chunk", type=int, default=0, help="images per depth-first trunk chunk (0 = default)")
+    ap.add_argument("--cpu-sample", type=int, default=16, help="pairs in the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-tail", action="store_true", help="time the network only (BASELINE config 2 shape)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from airpose_amd import copenet_model, pipeline, smplx, smplx_model
+    from airpose_amd import weights as W
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+    assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    B = args.batch
+    sd = W.to_torch(W.copenet_state_dict(20240901, MEAN))
+    md = smplx_model.make_synthetic_model(4321)
+    net = copenet_model.getcopenet(MEAN, precision=args.precision).eval()
+    net.load_state_dict(sd)
+    body = smplx.SMPLX(model_data=md)
+    pipe = pipeline.TwoViewInference(net, body, iters=3)
+    batch = {k: torch.from_numpy(v).to(dev) for k, v in W.synthetic_inputs(1234 + rank, B).items()}
+    if args.chunk:
+        torch.zeros(1, device=dev)
+        net.set_chunk(args.chunk)
+
+    def step():
+        if args.no_tail:
+            return pipe.forward_net(batch["im0"], batch["im1"], batch["bb0"], batch["bb1"])
+        return pipe(batch, want_rotmat=True)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(max(args.warmup, 1)):
+        out = step()
+    torch.cuda.synchronize()
+    net.enable_timing(True)
+    net.timing(reset=True)
+    if not args.no_tail:
+        body.enable_timing(True)
+        body.timing(reset=True)
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tm = net.timing(reset=True)
+    tb = body.timing(reset=True) if not args.no_tail else None
+    del out
+
+    if rank == 0:
+        n_img = 2 * B
+        conv_flops_step = conv_stack_flops_per_image() * n_img
+        conv_ms_step = tm["conv_ms"] / max(tm["passes"], 1)
+        chunk = args.chunk or (64 if args.precision == "bf16" else 32)
+        launches = 52 * ((B + chunk - 1) // chunk) * 2
+        peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
+        achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
+        res = {
+            "metric": "two-view frames/sec at batch 256 (224x224)",
+            "value": world * B * args.steps / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": args.precision, "data": "synthetic",
+            "config": {"workload": "copenet_twoview forward (ResNet-50 x2 views, 3 IEF iterations) + SMPL-X LBS tail "
+                                   "(10475 verts, 127 joints, projection)" if not args.no_tail else
+                                   "copenet_twoview forward only (ResNet-50 x2 views, 3 IEF iterations)",
+                       "pairs_per_gpu": B, "global_pairs": world * B, "image": "224x224", "ief_iters": 3,
+                       "trunk_chunk_images": chunk, "sharding": "whole pairs per GPU, no data-path collective"},
+            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv + BN + residual + ReLU)",
+                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "traffic": None,
+                         "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,
+                         "avg_launch_ms": conv_ms_step / launches},
+            "stage_ms_per_step": {"stem_maxpool": tm["stem_ms"] / max(tm["passes"], 1), "conv_stack": conv_ms_step,
+                                  "avgpool": tm["avgpool_ms"] / max(tm["passes"], 1),
+                                  "regressor": tm["regressor_ms"] / max(tm["passes"], 1)},
+            "path_tflops": (conv_flops_step + STEM_FLOPS_PER_IMAGE * n_img + REG_FLOPS_PER_PAIR * B) * args.steps
+                           / elapsed / 1e12,
+        }
+        if tb is not None:
+            p = max(tb["passes"], 1)
+            tail_ms = (tb["prep_ms"] + tb["skin_ms"] + tb["joints_ms"]) / p
+            tail_bytes = n_img * 129084 + 25.5e6
+            res["stage_ms_per_step"].update({"smplx_prep": tb["prep_ms"] / p, "smplx_blend_gemm": tb["blend_gemm_ms"] / p,
+                                             "smplx_skin": tb["skin_ms"] / p, "smplx_joints": tb["joints_ms"] / p})
+            res["smplx_tail_roofline"] = {"bound": "hbm", "achieved": tail_bytes / (tail_ms * 1e-3) / 1e9,
+                                          "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                                          "frac": tail_bytes / (tail_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
+            gemm_flops = 2.0 * 224 * 31425 * n_img
+            res["smplx_blend_roofline"] = {"bound": "mfma-fp32", "achieved": gemm_flops / (tb["blend_gemm_ms"] / p * 1e-3) / 1e12,
+                                           "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s"}
+        if world == 1 and args.cpu_sample > 0:
+            res["cpu_baseline"] = cpu_baseline(sd, md, args.cpu_sample)
+        print(json.dumps(res))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
