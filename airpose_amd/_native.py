@@ -42,6 +42,7 @@ SIGNATURES = {
     "ap_regressor_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ap_copenet_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_conv2d_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 9 + [_vp]),
+    "ap_set_conv_config": (_i, [_i]),
     "ap_net_enable_timing": (_i, [_vp, _i]),
     "ap_net_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
     "ap_net_set_chunk": (_i, [_vp, _i]),

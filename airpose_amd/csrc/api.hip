@@ -113,6 +113,38 @@ struct Timing {
 };
 
 constexpr double BN_EPS = 1e-5;
+
+int g_conv_cfg = -1;            // -1 auto, 0..3 conv_pipe config, 100 = legacy register-staged kernel
+void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
+
+hipError_t zero_line(const void** out) {
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    if (dev < 0 || dev >= 16) return hipErrorInvalidDevice;
+    if (!g_zero[dev]) {
+        e = hipMalloc(&g_zero[dev], 256);
+        if (e != hipSuccess) return e;
+        e = hipMemset(g_zero[dev], 0, 256);
+        if (e != hipSuccess) return e;
+    }
+    *out = g_zero[dev];
+    return hipSuccess;
+}
+
+// choose the tile configuration: large tiles need enough tiles to fill 256 CUs (1 workgroup per CU)
+hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
+    int cfg = g_conv_cfg;
+    if (cfg < 0) {
+        const long mt256 = (a.M + 255) / 256, mt128 = (a.M + 127) / 128, nt128 = (a.Cout + 127) / 128;
+        if (a.Cout <= 64) cfg = mt256 >= 512 ? 3 : (mt128 >= 256 ? 2 : 100);
+        else cfg = mt256 * nt128 >= 512 ? 0 : (mt128 * nt128 >= 256 ? 1 : 100);
+    }
+    if (cfg == 100) return ap_launch_conv(a, is_bf16, st);
+    hipError_t e = zero_line(&a.zero);
+    if (e != hipSuccess) return e;
+    return ap_launch_conv_pipe(a, is_bf16, cfg, st);
+}
 constexpr int ST = 148, SLD = 288, DLD = 148;
 
 }  // namespace
@@ -238,7 +270,7 @@ int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const 
     a.M = N * a.Ho * a.Wo;
     a.ldx = L.cin; a.ldy = L.cout; a.ldr = L.cout; a.wld = L.wld;
     a.relu = relu;
-    HIP_TRY(ap_launch_conv(a, is_bf16, st));
+    HIP_TRY(dispatch_conv(a, is_bf16, st));
     return AP_OK;
 }
 
@@ -253,7 +285,7 @@ int run_gemm(const Layer& L, const float* x, int ldx, int K, int M, float* y, in
     a.M = M;
     a.ldx = ldx; a.ldy = ldy; a.ldr = ldr; a.wld = L.wld;
     a.relu = 0;
-    HIP_TRY(ap_launch_conv(a, 0, st));
+    HIP_TRY(dispatch_conv(a, 0, st));
     return AP_OK;
 }
 
@@ -371,7 +403,7 @@ int trunk_chunk(ap_net* h, const float* x, int n, float* feat, hipStream_t st) {
 int trunk_fwd(ap_net* h, const float* x, int n_img, float* feat, hipStream_t st) {
     if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
     if (n_img <= 0 || !x || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
-    int chunk = h->chunk > 0 ? h->chunk : (h->prec == AP_PREC_BF16 ? 64 : 32);
+    int chunk = h->chunk > 0 ? h->chunk : 256;
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
         const int n = std::min(chunk, n_img - i0);
         int rc = trunk_chunk(h, x + (size_t)i0 * 3 * 224 * 224, n, feat + (size_t)i0 * 2048, st);
@@ -557,7 +589,13 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
     a.Cout = Cout; a.KH = a.KW = ksize; a.stride = stride; a.pad = pad;
     a.M = N * a.Ho * a.Wo;
     a.ldx = Cin; a.ldy = Cout; a.ldr = Cout; a.wld = ksize * ksize * Cin; a.relu = relu;
-    HIP_TRY(ap_launch_conv(a, bf, (hipStream_t)stream));
+    HIP_TRY(dispatch_conv(a, bf, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_set_conv_config(int cfg) {
+    if (cfg != -1 && cfg != 100 && (cfg < 0 || cfg > 3)) return fail(AP_EINVAL, "ap_set_conv_config: -1, 0..3 or 100");
+    g_conv_cfg = cfg;
     return AP_OK;
 }
 
@@ -743,7 +781,7 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     g.res = nullptr; g.y = h->ws_vposed.p;
     g.N = n; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = K; g.Cout = h->dirs.cout; g.KH = g.KW = 1; g.stride = 1; g.pad = 0;
     g.M = n; g.ldx = m.ncoef; g.ldy = m.ldv; g.ldr = 0; g.wld = h->dirs.wld; g.relu = 0;
-    HIP_TRY(ap_launch_conv(g, 0, st));
+    HIP_TRY(dispatch_conv(g, 0, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[2]));
     HIP_TRY(ap_launch_smplx_skin(m, a, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[3]));

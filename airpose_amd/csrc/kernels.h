@@ -10,6 +10,7 @@ struct ConvArgs {
     const float* shift;   // [Cout_pad]
     const void* res;      // optional residual [M][ldr], element type T
     void* y;              // [M][ldy]
+    const void* zero;     // >= 16 bytes of zeros (DMA source of predicated-off rows; conv_pipe only)
     int N, H, W, Cin;
     int Ho, Wo, Cout;     // Cout: number of stored channels (multiple of 16 B / sizeof(T))
     int KH, KW, stride, pad;
@@ -21,6 +22,8 @@ struct ConvArgs {
 
 int ap_conv_cout_pad(void);
 hipError_t ap_launch_conv(const ConvArgs& a, int is_bf16, hipStream_t st);
+// software-pipelined (LDS-DMA ring) variant; cfg: 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 256x64
+hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStream_t st);
 
 // ---- stem / pooling (stem.hip)
 // conv 7x7/2 p3 (3->64) + BN + ReLU from NCHW fp32 into NHWC T [N][112][112][64]

@@ -149,7 +149,7 @@ def main():
         n_img = 2 * B
         conv_flops_step = conv_stack_flops_per_image() * n_img
         conv_ms_step = tm["conv_ms"] / max(tm["passes"], 1)
-        chunk = args.chunk or (64 if args.precision == "bf16" else 32)
+        chunk = args.chunk or 256
         launches = 52 * ((B + chunk - 1) // chunk) * 2
         peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12

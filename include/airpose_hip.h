@@ -90,6 +90,11 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
                    const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
                    int relu, void* stream);
 
+/* Tuning/testing knob (process-wide): tile configuration of the convolution kernels.  -1 = automatic,
+ * 0..3 = software-pipelined LDS-DMA kernel with 256x128 / 128x128 / 128x64 / 256x64 tiles,
+ * 100 = register-staged 2-stage kernel.  Results are identical for every setting. */
+int ap_set_conv_config(int cfg);
+
 /* Stage timing for bench.py: when enabled, HIP events bracket the stem, the implicit-GEMM conv stack,
  * the pooling tail and the regressor on the caller's stream.  ap_net_timing synchronises on the last
  * recorded events and returns the ACCUMULATED milliseconds and the number of recorded passes since

@@ -110,15 +110,37 @@ CONV_CASES = [
 ]
 
 
+# -1 = automatic choice; 0..3 = LDS-DMA pipelined kernel (256x128, 128x128, 128x64, 256x64 tiles); 100 = register-staged
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 100])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
-def test_conv_primitive(dev, prec, case):
+def test_conv_primitive(dev, prec, case, cfg):
+    from airpose_amd import _native as Nn
     N, H, Cin, Cout, k, stride, pad, relu, use_res = case
-    got, ref = _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed=hash(case) % 10000)
+    Nn.check(Nn.lib().ap_set_conv_config(cfg), "ap_set_conv_config")
+    try:
+        got, ref = _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed=hash(case) % 10000)
+    finally:
+        Nn.lib().ap_set_conv_config(-1)
     assert torch.isfinite(got).all()
     # operands identical: fp32 differs only by accumulation order, bf16 additionally by the output rounding
     tol = 2e-5 if prec == "fp32" else 6e-3
     assert rel_err(got.numpy(), ref.numpy()) < tol
+
+
+def test_conv_configs_agree_bitwise(dev):
+    """Every tile configuration accumulates each output element in the same K order."""
+    from airpose_amd import _native as Nn
+    outs = []
+    for cfg in (0, 1, 2, 3, 100):
+        Nn.lib().ap_set_conv_config(cfg)
+        try:
+            got, _ = _conv_case(dev, "bf16", 3, 28, 128, 192, 3, 1, 1, True, True, seed=5)
+        finally:
+            Nn.lib().ap_set_conv_config(-1)
+        outs.append(got)
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
 
 
 # ------------------------------------------------------------------------------------------------ trunk / IEF / forward

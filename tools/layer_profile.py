@@ -1,0 +1,42 @@
+#!/usr/bin/env python
+"""Per-layer table (time, TF/s, GB/s) of one trunk pass from a rocprofv3 kernel-trace sqlite db.
+usage: tools/layer_profile.py results.db images_per_chunk"""
+import sqlite3
+import sys
+
+db, n = sys.argv[1], int(sys.argv[2])
+c = sqlite3.connect(db)
+rows = list(c.execute("select name, start, end, duration, grid_x from kernels order by start"))
+idx = [i for i, r in enumerate(rows) if "stem" in r[0]]
+i0 = idx[-2]
+layers, planes = (3, 4, 6, 3), (64, 128, 256, 512)
+shapes, inpl, H = [], 64, 56
+for li, (pl, nb) in enumerate(zip(planes, layers)):
+    for bi in range(nb):
+        st = 2 if (bi == 0 and li > 0) else 1
+        Ho = H // st
+        shapes.append(("l%d.%d.c1" % (li + 1, bi), n * H * H, pl, inpl, n * H * H * inpl, 0))
+        shapes.append(("l%d.%d.c2" % (li + 1, bi), n * Ho * Ho, pl, pl * 9, n * H * H * pl, 0))
+        if bi == 0:
+            shapes.append(("l%d.%d.ds" % (li + 1, bi), n * Ho * Ho, pl * 4, inpl, n * H * H * inpl // (st * st), 0))
+        shapes.append(("l%d.%d.c3" % (li + 1, bi), n * Ho * Ho, pl * 4, pl, n * Ho * Ho * pl, 1))
+        inpl, H = pl * 4, Ho
+k = i0 + 1
+while "conv_igemm" not in rows[k][0]:
+    print("%-40s %8.1f us" % (rows[k][0][:40], rows[k][3] / 1e3))
+    k += 1
+print("%-40s %8.1f us" % (rows[i0][0][:40], rows[i0][3] / 1e3))
+tot = 0
+bylayer = {}
+for (nm, M, N, K, inel, res) in shapes:
+    r = rows[k]
+    k += 1
+    assert "conv_igemm" in r[0], r[0]
+    cfg = r[0].split("<")[1].split(">")[0].replace("unsigned short", "bf16")
+    fl, dur = 2.0 * M * N * K, r[3] / 1e3
+    tot += dur
+    by = (inel + M * N * (1 + res)) * 2
+    bylayer[nm[:2]] = bylayer.get(nm[:2], 0) + dur
+    print("%-9s M=%7d N=%4d K=%4d %-18s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
+        nm, M, N, K, cfg, r[4] // 256, dur, fl / dur / 1e6, by / 1e6, by / dur / 1e3))
+print("total conv us", tot, bylayer)
