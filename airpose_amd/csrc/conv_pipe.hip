@@ -43,9 +43,12 @@ __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-                for (int fn = 0; fn < FN; ++fn)
+                for (int fn = 0; fn < FN; ++fn) {
+                    const uint32_t wv = t == 0 ? wf[fn].x : t == 1 ? wf[fn].y : t == 2 ? wf[fn].z : wf[fn].w;
+                    const uint32_t xv = t == 0 ? xf[fm].x : t == 1 ? xf[fm].y : t == 2 ? xf[fm].z : xf[fm].w;
                     acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x4f32(
-                        __builtin_bit_cast(float, wf[fn][t]), __builtin_bit_cast(float, xf[fm][t]), acc[fm][fn], 0, 0, 0);
+                        __builtin_bit_cast(float, wv), __builtin_bit_cast(float, xv), acc[fm][fn], 0, 0, 0);
+                }
     }
 }
 
@@ -226,8 +229,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
         } else {
             float4 a = *(const float4*)sp;
             if (rg) {
-                a.x += __builtin_bit_cast(float, rv[it][0]); a.y += __builtin_bit_cast(float, rv[it][1]);
-                a.z += __builtin_bit_cast(float, rv[it][2]); a.w += __builtin_bit_cast(float, rv[it][3]);
+                // (copy the lanes out first: bit_cast applied directly to a vector element mis-compiles)
+                const uint32_t r0 = rv[it].x, r1 = rv[it].y, r2 = rv[it].z, r3 = rv[it].w;
+                a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
+                a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
             }
             if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
