@@ -136,9 +136,12 @@ hipError_t zero_line(const void** out) {
 hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
     int cfg = g_conv_cfg;
     if (cfg < 0) {
-        const long mt256 = (a.M + 255) / 256, mt128 = (a.M + 127) / 128, nt128 = (a.Cout + 127) / 128;
-        if (a.Cout <= 64) cfg = mt256 >= 512 ? 3 : (mt128 >= 256 ? 2 : 100);
-        else cfg = mt256 * nt128 >= 512 ? 0 : (mt128 * nt128 >= 256 ? 1 : 100);
+        // measured on MI355X (tools/conv_bench.py): the 256x128 LDS-DMA ring wins on deep contractions and on the
+        // residual (1x1 expand) layers; the register-staged kernel (2 workgroups per CU) wins on the short-K,
+        // bandwidth-bound layers with <= 64 output channels and whenever 256-row tiles cannot fill the chip
+        const long mt256 = (a.M + 255) / 256, nt128 = (a.Cout + 127) / 128;
+        const int K = a.KH * a.KW * a.Cin;
+        cfg = (a.Cout >= 128 && (K >= 512 || a.res != nullptr) && mt256 * nt128 >= 200) ? 0 : 100;
     }
     if (cfg == 100) return ap_launch_conv(a, is_bf16, st);
     hipError_t e = zero_line(&a.zero);
@@ -154,7 +157,7 @@ struct ap_net {
     bool finalized = false;
     std::map<std::string, HostTensor> tensors;
     // trunk
-    DevBuf stem_w, stem_scale, stem_shift;
+    DevBuf stem_w, stem_wpk, stem_scale, stem_shift;
     struct Block { Layer c1, c2, c3, down; bool has_down = false; };
     std::vector<Block> blocks;
     // regressor (fp32)
@@ -300,6 +303,15 @@ int finalize_trunk(ap_net* h) {
             for (int r = 0; r < 7; ++r)
                 for (int s = 0; s < 7; ++s) sw[((r * 7 + s) * 3 + c) * 64 + o] = w->data[((o * 3 + c) * 7 + r) * 7 + s];
     HIP_TRY(upload(h->stem_w, sw.data(), sw.size() * 4));
+    {   // MFMA stem operand: [64][200] bf16, k' = r*24 + s*3 + c (zero elsewhere)
+        std::vector<uint16_t> pk(64 * 200, 0);
+        for (int o = 0; o < 64; ++o)
+            for (int c = 0; c < 3; ++c)
+                for (int r = 0; r < 7; ++r)
+                    for (int s2 = 0; s2 < 7; ++s2)
+                        pk[o * 200 + r * 24 + s2 * 3 + c] = host_f32_to_bf16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
+        HIP_TRY(upload(h->stem_wpk, pk.data(), pk.size() * 2));
+    }
     std::vector<float> sc, sh;
     int rc = bn_fold(h, "bn1", 64, sc, sh);
     if (rc) return rc;
@@ -358,9 +370,11 @@ int finalize_regressor(ap_net* h) {
     return AP_OK;
 }
 
-int trunk_chunk(ap_net* h, const float* x, int n, float* feat, hipStream_t st) {
+// one depth-first pass over n = n0 + n1 images: the first n0 from x0, the rest from x1 (two views, one pass)
+int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
     const int bf = h->prec == AP_PREC_BF16;
     const size_t es = h->esize();
+    const int n = n0 + n1;
     HIP_TRY(h->ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
     HIP_TRY(h->ws_a.reserve((size_t)n * 802816 * es));
     HIP_TRY(h->ws_b.reserve((size_t)n * 802816 * es));
@@ -369,8 +383,17 @@ int trunk_chunk(ap_net* h, const float* x, int n, float* feat, hipStream_t st) {
     HIP_TRY(h->ws_t2.reserve((size_t)n * 200704 * es));
     size_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e0));
-    HIP_TRY(ap_launch_stem_conv(x, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                h->ws_stem.p, n, bf, st));
+    if (bf) {
+        HIP_TRY(ap_launch_stem_conv_mfma(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
+                                         h->stem_shift.as<float>(), h->ws_stem.p, n, st));
+    } else {
+        if (n0)
+            HIP_TRY(ap_launch_stem_conv(x0, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
+                                        h->ws_stem.p, n0, 0, st));
+        if (n1)
+            HIP_TRY(ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
+                                        (char*)h->ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, 0, st));
+    }
     HIP_TRY(ap_launch_maxpool(h->ws_stem.p, h->ws_a.p, n, bf, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
     void *cur = h->ws_a.p, *nxt = h->ws_b.p;
@@ -400,13 +423,19 @@ int trunk_chunk(ap_net* h, const float* x, int n, float* feat, hipStream_t st) {
     return AP_OK;
 }
 
-int trunk_fwd(ap_net* h, const float* x, int n_img, float* feat, hipStream_t st) {
+// trunk over the concatenation [x0 (n0 images) | x1 (n1 images)]; feat rows follow the same order
+int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
     if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
-    if (n_img <= 0 || !x || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
-    int chunk = h->chunk > 0 ? h->chunk : 256;
+    const int n_img = n0 + n1;
+    if (n0 <= 0 || n1 < 0 || !x0 || (n1 && !x1) || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
+    const int chunk = h->chunk > 0 ? h->chunk : 512;
+    const size_t IMG_ELEMS = (size_t)3 * 224 * 224;
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
-        const int n = std::min(chunk, n_img - i0);
-        int rc = trunk_chunk(h, x + (size_t)i0 * 3 * 224 * 224, n, feat + (size_t)i0 * 2048, st);
+        const int i1 = std::min(n_img, i0 + chunk);
+        const int a0 = std::min(i0, n0), a1 = std::min(i1, n0);          // part taken from x0
+        const int b0 = std::max(i0, n0) - n0, b1 = std::max(i1, n0) - n0; // part taken from x1
+        int rc = trunk_chunk(h, x0 + a0 * IMG_ELEMS, a1 - a0, x1 ? x1 + b0 * IMG_ELEMS : nullptr, b1 - b0,
+                             feat + (size_t)i0 * 2048, st);
         if (rc) return rc;
     }
     if (h->tm.on) h->tm.passes++;
@@ -487,7 +516,7 @@ void ap_net_destroy(ap_net* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&h->stem_w, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->ws_stem, &h->ws_a,
+    for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->ws_stem, &h->ws_a,
                       &h->ws_b, &h->ws_t1, &h->ws_t2, &h->ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
                       &h->ws_D, &h->ws_state})
         b->release();
@@ -527,7 +556,7 @@ int ap_net_precision(const ap_net* h) { return h ? h->prec : AP_EINVAL; }
 
 int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* stream) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    return trunk_fwd(h, x_nchw, n_img, feat, (hipStream_t)stream);
+    return trunk_fwd(h, x_nchw, n_img, nullptr, 0, feat, (hipStream_t)stream);
 }
 
 int ap_regressor_fwd(ap_net* h, const float* xf0, const float* xf1, const float* bb0, const float* bb1,
@@ -562,10 +591,8 @@ int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0
     HIP_TRY(h->ws_feat.reserve((size_t)2 * B * 2048 * 4));
     float* f0 = h->ws_feat.as<float>();
     float* f1 = f0 + (size_t)B * 2048;
-    int rc = trunk_fwd(h, x0, B, f0, st);
+    int rc = trunk_fwd(h, x0, B, x1, B, f0, st);      // both views in one pass (shared weights)
     if (rc) return rc;
-    if ((rc = trunk_fwd(h, x1, B, f1, st))) return rc;
-    if (h->tm.on) h->tm.passes--;   // two trunk calls = one forward pass
     return ap_regressor_fwd(h, f0, f1, bb0, bb1, pos0, pos1, init_theta0, theta0_bs, init_theta1, theta1_bs,
                             init_shape0, shape0_bs, init_shape1, shape1_bs, B, iters, pose0, betas0, pose1, betas1,
                             stream);

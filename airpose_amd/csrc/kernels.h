@@ -29,8 +29,10 @@ hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStrea
 // conv 7x7/2 p3 (3->64) + BN + ReLU from NCHW fp32 into NHWC T [N][112][112][64]
 hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, const float* scale, const float* shift,
                                void* y, int n_img, int is_bf16, hipStream_t st);
-hipError_t ap_launch_stem_conv_mfma(const float* x_nchw, const void* w_packed, const float* scale, const float* shift,
-                                    void* y_pooled, int n_img, hipStream_t st);
+// bf16 MFMA stem: images [0, n_split) come from x0, the rest from x1 (both views in one pass);
+// w_packed: [64][200] bf16, k' = r*24 + s*3 + c
+hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_split, const void* w_packed,
+                                    const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
 // maxpool 3x3/2 p1: [N][112][112][64] -> [N][56][56][64]
 hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int is_bf16, hipStream_t st);
 // global 7x7 average: [N][49][C] T -> [N][C] fp32

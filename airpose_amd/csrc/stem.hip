@@ -72,6 +72,89 @@ __global__ void __launch_bounds__(256) stem_direct_kernel(const float* __restric
 }
 
 // ------------------------------------------------------------------------------------------------
+// MFMA stem (bf16 throughput path).  One workgroup = 16x16 conv outputs x 64 channels.
+// GEMM view: M = pixels, N = 64, K' = 7 kernel rows x 24 (21 = 7 taps x 3 channels, 3 zero pad) = 168 -> 192.
+// The input patch sits in LDS as bf16 [iy][ix][c] (channel-interleaved), so the 8 consecutive k' a lane feeds
+// to v_mfma_f32_16x16x32_bf16 are 8 consecutive bf16 of one patch row: no im2col buffer.  k' >= 21 within a
+// kernel row reads the neighbouring pixels' (finite) data against zero weights.
+constexpr int SP = 37;                       // patch rows / cols for a 16x16 output tile
+constexpr int SPW = 38;                      // patch row stride in pixels (even: keeps every 8-run dword aligned)
+constexpr int SWLD = 200;                    // packed weight row stride (bf16): 400 B, conflict-free b128 reads
+constexpr int SKB = 6;                       // 6 x 32 = 192 padded K
+
+__global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                        int n_split, const bf16_t* __restrict__ wpk,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, bf16_t* __restrict__ y) {
+    __shared__ __attribute__((aligned(16))) bf16_t wsm[64 * SWLD];
+    __shared__ __attribute__((aligned(16))) bf16_t patch[SP * SPW * 3 + 32];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.z, ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
+    {   // weights: 64 x 400 B
+        const u32x4* src = (const u32x4*)wpk;
+        u32x4* dst = (u32x4*)wsm;
+        for (int i = tid; i < 64 * SWLD * 2 / 16; i += 256) dst[i] = src[i];
+    }
+    const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
+    for (int i = tid; i < 3 * SP * SP; i += 256) {
+        const int c = i / (SP * SP), rem = i - c * SP * SP, py = rem / SP, px = rem - py * SP;
+        const int iy = 2 * ty0 - 3 + py, ix = 2 * tx0 - 3 + px;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)IMG && (unsigned)ix < (unsigned)IMG) v = xin[(c * IMG + iy) * IMG + ix];
+        patch[(py * SPW + px) * 3 + c] = f32_to_bf16(v);
+    }
+    if (tid < 32) patch[SP * SPW * 3 + tid] = 0;
+    if (tid < SP * 3) patch[((tid / 3) * SPW + SP) * 3 + tid % 3] = 0;       // pad column
+    __syncthreads();
+
+    const int lr = lane & 15, g = lane >> 4;
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < SKB; ++kb) {
+        const int k0 = kb * 32 + g * 8;                     // first of this lane's 8 k'
+        const int r = k0 / 24, t0 = k0 - r * 24;            // kernel row, offset inside the 24-wide row slot
+        u32x4 wf[4], xf[4];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) wf[fn] = *(const u32x4*)(wsm + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
+        if (r < 7) {
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm) {
+                const int ty = wave * 4 + fm;
+                const uint32_t* pp = (const uint32_t*)(patch + ((2 * ty + r) * SPW + 2 * lr) * 3 + t0);
+                xf[fm].x = pp[0]; xf[fm].y = pp[1]; xf[fm].z = pp[2]; xf[fm].w = pp[3];
+            }
+        } else {
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm) xf[fm] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+    }
+    // epilogue: lane = pixel (tile row wave*4+fm, col lr), channels fn*16 + g*4 .. +3
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        const int ch = fn * 16 + g * 4;
+        const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+            const int oy = ty0 + wave * 4 + fm, ox = tx0 + lr;
+            uint2 o;
+            o.x = pack_bf16x2(fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f), fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f));
+            o.y = pack_bf16x2(fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f), fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f));
+            *(uint2*)(y + (((size_t)n * SO + oy) * SO + ox) * SC + ch) = o;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int total) {
     constexpr int EPC = 16 / sizeof(T), CPP = SC / EPC;          // chunks per pixel
@@ -152,6 +235,13 @@ hipError_t ap_launch_stem_conv(const float* x, const float* w, const float* scal
         hipLaunchKernelGGL(stem_direct_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, scale, shift, (bf16_t*)y);
     else
         hipLaunchKernelGGL(stem_direct_kernel<float>, grid, dim3(256), 0, st, x, w, scale, shift, (float*)y);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_split, const void* w_packed,
+                                    const float* scale, const float* shift, void* y, int n_img, hipStream_t st) {
+    hipLaunchKernelGGL(stem_mfma_kernel, dim3(SO / 16, SO / 16, n_img), dim3(256), 0, st, x0, x1, n_split,
+                       (const bf16_t*)w_packed, scale, shift, (bf16_t*)y);
     return hipGetLastError();
 }
 

@@ -149,8 +149,8 @@ def main():
         n_img = 2 * B
         conv_flops_step = conv_stack_flops_per_image() * n_img
         conv_ms_step = tm["conv_ms"] / max(tm["passes"], 1)
-        chunk = args.chunk or 256
-        launches = 52 * ((B + chunk - 1) // chunk) * 2
+        chunk = args.chunk or 512
+        launches = 52 * ((2 * B + chunk - 1) // chunk)
         peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
         res = {
