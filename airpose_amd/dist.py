@@ -1,0 +1,64 @@
+"""Multi-GPU host logic (one process per GPU, torch.distributed: "nccl" = RCCL over xGMI on the box,
+"gloo" in the CPU tests).
+
+Default sharding needs no collective: pairs are independent, rank r owns a contiguous block of whole
+pairs.  A collective exists only in VIEW-SPLIT mode -- view 0 on rank 2k, view 1 on rank
+2k+1, the on-drone topology of the reference (README.md:238-241: step1/step2/step3 with the partner's
+state exchanged between steps).  What moves per exchange is the partner's [art_pose(126) | shape(10)]
+= 136 floats = 544 B per sample (model_copenet.py:185,192); it is latency-bound, so it is a 2-rank
+all_gather on a pair group (the direct xGMI link), never a ring over all ranks.
+"""
+import torch
+import torch.distributed as dist
+
+
+def shard_pairs(n_global, rank, world):
+    """Contiguous [start, stop) block of pairs owned by `rank` (remainder spread over the first ranks)."""
+    q, r = divmod(n_global, world)
+    start = rank * q + min(rank, r)
+    return start, start + q + (1 if rank < r else 0)
+
+
+def make_pair_groups(world):
+    """One 2-rank group per (2k, 2k+1); every rank must call this (new_group is collective)."""
+    if world % 2:
+        raise ValueError("view-split mode needs an even number of ranks")
+    return [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
+
+
+def pack_wire(pose, betas):
+    """The reference's published result vector (copenet_real/scripts/copenet_rosViz.py:83-85):
+    145 floats = beta(10) | trans(3) | 6D pose (132)."""
+    return torch.cat([betas, pose[:, :3], pose[:, 3:]], dim=1)
+
+
+def unpack_wire(msg):
+    return torch.cat([msg[:, 10:13], msg[:, 13:]], dim=1), msg[:, :10]
+
+
+class ViewSplitIEF(object):
+    """IEF loop of model_copenet.py:144-157 with the two views on two ranks.
+
+    step_fn(xf, bb, pose (B,135), betas (B,10), partner (B,136)) -> (pose, betas) is one forward_reg
+    evaluation for this rank's view: airpose_amd.copenet_model.copenet.regressor_step on the GPU.
+    """
+
+    def __init__(self, step_fn, pair_group, pair_ranks):
+        self.step_fn, self.group, self.ranks = step_fn, pair_group, tuple(pair_ranks)
+        self.me = self.ranks.index(dist.get_rank())
+
+    def exchange(self, pose, betas):
+        mine = torch.cat([pose[:, 9:], betas], dim=1).contiguous()        # art_pose | shape
+        both = [torch.empty_like(mine), torch.empty_like(mine)]
+        dist.all_gather(both, mine, group=self.group)
+        return both[1 - self.me]
+
+    def run(self, xf, bb, init_position, init_theta, init_shape, iters=3):
+        B = xf.shape[0]
+        theta = init_theta[:, :132].expand(B, -1)
+        pose = torch.cat([init_position, theta], dim=1).contiguous()
+        betas = init_shape.expand(B, -1).contiguous()
+        for _ in range(int(iters)):
+            partner = self.exchange(pose, betas)
+            pose, betas = self.step_fn(xf, bb, pose, betas, partner)
+        return pose, betas

@@ -1,0 +1,86 @@
+"""Multi-process (world size 2, gloo, CPU) tests of the N>1 host logic: pair sharding and the view-split
+IEF exchange.  The per-view step function is the oracle here (no GPU in this container); on the GPU box
+the same driver runs ap_regressor_step (tests/test_gpu_parity.py checks that step against the oracle)."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import MEAN_PARAMS, REPO
+
+
+def test_shard_pairs_cover_and_balance():
+    from airpose_amd.dist import shard_pairs
+    for n, w in ((2048, 8), (10, 4), (7, 8), (256, 1)):
+        spans = [shard_pairs(n, r, w) for r in range(w)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [b - a for a, b in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_wire_format_roundtrip():
+    from airpose_amd.dist import pack_wire, unpack_wire
+    pose, betas = torch.randn(3, 135), torch.randn(3, 10)
+    msg = pack_wire(pose, betas)
+    assert msg.shape == (3, 145)
+    assert torch.equal(msg[:, :10], betas) and torch.equal(msg[:, 10:13], pose[:, :3])
+    p2, b2 = unpack_wire(msg)
+    assert torch.equal(p2, pose) and torch.equal(b2, betas)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from airpose_amd import dist as D
+    from airpose_amd import weights as W
+    from oracle import copenet_ref
+    sd = W.to_torch(W.copenet_state_dict(20240901, MEAN_PARAMS))
+    g = torch.Generator().manual_seed(17)                      # same data on both ranks
+    B = 3
+    xf = [torch.randn(B, 2048, generator=g), torch.randn(B, 2048, generator=g)]
+    bb = [torch.rand(B, 3, generator=g), torch.rand(B, 3, generator=g)]
+    pos = [torch.randn(B, 3, generator=g) * 0.3, torch.randn(B, 3, generator=g) * 0.3]
+
+    def step(xf_v, bb_v, pose, betas, partner):
+        # this view's half of forward_reg (model_copenet.py:185-188,198-199) from the oracle's linear layers
+        xc = torch.cat([xf_v, bb_v, pose[:, :3], pose[:, 3:9], pose[:, 9:], betas, partner[:, :126], partner[:, 126:]], 1)
+        h = copenet_ref._lin(copenet_ref._lin(xc, sd, "fc1"), sd, "fc2")
+        return pose + copenet_ref._lin(h, sd, "decpose"), betas + copenet_ref._lin(h, sd, "decshape")
+
+    groups = D.make_pair_groups(world)
+    ief = D.ViewSplitIEF(step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
+    with torch.no_grad():
+        pose, betas = ief.run(xf[rank], bb[rank], pos[rank], sd["init_pose"], sd["init_shape"], iters=3)
+        want = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], iters=3)
+    np.savez(os.path.join(out_dir, "r%d.npz" % rank), pose=pose.numpy(), betas=betas.numpy(),
+             want_pose=want[2 * rank].numpy(), want_betas=want[2 * rank + 1].numpy())
+    # default sharding: no collective on the data path -- only the bench's barrier / max-reduce
+    t = torch.tensor([float(rank + 1)])
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    assert t.item() == world
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_split_ief_matches_two_view_oracle(tmp_path):
+    world, port = 2, _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = np.load(str(tmp_path / ("r%d.npz" % r)))
+        assert np.allclose(d["pose"], d["want_pose"], rtol=0, atol=2e-6)
+        assert np.allclose(d["betas"], d["want_betas"], rtol=0, atol=2e-6)

@@ -22,7 +22,7 @@ for li, (pl, nb) in enumerate(zip(planes, layers)):
         shapes.append(("l%d.%d.c3" % (li + 1, bi), n * Ho * Ho, pl * 4, pl, n * Ho * Ho * pl, 1))
         inpl, H = pl * 4, Ho
 k = i0 + 1
-while "conv_igemm" not in rows[k][0]:
+while "conv_" not in rows[k][0]:
     print("%-40s %8.1f us" % (rows[k][0][:40], rows[k][3] / 1e3))
     k += 1
 print("%-40s %8.1f us" % (rows[i0][0][:40], rows[i0][3] / 1e3))
@@ -31,7 +31,7 @@ bylayer = {}
 for (nm, M, N, K, inel, res) in shapes:
     r = rows[k]
     k += 1
-    assert "conv_igemm" in r[0], r[0]
+    assert "conv_" in r[0], r[0]
     cfg = r[0].split("<")[1].split(">")[0].replace("unsigned short", "bf16")
     fl, dur = 2.0 * M * N * K, r[3] / 1e3
     tot += dur
