@@ -11,7 +11,7 @@ import threading
 import torch  # noqa: F401  (must be imported first so that libamdhip64 is the one torch loaded)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libairpose_hip.so")
+LIB_PATH = os.environ.get("AIRPOSE_HIP_LIB", os.path.join(_HERE, "libairpose_hip.so"))   # override: profiling builds
 
 AP_PREC_FP32, AP_PREC_BF16 = 0, 1
 PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16}
@@ -43,6 +43,7 @@ SIGNATURES = {
     "ap_copenet_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_conv2d_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 9 + [_vp]),
     "ap_set_conv_config": (_i, [_i]),
+    "ap_debug_set_trace": (_i, [_vp]),
     "ap_net_enable_timing": (_i, [_vp, _i]),
     "ap_net_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
     "ap_net_set_chunk": (_i, [_vp, _i]),

@@ -114,6 +114,7 @@ struct Timing {
 
 constexpr double BN_EPS = 1e-5;
 
+unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_trace)
 int g_conv_cfg = -1;            // -1 auto, 0..3 conv_pipe config, 100 = legacy register-staged kernel
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
@@ -136,16 +137,25 @@ hipError_t zero_line(const void** out) {
 hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
     int cfg = g_conv_cfg;
     if (cfg < 0) {
-        // measured on MI355X (tools/conv_bench.py): the 256x128 LDS-DMA ring wins on deep contractions and on the
-        // residual (1x1 expand) layers; the register-staged kernel (2 workgroups per CU) wins on the short-K,
-        // bandwidth-bound layers with <= 64 output channels and whenever 256-row tiles cannot fill the chip
-        const long mt256 = (a.M + 255) / 256, nt128 = (a.Cout + 127) / 128;
+        // Measured on MI355X at 512 images (tools/conv_bench.py, profiles/r01_c_conv_configs.txt):
+        //   9  128x64  LDS-DMA ring, 3 workgroups/CU : the 64-channel layers of layer1
+        //   8  128x128 LDS-DMA ring, 2 workgroups/CU : everything else (two tiles per CU overlap one tile's
+        //      HBM-bound epilogue with the other's K loop)
+        //   0  256x128 ring, 8 waves, 1 workgroup/CU : deep contractions with 512 outputs (layer4 conv1/conv2)
+        //   100 register-staged kernel               : single-K-step / short-K layers without residual at
+        //      layer1 size, and small problems (64x64 tiles)
+        const long mt128 = (a.M + 127) / 128, nt128 = (a.Cout + 127) / 128;
         const int K = a.KH * a.KW * a.Cin;
-        cfg = (a.Cout >= 128 && (K >= 512 || a.res != nullptr) && mt256 * nt128 >= 200) ? 0 : 100;
+        if (mt128 * nt128 < 256) cfg = 100;
+        else if (a.Cout <= 64) cfg = K <= 64 ? 100 : 9;
+        else if (!a.res && K <= 256 && a.M >= 1000000) cfg = 100;
+        else if (K >= 1024 && a.Cout == 512 && mt128 * nt128 >= 1024) cfg = 0;
+        else cfg = 8;
     }
     if (cfg == 100) return ap_launch_conv(a, is_bf16, st);
     hipError_t e = zero_line(&a.zero);
     if (e != hipSuccess) return e;
+    a.dbg = g_conv_dbg;
     return ap_launch_conv_pipe(a, is_bf16, cfg, st);
 }
 constexpr int ST = 148, SLD = 288, DLD = 148;
@@ -620,8 +630,13 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
     return AP_OK;
 }
 
+int ap_debug_set_trace(void* device_buf_160_u64) {
+    g_conv_dbg = (unsigned long long*)device_buf_160_u64;
+    return AP_OK;
+}
+
 int ap_set_conv_config(int cfg) {
-    if (cfg != -1 && cfg != 100 && (cfg < 0 || cfg > 3)) return fail(AP_EINVAL, "ap_set_conv_config: -1, 0..3 or 100");
+    if (cfg != -1 && cfg != 100 && (cfg < 0 || cfg > 9)) return fail(AP_EINVAL, "ap_set_conv_config: -1, 0..9 or 100");
     g_conv_cfg = cfg;
     return AP_OK;
 }

@@ -28,6 +28,18 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);      // keep register-only MFMAs below the wait (they ignore "memory")
+}
+// LDS fragment read the compiler does not count: hipcc answers a ds_read pending across the loop back-edge
+// with lgkmcnt(0), which serialises the fragment double-buffering; the waits are placed by hand instead.
+template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN]) {
     if constexpr (sizeof(T) == 2) {
@@ -52,7 +64,38 @@ __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&
     }
 }
 
-template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int S>
+// MFMA cluster with NP callbacks (one LDS-DMA piece each) spread evenly between the MFMAs
+template <typename T, int FM, int FN, int NP, typename F>
+__device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN], F&& piece) {
+    constexpr int NM = FM * FN;
+    static_assert(NM >= NP + 1, "need more MFMAs than DMA pieces per cluster");
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int fm = j / FN, fn = j % FN;
+        if constexpr (sizeof(T) == 2) {
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const uint32_t wv = t == 0 ? wf[fn].x : t == 1 ? wf[fn].y : t == 2 ? wf[fn].z : wf[fn].w;
+                const uint32_t xv = t == 0 ? xf[fm].x : t == 1 ? xf[fm].y : t == 2 ? xf[fm].z : xf[fm].w;
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x4f32(
+                    __builtin_bit_cast(float, wv), __builtin_bit_cast(float, xv), acc[fm][fn], 0, 0, 0);
+            }
+        }
+        // piece k goes after MFMA number (k+1)*NM/(NP+1)  (all indices fold at compile time)
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if ((k + 1) * NM / (NP + 1) == j + 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                piece(k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
+template <typename T, int BM, int BN, int WAVES_M, int WAVES_N, int S, bool DIRECT>
 __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const ConvArgs p) {
     constexpr int EPC = Elem2<T>::EPC;
     constexpr int BK = 8 * EPC;
@@ -64,9 +107,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
     constexpr int CLD = BN + 4;
     static_assert(ROWS % (8 * NW) == 0 && BM % 8 == 0, "tile rows must split into 8-row pieces per wave");
     static_assert(S >= 2 && (S - 2) * LPW < 64, "vmcnt immediate");
-    static_assert(BM * CLD * 4 <= S * STAGE, "epilogue tile must fit in the ring");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-
+#ifdef AP_TRACE
+#define AP_BSTAMP(k) do { if (p.dbg && blockIdx.x == 0 && threadIdx.x == 0) p.dbg[160 + (k)] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AP_BSTAMP(k) do {} while (0)
+#endif
+    AP_BSTAMP(0);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
@@ -106,27 +153,41 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
     }
     const int cpb = p.Cin / BK;
     const int KT = p.KH * p.KW * cpb;
-    int r = 0, s = 0, cb = 0, ktl = 0;                       // tap / chunk / index of the tile being ISSUED
-
-    auto issue_tile = [&](int stage) {
-        const ptrdiff_t xoff = (((ptrdiff_t)r * p.W + s) * p.ldx + cb * BK) * (ptrdiff_t)sizeof(T);
-        const ptrdiff_t woff = (ptrdiff_t)ktl * BK * (ptrdiff_t)sizeof(T);
+    int r = 0, s = 0, cb = 0;                                // tap / channel chunk of the tile being ISSUED
+    // Per-piece running source pointers.  Address arithmetic is done once per TAP (every cpb K steps), a K
+    // step inside a tap only adds the per-lane increment (0 for predicated-off lanes, which sit on the zero
+    // line): the VALU work between the barrier and the MFMAs was what the 8 lock-stepped waves were waiting on.
+    const unsigned char* cur[LPW];
+    uint32_t inc[LPW];
 #pragma unroll
-        for (int i = 0; i < LPW; ++i) {
-            const int piece = wave * LPW + i;
-            const unsigned char* g;
-            if (piece * 8 < BM) {
-                const bool ok = (unsigned)(hi0[i] + r) < (unsigned)p.H && (unsigned)(wi0[i] + s) < (unsigned)p.W;
-                g = ok ? src[i] + xoff : zg;
-            } else {
-                g = src[i] + woff;
-            }
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                             (__attribute__((address_space(3))) void*)(smem + stage * STAGE + piece * 1024),
-                                             16, 0, 0);
+    for (int i = 0; i < LPW; ++i) {
+        cur[i] = src[i];
+        inc[i] = BK * sizeof(T);
+    }
+
+    // per-tap pointer refresh for one piece (only when a new tap starts: wave-uniform branch)
+    auto prep_piece = [&](int i) {
+        if (cb == 0 && (wave * LPW + i) * 8 < BM) {
+            const ptrdiff_t xoff = ((ptrdiff_t)r * p.W + s) * p.ldx * (ptrdiff_t)sizeof(T);
+            const bool ok = (unsigned)(hi0[i] + r) < (unsigned)p.H && (unsigned)(wi0[i] + s) < (unsigned)p.W;
+            cur[i] = ok ? src[i] + xoff : zg;
+            inc[i] = ok ? (uint32_t)(BK * sizeof(T)) : 0u;
         }
-        ++ktl;
-        if (++cb == cpb) { cb = 0; if (++s == p.KW) { s = 0; ++r; } }
+    };
+    auto advance_tap = [&]() { if (++cb == cpb) { cb = 0; if (++s == p.KW) { s = 0; ++r; } } };
+    auto issue_piece = [&](int i, int stage) {               // one 1-KiB LDS-DMA piece of the tile
+        const int piece = wave * LPW + i;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)cur[i],
+                                         (__attribute__((address_space(3))) void*)(smem + stage * STAGE + piece * 1024),
+                                         16, 0, 0);
+        cur[i] += inc[i];
+    };
+    auto issue_tile = [&](int stage) {
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) prep_piece(i);
+        advance_tap();
+#pragma unroll
+        for (int i = 0; i < LPW; ++i) issue_piece(i, stage);
     };
 
     // ---------------------------------------------------------------- MFMA state
@@ -140,32 +201,160 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // prologue: S-1 tiles in flight
+    // DIRECT epilogue: the residual is fetched in the accumulator layout (4 channels of one pixel per lane and
+    // fragment) before the K loop starts, so its latency hides under the whole loop
+    constexpr int RW = sizeof(T) == 2 ? 2 : 4;               // dwords of 4 channels
+    uint32_t rpre[DIRECT ? FM * FN * RW : 1];
+    if constexpr (DIRECT) {
+        if (p.res) {
 #pragma unroll
-    for (int t = 0; t < S - 1; ++t)
-        if (t < KT) issue_tile(t);
-
-    int cs = 0, is = S - 1;                                  // stage being computed / issued
-    for (int kt = 0; kt < KT; ++kt) {
-        if (kt + S - 2 < KT) wait_vmcnt<(S - 2) * LPW>();
-        else wait_vmcnt<0>();
-        __builtin_amdgcn_s_barrier();
-        if (kt + S - 1 < KT) issue_tile(is);
-        if (++is == S) is = 0;
-        const unsigned char* sb = smem + cs * STAGE;
-        if (++cs == S) cs = 0;
-        u32x4 xf[FM], wf[FN];
+            for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) xf[fm] = *(const u32x4*)(sb + xfrag + fm * 16 * 128 + sw0);
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) wf[fn] = *(const u32x4*)(sb + wfrag + fn * 16 * 128 + sw0);
-        mma_chunk2<T, FM, FN>(xf, wf, acc);
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) xf[fm] = *(const u32x4*)(sb + xfrag + fm * 16 * 128 + sw1);
-#pragma unroll
-        for (int fn = 0; fn < FN; ++fn) wf[fn] = *(const u32x4*)(sb + wfrag + fn * 16 * 128 + sw1);
-        mma_chunk2<T, FM, FN>(xf, wf, acc);
+                for (int fn = 0; fn < FN; ++fn) {
+                    const int m = bm * BM + wm * (BM / WAVES_M) + fm * 16 + (lane & 15);
+                    const int ch = bn * BN + wn * (BN / WAVES_N) + fn * 16 + (lane >> 4) * 4;
+                    const bool ok = m < p.M && ch < p.Cout;
+                    const T* rp = ok ? (const T*)p.res + (size_t)m * p.ldr + ch : (const T*)p.zero;
+                    if constexpr (sizeof(T) == 2) {
+                        const uint2 v = *(const uint2*)rp;
+                        rpre[(fm * FN + fn) * 2] = v.x; rpre[(fm * FN + fn) * 2 + 1] = v.y;
+                    } else {
+                        const uint4 v = *(const uint4*)rp;
+                        rpre[(fm * FN + fn) * 4] = v.x; rpre[(fm * FN + fn) * 4 + 1] = v.y;
+                        rpre[(fm * FN + fn) * 4 + 2] = v.z; rpre[(fm * FN + fn) * 4 + 3] = v.w;
+                    }
+                }
+        }
     }
+
+    // residual tile prefetch in the epilogue's coalesced layout (16 B per thread and row chunk): issued before
+    // the K loop so that its HBM latency is covered by the whole loop instead of stalling the epilogue
+    constexpr int CPR = BN / EPC;                            // 16-byte output chunks per tile row
+    constexpr int NIT = BM * CPR / NT;
+    static_assert(BM * CPR % NT == 0, "epilogue chunks must divide evenly");
+    const T* __restrict__ rg = (const T*)p.res;
+    u32x4 rv[DIRECT ? 1 : NIT];
+    // prologue: the whole ring (S tiles) in flight
+    AP_BSTAMP(1);
+#pragma unroll
+    for (int t = 0; t < S; ++t)
+        if (t < KT) issue_tile(t);
+    AP_BSTAMP(2);
+    // K loop.  One barrier per K step, between the two MFMA clusters.  Before it every wave has COMPLETED its
+    // reads of tile kt (first half read one step earlier, second half waited with lgkmcnt(0)), so the barrier
+    // both publishes tile kt+1 and frees slot kt%S, which is refilled with tile kt+S at once: S-1 K steps of
+    // DMA latency cover.  Fragment reads of the next half step are always in flight under the current MFMAs;
+    // the address refresh runs between the MFMAs of cluster 0, the DMA pieces between those of cluster 1
+    // (the vector-memory path moves 64 B/clk/CU: a tile's 48 KiB are ~770 cycles of TA time that must run
+    // UNDER the matrix pipe, not in front of it).
+    u32x4 xf0[FM], wf0[FN], xf1[FM], wf1[FN];
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const uint32_t xa0 = lds0 + xfrag + sw0, xa1 = lds0 + xfrag + sw1, wa0 = lds0 + wfrag + sw0, wa1 = lds0 + wfrag + sw1;
+    constexpr int NFR = FM + FN;                             // ds_reads per half K step
+    auto load_frags = [&](uint32_t xa, uint32_t wa, u32x4 (&xf)[FM], u32x4 (&wf)[FN]) {
+        static_assert(FM <= 4 && FN <= 4, "fragment unroll");
+        if constexpr (FM > 0) xf[0] = lds_read_b128<0>(xa);
+        if constexpr (FM > 1) xf[1] = lds_read_b128<2048>(xa);
+        if constexpr (FM > 2) xf[2] = lds_read_b128<4096>(xa);
+        if constexpr (FM > 3) xf[3] = lds_read_b128<6144>(xa);
+        if constexpr (FN > 0) wf[0] = lds_read_b128<0>(wa);
+        if constexpr (FN > 1) wf[1] = lds_read_b128<2048>(wa);
+        if constexpr (FN > 2) wf[2] = lds_read_b128<4096>(wa);
+        if constexpr (FN > 3) wf[3] = lds_read_b128<6144>(wa);
+    };
+    // tile 0 landed (tiles 1 .. S-1 may still be in flight)
+    if (KT >= S) wait_vmcnt<(S - 1) * LPW>();
+    else wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    AP_BSTAMP(3);
+    load_frags(xa0, wa0, xf0, wf0);
+
+#ifdef AP_TRACE
+    const bool trace = p.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
+#define AP_STAMP(k)                                                                                          \
+    do {                                                                                                     \
+        if (trace && kt >= 8 && kt < 16) p.dbg[((wave >> 2) * 8 + (kt - 8)) * 10 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define AP_STAMP(k) do {} while (0)
+#endif
+    int cs = 0;                                              // ring slot of tile kt
+    for (int kt = 0; kt < KT; ++kt) {
+        AP_STAMP(0);
+        const uint32_t so = cs * STAGE;
+        const bool refill = kt + S < KT;                     // tile kt+S goes into the slot of tile kt
+        load_frags(xa1 + so, wa1 + so, xf1, wf1);            // second half of tile kt
+        AP_STAMP(1);
+        wait_lgkmcnt<NFR>();                                 // first half (read one phase earlier) has landed
+        AP_STAMP(2);
+        mma_issue<T, FM, FN, LPW>(xf0, wf0, acc, [&](int i) { if (refill) prep_piece(i); });
+        if (refill) advance_tap();
+        __builtin_amdgcn_sched_barrier(0);
+        AP_STAMP(3);
+        wait_lgkmcnt<0>();                                   // all of this wave's reads of tile kt are done
+        AP_STAMP(4);
+        if (kt + 1 < KT) {
+            // tile kt+1 must have landed; the younger tiles kt+2 .. kt+S-1 may stay in flight
+            const int younger = KT - 2 - kt;                 // tiles issued after kt+1
+            if (younger >= S - 2) wait_vmcnt<(S - 2) * LPW>();
+            else if (S > 3 && younger == 1) wait_vmcnt<LPW>();
+            else wait_vmcnt<0>();
+            AP_STAMP(5);
+            __builtin_amdgcn_s_barrier();
+            AP_STAMP(6);
+            const int ns = cs + 1 == S ? 0 : cs + 1;
+            load_frags(xa0 + ns * STAGE, wa0 + ns * STAGE, xf0, wf0);   // first half of tile kt+1
+        }
+        AP_STAMP(7);
+        mma_issue<T, FM, FN, LPW>(xf1, wf1, acc, [&](int i) { if (refill) issue_piece(i, cs); });
+        if (++cs == S) cs = 0;
+        __builtin_amdgcn_sched_barrier(0);
+        AP_STAMP(8);
+        AP_STAMP(9);
+    }
+#undef AP_STAMP
+    if constexpr (DIRECT) {
+        // ------------------------------------------------------------ epilogue straight from the accumulators:
+        // lane = (pixel lr, channels g4*4..+3) per fragment; 8-byte (bf16) / 16-byte (fp32) stores, the four
+        // fn fragments of a wave complete each pixel's 128-byte line
+        T* __restrict__ yg = (T*)p.y;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int ch = bn * BN + wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
+            const float4 sc = *(const float4*)(p.scale + ch);
+            const float4 sh = *(const float4*)(p.shift + ch);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m = bm * BM + wm * (BM / WAVES_M) + fm * 16 + lr;
+                float v0 = acc[fm][fn][0] * sc.x + sh.x, v1 = acc[fm][fn][1] * sc.y + sh.y;
+                float v2 = acc[fm][fn][2] * sc.z + sh.z, v3 = acc[fm][fn][3] * sc.w + sh.w;
+                if (p.res) {
+                    if constexpr (sizeof(T) == 2) {
+                        float lo, hi;
+                        unpack_bf16x2(rpre[(fm * FN + fn) * 2], lo, hi); v0 += lo; v1 += hi;
+                        unpack_bf16x2(rpre[(fm * FN + fn) * 2 + 1], lo, hi); v2 += lo; v3 += hi;
+                    } else {
+                        v0 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4]);
+                        v1 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4 + 1]);
+                        v2 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4 + 2]);
+                        v3 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4 + 3]);
+                    }
+                }
+                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (m < p.M && ch < p.Cout) {
+                    if constexpr (sizeof(T) == 2) {
+                        uint2 o;
+                        o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                        *(uint2*)(yg + (size_t)m * p.ldy + ch) = o;
+                    } else {
+                        *(float4*)(yg + (size_t)m * p.ldy + ch) = make_float4(v0, v1, v2, v3);
+                    }
+                }
+            }
+        }
+        return;
+    }
+    AP_BSTAMP(4);
     __syncthreads();                                         // all MFMA reads done before the ring is reused
 
     // ---------------------------------------------------------------- epilogue (as conv_igemm.hip)
@@ -187,22 +376,23 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             *(float4*)(ct + px * CLD + chl) = v;
         }
     }
+    AP_BSTAMP(5);
     __syncthreads();
-    constexpr int CPR = BN / EPC;
-    constexpr int NIT = BM * CPR / NT;
-    static_assert(BM * CPR % NT == 0, "epilogue chunks must divide evenly");
+    AP_BSTAMP(6);
     T* __restrict__ yg = (T*)p.y;
-    const T* __restrict__ rg = (const T*)p.res;
-    u32x4 rv[NIT];
-    if (rg) {
+    if constexpr (!DIRECT) {
+        if (rg) {
 #pragma unroll
-        for (int it = 0; it < NIT; ++it) {
-            const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
-            const int m = bm * BM + px, ch = bn * BN + cc * EPC;
-            const bool ok = m < p.M && ch < p.Cout;
-            rv[it] = *(const u32x4*)(ok ? rg + (size_t)m * p.ldr + ch : (const T*)p.zero);
+            for (int it = 0; it < NIT; ++it) {
+                const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
+                const int m = bm * BM + px, ch = bn * BN + cc * EPC;
+                const bool ok = m < p.M && ch < p.Cout;
+                rv[it] = *(const u32x4*)(ok ? rg + (size_t)m * p.ldr + ch : (const T*)p.zero);
+            }
         }
     }
+
+
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
@@ -238,13 +428,15 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
         }
     }
+    AP_BSTAMP(7);
 }
 
-template <typename T, int BM, int BN, int WM, int WN, int S>
+template <typename T, int BM, int BN, int WM, int WN, int S, bool DIRECT>
 hipError_t launch_pipe(ConvArgs a, hipStream_t st) {
     static bool attr_set = false;
-    auto kern = conv_pipe_kernel<T, BM, BN, WM, WN, S>;
-    constexpr int lds = S * (BM + BN) * 128;
+    auto kern = conv_pipe_kernel<T, BM, BN, WM, WN, S, DIRECT>;
+    constexpr int ring = S * (BM + BN) * 128, epi = BM * (BN + 4) * 4;
+    constexpr int lds = ring > epi ? ring : epi;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
@@ -259,22 +451,35 @@ hipError_t launch_pipe(ConvArgs a, hipStream_t st) {
 }  // namespace
 
 // cfg: 0 = 256x128 (8 waves, 3 stages), 1 = 128x128 (4 waves, 4 stages), 2 = 128x64 (4 waves, 4 stages),
-//      3 = 256x64 (8 waves, 3 stages)
+//      3 = 256x64 (8 waves, 3 stages); +4 = same tiles with the register (LDS-free) epilogue;
+//      8 = 128x128 / 9 = 128x64, 4 waves, 2 stages: small LDS footprint, 2-3 workgroups per CU
 hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStream_t st) {
     if (!a.zero) return hipErrorInvalidValue;
     if (is_bf16) {
         switch (cfg) {
-            case 0: return launch_pipe<bf16_t, 256, 128, 4, 2, 3>(a, st);
-            case 1: return launch_pipe<bf16_t, 128, 128, 2, 2, 4>(a, st);
-            case 2: return launch_pipe<bf16_t, 128, 64, 2, 2, 4>(a, st);
-            case 3: return launch_pipe<bf16_t, 256, 64, 4, 2, 3>(a, st);
+            case 0: return launch_pipe<bf16_t, 256, 128, 4, 2, 3, false>(a, st);
+            case 1: return launch_pipe<bf16_t, 128, 128, 2, 2, 4, false>(a, st);
+            case 2: return launch_pipe<bf16_t, 128, 64, 2, 2, 4, false>(a, st);
+            case 3: return launch_pipe<bf16_t, 256, 64, 4, 2, 3, false>(a, st);
+            case 4: return launch_pipe<bf16_t, 256, 128, 4, 2, 3, true>(a, st);
+            case 5: return launch_pipe<bf16_t, 128, 128, 2, 2, 4, true>(a, st);
+            case 6: return launch_pipe<bf16_t, 128, 64, 2, 2, 4, true>(a, st);
+            case 7: return launch_pipe<bf16_t, 256, 64, 4, 2, 3, true>(a, st);
+            case 8: return launch_pipe<bf16_t, 128, 128, 2, 2, 2, false>(a, st);
+            case 9: return launch_pipe<bf16_t, 128, 64, 2, 2, 2, false>(a, st);
         }
     } else {
         switch (cfg) {
-            case 0: return launch_pipe<float, 256, 128, 4, 2, 3>(a, st);
-            case 1: return launch_pipe<float, 128, 128, 2, 2, 4>(a, st);
-            case 2: return launch_pipe<float, 128, 64, 2, 2, 4>(a, st);
-            case 3: return launch_pipe<float, 256, 64, 4, 2, 3>(a, st);
+            case 0: return launch_pipe<float, 256, 128, 4, 2, 3, false>(a, st);
+            case 1: return launch_pipe<float, 128, 128, 2, 2, 4, false>(a, st);
+            case 2: return launch_pipe<float, 128, 64, 2, 2, 4, false>(a, st);
+            case 3: return launch_pipe<float, 256, 64, 4, 2, 3, false>(a, st);
+            case 4: return launch_pipe<float, 256, 128, 4, 2, 3, true>(a, st);
+            case 5: return launch_pipe<float, 128, 128, 2, 2, 4, true>(a, st);
+            case 6: return launch_pipe<float, 128, 64, 2, 2, 4, true>(a, st);
+            case 7: return launch_pipe<float, 256, 64, 4, 2, 3, true>(a, st);
+            case 8: return launch_pipe<float, 128, 128, 2, 2, 2, false>(a, st);
+            case 9: return launch_pipe<float, 128, 64, 2, 2, 2, false>(a, st);
         }
     }
     return hipErrorInvalidValue;

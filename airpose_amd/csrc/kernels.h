@@ -11,6 +11,7 @@ struct ConvArgs {
     const void* res;      // optional residual [M][ldr], element type T
     void* y;              // [M][ldy]
     const void* zero;     // >= 16 bytes of zeros (DMA source of predicated-off rows; conv_pipe only)
+    unsigned long long* dbg;  // optional per-phase cycle stamps (profiling builds; NULL otherwise)
     int N, H, W, Cin;
     int Ho, Wo, Cout;     // Cout: number of stored channels (multiple of 16 B / sizeof(T))
     int KH, KW, stride, pad;

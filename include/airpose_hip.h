@@ -94,6 +94,9 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
  * 0..3 = software-pipelined LDS-DMA kernel with 256x128 / 128x128 / 128x64 / 256x64 tiles,
  * 100 = register-staged 2-stage kernel.  Results are identical for every setting. */
 int ap_set_conv_config(int cfg);
+/* Profiling aid: device buffer of 160 uint64 receiving per-phase cycle stamps of workgroup 0 of the pipelined
+ * convolution kernel (2 waves x 8 K steps x 10 stamps); NULL (default) disables it. */
+int ap_debug_set_trace(void* device_buf_160_u64);
 
 /* Stage timing for bench.py: when enabled, HIP events bracket the stem, the implicit-GEMM conv stack,
  * the pooling tail and the regressor on the caller's stream.  ap_net_timing synchronises on the last
