@@ -249,6 +249,11 @@ class copenet(nn.Module):
         N.check(N.lib().ap_net_timing(self._handle, ms, ctypes.byref(n), int(reset)), "ap_net_timing")
         return {"stem_ms": ms[0], "conv_ms": ms[1], "avgpool_ms": ms[2], "regressor_ms": ms[3], "passes": n.value}
 
+    def set_fold(self, on):
+        """Evaluate fc1 -> fc2 -> dec as one folded affine map (default) or as the literal chain."""
+        N.check(N.lib().ap_net_set_fold(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+                "ap_net_set_fold")
+
     def set_chunk(self, images):
         N.check(N.lib().ap_net_set_chunk(self._native(torch.device("cuda", torch.cuda.current_device())), int(images)),
                 "ap_net_set_chunk")

@@ -172,6 +172,8 @@ struct ap_net {
     std::vector<Block> blocks;
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
+    Layer fold_feat, fold_state;   // dec o fc2 o fc1 folded into one 145 x 2332 map (no activation between them)
+    bool fold = true;
     DevBuf mean_pose, mean_shape;
     // workspace
     int chunk = 0;
@@ -373,6 +375,35 @@ int finalize_regressor(ap_net* h) {
     memcpy(bd.data(), bp->data.data(), 135 * 4);
     memcpy(bd.data() + 135, bsh->data.data(), 10 * 4);
     if ((rc = pack_linear(wd.data(), 1024, 0, 1024, 145, bd.data(), h->dec))) return rc;
+    {
+        // forward_reg is fc1 -> dropout(identity in eval) -> fc2 -> dropout -> decpose/decshape with NO activation
+        // (model_copenet.py:186-202), i.e. one affine map.  Fold it once in fp64:
+        //   Wf = Wd W2 W1 (145 x 2332),  bf = Wd (W2 b1 + b2) + bd
+        std::vector<double> A((size_t)145 * 1024, 0.0);                       // Wd W2
+        for (int o = 0; o < 145; ++o)
+            for (int k = 0; k < 1024; ++k) {
+                const double wv = wd[(size_t)o * 1024 + k];
+                const float* w2r = &w2->data[(size_t)k * 1024];
+                double* ar = &A[(size_t)o * 1024];
+                for (int j = 0; j < 1024; ++j) ar[j] += wv * w2r[j];
+            }
+        std::vector<float> wf((size_t)145 * 2332), bfv(145);
+        std::vector<double> row(2332);
+        for (int o = 0; o < 145; ++o) {
+            std::fill(row.begin(), row.end(), 0.0);
+            double bacc = bd[o];
+            for (int k = 0; k < 1024; ++k) {
+                const double av = A[(size_t)o * 1024 + k];
+                const float* w1r = &w1->data[(size_t)k * 2332];
+                for (int j = 0; j < 2332; ++j) row[j] += av * w1r[j];
+                bacc += av * b1->data[k] + (double)wd[(size_t)o * 1024 + k] * b2->data[k];
+            }
+            for (int j = 0; j < 2332; ++j) wf[(size_t)o * 2332 + j] = (float)row[j];
+            bfv[o] = (float)bacc;
+        }
+        if ((rc = pack_linear(wf.data(), 2332, 0, 2048, 145, bfv.data(), h->fold_feat))) return rc;
+        if ((rc = pack_linear(wf.data(), 2332, 2048, 284, 145, nullptr, h->fold_state))) return rc;
+    }
     std::vector<float> mp(144, 0.f);
     memcpy(mp.data(), ip->data.data(), std::min<size_t>(144, ip->numel()) * 4);
     HIP_TRY(upload(h->mean_pose, mp.data(), 144 * 4));
@@ -476,10 +507,16 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
     float *Hb = h->ws_H.as<float>(), *T1 = h->ws_T1.as<float>(), *T2 = h->ws_T2.as<float>(), *S = h->ws_S.as<float>(),
           *D = h->ws_D.as<float>(), *state = h->ws_state.as<float>();
     int rc;
-    // trunk-feature part of fc1 (+ bias), constant over the iterations
-    if ((rc = run_gemm(h->fc1_feat, in.xf0, 2048, 2048, B, Hb, 1024, nullptr, 0, st))) return rc;
-    if (two_view)
-        if ((rc = run_gemm(h->fc1_feat, in.xf1, 2048, 2048, B, Hb + (size_t)B * 1024, 1024, nullptr, 0, st))) return rc;
+    // trunk-feature part (+ bias), constant over the iterations: of fc1 (literal chain) or of the folded map
+    const Layer& Lf = h->fold ? h->fold_feat : h->fc1_feat;
+    const int hld = h->fold ? DLD : 1024;
+    if (two_view && in.xf1 == in.xf0 + (size_t)B * 2048) {          // both views contiguous: one launch
+        if ((rc = run_gemm(Lf, in.xf0, 2048, 2048, 2 * B, Hb, hld, nullptr, 0, st))) return rc;
+    } else {
+        if ((rc = run_gemm(Lf, in.xf0, 2048, 2048, B, Hb, hld, nullptr, 0, st))) return rc;
+        if (two_view)
+            if ((rc = run_gemm(Lf, in.xf1, 2048, 2048, B, Hb + (size_t)B * hld, hld, nullptr, 0, st))) return rc;
+    }
     RegInitArgs ia{};
     ia.pos0 = in.pos0; ia.pos1 = in.pos1; ia.theta0 = in.th0; ia.theta1 = in.th1; ia.shape0 = in.sh0; ia.shape1 = in.sh1;
     ia.theta0_bs = in.th0_bs; ia.theta1_bs = in.th1_bs; ia.shape0_bs = in.sh0_bs; ia.shape1_bs = in.sh1_bs;
@@ -490,9 +527,13 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
     for (int it = 0; it < iters; ++it) {
         HIP_TRY(ap_launch_reg_update_assemble(state, it ? D : nullptr, DLD, in.bb0, in.bb1, partner, partner_ld, S, B,
                                               two_view, st));
-        if ((rc = run_gemm(h->fc1_state, S, SLD, SLD, rows, T1, 1024, Hb, 1024, st))) return rc;
-        if ((rc = run_gemm(h->fc2, T1, 1024, 1024, rows, T2, 1024, nullptr, 0, st))) return rc;
-        if ((rc = run_gemm(h->dec, T2, 1024, 1024, rows, D, DLD, nullptr, 0, st))) return rc;
+        if (h->fold) {
+            if ((rc = run_gemm(h->fold_state, S, SLD, SLD, rows, D, DLD, Hb, DLD, st))) return rc;
+        } else {
+            if ((rc = run_gemm(h->fc1_state, S, SLD, SLD, rows, T1, 1024, Hb, 1024, st))) return rc;
+            if ((rc = run_gemm(h->fc2, T1, 1024, 1024, rows, T2, 1024, nullptr, 0, st))) return rc;
+            if ((rc = run_gemm(h->dec, T2, 1024, 1024, rows, D, DLD, nullptr, 0, st))) return rc;
+        }
     }
     // fold the last delta into the state and emit
     HIP_TRY(ap_launch_reg_update_assemble(state, D, DLD, in.bb0, in.bb1, partner, partner_ld, S, B, two_view, st));
@@ -532,7 +573,7 @@ void ap_net_destroy(ap_net* h) {
         b->release();
     auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
     for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); }
-    rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec);
+    rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec); rel(h->fold_feat); rel(h->fold_state);
     h->tm.destroy();
     delete h;
 }
@@ -650,6 +691,12 @@ int ap_net_enable_timing(ap_net* h, int on) {
 int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset) {
     if (!h || !ms || !passes) return fail(AP_EINVAL, "ap_net_timing: null argument");
     HIP_TRY(h->tm.collect(ms, 4, passes, reset != 0));
+    return AP_OK;
+}
+
+int ap_net_set_fold(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fold = on != 0;
     return AP_OK;
 }
 

@@ -104,6 +104,11 @@ int ap_debug_set_trace(void* device_buf_160_u64);
  * the last reset.  ms[0]=stem+maxpool, ms[1]=conv stack (52 launches/pass), ms[2]=avgpool, ms[3]=regressor. */
 int ap_net_enable_timing(ap_net* h, int on);
 int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset);
+/* forward_reg has no activation between fc1, fc2 and the decoders (dropout is the identity in eval mode,
+ * model_copenet.py:186-202), so ap_net_finalize also folds them, in fp64, into one 145 x 2332 affine map
+ * (like the BatchNorm fold).  on = 1 (default) evaluates the folded map, on = 0 the literal three-GEMM chain;
+ * both are parity-tested against the reference. */
+int ap_net_set_fold(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);
 

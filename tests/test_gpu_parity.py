@@ -177,7 +177,10 @@ def test_trunk_batch_and_chunk_invariance(net32, dev):
     assert rel_err(single.cpu().numpy(), full.cpu().numpy()) < 1e-6
 
 
-def test_ief_fp32_matches_golden(golden, net32, copenet_inputs, dev):
+@pytest.mark.parametrize("fold", [1, 0])
+def test_ief_fp32_matches_golden(golden, net32, copenet_inputs, dev, fold):
+    """fold = 1: fc1 -> fc2 -> dec evaluated as the folded affine map; fold = 0: the literal chain."""
+    net32.set_fold(fold)
     g = golden["copenet_b2"]
     t = lambda k: torch.from_numpy(g[k]).to(dev)
     pos = t("init_position")
@@ -191,6 +194,7 @@ def test_ief_fp32_matches_golden(golden, net32, copenet_inputs, dev):
                                        init_shape0=t("ci_shape0"), init_shape1=t("ci_shape1"), iters=2)
     assert rel_err(p0.cpu().numpy(), g["ci_pose0"]) < TOL32 and rel_err(p1.cpu().numpy(), g["ci_pose1"]) < TOL32
     assert rel_err(b0.cpu().numpy(), g["ci_betas0"]) < TOL32 and rel_err(b1.cpu().numpy(), g["ci_betas1"]) < TOL32
+    net32.set_fold(1)
 
 
 def test_forward_fp32_matches_golden(golden, net32, copenet_inputs, dev):
