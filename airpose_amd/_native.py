@@ -48,6 +48,7 @@ SIGNATURES = {
     "ap_net_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
     "ap_net_set_chunk": (_i, [_vp, _i]),
     "ap_net_set_fold": (_i, [_vp, _i]),
+    "ap_net_set_fuse_stem": (_i, [_vp, _i]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),
     "ap_smplx_destroy": (None, [_vp]),
     "ap_smplx_num_joints_out": (_i, [_vp]),

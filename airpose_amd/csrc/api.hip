@@ -174,6 +174,7 @@ struct ap_net {
     Layer fc1_feat, fc1_state, fc2, dec;
     Layer fold_feat, fold_state;   // dec o fc2 o fc1 folded into one 145 x 2332 map (no activation between them)
     bool fold = true;
+    bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape;
     // workspace
     int chunk = 0;
@@ -416,7 +417,7 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
     const int bf = h->prec == AP_PREC_BF16;
     const size_t es = h->esize();
     const int n = n0 + n1;
-    HIP_TRY(h->ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
+    if (!(bf && h->fuse_stem)) HIP_TRY(h->ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
     HIP_TRY(h->ws_a.reserve((size_t)n * 802816 * es));
     HIP_TRY(h->ws_b.reserve((size_t)n * 802816 * es));
     HIP_TRY(h->ws_ds.reserve((size_t)n * 802816 * es));
@@ -424,7 +425,10 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
     HIP_TRY(h->ws_t2.reserve((size_t)n * 200704 * es));
     size_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e0));
-    if (bf) {
+    if (bf && h->fuse_stem) {
+        HIP_TRY(ap_launch_stem_pool(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
+                                    h->ws_a.p, n, st));
+    } else if (bf) {
         HIP_TRY(ap_launch_stem_conv_mfma(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
                                          h->stem_shift.as<float>(), h->ws_stem.p, n, st));
     } else {
@@ -435,7 +439,7 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
             HIP_TRY(ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
                                         (char*)h->ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, 0, st));
     }
-    HIP_TRY(ap_launch_maxpool(h->ws_stem.p, h->ws_a.p, n, bf, st));
+    if (!(bf && h->fuse_stem)) HIP_TRY(ap_launch_maxpool(h->ws_stem.p, h->ws_a.p, n, bf, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
     void *cur = h->ws_a.p, *nxt = h->ws_b.p;
     int H = 56;
@@ -691,6 +695,12 @@ int ap_net_enable_timing(ap_net* h, int on) {
 int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset) {
     if (!h || !ms || !passes) return fail(AP_EINVAL, "ap_net_timing: null argument");
     HIP_TRY(h->tm.collect(ms, 4, passes, reset != 0));
+    return AP_OK;
+}
+
+int ap_net_set_fuse_stem(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fuse_stem = on != 0;
     return AP_OK;
 }
 

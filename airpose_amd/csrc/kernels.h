@@ -34,6 +34,9 @@ hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, cons
 // w_packed: [64][200] bf16, k' = r*24 + s*3 + c
 hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_split, const void* w_packed,
                                     const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
+// fused bf16 MFMA stem + maxpool: NCHW fp32 crops -> [N][56][56][64] bf16
+hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
+                                const float* shift, void* y_pooled, int n_img, hipStream_t st);
 // maxpool 3x3/2 p1: [N][112][112][64] -> [N][56][56][64]
 hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int is_bf16, hipStream_t st);
 // global 7x7 average: [N][49][C] T -> [N][C] fp32

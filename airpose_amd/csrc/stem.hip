@@ -155,6 +155,130 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused MFMA stem + 3x3/2 max-pool (bf16 throughput path): conv1 -> bn1 -> relu -> maxpool in one kernel,
+// the 112x112x64 stem activation (1.6 MB/image) never touches HBM.
+// One workgroup = 7 waves = one image x a strip of 2 pooled rows (5 conv rows, 15 input rows); wave w owns the
+// 16-pixel column segment w of all 5 conv rows (5 x 4 accumulator fragments).  Vertical 3-max in registers,
+// horizontal 3-max through a 28 KiB LDS tile aliased onto the dead patch/weight area.  Post-ReLU values are
+// >= 0, so padding positions may be treated as 0 and bf16 rounding (monotonic) commutes with max: the result
+// is bit-identical to stem_mfma_kernel followed by maxpool_kernel.
+constexpr int FPW = 232;                                   // patch row stride in pixels (230 used, even)
+constexpr int FROWS = 15;                                  // input rows of a strip
+__global__ void __launch_bounds__(448) stem_pool_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                        int n_split, const bf16_t* __restrict__ wpk,
+                                                        const float* __restrict__ scale,
+                                                        const float* __restrict__ shift, bf16_t* __restrict__ y) {
+    constexpr int WBYTES = 64 * SWLD * 2, PBYTES = (FROWS * FPW * 3 + 32) * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + PBYTES];
+    bf16_t* wsm = (bf16_t*)lds;
+    bf16_t* patch = (bf16_t*)(lds + WBYTES);
+    bf16_t* vm = (bf16_t*)lds;                              // [2][112][64], aliased after the MFMAs
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int strip = blockIdx.x, n = blockIdx.y, py0 = strip * 2;
+    {
+        const u32x4* src = (const u32x4*)wpk;
+        u32x4* dst = (u32x4*)wsm;
+        for (int i = tid; i < WBYTES / 16; i += 448) dst[i] = src[i];
+    }
+    const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
+    const int iy0 = 4 * py0 - 5;
+    for (int i = tid; i < 3 * FROWS * 56; i += 448) {      // float4 granules: (c, row, x4)
+        const int x4 = i % 56, t = i / 56, row = t % FROWS, c = t / FROWS;
+        const int iy = iy0 + row;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if ((unsigned)iy < (unsigned)IMG) v = *(const float4*)(xin + ((size_t)c * IMG + iy) * IMG + 4 * x4);
+        bf16_t* d = patch + (row * FPW + 4 * x4 + 3) * 3 + c;
+        d[0] = f32_to_bf16(v.x); d[3] = f32_to_bf16(v.y); d[6] = f32_to_bf16(v.z); d[9] = f32_to_bf16(v.w);
+    }
+    for (int i = tid; i < FROWS * 8 * 3; i += 448) {       // left 3 / right 5 pad pixels of every row
+        const int c = i % 3, t = i / 3, q = t % 8, row = t / 8;
+        const int px = q < 3 ? q : 227 + (q - 3);
+        patch[(row * FPW + px) * 3 + c] = 0;
+    }
+    if (tid < 32) patch[FROWS * FPW * 3 + tid] = 0;
+    __syncthreads();
+
+    const int lr = lane & 15, g = lane >> 4;
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int fm = 0; fm < 5; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int xo = wave * 16 + lr;                          // conv column of this lane
+#pragma unroll
+    for (int kb = 0; kb < SKB; ++kb) {
+        const int k0 = kb * 32 + g * 8;
+        const int r = k0 / 24, t0 = k0 - r * 24;
+        u32x4 wf[4], xf[5];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) wf[fn] = *(const u32x4*)(wsm + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
+        if (r < 7) {
+#pragma unroll
+            for (int fm = 0; fm < 5; ++fm) {
+                const uint32_t* pp = (const uint32_t*)(patch + ((2 * fm + r) * FPW + 2 * xo) * 3 + t0);
+                xf[fm].x = pp[0]; xf[fm].y = pp[1]; xf[fm].z = pp[2]; xf[fm].w = pp[3];
+            }
+        } else {
+#pragma unroll
+            for (int fm = 0; fm < 5; ++fm) xf[fm] = u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int fm = 0; fm < 5; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn)
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+    }
+    __syncthreads();                                        // patch / weights dead: vm may overwrite them
+    const bool row0_valid = py0 > 0;                        // conv row 2*py0-1 exists
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        const int ch = fn * 16 + g * 4;
+        const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
+        float v[5][4];
+#pragma unroll
+        for (int fm = 0; fm < 5; ++fm) {
+            v[fm][0] = fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f);
+            v[fm][1] = fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f);
+            v[fm][2] = fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f);
+            v[fm][3] = fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f);
+        }
+        if (!row0_valid) { v[0][0] = v[0][1] = v[0][2] = v[0][3] = 0.f; }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            uint2 o;
+            o.x = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][0], v[2 * pr + 1][0]), v[2 * pr + 2][0]),
+                              fmaxf(fmaxf(v[2 * pr][1], v[2 * pr + 1][1]), v[2 * pr + 2][1]));
+            o.y = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][2], v[2 * pr + 1][2]), v[2 * pr + 2][2]),
+                              fmaxf(fmaxf(v[2 * pr][3], v[2 * pr + 1][3]), v[2 * pr + 2][3]));
+            *(uint2*)(vm + ((pr * SO + xo) * SC + ch)) = o;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * PO * 8; i += 448) {           // (pr, px, 8-channel chunk)
+        const int c8 = i & 7, t = i >> 3, px = t % PO, pr = t / PO;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 0.f;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int cx = 2 * px + dx;
+            if (cx < 0) continue;
+            const u32x4 q = *(const u32x4*)(vm + ((pr * SO + cx) * SC + c8 * 8));
+            float lo, hi;
+            unpack_bf16x2(q.x, lo, hi); m[0] = fmaxf(m[0], lo); m[1] = fmaxf(m[1], hi);
+            unpack_bf16x2(q.y, lo, hi); m[2] = fmaxf(m[2], lo); m[3] = fmaxf(m[3], hi);
+            unpack_bf16x2(q.z, lo, hi); m[4] = fmaxf(m[4], lo); m[5] = fmaxf(m[5], hi);
+            unpack_bf16x2(q.w, lo, hi); m[6] = fmaxf(m[6], lo); m[7] = fmaxf(m[7], hi);
+        }
+        u32x4 o;
+        o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
+        o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
+        *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int total) {
     constexpr int EPC = 16 / sizeof(T), CPP = SC / EPC;          // chunks per pixel
@@ -242,6 +366,13 @@ hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_spli
                                     const float* scale, const float* shift, void* y, int n_img, hipStream_t st) {
     hipLaunchKernelGGL(stem_mfma_kernel, dim3(SO / 16, SO / 16, n_img), dim3(256), 0, st, x0, x1, n_split,
                        (const bf16_t*)w_packed, scale, shift, (bf16_t*)y);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
+                                const float* shift, void* y_pooled, int n_img, hipStream_t st) {
+    hipLaunchKernelGGL(stem_pool_kernel, dim3(PO / 2, n_img), dim3(448), 0, st, x0, x1, n_split,
+                       (const bf16_t*)w_packed, scale, shift, (bf16_t*)y_pooled);
     return hipGetLastError();
 }
 

@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--chunk", type=int, default=0, help="images per depth-first trunk chunk (0 = default)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-tail", action="store_true", help="time the network only (BASELINE config 2 shape)")
+    ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test aid)")
     args = ap.parse_args()
 
     import torch
@@ -96,8 +97,10 @@ def main():
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.batch
@@ -119,7 +122,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -137,7 +140,7 @@ def main():
         out = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -192,7 +195,7 @@ def main():
         if world == 1 and args.cpu_sample > 0:
             res["cpu_baseline"] = cpu_baseline(sd, md, args.cpu_sample)
         print(json.dumps(res))
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

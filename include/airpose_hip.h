@@ -109,6 +109,9 @@ int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset);
  * (like the BatchNorm fold).  on = 1 (default) evaluates the folded map, on = 0 the literal three-GEMM chain;
  * both are parity-tested against the reference. */
 int ap_net_set_fold(ap_net* h, int on);
+/* bf16 mode: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool kernels
+ * (bit-identical results; kept for A/B measurement). */
+int ap_net_set_fuse_stem(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);
 

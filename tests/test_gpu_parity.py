@@ -162,6 +162,18 @@ def test_trunk_bf16_close_to_golden(golden, netbf, copenet_inputs, dev):
     assert e0 < TOLBF
 
 
+def test_fused_stem_pool_is_bit_identical(netbf, dev):
+    """conv1+bn1+relu+maxpool fused kernel == stem kernel followed by the max-pool kernel, bit for bit."""
+    from airpose_amd import weights as W
+    x = torch.from_numpy(W.synthetic_inputs(5, 3)["im1"]).to(dev)
+    netbf.set_fuse_stem(1)
+    a = netbf.forward_feat_ext(x)
+    netbf.set_fuse_stem(0)
+    b = netbf.forward_feat_ext(x)
+    netbf.set_fuse_stem(1)
+    assert torch.equal(a, b)
+
+
 def test_trunk_batch_and_chunk_invariance(net32, dev):
     """Ragged batches and the depth-first chunking must not change any value (each output element has a
     fixed accumulation order)."""
