@@ -52,6 +52,16 @@ STEM_FLOPS_PER_IMAGE = 2 * 112 * 112 * 64 * 147
 REG_FLOPS_PER_PAIR = 2 * 3 * 2 * (2332 * 1024 + 1024 * 1024 + 1024 * 145)
 
 
+def pmc_traffic():
+    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+    profiles/r01_c_pmc_hbm_traffic.csv): counters cannot be collected inside the timed run itself."""
+    try:
+        with open(os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")) as f:
+            return json.load(f)["traffic_bytes_per_launch"]
+    except Exception:
+        return None
+
+
 def cpu_baseline(sd, md, sample_pairs):
     """Time the oracle (pure torch CPU restatement of the reference path) on a bounded sample."""
     import torch
@@ -169,9 +179,11 @@ def main():
                                    "copenet_twoview forward only (ResNet-50 x2 views, 3 IEF iterations)",
                        "pairs_per_gpu": B, "global_pairs": world * B, "image": "224x224", "ief_iters": 3,
                        "trunk_chunk_images": chunk, "sharding": "whole pairs per GPU, no data-path collective"},
-            "roofline": {"bound": "mfma", "kernel": "conv_igemm_kernel (implicit-GEMM conv + BN + residual + ReLU)",
+            "roofline": {"bound": "mfma",
+                         "kernel": "conv_pipe_kernel / conv_igemm_kernel: the 52 fused conv+BN(+residual)+ReLU launches "
+                                   "of one trunk pass (dominant instance conv_pipe_kernel<bf16,128,128,2,2,2>, 43 of 52)",
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
-                         "traffic": None,
+                         "traffic": pmc_traffic(),
                          "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,
                          "avg_launch_ms": conv_ms_step / launches},
             "stage_ms_per_step": {"stem_maxpool": tm["stem_ms"] / max(tm["passes"], 1), "conv_stack": conv_ms_step,
