@@ -126,6 +126,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
     const unsigned char* src[LPW];                           // row base + chunk, bytes
     int hi0[LPW], wi0[LPW];
     const int HoWo = p.Ho * p.Wo;
+    const bool pointwise = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
     const unsigned char* xg = (const unsigned char*)p.x;
     const unsigned char* wg = (const unsigned char*)p.w;
     const unsigned char* zg = (const unsigned char*)p.zero;
@@ -134,7 +135,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
         const int row = (wave * LPW + i) * 8 + prow;
         if ((wave * LPW + i) * 8 < BM) {                     // activation row (wave-uniform test)
             const int m = bm * BM + row;
-            if (m < p.M) {
+            if (m < p.M && pointwise) {
+                // 1x1 stride-1 conv (36 of the 52 trunk layers): output pixel m reads input pixel m, no decode
+                hi0[i] = 0;
+                wi0[i] = 0;
+                src[i] = xg + ((size_t)m * p.ldx + pchunk * EPC) * sizeof(T);
+            } else if (m < p.M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
                 hi0[i] = ho * p.stride - p.pad;
