@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
 // is bit-identical to stem_mfma_kernel followed by maxpool_kernel.
 constexpr int FPW = 232;                                   // patch row stride in pixels (230 used, even)
 constexpr int FROWS = 15;                                  // input rows of a strip
-__global__ void __launch_bounds__(448) stem_pool_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+__global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                         int n_split, const bf16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, bf16_t* __restrict__ y) {
