@@ -137,20 +137,15 @@ hipError_t zero_line(const void** out) {
 hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
     int cfg = g_conv_cfg;
     if (cfg < 0) {
-        // Measured on MI355X at 512 images (tools/conv_bench.py, profiles/r01_c_conv_configs.txt):
-        //   9  128x64  LDS-DMA ring, 3 workgroups/CU : the 64-channel layers of layer1
-        //   8  128x128 LDS-DMA ring, 2 workgroups/CU : everything else (two tiles per CU overlap one tile's
-        //      HBM-bound epilogue with the other's K loop)
-        //   0  256x128 ring, 8 waves, 1 workgroup/CU : deep contractions with 512 outputs (layer4 conv1/conv2)
-        //   100 register-staged kernel               : single-K-step / short-K layers without residual at
-        //      layer1 size, and small problems (64x64 tiles)
+        // Measured on MI355X at 512 images (tools/conv_bench.py, profiles/r01_d_conv_configs.txt): the 2-stage
+        // LDS-DMA ring with 8 waves per 128-row tile wins on every trunk layer -- two workgroups (16 waves) per CU
+        // run out of phase, so one tile's HBM-bound prologue/epilogue overlaps the other's MFMA loop:
+        //   11  128x128 tile, waves 2(M) x 4(N)   C_out >= 128
+        //   12  128x64  tile, waves 4(M) x 2(N)   C_out <= 64 (layer1 conv1/conv2)
+        //   100 register-staged kernel, 64x64 tiles: problems too small to fill the chip with 128-row tiles
         const long mt128 = (a.M + 127) / 128, nt128 = (a.Cout + 127) / 128;
-        const int K = a.KH * a.KW * a.Cin;
         if (mt128 * nt128 < 256) cfg = 100;
-        else if (a.Cout <= 64) cfg = K <= 64 ? 100 : 9;
-        else if (!a.res && K <= 256 && a.M >= 1000000) cfg = 100;
-        else if (K >= 1024 && a.Cout == 512 && mt128 * nt128 >= 1024) cfg = 0;
-        else cfg = 8;
+        else cfg = a.Cout <= 64 ? 12 : 11;
     }
     if (cfg == 100) return ap_launch_conv(a, is_bf16, st);
     hipError_t e = zero_line(&a.zero);
@@ -681,7 +676,7 @@ int ap_debug_set_trace(void* device_buf_160_u64) {
 }
 
 int ap_set_conv_config(int cfg) {
-    if (cfg != -1 && cfg != 100 && (cfg < 0 || cfg > 9)) return fail(AP_EINVAL, "ap_set_conv_config: -1, 0..9 or 100");
+    if (cfg != -1 && cfg != 100 && (cfg < 0 || cfg > 13)) return fail(AP_EINVAL, "ap_set_conv_config: -1, 0..13 or 100");
     g_conv_cfg = cfg;
     return AP_OK;
 }

@@ -473,6 +473,10 @@ hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStrea
             case 7: return launch_pipe<bf16_t, 256, 64, 4, 2, 3, true>(a, st);
             case 8: return launch_pipe<bf16_t, 128, 128, 2, 2, 2, false>(a, st);
             case 9: return launch_pipe<bf16_t, 128, 64, 2, 2, 2, false>(a, st);
+            case 10: return launch_pipe<bf16_t, 128, 128, 4, 2, 2, false>(a, st);
+            case 11: return launch_pipe<bf16_t, 128, 128, 2, 4, 2, false>(a, st);
+            case 12: return launch_pipe<bf16_t, 128, 64, 4, 2, 2, false>(a, st);
+            case 13: return launch_pipe<bf16_t, 128, 64, 8, 1, 2, false>(a, st);
         }
     } else {
         switch (cfg) {
@@ -486,6 +490,10 @@ hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStrea
             case 7: return launch_pipe<float, 256, 64, 4, 2, 3, true>(a, st);
             case 8: return launch_pipe<float, 128, 128, 2, 2, 2, false>(a, st);
             case 9: return launch_pipe<float, 128, 64, 2, 2, 2, false>(a, st);
+            case 10: return launch_pipe<float, 128, 128, 4, 2, 2, false>(a, st);
+            case 11: return launch_pipe<float, 128, 128, 2, 4, 2, false>(a, st);
+            case 12: return launch_pipe<float, 128, 64, 4, 2, 2, false>(a, st);
+            case 13: return launch_pipe<float, 128, 64, 8, 1, 2, false>(a, st);
         }
     }
     return hipErrorInvalidValue;

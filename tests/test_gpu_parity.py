@@ -111,8 +111,8 @@ CONV_CASES = [
 
 
 # -1 = automatic choice; 0..3 = LDS-DMA pipelined kernel (256x128, 128x128, 128x64, 256x64 tiles), 4..7 = the same
-# with the register epilogue; 100 = register-staged kernel
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 100])
+# with the register epilogue; 8..13 = 2-stage rings with 4 or 8 waves; 100 = register-staged kernel
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 100])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_primitive(dev, prec, case, cfg):
@@ -133,7 +133,7 @@ def test_conv_configs_agree_bitwise(dev):
     """Every tile configuration accumulates each output element in the same K order."""
     from airpose_amd import _native as Nn
     outs = []
-    for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 100):
+    for cfg in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 100):
         Nn.lib().ap_set_conv_config(cfg)
         try:
             got, _ = _conv_case(dev, "bf16", 3, 28, 128, 192, 3, 1, 1, True, True, seed=5)
