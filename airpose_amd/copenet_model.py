@@ -254,6 +254,10 @@ class copenet(nn.Module):
         N.check(N.lib().ap_net_set_fold(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_fold")
 
+    def set_fuse_ds(self, on):
+        N.check(N.lib().ap_net_set_fuse_ds(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+                "ap_net_set_fuse_ds")
+
     def set_fuse_stem(self, on):
         N.check(N.lib().ap_net_set_fuse_stem(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_fuse_stem")

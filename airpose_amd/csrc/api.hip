@@ -67,6 +67,7 @@ struct HostTensor {
 struct Layer {                  // a conv or linear layer in packed device form
     int cin = 0, cout = 0, k = 1, stride = 1, pad = 0;
     int wld = 0, cout_pad = 0;
+    int cin2 = 0, stride2 = 1;      // second K segment (downsample folded into conv3)
     DevBuf w, scale, shift;
 };
 
@@ -163,12 +164,13 @@ struct ap_net {
     std::map<std::string, HostTensor> tensors;
     // trunk
     DevBuf stem_w, stem_wpk, stem_scale, stem_shift;
-    struct Block { Layer c1, c2, c3, down; bool has_down = false; };
+    struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false; };
     std::vector<Block> blocks;
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
     Layer fold_feat, fold_state;   // dec o fc2 o fc1 folded into one 145 x 2332 map (no activation between them)
     bool fold = true;
+    bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
     bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape;
     // workspace
@@ -251,6 +253,41 @@ int pack_conv(ap_net* h, const std::string& wname, const std::string& bnname, in
     return AP_OK;
 }
 
+// conv3 (1x1, planes -> cout) and the downsample conv (1x1 stride s, inplanes -> cout) of a stage's first block
+// share the output: relu(bn3(conv3(t)) + bn_ds(conv_ds(x))).  Fold each BN scale into its weights (fp64) and
+// concatenate along K: one GEMM over [t | x(strided)] with shift = shift3 + shift_ds, no residual tensor.
+int pack_c3_ds(ap_net* h, const std::string& P, int planes, int inplanes, int stride, Layer& L) {
+    const HostTensor *w3 = find(h, P + ".conv3.weight"), *wd = find(h, P + ".downsample.0.weight");
+    if (!w3 || !wd) return fail(AP_ESTATE, "missing conv3/downsample weights for " + P);
+    const int cout = planes * 4, K1 = planes, K2 = inplanes;
+    if ((int)w3->numel() != cout * K1 || (int)wd->numel() != cout * K2) return fail(AP_ESHAPE, "shape mismatch in " + P);
+    std::vector<float> s3, h3, sd, hd;
+    int rc = bn_fold(h, P + ".bn3", cout, s3, h3);
+    if (rc) return rc;
+    if ((rc = bn_fold(h, P + ".downsample.1", cout, sd, hd))) return rc;
+    L.cin = K1; L.cout = cout; L.k = 1; L.stride = 1; L.pad = 0;
+    L.cin2 = K2; L.stride2 = stride;
+    L.wld = K1 + K2;
+    L.cout_pad = ((cout + 127) / 128) * 128;
+    const size_t n = (size_t)L.cout_pad * L.wld;
+    std::vector<float> pk(n, 0.f), scale(L.cout_pad, 1.f), shift(L.cout_pad, 0.f);
+    for (int o = 0; o < cout; ++o) {
+        for (int c = 0; c < K1; ++c) pk[(size_t)o * L.wld + c] = (float)((double)w3->data[(size_t)o * K1 + c] * (double)s3[o]);
+        for (int c = 0; c < K2; ++c) pk[(size_t)o * L.wld + K1 + c] = (float)((double)wd->data[(size_t)o * K2 + c] * (double)sd[o]);
+        shift[o] = h3[o] + hd[o];
+    }
+    if (h->prec == AP_PREC_BF16) {
+        std::vector<uint16_t> pb(n);
+        for (size_t i = 0; i < n; ++i) pb[i] = host_f32_to_bf16(pk[i]);
+        HIP_TRY(upload(L.w, pb.data(), n * 2));
+    } else {
+        HIP_TRY(upload(L.w, pk.data(), n * 4));
+    }
+    HIP_TRY(upload(L.scale, scale.data(), scale.size() * 4));
+    HIP_TRY(upload(L.shift, shift.data(), shift.size() * 4));
+    return AP_OK;
+}
+
 // fp32 GEMM operand from rows [out][ld_src] taking columns [col0, col0+ncols); K padded to 32
 int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const float* bias, Layer& L) {
     L.cin = ((ncols + 31) / 32) * 32;
@@ -281,6 +318,21 @@ int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const 
     a.M = N * a.Ho * a.Wo;
     a.ldx = L.cin; a.ldy = L.cout; a.ldr = L.cout; a.wld = L.wld;
     a.relu = relu;
+    HIP_TRY(dispatch_conv(a, is_bf16, st));
+    return AP_OK;
+}
+
+// fused conv3 + downsample of a stage's first block: t [N][Ho][Ho][cin] (pointwise) and x [N][Hin][Hin][cin2]
+// sampled with stride2, concatenated along K
+int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int Hin, void* y, int is_bf16,
+              hipStream_t st) {
+    ConvArgs a{};
+    a.x = t; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = nullptr; a.y = y;
+    a.N = N; a.H = Ho; a.W = Ho; a.Cin = L.cin; a.Ho = Ho; a.Wo = Ho; a.Cout = L.cout;
+    a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
+    a.M = N * Ho * Ho;
+    a.ldx = L.cin; a.ldy = L.cout; a.ldr = L.cout; a.wld = L.wld; a.relu = 1;
+    a.x2 = x; a.H2 = Hin; a.W2 = Hin; a.Cin2 = L.cin2; a.stride2 = L.stride2; a.ldx2 = L.cin2;
     HIP_TRY(dispatch_conv(a, is_bf16, st));
     return AP_OK;
 }
@@ -341,10 +393,12 @@ int finalize_trunk(ap_net* h) {
             if ((rc = pack_conv(h, P + ".conv2.weight", P + ".bn2", pl, pl, 3, stride, 1, B.c2))) return rc;
             if ((rc = pack_conv(h, P + ".conv3.weight", P + ".bn3", pl, pl * 4, 1, 1, 0, B.c3))) return rc;
             B.has_down = bi == 0;
-            if (B.has_down)
+            if (B.has_down) {
                 if ((rc = pack_conv(h, P + ".downsample.0.weight", P + ".downsample.1", inpl, pl * 4, 1, stride, 0,
                                     B.down)))
                     return rc;
+                if ((rc = pack_c3_ds(h, P, pl, inpl, stride, B.c3ds))) return rc;
+            }
             inpl = pl * 4;
         }
     return AP_OK;
@@ -443,12 +497,16 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
         if ((rc = run_conv(B.c1, cur, n, H, H, h->ws_t1.p, nullptr, 1, bf, st))) return rc;
         if ((rc = run_conv(B.c2, h->ws_t1.p, n, H, H, h->ws_t2.p, nullptr, 1, bf, st))) return rc;
-        const void* res = cur;
-        if (B.has_down) {
-            if ((rc = run_conv(B.down, cur, n, H, H, h->ws_ds.p, nullptr, 0, bf, st))) return rc;
-            res = h->ws_ds.p;
+        if (B.has_down && h->fuse_ds) {
+            if ((rc = run_c3_ds(B.c3ds, h->ws_t2.p, cur, n, Ho, H, nxt, bf, st))) return rc;
+        } else {
+            const void* res = cur;
+            if (B.has_down) {
+                if ((rc = run_conv(B.down, cur, n, H, H, h->ws_ds.p, nullptr, 0, bf, st))) return rc;
+                res = h->ws_ds.p;
+            }
+            if ((rc = run_conv(B.c3, h->ws_t2.p, n, Ho, Ho, nxt, res, 1, bf, st))) return rc;
         }
-        if ((rc = run_conv(B.c3, h->ws_t2.p, n, Ho, Ho, nxt, res, 1, bf, st))) return rc;
         std::swap(cur, nxt);
         H = Ho;
     }
@@ -571,7 +629,7 @@ void ap_net_destroy(ap_net* h) {
                       &h->ws_D, &h->ws_state})
         b->release();
     auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
-    for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); }
+    for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); rel(B.c3ds); }
     rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec); rel(h->fold_feat); rel(h->fold_state);
     h->tm.destroy();
     delete h;
@@ -690,6 +748,12 @@ int ap_net_enable_timing(ap_net* h, int on) {
 int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset) {
     if (!h || !ms || !passes) return fail(AP_EINVAL, "ap_net_timing: null argument");
     HIP_TRY(h->tm.collect(ms, 4, passes, reset != 0));
+    return AP_OK;
+}
+
+int ap_net_set_fuse_ds(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fuse_ds = on != 0;
     return AP_OK;
 }
 

@@ -96,24 +96,46 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     const T* wptr[WR];
 #pragma unroll
     for (int j = 0; j < WR; ++j) wptr[j] = wg + (size_t)(bn * BN + lrow0 + 32 * j) * p.wld + lc * EPC;
+    // second K segment (downsample branch): row pointers into x2 at the strided pixel
+    const T* x2ptr[XR];
+#pragma unroll
+    for (int i = 0; i < XR; ++i) {
+        const int m = bm * BM + lrow0 + 32 * i;
+        x2ptr[i] = nullptr;
+        if (p.x2 && m < p.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            x2ptr[i] = (const T*)p.x2 + (((size_t)n * p.H2 + (size_t)ho * p.stride2) * p.W2 + (size_t)wo * p.stride2) * p.ldx2 + lc * EPC;
+        }
+    }
 
     u32x4 xs[XR], ws[WR];
     const int cpb = p.Cin / BK;                 // channel chunks per tap
-    const int KT = p.KH * p.KW * cpb;
+    const int cpb2 = p.x2 ? p.Cin2 / BK : 0;    // chunks of the second K segment
+    const int KT = p.KH * p.KW * cpb + cpb2;
     int r = 0, s = 0, cb = 0;                   // tap / channel-chunk of the tile being LOADED
 
     auto load_tile = [&](int kt) {
-        const ptrdiff_t xoff = ((ptrdiff_t)r * p.W + s) * p.ldx + cb * BK;
+        if (r < p.KH) {
+            const ptrdiff_t xoff = ((ptrdiff_t)r * p.W + s) * p.ldx + cb * BK;
 #pragma unroll
-        for (int i = 0; i < XR; ++i) {
-            // unconditional load from a safe address + select: no branch, no scratch
-            const bool ok = (unsigned)(hi0[i] + r) < (unsigned)p.H && (unsigned)(wi0[i] + s) < (unsigned)p.W;
-            const u32x4 v = *(const u32x4*)(ok ? xptr[i] + xoff : xg);
-            xs[i].x = ok ? v.x : 0u; xs[i].y = ok ? v.y : 0u; xs[i].z = ok ? v.z : 0u; xs[i].w = ok ? v.w : 0u;
+            for (int i = 0; i < XR; ++i) {
+                // unconditional load from a safe address + select: no branch, no scratch
+                const bool ok = (unsigned)(hi0[i] + r) < (unsigned)p.H && (unsigned)(wi0[i] + s) < (unsigned)p.W;
+                const u32x4 v = *(const u32x4*)(ok ? xptr[i] + xoff : xg);
+                xs[i].x = ok ? v.x : 0u; xs[i].y = ok ? v.y : 0u; xs[i].z = ok ? v.z : 0u; xs[i].w = ok ? v.w : 0u;
+            }
+        } else {                                // second segment: 1x1 on x2
+#pragma unroll
+            for (int i = 0; i < XR; ++i) {
+                const bool ok = x2ptr[i] != nullptr;
+                const u32x4 v = *(const u32x4*)(ok ? x2ptr[i] + cb * BK : xg);
+                xs[i].x = ok ? v.x : 0u; xs[i].y = ok ? v.y : 0u; xs[i].z = ok ? v.z : 0u; xs[i].w = ok ? v.w : 0u;
+            }
         }
 #pragma unroll
         for (int j = 0; j < WR; ++j) ws[j] = *(const u32x4*)(wptr[j] + (size_t)kt * BK);
-        if (++cb == cpb) { cb = 0; if (++s == p.KW) { s = 0; ++r; } }
+        if (++cb == (r < p.KH ? cpb : cpb2)) { cb = 0; if (r < p.KH && ++s == p.KW) { s = 0; ++r; } }
     };
     const int st_off = lrow0 * 128 + ((lc ^ (lrow0 & 7)) << 4);
     auto store_tile = [&](int buf) {

@@ -124,7 +124,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
     const int prow = lane >> 3;                              // row within an 8-row piece
     const int pchunk = (lane & 7) ^ prow;                    // source chunk (swizzle on the source side)
     const unsigned char* src[LPW];                           // row base + chunk, bytes
-    int hi0[LPW], wi0[LPW];
+    int hw0[LPW];                                            // (hi0 << 16) | (wi0 & 0xffff), both small signed
     const int HoWo = p.Ho * p.Wo;
     const bool pointwise = p.KH == 1 && p.KW == 1 && p.stride == 1 && p.pad == 0;
     const unsigned char* xg = (const unsigned char*)p.x;
@@ -137,56 +137,75 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             const int m = bm * BM + row;
             if (m < p.M && pointwise) {
                 // 1x1 stride-1 conv (36 of the 52 trunk layers): output pixel m reads input pixel m, no decode
-                hi0[i] = 0;
-                wi0[i] = 0;
+                hw0[i] = 0;
                 src[i] = xg + ((size_t)m * p.ldx + pchunk * EPC) * sizeof(T);
             } else if (m < p.M) {
                 const int n = m / HoWo, rem = m - n * HoWo;
                 const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-                hi0[i] = ho * p.stride - p.pad;
-                wi0[i] = wo * p.stride - p.pad;
-                src[i] = xg + (((size_t)n * p.H * p.W + (ptrdiff_t)hi0[i] * p.W + wi0[i]) * p.ldx + pchunk * EPC) * sizeof(T);
+                const int h0 = ho * p.stride - p.pad, w0 = wo * p.stride - p.pad;
+                hw0[i] = (h0 << 16) | (w0 & 0xffff);
+                src[i] = xg + (((size_t)n * p.H * p.W + (ptrdiff_t)h0 * p.W + w0) * p.ldx + pchunk * EPC) * sizeof(T);
             } else {
-                hi0[i] = -0x40000000;
-                wi0[i] = 0;
+                hw0[i] = (int)0xc0000000;                    // hi0 = -16384: never passes the bounds test
                 src[i] = zg;
             }
         } else {                                             // weight row: always valid (rows padded to 128)
-            hi0[i] = 0;
-            wi0[i] = 0;
+            hw0[i] = 0;
             src[i] = wg + ((size_t)(bn * BN + row - BM) * p.wld + pchunk * EPC) * sizeof(T);
         }
     }
     const int cpb = p.Cin / BK;
-    const int KT = p.KH * p.KW * cpb;
+    constexpr bool SEG2 = BN >= 128;                         // 64-channel tiles never see a folded downsample
+    const int cpb2 = (SEG2 && p.x2) ? p.Cin2 / BK : 0;       // chunks of the second K segment (folded downsample)
+    const int KT = p.KH * p.KW * cpb + cpb2;
     int r = 0, s = 0, cb = 0;                                // tap / channel chunk of the tile being ISSUED
+    // second K segment: per-piece byte offsets into x2 at the strided pixel (1x1, always in bounds; 32-bit keeps
+    // the kernel inside the 128-VGPR budget of two 8-wave workgroups per CU)
+    uint32_t off2[SEG2 ? LPW : 1];
+#pragma unroll
+    for (int i = 0; i < (SEG2 ? LPW : 0); ++i) {
+        off2[i] = 0xffffffffu;
+        const int m = bm * BM + (wave * LPW + i) * 8 + prow;
+        if (p.x2 && (wave * LPW + i) * 8 < BM && m < p.M) {
+            const int n = m / HoWo, rem = m - n * HoWo;
+            const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            off2[i] = (uint32_t)(((((size_t)n * p.H2 + (size_t)ho * p.stride2) * p.W2 + (size_t)wo * p.stride2) * p.ldx2 +
+                                  pchunk * EPC) * sizeof(T));
+        }
+    }
     // Per-piece running source pointers.  Address arithmetic is done once per TAP (every cpb K steps), a K
     // step inside a tap only adds the per-lane increment (0 for predicated-off lanes, which sit on the zero
     // line): the VALU work between the barrier and the MFMAs was what the 8 lock-stepped waves were waiting on.
     const unsigned char* cur[LPW];
-    uint32_t inc[LPW];
+    uint32_t live = 0xffffffffu;                             // bit i: piece i advances (0 = parked on the zero line)
 #pragma unroll
-    for (int i = 0; i < LPW; ++i) {
-        cur[i] = src[i];
-        inc[i] = BK * sizeof(T);
-    }
+    for (int i = 0; i < LPW; ++i) cur[i] = src[i];
 
     // per-tap pointer refresh for one piece (only when a new tap starts: wave-uniform branch)
     auto prep_piece = [&](int i) {
         if (cb == 0 && (wave * LPW + i) * 8 < BM) {
-            const ptrdiff_t xoff = ((ptrdiff_t)r * p.W + s) * p.ldx * (ptrdiff_t)sizeof(T);
-            const bool ok = (unsigned)(hi0[i] + r) < (unsigned)p.H && (unsigned)(wi0[i] + s) < (unsigned)p.W;
-            cur[i] = ok ? src[i] + xoff : zg;
-            inc[i] = ok ? (uint32_t)(BK * sizeof(T)) : 0u;
+            if (r < p.KH) {
+                const ptrdiff_t xoff = ((ptrdiff_t)r * p.W + s) * p.ldx * (ptrdiff_t)sizeof(T);
+                const int h0 = hw0[i] >> 16, w0 = (int)(short)(hw0[i] & 0xffff);
+                const bool ok = (unsigned)(h0 + r) < (unsigned)p.H && (unsigned)(w0 + s) < (unsigned)p.W;
+                cur[i] = ok ? src[i] + xoff : zg;
+                live = ok ? (live | (1u << i)) : (live & ~(1u << i));
+            } else if constexpr (SEG2) {                     // entering the second K segment
+                const bool ok = off2[i] != 0xffffffffu;
+                cur[i] = ok ? (const unsigned char*)p.x2 + off2[i] : zg;
+                live = ok ? (live | (1u << i)) : (live & ~(1u << i));
+            }
         }
     };
-    auto advance_tap = [&]() { if (++cb == cpb) { cb = 0; if (++s == p.KW) { s = 0; ++r; } } };
+    auto advance_tap = [&]() {
+        if (++cb == (r < p.KH ? cpb : cpb2)) { cb = 0; if (r < p.KH && ++s == p.KW) { s = 0; ++r; } }
+    };
     auto issue_piece = [&](int i, int stage) {               // one 1-KiB LDS-DMA piece of the tile
         const int piece = wave * LPW + i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)cur[i],
                                          (__attribute__((address_space(3))) void*)(smem + stage * STAGE + piece * 1024),
                                          16, 0, 0);
-        cur[i] += inc[i];
+        cur[i] += ((live >> i) & 1u) ? (uint32_t)(BK * sizeof(T)) : 0u;
     };
     auto issue_tile = [&](int stage) {
 #pragma unroll

@@ -12,6 +12,11 @@ struct ConvArgs {
     void* y;              // [M][ldy]
     const void* zero;     // >= 16 bytes of zeros (DMA source of predicated-off rows; conv_pipe only)
     unsigned long long* dbg;  // optional per-phase cycle stamps (profiling builds; NULL otherwise)
+    // optional second K segment (downsample branch folded into conv3): after the KH*KW*Cin regular columns the
+    // contraction continues over Cin2 channels of x2 sampled at pixel (ho*stride2, wo*stride2) -- a 1x1 conv whose
+    // weights follow in the same packed row (wld = KH*KW*Cin + Cin2)
+    const void* x2;
+    int H2, W2, Cin2, stride2, ldx2;
     int N, H, W, Cin;
     int Ho, Wo, Cout;     // Cout: number of stored channels (multiple of 16 B / sizeof(T))
     int KH, KW, stride, pad;

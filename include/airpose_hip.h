@@ -109,6 +109,11 @@ int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset);
  * (like the BatchNorm fold).  on = 1 (default) evaluates the folded map, on = 0 the literal three-GEMM chain;
  * both are parity-tested against the reference. */
 int ap_net_set_fold(ap_net* h, int on);
+/* First block of a stage: on = 1 (default) folds the downsample branch into conv3 as a second K segment
+ * (relu(bn3(conv3(t)) + bn_ds(conv_ds(x))) as ONE GEMM over [t | x]: both BN scales folded into the weights in
+ * fp64, no downsample tensor written or re-read); on = 0 runs the two convolutions of Bottleneck.forward
+ * (model_copenet.py:38-45) separately.  Both are parity-tested. */
+int ap_net_set_fuse_ds(ap_net* h, int on);
 /* bf16 mode: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool kernels
  * (bit-identical results; kept for A/B measurement). */
 int ap_net_set_fuse_stem(ap_net* h, int on);

@@ -174,6 +174,22 @@ def test_fused_stem_pool_is_bit_identical(netbf, dev):
     assert torch.equal(a, b)
 
 
+def test_folded_downsample_matches_separate_convs(net32, netbf, golden, copenet_inputs, dev):
+    """Downsample branch folded into conv3 (second K segment) vs the two separate convolutions."""
+    x = copenet_inputs["im0"].to(dev)
+    g = golden["copenet_b2"]
+    for net, tol in ((net32, 1e-5), (netbf, 2e-2)):
+        net.set_fuse_ds(1)
+        a = net.forward_feat_ext(x)
+        net.set_fuse_ds(0)
+        b = net.forward_feat_ext(x)
+        net.set_fuse_ds(1)
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < tol
+    net32.set_fuse_ds(0)
+    assert rel_err(net32.forward_feat_ext(x).cpu().numpy(), g["xf0"]) < TOL32      # literal path still at parity
+    net32.set_fuse_ds(1)
+
+
 def test_trunk_batch_and_chunk_invariance(net32, dev):
     """Ragged batches and the depth-first chunking must not change any value (each output element has a
     fixed accumulation order)."""
