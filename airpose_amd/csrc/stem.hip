@@ -159,9 +159,12 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
 // the 112x112x64 stem activation (1.6 MB/image) never touches HBM.
 // One workgroup = 7 waves = one image x a strip of 2 pooled rows (5 conv rows, 15 input rows); wave w owns the
 // 16-pixel column segment w of all 5 conv rows (5 x 4 accumulator fragments).  Vertical 3-max in registers,
-// horizontal 3-max through a 28 KiB LDS tile aliased onto the dead patch/weight area.  Post-ReLU values are
+// horizontal 3-max through a 28 KiB LDS tile.  Post-ReLU values are
 // >= 0, so padding positions may be treated as 0 and bf16 rounding (monotonic) commutes with max: the result
 // is bit-identical to stem_mfma_kernel followed by maxpool_kernel.
+#ifndef AP_STEM_PASSES
+#define AP_STEM_PASSES 1
+#endif
 constexpr int FPW = 232;                                   // patch row stride in pixels (230 used, even)
 constexpr int FROWS = 15;                                  // input rows of a strip
 __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
@@ -169,10 +172,11 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, bf16_t* __restrict__ y) {
     constexpr int WBYTES = 64 * SWLD * 2, PBYTES = (FROWS * FPW * 3 + 32) * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + PBYTES];
+    constexpr int VBYTES = 2 * SO * SC * 2;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + PBYTES + VBYTES];
     bf16_t* wsm = (bf16_t*)lds;
     bf16_t* patch = (bf16_t*)(lds + WBYTES);
-    bf16_t* vm = (bf16_t*)lds;                              // [2][112][64], aliased after the MFMAs
+    bf16_t* vm = (bf16_t*)(lds + WBYTES + PBYTES);           // [2][112][64] vertically pooled rows
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int strip = blockIdx.x, n = blockIdx.y, py0 = strip * 2;
     {
@@ -199,59 +203,66 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
     __syncthreads();
 
     const int lr = lane & 15, g = lane >> 4;
-    f32x4 acc[5][4];
-#pragma unroll
-    for (int fm = 0; fm < 5; ++fm)
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int xo = wave * 16 + lr;                          // conv column of this lane
-#pragma unroll
-    for (int kb = 0; kb < SKB; ++kb) {
-        const int k0 = kb * 32 + g * 8;
-        const int r = k0 / 24, t0 = k0 - r * 24;
-        u32x4 wf[4], xf[5];
-#pragma unroll
-        for (int fn = 0; fn < 4; ++fn) wf[fn] = *(const u32x4*)(wsm + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
-        if (r < 7) {
-#pragma unroll
-            for (int fm = 0; fm < 5; ++fm) {
-                const uint32_t* pp = (const uint32_t*)(patch + ((2 * fm + r) * FPW + 2 * xo) * 3 + t0);
-                xf[fm].x = pp[0]; xf[fm].y = pp[1]; xf[fm].z = pp[2]; xf[fm].w = pp[3];
-            }
-        } else {
-#pragma unroll
-            for (int fm = 0; fm < 5; ++fm) xf[fm] = u32x4{0u, 0u, 0u, 0u};
-        }
+    const bool row0_valid = py0 > 0;                        // conv row 2*py0-1 exists
+    // AP_STEM_PASSES = 1: all 64 output channels in one pass over K (80 accumulator registers, 124 VGPRs, no
+    // spill as long as the K-block loop is NOT unrolled: unrolling makes hipcc pre-compute every fragment address
+    // and spill accumulators to scratch).  = 2: two passes of 32 channels (79 VGPRs), measured 15 % slower.
+    constexpr int NH = AP_STEM_PASSES, FNH = 4 / NH;
+#pragma unroll 1
+    for (int half = 0; half < NH; ++half) {
+        f32x4 acc[5][FNH];
 #pragma unroll
         for (int fm = 0; fm < 5; ++fm)
 #pragma unroll
-            for (int fn = 0; fn < 4; ++fn)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
-    }
-    __syncthreads();                                        // patch / weights dead: vm may overwrite them
-    const bool row0_valid = py0 > 0;                        // conv row 2*py0-1 exists
+            for (int fn = 0; fn < FNH; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+        for (int kb = 0; kb < SKB; ++kb) {
+            const int k0 = kb * 32 + g * 8;
+            const int r = k0 / 24, t0 = k0 - r * 24;
+            u32x4 wf[FNH], xf[5];
 #pragma unroll
-    for (int fn = 0; fn < 4; ++fn) {
-        const int ch = fn * 16 + g * 4;
-        const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
-        float v[5][4];
+            for (int fn = 0; fn < FNH; ++fn)
+                wf[fn] = *(const u32x4*)(wsm + ((half * FNH + fn) * 16 + lr) * SWLD + kb * 32 + g * 8);
+            if (r < 7) {
 #pragma unroll
-        for (int fm = 0; fm < 5; ++fm) {
-            v[fm][0] = fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f);
-            v[fm][1] = fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f);
-            v[fm][2] = fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f);
-            v[fm][3] = fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f);
+                for (int fm = 0; fm < 5; ++fm) {
+                    const uint32_t* pp = (const uint32_t*)(patch + ((2 * fm + r) * FPW + 2 * xo) * 3 + t0);
+                    xf[fm].x = pp[0]; xf[fm].y = pp[1]; xf[fm].z = pp[2]; xf[fm].w = pp[3];
+                }
+            } else {
+#pragma unroll
+                for (int fm = 0; fm < 5; ++fm) xf[fm] = u32x4{0u, 0u, 0u, 0u};
+            }
+#pragma unroll
+            for (int fm = 0; fm < 5; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FNH; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
         }
-        if (!row0_valid) { v[0][0] = v[0][1] = v[0][2] = v[0][3] = 0.f; }
 #pragma unroll
-        for (int pr = 0; pr < 2; ++pr) {
-            uint2 o;
-            o.x = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][0], v[2 * pr + 1][0]), v[2 * pr + 2][0]),
-                              fmaxf(fmaxf(v[2 * pr][1], v[2 * pr + 1][1]), v[2 * pr + 2][1]));
-            o.y = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][2], v[2 * pr + 1][2]), v[2 * pr + 2][2]),
-                              fmaxf(fmaxf(v[2 * pr][3], v[2 * pr + 1][3]), v[2 * pr + 2][3]));
-            *(uint2*)(vm + ((pr * SO + xo) * SC + ch)) = o;
+        for (int fn = 0; fn < FNH; ++fn) {
+            const int ch = (half * FNH + fn) * 16 + g * 4;
+            const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
+            float v[5][4];
+#pragma unroll
+            for (int fm = 0; fm < 5; ++fm) {
+                v[fm][0] = fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f);
+                v[fm][1] = fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f);
+                v[fm][2] = fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f);
+                v[fm][3] = fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f);
+            }
+            if (!row0_valid) { v[0][0] = v[0][1] = v[0][2] = v[0][3] = 0.f; }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                uint2 o;
+                o.x = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][0], v[2 * pr + 1][0]), v[2 * pr + 2][0]),
+                                  fmaxf(fmaxf(v[2 * pr][1], v[2 * pr + 1][1]), v[2 * pr + 2][1]));
+                o.y = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][2], v[2 * pr + 1][2]), v[2 * pr + 2][2]),
+                                  fmaxf(fmaxf(v[2 * pr][3], v[2 * pr + 1][3]), v[2 * pr + 2][3]));
+                *(uint2*)(vm + ((pr * SO + xo) * SC + ch)) = o;
+            }
         }
     }
     __syncthreads();

@@ -54,9 +54,9 @@ REG_FLOPS_PER_PAIR = 2 * 3 * 2 * (2332 * 1024 + 1024 * 1024 + 1024 * 145)
 
 def pmc_traffic():
     """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
-    profiles/r01_c_pmc_hbm_traffic.csv): counters cannot be collected inside the timed run itself."""
+    profiles/r01_d_pmc_hbm_traffic.csv): counters cannot be collected inside the timed run itself."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_c_pmc_traffic.json")) as f:
+        with open(os.path.join(REPO, "profiles", "r01_d_pmc_traffic.json")) as f:
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None

@@ -5,6 +5,7 @@ import sqlite3
 import sys
 
 db, n = sys.argv[1], int(sys.argv[2])
+FUSED_DS = len(sys.argv) > 3 and sys.argv[3] == "fused_ds"
 c = sqlite3.connect(db)
 rows = list(c.execute("select name, start, end, duration, grid_x from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if "stem" in r[0]]
@@ -17,9 +18,13 @@ for li, (pl, nb) in enumerate(zip(planes, layers)):
         Ho = H // st
         shapes.append(("l%d.%d.c1" % (li + 1, bi), n * H * H, pl, inpl, n * H * H * inpl, 0))
         shapes.append(("l%d.%d.c2" % (li + 1, bi), n * Ho * Ho, pl, pl * 9, n * H * H * pl, 0))
-        if bi == 0:
+        if bi == 0 and not FUSED_DS:
             shapes.append(("l%d.%d.ds" % (li + 1, bi), n * Ho * Ho, pl * 4, inpl, n * H * H * inpl // (st * st), 0))
-        shapes.append(("l%d.%d.c3" % (li + 1, bi), n * Ho * Ho, pl * 4, pl, n * Ho * Ho * pl, 1))
+        if bi == 0 and FUSED_DS:   # conv3 + downsample as one GEMM over K = planes + inplanes
+            shapes.append(("l%d.%d.c3d" % (li + 1, bi), n * Ho * Ho, pl * 4, pl + inpl,
+                           n * Ho * Ho * pl + n * H * H * inpl // (st * st), 0))
+        else:
+            shapes.append(("l%d.%d.c3" % (li + 1, bi), n * Ho * Ho, pl * 4, pl, n * Ho * Ho * pl, 1))
         inpl, H = pl * 4, Ho
 k = i0 + 1
 while "conv_" not in rows[k][0]:
