@@ -172,7 +172,7 @@ struct ap_net {
     bool fold = true;
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
     bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
-    DevBuf mean_pose, mean_shape;
+    DevBuf mean_pose, mean_shape, mean_cam;
     // workspace
     int chunk = 0;
     DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds, ws_feat;
@@ -411,7 +411,53 @@ int finalize_regressor(ap_net* h) {
                      *is = find(h, "init_shape");
     if (!w1 || !b1 || !w2 || !b2 || !wp || !bp || !wsh || !bsh || !ip || !is)
         return fail(AP_ESTATE, "missing regressor tensors (fc1/fc2/decpose/decshape/init_pose/init_shape)");
-    if (h->variant != 0) return AP_OK;   // hmr head: trunk only in this build
+    if (h->variant == 1) {
+        // single-view HMR head (model_hmr.py:160-172): xc = [xf | pose132 | shape10 | cam3] -> fc1 -> fc2 ->
+        // decpose/decshape/deccam, all affine: folded like the copenet head into Wf (145 x 2193), bf
+        const HostTensor *wc = find(h, "deccam.weight"), *bc = find(h, "deccam.bias"), *ic = find(h, "init_cam");
+        if (!wc || !bc || !ic) return fail(AP_ESTATE, "missing deccam / init_cam tensors");
+        if (w1->numel() != (size_t)1024 * 2193 || w2->numel() != (size_t)1024 * 1024 || wp->numel() != (size_t)132 * 1024 ||
+            wsh->numel() != (size_t)10 * 1024 || wc->numel() != (size_t)3 * 1024 || ip->numel() < 132 || is->numel() != 10)
+            return fail(AP_ESHAPE, "hmr regressor tensor shape mismatch");
+        std::vector<float> wd((size_t)145 * 1024), bd(145);
+        memcpy(wd.data(), wp->data.data(), (size_t)132 * 1024 * 4);
+        memcpy(wd.data() + (size_t)132 * 1024, wsh->data.data(), (size_t)10 * 1024 * 4);
+        memcpy(wd.data() + (size_t)142 * 1024, wc->data.data(), (size_t)3 * 1024 * 4);
+        memcpy(bd.data(), bp->data.data(), 132 * 4);
+        memcpy(bd.data() + 132, bsh->data.data(), 10 * 4);
+        memcpy(bd.data() + 142, bc->data.data(), 3 * 4);
+        std::vector<double> A((size_t)145 * 1024, 0.0);
+        for (int o = 0; o < 145; ++o)
+            for (int k = 0; k < 1024; ++k) {
+                const double wv = wd[(size_t)o * 1024 + k];
+                const float* w2r = &w2->data[(size_t)k * 1024];
+                double* ar = &A[(size_t)o * 1024];
+                for (int j = 0; j < 1024; ++j) ar[j] += wv * w2r[j];
+            }
+        std::vector<float> wf((size_t)145 * 2193), bfv(145);
+        std::vector<double> row(2193);
+        for (int o = 0; o < 145; ++o) {
+            std::fill(row.begin(), row.end(), 0.0);
+            double bacc = bd[o];
+            for (int k = 0; k < 1024; ++k) {
+                const double av = A[(size_t)o * 1024 + k];
+                const float* w1r = &w1->data[(size_t)k * 2193];
+                for (int j = 0; j < 2193; ++j) row[j] += av * w1r[j];
+                bacc += av * b1->data[k] + (double)wd[(size_t)o * 1024 + k] * b2->data[k];
+            }
+            for (int j = 0; j < 2193; ++j) wf[(size_t)o * 2193 + j] = (float)row[j];
+            bfv[o] = (float)bacc;
+        }
+        int rc2;
+        if ((rc2 = pack_linear(wf.data(), 2193, 0, 2048, 145, bfv.data(), h->fold_feat))) return rc2;
+        if ((rc2 = pack_linear(wf.data(), 2193, 2048, 145, 145, nullptr, h->fold_state))) return rc2;
+        std::vector<float> mp(144, 0.f);
+        memcpy(mp.data(), ip->data.data(), std::min<size_t>(144, ip->numel()) * 4);
+        HIP_TRY(upload(h->mean_pose, mp.data(), 144 * 4));
+        HIP_TRY(upload(h->mean_shape, is->data.data(), 10 * 4));
+        HIP_TRY(upload(h->mean_cam, ic->data.data(), 3 * 4));
+        return AP_OK;
+    }
     if (w1->numel() != (size_t)1024 * 2332 || w2->numel() != (size_t)1024 * 1024 || wp->numel() != (size_t)135 * 1024 ||
         wsh->numel() != (size_t)10 * 1024 || ip->numel() < 132 || is->numel() != 10)
         return fail(AP_ESHAPE, "regressor tensor shape mismatch");
@@ -624,7 +670,7 @@ void ap_net_destroy(ap_net* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->ws_stem, &h->ws_a,
+    for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->mean_cam, &h->ws_stem, &h->ws_a,
                       &h->ws_b, &h->ws_t1, &h->ws_t2, &h->ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
                       &h->ws_D, &h->ws_state})
         b->release();
@@ -736,6 +782,30 @@ int ap_debug_set_trace(void* device_buf_160_u64) {
 int ap_set_conv_config(int cfg) {
     if (cfg != -1 && cfg != 100 && (cfg < 0 || cfg > 13)) return fail(AP_EINVAL, "ap_set_conv_config: -1, 0..13 or 100");
     g_conv_cfg = cfg;
+    return AP_OK;
+}
+
+int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_theta, int theta_bs,
+               const float* init_shape, int shape_bs, const float* init_cam, int cam_bs, float* rotmat, float* betas,
+               float* cam, void* stream) {
+    if (!h || !x || B <= 0 || iters < 1 || !rotmat || !betas || !cam) return fail(AP_EINVAL, "ap_hmr_fwd: bad argument");
+    if (h->variant != 1) return fail(AP_ESTATE, "ap_hmr_fwd needs an hmr (variant 1) handle");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(h->ws_feat.reserve((size_t)B * 2048 * 4));
+    HIP_TRY(h->ws_H.reserve((size_t)B * DLD * 4));
+    HIP_TRY(h->ws_D.reserve((size_t)B * DLD * 4));
+    HIP_TRY(h->ws_state.reserve((size_t)B * 160 * 4));
+    float *feat = h->ws_feat.as<float>(), *Hb = h->ws_H.as<float>(), *D = h->ws_D.as<float>(), *state = h->ws_state.as<float>();
+    int rc = trunk_fwd(h, x, B, nullptr, 0, feat, st);
+    if (rc) return rc;
+    if ((rc = run_gemm(h->fold_feat, feat, 2048, 2048, B, Hb, DLD, nullptr, 0, st))) return rc;
+    HIP_TRY(ap_launch_hmr_init(init_theta, theta_bs, init_shape, shape_bs, init_cam, cam_bs, h->mean_pose.as<float>(),
+                               h->mean_shape.as<float>(), h->mean_cam.as<float>(), state, B, st));
+    for (int it = 0; it < iters; ++it) {
+        if ((rc = run_gemm(h->fold_state, state, 160, 160, B, D, DLD, Hb, DLD, st))) return rc;
+        HIP_TRY(ap_launch_hmr_update(state, D, DLD, B, st));
+    }
+    HIP_TRY(ap_launch_hmr_output(state, rotmat, betas, cam, B, st));
     return AP_OK;
 }
 

@@ -68,6 +68,13 @@ hipError_t ap_launch_reg_update_assemble(float* state, const float* delta, int l
 hipError_t ap_launch_reg_output(const float* state, float* pose0, float* betas0, float* pose1, float* betas1,
                                 int B, int two_view, hipStream_t st);
 
+// single-view HMR head glue (regressor.hip): state rows of 160 floats = pose132 | shape10 | cam3 | pad
+hipError_t ap_launch_hmr_init(const float* theta, int theta_bs, const float* shape, int shape_bs, const float* cam,
+                              int cam_bs, const float* mean_pose, const float* mean_shape, const float* mean_cam,
+                              float* state, int B, hipStream_t st);
+hipError_t ap_launch_hmr_update(float* state, const float* delta, int ldd, int B, hipStream_t st);
+hipError_t ap_launch_hmr_output(const float* state, float* rotmat, float* betas, float* cam, int B, hipStream_t st);
+
 // ---- SMPL-X (smplx.hip)
 struct SmplxModelDev {
     int V, J, K;                  // vertices, joints (55), bones per vertex

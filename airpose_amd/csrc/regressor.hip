@@ -77,7 +77,69 @@ __global__ void reg_output_kernel(const float* __restrict__ state, float* __rest
     }
 }
 
+// ---- single-view HMR head (model_hmr.py:112-172): state = pose132 | shape10 | cam3 (145), row stride 160
+__global__ void hmr_init_kernel(const float* __restrict__ theta, int theta_bs, const float* __restrict__ shape,
+                                int shape_bs, const float* __restrict__ cam, int cam_bs,
+                                const float* __restrict__ mean_pose, const float* __restrict__ mean_shape,
+                                const float* __restrict__ mean_cam, float* __restrict__ state) {
+    const int b = blockIdx.x;
+    const float* th = theta ? theta + (size_t)b * theta_bs : mean_pose;
+    const float* sh = shape ? shape + (size_t)b * shape_bs : mean_shape;
+    const float* cm = cam ? cam + (size_t)b * cam_bs : mean_cam;
+    for (int i = threadIdx.x; i < 160; i += blockDim.x)
+        state[(size_t)b * 160 + i] = i < 132 ? th[i] : i < 142 ? sh[i - 132] : i < 145 ? cm[i - 142] : 0.f;
+}
+
+__global__ void hmr_update_kernel(float* __restrict__ state, const float* __restrict__ delta, int ldd) {
+    const int b = blockIdx.x;
+    for (int i = threadIdx.x; i < 145; i += blockDim.x) state[(size_t)b * 160 + i] += delta[(size_t)b * ldd + i];
+}
+
+__device__ __forceinline__ void rot6d_rows(const float* __restrict__ x, float* R) {   // geometry.py:47-61
+    const float a1x = x[0], a1y = x[2], a1z = x[4], a2x = x[1], a2y = x[3], a2z = x[5];
+    const float n1 = fmaxf(sqrtf(a1x * a1x + a1y * a1y + a1z * a1z), 1e-12f);
+    const float b1x = a1x / n1, b1y = a1y / n1, b1z = a1z / n1;
+    const float d = b1x * a2x + b1y * a2y + b1z * a2z;
+    const float ux = a2x - d * b1x, uy = a2y - d * b1y, uz = a2z - d * b1z;
+    const float n2 = fmaxf(sqrtf(ux * ux + uy * uy + uz * uz), 1e-12f);
+    const float b2x = ux / n2, b2y = uy / n2, b2z = uz / n2;
+    R[0] = b1x; R[1] = b2x; R[2] = b1y * b2z - b1z * b2y;
+    R[3] = b1y; R[4] = b2y; R[5] = b1z * b2x - b1x * b2z;
+    R[6] = b1z; R[7] = b2z; R[8] = b1x * b2y - b1y * b2x;
+}
+
+__global__ void hmr_output_kernel(const float* __restrict__ state, float* __restrict__ rotmat,
+                                  float* __restrict__ betas, float* __restrict__ cam) {
+    const int b = blockIdx.x, t = threadIdx.x;
+    const float* s = state + (size_t)b * 160;
+    if (t < 22) {
+        float R[9];
+        rot6d_rows(s + 6 * t, R);
+        for (int e = 0; e < 9; ++e) rotmat[((size_t)b * 22 + t) * 9 + e] = R[e];
+    } else if (t < 32) {
+        betas[(size_t)b * 10 + (t - 22)] = s[132 + (t - 22)];
+    } else if (t < 35) {
+        cam[(size_t)b * 3 + (t - 32)] = s[142 + (t - 32)];
+    }
+}
+
 }  // namespace
+
+hipError_t ap_launch_hmr_init(const float* theta, int theta_bs, const float* shape, int shape_bs, const float* cam,
+                              int cam_bs, const float* mean_pose, const float* mean_shape, const float* mean_cam,
+                              float* state, int B, hipStream_t st) {
+    hipLaunchKernelGGL(hmr_init_kernel, dim3(B), dim3(64), 0, st, theta, theta_bs, shape, shape_bs, cam, cam_bs,
+                       mean_pose, mean_shape, mean_cam, state);
+    return hipGetLastError();
+}
+hipError_t ap_launch_hmr_update(float* state, const float* delta, int ldd, int B, hipStream_t st) {
+    hipLaunchKernelGGL(hmr_update_kernel, dim3(B), dim3(64), 0, st, state, delta, ldd);
+    return hipGetLastError();
+}
+hipError_t ap_launch_hmr_output(const float* state, float* rotmat, float* betas, float* cam, int B, hipStream_t st) {
+    hipLaunchKernelGGL(hmr_output_kernel, dim3(B), dim3(64), 0, st, state, rotmat, betas, cam);
+    return hipGetLastError();
+}
 
 hipError_t ap_launch_reg_init(const RegInitArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(reg_init_kernel, dim3(a.rows), dim3(64), 0, st, a);

@@ -46,7 +46,7 @@ const char* ap_last_error(void);
  * (conv OIHW, linear [out][in]); ap_net_finalize folds BN into a per-channel scale/shift, repacks
  * the weights K-contiguous NHWC in the handle's precision and uploads them.  Calling set_tensor +
  * finalize again re-packs (fine-tuned weights).
- * variant: 0 = copenet two-view (fc1 in = 2332), 1 = hmr single view head (fc1 in = 2193; trunk only used). */
+ * variant: 0 = copenet two-view (fc1 in = 2332), 1 = hmr single-view head (fc1 in = 2193, ap_hmr_fwd). */
 int ap_net_create(ap_net** out, int device, int precision, int variant);
 void ap_net_destroy(ap_net* h);
 int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
@@ -80,6 +80,14 @@ int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0
                    const float* init_theta1, int theta1_bs, const float* init_shape0, int shape0_bs,
                    const float* init_shape1, int shape1_bs, int B, int iters, float* pose0, float* betas0,
                    float* pose1, float* betas1, void* stream);
+
+/* model_hmr.copenet.forward (copenet/src/copenet/models/model_hmr.py:112-141; BASELINE config 0's network):
+ * single view, trunk + 3 x forward_reg (:160-172) + rot6d_to_rotmat.  Needs a variant-1 handle.
+ * init_theta [tb][>=132] / init_shape [sb][10] / init_cam [cb][3] with batch strides (0 = broadcast) or NULL =
+ * the model's mean parameters.  Outputs rotmat [B][22][3][3], betas [B][10], cam [B][3]. */
+int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_theta, int theta_bs,
+               const float* init_shape, int shape_bs, const float* init_cam, int cam_bs, float* rotmat, float* betas,
+               float* cam, void* stream);
 
 /* One fused convolution of the trunk: y = act(conv(x, w) * scale + shift (+ res)), the building block of
  * Bottleneck.forward (model_copenet.py:27-47: conv -> BN -> [+ residual] -> ReLU).  Exposed so the kernel can be

@@ -395,6 +395,26 @@ def test_full_size_properties_bf16(netbf, body, dev):
     assert rel_err(two["pred_vertices_cam1"].cpu().numpy(), out["pred_vertices_cam1"][:2].cpu().numpy()) < 1e-6
 
 
+def test_hmr_config1_on_gpu_matches_reference(golden, dev):
+    """BASELINE config 0 (hmr single view, batch 1, 3 iterations) through ap_hmr_fwd vs the reference's output."""
+    from airpose_amd import hmr_model
+    from airpose_amd import weights as W
+    g = golden["hmr_b1"]
+    sd = W.to_torch(W.copenet_state_dict(int(g["weights_seed"]), MEAN_PARAMS, variant="hmr"))
+    x = torch.from_numpy(W.synthetic_inputs(int(g["inputs_seed"]), 1)["im0"]).to(dev)
+    net = hmr_model.getcopenet(MEAN_PARAMS, precision="fp32").eval()
+    net.load_state_dict(sd, strict=True)
+    rot, betas, cam = net(x, iters=3)
+    assert rot.shape == (1, 22, 3, 3)
+    errs = [rel_err(rot.cpu().numpy(), g["rotmat"]), rel_err(betas.cpu().numpy(), g["betas"]), rel_err(cam.cpu().numpy(), g["cam"])]
+    print("hmr fp32 rel errs", errs)
+    assert max(errs) < TOL32
+    netb = hmr_model.getcopenet(MEAN_PARAMS, precision="bf16").eval()
+    netb.load_state_dict(sd, strict=True)
+    rotb, betasb, camb = netb(x, iters=3)
+    assert rel_err(betasb.cpu().numpy(), g["betas"]) < TOLBF and rel_err(rotb.cpu().numpy(), g["rotmat"]) < TOLBF
+
+
 def test_errors_are_loud(net32, dev):
     with pytest.raises(RuntimeError):
         net32.forward_feat_ext(torch.zeros(1, 3, 224, 224))          # CPU tensor: no fallback
