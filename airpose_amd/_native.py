@@ -51,6 +51,8 @@ SIGNATURES = {
     "ap_net_set_fold": (_i, [_vp, _i]),
     "ap_net_set_fuse_stem": (_i, [_vp, _i]),
     "ap_net_set_fuse_ds": (_i, [_vp, _i]),
+    "ap_net_set_fuse_block": (_i, [_vp, _i]),
+    "ap_bottleneck64_nhwc": (_i, [_vp] * 11 + [_i] * 5 + [_vp]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),
     "ap_smplx_destroy": (None, [_vp]),
     "ap_smplx_num_joints_out": (_i, [_vp]),

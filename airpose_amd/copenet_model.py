@@ -258,6 +258,11 @@ class copenet(nn.Module):
         N.check(N.lib().ap_net_set_fuse_ds(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_fuse_ds")
 
+    def set_fuse_block(self, on):
+        """bf16: run each layer1 bottleneck as one fused kernel (default) or as separate convolutions."""
+        N.check(N.lib().ap_net_set_fuse_block(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+                "ap_net_set_fuse_block")
+
     def set_fuse_stem(self, on):
         N.check(N.lib().ap_net_set_fuse_stem(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_fuse_stem")

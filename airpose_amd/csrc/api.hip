@@ -171,6 +171,7 @@ struct ap_net {
     Layer fold_feat, fold_state;   // dec o fc2 o fc1 folded into one 145 x 2332 map (no activation between them)
     bool fold = true;
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
+    bool fuse_block = true;        // bf16: layer1 bottlenecks as one kernel each (bottleneck.hip)
     bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape, mean_cam;
     // workspace
@@ -334,6 +335,22 @@ int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int H
     a.ldx = L.cin; a.ldy = L.cout; a.ldr = L.cout; a.wld = L.wld; a.relu = 1;
     a.x2 = x; a.H2 = Hin; a.W2 = Hin; a.Cin2 = L.cin2; a.stride2 = L.stride2; a.ldx2 = L.cin2;
     HIP_TRY(dispatch_conv(a, is_bf16, st));
+    return AP_OK;
+}
+
+// fused layer1 bottleneck (bf16): x [N][H][H][c1.cin] -> y [N][H][H][256]
+int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, const void* x, int N, int H, void* y,
+                hipStream_t st) {
+    BneckArgs a{};
+    a.x = x; a.y = y;
+    a.w1 = c1.w.p; a.w2 = c2.w.p; a.w3 = c3.w.p;
+    a.s1 = c1.scale.as<float>(); a.h1 = c1.shift.as<float>();
+    a.s2 = c2.scale.as<float>(); a.h2 = c2.shift.as<float>();
+    a.s3 = c3.scale.as<float>(); a.h3 = c3.shift.as<float>();
+    a.N = N; a.H = H; a.W = H;
+    HIP_TRY(zero_line(&a.zero));
+    a.dbg = g_conv_dbg;
+    HIP_TRY(ap_launch_bneck64(a, c1.cin, ds ? 1 : 0, st));
     return AP_OK;
 }
 
@@ -541,6 +558,13 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
     int rc;
     for (auto& B : h->blocks) {
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
+        if (bf && h->fuse_block && B.c2.cout == 64 && B.c2.stride == 1 && H % 14 == 0 && (!B.has_down || B.c1.cin == 64)) {
+            // layer1: conv1 -> conv2 -> conv3 (+identity | folded downsample) in one kernel, intermediates in LDS
+            const Layer& L3 = B.has_down ? B.c3ds : B.c3;
+            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, st))) return rc;
+            std::swap(cur, nxt);
+            continue;
+        }
         if ((rc = run_conv(B.c1, cur, n, H, H, h->ws_t1.p, nullptr, 1, bf, st))) return rc;
         if ((rc = run_conv(B.c2, h->ws_t1.p, n, H, H, h->ws_t2.p, nullptr, 1, bf, st))) return rc;
         if (B.has_down && h->fuse_ds) {
@@ -774,6 +798,23 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
     return AP_OK;
 }
 
+int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
+                         const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
+                         int N, int H, int W, int Cin, int downsample, void* stream) {
+    if (!x || !w1 || !s1 || !h1 || !w2 || !s2 || !h2 || !w3 || !s3 || !h3 || !y || N <= 0)
+        return fail(AP_EINVAL, "ap_bottleneck64_nhwc: bad argument");
+    if (H <= 0 || W <= 0 || H % 14 || W % 14 || !((Cin == 256 && !downsample) || (Cin == 64 && downsample)))
+        return fail(AP_ESHAPE, "ap_bottleneck64_nhwc: H, W multiples of 14; Cin 256 (identity) or 64 (downsample)");
+    BneckArgs a{};
+    a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.w3 = w3;
+    a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3;
+    a.N = N; a.H = H; a.W = W;
+    HIP_TRY(zero_line(&a.zero));
+    a.dbg = g_conv_dbg;
+    HIP_TRY(ap_launch_bneck64(a, Cin, downsample ? 1 : 0, (hipStream_t)stream));
+    return AP_OK;
+}
+
 int ap_debug_set_trace(void* device_buf_160_u64) {
     g_conv_dbg = (unsigned long long*)device_buf_160_u64;
     return AP_OK;
@@ -824,6 +865,12 @@ int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset) {
 int ap_net_set_fuse_ds(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_ds = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_fuse_block(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fuse_block = on != 0;
     return AP_OK;
 }
 

@@ -1,0 +1,791 @@
+// Whole-bottleneck fusion for the 64-plane stage (layer1) of the trunk, bf16, gfx950.
+//
+// Reference: Bottleneck.forward, copenet/src/copenet/models/model_copenet.py:27-47
+//   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + (downsample(x) | x))
+// At 56x56 the three convs of a layer1 block are HBM-bound when run as separate GEMMs (the 64-channel
+// intermediates and the 256-channel block input are written and re-read: 3.3 GB per block at 512 images).
+// This kernel keeps both intermediates in LDS: one workgroup owns a 14x14 output tile of one image and runs
+//
+//   phase 1  mid1[16x16 halo px][64] = relu(bn1(W1 . x))         K = CIN, streamed in 64-channel steps (LDS-DMA ring)
+//   phase 2  mid2[14x14 px][64]      = relu(bn2(W2 * mid1))      9 taps x K 64, weights streamed per tap
+//   phase 3  y[14x14 px][256]        = relu(bn3(W3 . mid2) + x)  4 passes of 64 output channels; the identity tile
+//                                                               arrives by LDS-DMA one pass ahead, stores are 16-byte
+//                                                               coalesced through an LDS stage
+//   (DS variant, block 0: K3 = 128 = [mid2 | x] with the downsample conv and both BN scales folded into W3,
+//    pack_c3_ds in api.hip; x is the resident phase-1 tile, no identity add)
+//
+// so HBM sees the block input once (+ the 1.31x halo, which neighbouring tiles find in L2) and the output once.
+// MFMA operands as in conv_pipe.hip: weights are the A operand (rows = channels), pixels the B operand; every LDS
+// image is rows of 128 B (64 bf16) with the 16-byte chunk index XOR-swizzled by (row & 7), written lane-linearly by
+// global_load_lds with the swizzle on the SOURCE address.  Pixel rows are indexed on a 16-wide grid (row = y*16 + x)
+// so a 16-pixel MFMA column block is one tile row (columns 14, 15 are junk that is never stored).
+// All LDS traffic is inline asm and every s_waitcnt is counted by hand (a compiler-visible LDS access after an LDS-DMA
+// would be answered with vmcnt(0)); -DAP_BNECK_SAFE turns every counted wait into vmcnt(0) for cross-checking.
+#include <type_traits>
+
+#include "ap_common.h"
+#include "kernels.h"
+
+namespace {
+
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+constexpr int TS = 14;                                       // output tile edge
+// LDS map (bytes)
+constexpr int L_XR0 = 0;                                     // 256 rows: x step ring slot 0 | identity chunk (even pass) | DS: resident x tile
+constexpr int L_XR1 = 32768;                                 // 256 rows: x step ring slot 1 | identity chunk (odd pass)  | DS: W3 double buffer
+constexpr int L_WR = 65536;                                  // 4 x 64 rows: W1 steps / W2 taps / W3 chunks
+constexpr int L_M1 = 98304;                                  // 264 rows: mid1 on the 16-wide halo grid; phase 3: output stage
+constexpr int L_M2 = 132096;                                 // 224 rows: mid2 on the 16-wide grid
+constexpr int L_TOTAL = 160768;
+
+template <int N> __device__ __forceinline__ void vm() {
+#ifdef AP_BNECK_SAFE
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}
+template <int N> __device__ __forceinline__ void vmx() {   // x-wave / weight-wave waits of the persistent kernel (debug switches)
+#ifdef AP_BNECK_SAFE_X
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    vm<N>();
+#endif
+}
+template <int N> __device__ __forceinline__ void vmw() {
+#ifdef AP_BNECK_SAFE_W
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    vm<N>();
+#endif
+}
+template <int N> __device__ __forceinline__ void lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ void bar() { __builtin_amdgcn_s_barrier(); }
+
+template <int OFF> __device__ __forceinline__ u32x4 rd128(uint32_t addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ u32x2 rd64(uint32_t addr) {
+    u32x2 r;
+    asm volatile("ds_read_b64 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ void wr64(uint32_t addr, u32x2 v) {
+    asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+
+__device__ __forceinline__ void mma(f32x4& acc, const u32x4& w, const u32x4& x) {
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), acc, 0, 0, 0);
+}
+
+// N fragment reads at addr + OFF0 + k*2048 (16 rows of 128 B per MFMA block)
+template <int N, int OFF0> __device__ __forceinline__ void rd_blocks(uint32_t addr, u32x4 (&o)[N]) {
+    static_assert(N <= 8, "unroll");
+    if constexpr (N > 0) o[0] = rd128<OFF0>(addr);
+    if constexpr (N > 1) o[1] = rd128<OFF0 + 2048>(addr);
+    if constexpr (N > 2) o[2] = rd128<OFF0 + 4096>(addr);
+    if constexpr (N > 3) o[3] = rd128<OFF0 + 6144>(addr);
+    if constexpr (N > 4) o[4] = rd128<OFF0 + 8192>(addr);
+    if constexpr (N > 5) o[5] = rd128<OFF0 + 10240>(addr);
+    if constexpr (N > 6) o[6] = rd128<OFF0 + 12288>(addr);
+    if constexpr (N > 7) o[7] = rd128<OFF0 + 14336>(addr);
+}
+
+// one 64-deep contraction step of a [2 channel blocks] x [4 pixel blocks] wave tile.
+// wa0/wa1: weight fragment addresses of the two 32-deep halves; xa0/xa1: pixel fragment addresses (blocks 0..2 at
+// OFF + j*2048), xb0/xb1: the same for block 3 (a clamped duplicate of block 2 in the 3-row waves)
+template <int OFF>
+__device__ __forceinline__ void step_2x4(uint32_t wa0, uint32_t wa1, uint32_t xa0, uint32_t xa1, uint32_t xb0, uint32_t xb1,
+                                         f32x4 (&acc)[2][4]) {
+    u32x4 a0[2], a1[2], b0[4], b1[4];
+    rd_blocks<2, 0>(wa0, a0);
+    { u32x4 t[3]; rd_blocks<3, OFF>(xa0, t); b0[0] = t[0]; b0[1] = t[1]; b0[2] = t[2]; }
+    b0[3] = rd128<OFF + 6144>(xb0);
+    rd_blocks<2, 0>(wa1, a1);
+    { u32x4 t[3]; rd_blocks<3, OFF>(xa1, t); b1[0] = t[0]; b1[1] = t[1]; b1[2] = t[2]; }
+    b1[3] = rd128<OFF + 6144>(xb1);
+    lgkm<6>();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma(acc[i][j], a0[i], b0[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    lgkm<0>();
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mma(acc[i][j], a1[i], b1[j]);
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+__device__ __forceinline__ u32x2 bn_relu_pack(const f32x4& a, const float4& sc, const float4& sh, bool keep) {
+    float v0 = fmaxf(a[0] * sc.x + sh.x, 0.f), v1 = fmaxf(a[1] * sc.y + sh.y, 0.f);
+    float v2 = fmaxf(a[2] * sc.z + sh.z, 0.f), v3 = fmaxf(a[3] * sc.w + sh.w, 0.f);
+    u32x2 o;
+    o.x = keep ? pack_bf16x2(v0, v1) : 0u;
+    o.y = keep ? pack_bf16x2(v2, v3) : 0u;
+    return o;
+}
+
+template <int CIN, bool DS>
+__global__ void __launch_bounds__(512) bneck64_kernel(const BneckArgs p) {
+    static_assert(DS ? CIN == 64 : CIN == 256, "layer1 shapes");
+    constexpr int KC = CIN / 64;                             // phase-1 steps
+    constexpr int K3 = DS ? 128 : 64;                        // conv3 contraction ([mid2 | x] when the downsample is folded in)
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+#ifdef AP_TRACE   // cycle stamps of wave 0 of workgroups 0 and 4096 (40 slots each)
+    int stamp_i = 0;
+    const bool tracing = p.dbg && (blockIdx.x == 0 || blockIdx.x == 4096) && tid == 0;
+#define BSTAMP() do { if (tracing) p.dbg[(blockIdx.x ? 40 : 0) + stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
+#else
+#define BSTAMP() do {} while (0)
+#endif
+    BSTAMP();
+    const int lr = lane & 15, g4 = lane >> 4;
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;  // DMA piece geometry: 8 rows x 8 chunks, swizzled source
+    const int tile = xcd_remap(blockIdx.x, p.total);
+    const int n = tile / p.tiles_per_img, trem = tile - n * p.tiles_per_img;
+    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+    const int y0 = ty * TS, x0 = tx * TS;
+    const unsigned char* xg = (const unsigned char*)p.x;
+    const unsigned char* zg = (const unsigned char*)p.zero;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // wave roles.  phase 1: 4 channel blocks x 2 halves of the halo (8 pixel blocks each);
+    // phases 2/3: 2 channel-block pairs x 4 row groups of the 14 output rows (4, 4, 3, 3 rows)
+    const int wm = wave & 3, wn = wave >> 2;
+    const int wm2 = wave & 1, wn2 = wave >> 1;
+    const int rb = wn2 < 2 ? wn2 * 4 : 8 + (wn2 - 2) * 3;
+    const int nb = wn2 < 2 ? 4 : 3;
+    const uint32_t j3adj = nb == 4 ? 0u : (uint32_t)-2048;   // block 3 of a 3-row wave re-reads block 2
+
+    // ---------------------------------------------------------------- DMA sources (4 activation pieces per wave)
+    const unsigned char* xsrc[4];                            // phase 1: halo rows (wave*4+i)*8 + prow
+    const unsigned char* rsrc[4];                            // phase 3: identity rows on the 16-wide output grid
+    uint32_t xlive = 0, rlive = 0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int h = (wave * 4 + i) * 8 + prow;
+        const int yy = y0 - 1 + (h >> 4), xx = x0 - 1 + (h & 15);
+        const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        xsrc[i] = ok ? xg + ((((size_t)n * p.H + yy) * p.W + xx) * CIN + pchunk * 8) * 2 : zg;
+        xlive |= ok ? (1u << i) : 0u;
+        const int oy = h >> 4, ox = h & 15;
+        const bool rok = (wave * 4 + i) < 28 && ox < TS;
+        rsrc[i] = rok ? xg + ((((size_t)n * p.H + y0 + oy) * p.W + x0 + ox) * CIN + pchunk * 8) * 2 : zg;
+        rlive |= rok ? (1u << i) : 0u;
+    }
+    const unsigned char* w1src = (const unsigned char*)p.w1 + ((size_t)(wave * 8 + prow) * CIN + pchunk * 8) * 2;
+    const unsigned char* w2src = (const unsigned char*)p.w2 + ((size_t)(wave * 8 + prow) * 576 + pchunk * 8) * 2;
+    const unsigned char* w3src = (const unsigned char*)p.w3 + ((size_t)(wave * 8 + prow) * K3 + pchunk * 8) * 2;
+
+    auto dma = [&](const unsigned char* src, int lds_off) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+    };
+    auto issue_p1 = [&](int kc, int slot) {                  // 5 pieces: x channels [64kc, 64kc+64) of the halo + W1 columns
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dma(xsrc[i] + (((xlive >> i) & 1u) ? kc * 128 : 0), L_XR0 + slot * 32768 + (wave * 4 + i) * 1024);
+        dma(w1src + kc * 128, L_WR + slot * 8192 + wave * 1024);
+    };
+    auto issue_tap = [&](int t) {                            // 1 piece: W2[:, tap t, :] -> ring slot (t+2)&3
+        dma(w2src + t * 128, L_WR + ((t + 2) & 3) * 8192 + wave * 1024);
+    };
+    auto w3_buf = [&](int nc) { return DS ? L_XR1 + (nc & 1) * 16384 : L_WR + ((nc & 1) ? 0 : 3) * 8192; };
+    auto issue_w3 = [&](int nc) {                            // K3/64 pieces: W3 rows [64nc, 64nc+64)
+#pragma unroll
+        for (int u = 0; u < K3 / 64; ++u)
+            dma(w3src + (size_t)nc * 64 * K3 * 2 + u * 128, w3_buf(nc) + u * 8192 + wave * 1024);
+    };
+    auto issue_res = [&](int nc) {                           // 4 pieces: identity channels [64nc, 64nc+64) of the tile
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            dma(rsrc[i] + (((rlive >> i) & 1u) ? nc * 128 : 0), ((nc & 1) ? L_XR1 : L_XR0) + (wave * 4 + i) * 1024);
+    };
+
+    // ---------------------------------------------------------------- fragment addresses
+    const uint32_t sw0 = (uint32_t)((g4 ^ (lr & 7)) << 4), sw1 = (uint32_t)(((4 + g4) ^ (lr & 7)) << 4);
+    // mid1 / resident-x fragment bases for the three horizontal tap shifts (row = (rb + j + ky)*16 + lr + kx)
+    uint32_t m1a[3][2];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+            m1a[kx][s] = lds0 + L_M1 + (rb * 16 + lr + kx) * 128 + (uint32_t)(((g4 + 4 * s) ^ ((lr + kx) & 7)) << 4);
+    const uint32_t m2a0 = lds0 + L_M2 + (rb * 16 + lr) * 128 + sw0, m2a1 = lds0 + L_M2 + (rb * 16 + lr) * 128 + sw1;
+    const uint32_t wrow2 = (uint32_t)((32 * wm2 + lr) * 128);   // weight rows of this wave's channel-block pair
+
+    // ================================================================ prologue: fill the pipes
+    issue_p1(0, 0);
+    if constexpr (KC > 1) issue_p1(1, 1);
+    issue_tap(0);
+    issue_tap(1);
+    if constexpr (DS) { issue_w3(0); issue_w3(1); }
+    BSTAMP();
+
+    // BatchNorm constants in accumulator layout (4 consecutive channels per lane).  Queued behind the
+    // prologue DMA and pinned (empty asm) so that the compiler's own wait for them sits at the first pipeline wait
+    // instead of draining the DMA queue in front of epilogue 1
+    float4 s1 = *(const float4*)(p.s1 + 16 * wm + 4 * g4), h1 = *(const float4*)(p.h1 + 16 * wm + 4 * g4);
+    float4 s2[2], h2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        s2[i] = *(const float4*)(p.s2 + 32 * wm2 + 16 * i + 4 * g4);
+        h2[i] = *(const float4*)(p.h2 + 32 * wm2 + 16 * i + 4 * g4);
+    }
+    float4 s3[4][2], h3[4][2];
+#pragma unroll
+    for (int nc = 0; nc < 4; ++nc)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            s3[nc][i] = *(const float4*)(p.s3 + 64 * nc + 32 * wm2 + 16 * i + 4 * g4);
+            h3[nc][i] = *(const float4*)(p.h3 + 64 * nc + 32 * wm2 + 16 * i + 4 * g4);
+        }
+
+    auto pin = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
+    pin(s1); pin(h1);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) { pin(s2[i]); pin(h2[i]); }
+#pragma unroll
+    for (int nc = 0; nc < 4; ++nc)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) { pin(s3[nc][i]); pin(h3[nc][i]); }
+
+    // ================================================================ phase 1: mid1 = relu(bn1(W1 . x)) on the halo
+    f32x4 acc1[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto p1_compute = [&](int slot) {
+        const uint32_t wa = lds0 + L_WR + slot * 8192 + (16 * wm + lr) * 128;
+        const uint32_t xa = lds0 + L_XR0 + slot * 32768 + (wn * 128 + lr) * 128;
+        u32x4 b0[8], b1[8];
+        const u32x4 a0 = rd128<0>(wa + sw0);
+        rd_blocks<8, 0>(xa + sw0, b0);
+        const u32x4 a1 = rd128<0>(wa + sw1);
+        rd_blocks<8, 0>(xa + sw1, b1);
+        lgkm<9>();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mma(acc1[j], a0, b0[j]);
+        __builtin_amdgcn_sched_barrier(0);
+        lgkm<0>();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) mma(acc1[j], a1, b1[j]);
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    // vm<N>: N = DMA pieces this wave queued AFTER the ones needed now (the queue retires in order)
+    if constexpr (!DS) {
+        vm<7>(); bar(); p1_compute(0); bar(); BSTAMP(); issue_p1(2, 0);                       // after: P1(1) T0 T1
+        vm<7>(); bar(); p1_compute(1); bar(); BSTAMP(); issue_p1(3, 1);                       // after: T0 T1 P1(2)
+        vm<5>(); bar(); p1_compute(0); bar(); BSTAMP(); issue_tap(2);                         // after: P1(3)
+        vm<1>(); bar(); p1_compute(1); bar(); BSTAMP(); issue_tap(3); issue_res(0); issue_res(1);   // after: T2
+    } else {
+        vm<6>(); bar(); p1_compute(0); bar(); BSTAMP(); issue_tap(2); issue_tap(3);           // after: T0 T1 W3(0)x2 W3(1)x2
+    }
+    {   // epilogue 1: halo pixels outside the image are conv2's zero padding -> exactly 0, not relu(shift)
+        const uint32_t ea = lds0 + L_M1 + (wn * 128 + lr) * 128 + (uint32_t)(((2 * wm + (g4 >> 1)) ^ (lr & 7)) << 4) + (g4 & 1) * 8;
+        const bool xin = (unsigned)(x0 - 1 + lr) < (unsigned)p.W;
+        auto put = [&](auto J) {
+            constexpr int j = decltype(J)::value;
+            const bool ok = xin && (unsigned)(y0 - 1 + 8 * wn + j) < (unsigned)p.H;
+            wr64<j * 2048>(ea, bn_relu_pack(acc1[j], s1, h1, ok));
+        };
+        put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{});
+        put(std::integral_constant<int, 2>{}); put(std::integral_constant<int, 3>{});
+        put(std::integral_constant<int, 4>{}); put(std::integral_constant<int, 5>{});
+        put(std::integral_constant<int, 6>{}); put(std::integral_constant<int, 7>{});
+    }
+    lgkm<0>();
+    BSTAMP();
+
+    // ================================================================ phase 2: mid2 = relu(bn2(W2 * mid1))
+    f32x4 acc2[2][4];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto tap = [&](auto KY, auto KX, int slot) {
+        constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value;
+        const uint32_t wa = lds0 + L_WR + slot * 8192 + wrow2;
+        step_2x4<ky * 2048>(wa + sw0, wa + sw1, m1a[kx][0], m1a[kx][1], m1a[kx][0] + j3adj, m1a[kx][1] + j3adj, acc2);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    if constexpr (!DS) {
+        bar(); tap(I0{}, I0{}, 2); BSTAMP();                                                  // T0, T1 retired before P1(2)
+        tap(I0{}, I1{}, 3); BSTAMP();
+        vm<9>(); bar(); issue_tap(4); issue_tap(5); tap(I0{}, I2{}, 0); BSTAMP();             // after T2: T3 R0x4 R1x4
+        vm<10>(); bar(); tap(I1{}, I0{}, 1); BSTAMP();                                        // after T3: R0 R1 T4 T5
+        vm<1>(); bar(); issue_tap(6); issue_tap(7); tap(I1{}, I1{}, 2); BSTAMP();             // after T4: T5
+        vm<2>(); bar(); tap(I1{}, I2{}, 3); BSTAMP();                                         // after T5: T6 T7
+        vm<1>(); bar(); issue_tap(8); issue_w3(0); tap(I2{}, I0{}, 0); BSTAMP();              // after T6: T7
+        vm<2>(); bar(); tap(I2{}, I1{}, 1); BSTAMP();                                         // after T7: T8 W3(0)
+        vm<1>(); bar(); tap(I2{}, I2{}, 2); BSTAMP();                                         // after T8: W3(0)
+    } else {
+        vm<7>(); bar(); tap(I0{}, I0{}, 2); BSTAMP();                                         // after T0: T1 W3(0)x2 W3(1)x2 T2 T3
+        vm<6>(); bar(); tap(I0{}, I1{}, 3); BSTAMP();
+        vm<1>(); bar(); issue_tap(4); issue_tap(5); tap(I0{}, I2{}, 0); BSTAMP();             // after T2: T3
+        vm<2>(); bar(); tap(I1{}, I0{}, 1); BSTAMP();                                         // after T3: T4 T5
+        vm<1>(); bar(); issue_tap(6); issue_tap(7); tap(I1{}, I1{}, 2); BSTAMP();
+        vm<2>(); bar(); tap(I1{}, I2{}, 3); BSTAMP();
+        vm<1>(); bar(); issue_tap(8); tap(I2{}, I0{}, 0); BSTAMP();
+        vm<1>(); bar(); tap(I2{}, I1{}, 1); BSTAMP();
+        vm<0>(); bar(); tap(I2{}, I2{}, 2); BSTAMP();
+    }
+    // accumulator-layout addresses on the 16-wide output grid (mid2, identity, stage): row (rb + j)*16 + lr,
+    // 8 bytes at channel 32*wm2 + 16*i + 4*g4
+    uint32_t eoff[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        eoff[i] = (uint32_t)((rb * 16 + lr) * 128 + (((4 * wm2 + 2 * i + (g4 >> 1)) ^ (lr & 7)) << 4) + (g4 & 1) * 8);
+    {   // epilogue 2
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t ea = lds0 + L_M2 + eoff[i];
+            wr64<0>(ea, bn_relu_pack(acc2[i][0], s2[i], h2[i], true));
+            wr64<2048>(ea, bn_relu_pack(acc2[i][1], s2[i], h2[i], true));
+            wr64<4096>(ea, bn_relu_pack(acc2[i][2], s2[i], h2[i], true));
+            if (nb == 4) wr64<6144>(ea, bn_relu_pack(acc2[i][3], s2[i], h2[i], true));
+        }
+    }
+    lgkm<0>();
+    BSTAMP();
+
+    // ================================================================ phase 3: y = relu(bn3(W3 . [mid2 | x]) (+ x))
+    // coalesced store geometry: wave w stores the 196 valid 16-byte pieces w*196 .. w*196+195 of the
+    // [196 px][8 chunks] stage; every wave executes exactly four store instructions per pass
+    uint32_t st_lds[4];
+    unsigned char* st_dst[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = wave * 196 + it * 64 + (it < 3 ? lane : (lane & 3));
+        const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
+        st_lds[it] = lds0 + L_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4);
+        st_dst[it] = (unsigned char*)p.y + ((((size_t)n * p.H + y0 + oy) * p.W + x0 + ox) * 256 + c * 8) * 2;
+    }
+    auto pass = [&](auto NC) {
+        constexpr int nc = decltype(NC)::value;
+        // identity values in accumulator layout (landed one pass ago; read now so the latency hides under the MFMAs)
+        u32x2 rv[2][4];
+        if constexpr (!DS) {
+            const uint32_t rbase = lds0 + ((nc & 1) ? L_XR1 : L_XR0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                rv[i][0] = rd64<0>(rbase + eoff[i]);
+                rv[i][1] = rd64<2048>(rbase + eoff[i]);
+                rv[i][2] = rd64<4096>(rbase + eoff[i]);
+                rv[i][3] = rd64<6144>(rbase + eoff[i] + j3adj);
+            }
+        }
+        f32x4 acc[2][4];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const uint32_t wa = lds0 + w3_buf(nc) + wrow2;
+        step_2x4<0>(wa + sw0, wa + sw1, m2a0, m2a1, m2a0 + j3adj, m2a1 + j3adj, acc);
+        if constexpr (DS) {                                  // second K segment: the resident x tile at the centre pixels
+            const uint32_t xa0 = m1a[1][0] - L_M1 + L_XR0, xa1 = m1a[1][1] - L_M1 + L_XR0;
+            step_2x4<2048>(wa + 8192 + sw0, wa + 8192 + sw1, xa0, xa1, xa0 + j3adj, xa1 + j3adj, acc);
+        }
+        lgkm<0>();                                           // (identity reads; already retired in order)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t ea = lds0 + L_M1 + eoff[i];
+            auto out = [&](const f32x4& a, const u32x2& r) {
+                float v0 = a[0] * s3[nc][i].x + h3[nc][i].x, v1 = a[1] * s3[nc][i].y + h3[nc][i].y;
+                float v2 = a[2] * s3[nc][i].z + h3[nc][i].z, v3 = a[3] * s3[nc][i].w + h3[nc][i].w;
+                if constexpr (!DS) {
+                    float lo, hi;
+                    unpack_bf16x2(r.x, lo, hi); v0 += lo; v1 += hi;
+                    unpack_bf16x2(r.y, lo, hi); v2 += lo; v3 += hi;
+                }
+                u32x2 o;
+                o.x = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+                o.y = pack_bf16x2(fmaxf(v2, 0.f), fmaxf(v3, 0.f));
+                return o;
+            };
+            wr64<0>(ea, out(acc[i][0], rv[i][0]));
+            wr64<2048>(ea, out(acc[i][1], rv[i][1]));
+            wr64<4096>(ea, out(acc[i][2], rv[i][2]));
+            if (nb == 4) wr64<6144>(ea, out(acc[i][3], rv[i][3]));
+        }
+        lgkm<0>();
+        bar();                                               // stage complete
+        u32x4 v[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) v[it] = rd128<0>(st_lds[it]);
+        lgkm<0>();
+#pragma unroll
+        for (int it = 0; it < 3; ++it) *(u32x4*)(st_dst[it] + nc * 128) = v[it];
+        if (lane < 4) *(u32x4*)(st_dst[3] + nc * 128) = v[3];
+    };
+    using I3 = std::integral_constant<int, 3>;
+    if constexpr (!DS) {
+        vm<0>(); bar(); issue_w3(1); pass(I0{}); BSTAMP();                                    // W3(0), R0, R1 landed; mid2 visible
+        vm<4>(); bar(); issue_w3(2); issue_res(2); pass(I1{}); BSTAMP();                      // after W3(1): 4 stores
+        vm<4>(); bar(); issue_w3(3); issue_res(3); pass(I2{}); BSTAMP();                      // after W3(2) R2: 4 stores
+        vm<4>(); bar(); pass(I3{}); BSTAMP();
+    } else {
+        bar(); pass(I0{}); BSTAMP();                                                          // W3(0), W3(1) retired before T2
+        bar(); issue_w3(2); pass(I1{}); BSTAMP();
+        vm<4>(); bar(); issue_w3(3); pass(I2{}); BSTAMP();                                    // after W3(2): 4 stores
+        vm<4>(); bar(); pass(I3{}); BSTAMP();
+    }
+}
+
+// =====================================================================================================================
+// Identity blocks (CIN = 256): persistent, wave-specialised version.
+//
+// In-kernel cycle stamps of the one-tile-per-workgroup kernel above showed a workgroup waiting ~10k cycles for its
+// first operands and ~1.5k cycles per pass for the identity tile, with one workgroup per CU (LDS) nothing covers them.
+// Here a workgroup loops over tiles (grid = #CUs) and
+//   * the first two 64-channel steps of the NEXT tile's x halo are fetched into the (then idle) step ring during
+//     phases 2-3; steps 2 and 3 land in the mid1 / mid2 buffers, which are idle during phase 1;
+//   * the identity values are captured from the x steps in LDS during phase 1 (chunk kc of x is exactly what pass
+//     nc = kc adds), in accumulator layout: no second read of x at all;
+//   * DMA issue is split by wave: waves 0-3 stream the weight chunks (L2-resident, short latency), waves 4-7 the x
+//     steps (HBM, long latency).  s_waitcnt vmcnt retires in order PER WAVE, so the weight waits of phases 2-3 never
+//     queue behind the long-latency prefetch; the other role needs no wait at all, the barrier publishes;
+//   * BatchNorm constants live in LDS (3 KiB) to keep the 64 identity registers under the 256-VGPR budget.
+// LDS map (bytes): x step ring 2 x 32 KiB | mid1 / stage / x step 2 (32 KiB) | mid2 / x step 3 (32 KiB) |
+// weight ring 3 x 8 KiB | constants.  mid1 rows 256, 257 (read by junk columns only) alias the first mid2 rows.
+constexpr int P_XR0 = 0, P_XR1 = 32768, P_M1 = 65536, P_M2 = 98304, P_WR = 131072, P_CONST = 155648, P_TOTAL = 158720;
+constexpr int C_S1 = 0, C_H1 = 64, C_S2 = 128, C_H2 = 192, C_S3 = 256, C_H3 = 512;   // float offsets in the constant block
+
+template <int OFF> __device__ __forceinline__ void wr128(uint32_t addr, u32x4 v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ float4 rd_f4(uint32_t addr) {
+    const u32x4 r = rd128<OFF>(addr);
+    lgkm<0>();
+    const uint32_t a = r.x, b = r.y, c = r.z, d = r.w;
+    return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c),
+                       __builtin_bit_cast(float, d));
+}
+
+__global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
+    constexpr int CIN = 256;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g4 = lane >> 4;
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const bool xw = wave >= 4;                               // DMA role: x steps (waves 4-7) or weight chunks (0-3)
+    const int wq = wave & 3;
+    const int G = gridDim.x;
+#ifdef AP_TRACE   // cycle stamps of wave 0 / wave 4 of workgroup 0, third tile (40 slots each)
+    int stamp_i = 0, tile_no = 0;
+#define PSTAMP() do { if (p.dbg && blockIdx.x == 0 && tile_no == 2 && (tid == 0 || tid == 256)) \
+        p.dbg[(tid ? 40 : 0) + stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
+#else
+#define PSTAMP() do {} while (0)
+#endif
+
+    // compute roles: 2 channel-block pairs x 4 pixel-block groups.  Phase 1: halo rows 4*wn2 .. +3;
+    // phases 2/3: output rows rb .. rb+nb-1 (4, 4, 3, 3)
+    const int wm2 = wave & 1, wn2 = wave >> 1;
+    const int rb = wn2 < 2 ? wn2 * 4 : 8 + (wn2 - 2) * 3;
+    const int nb = wn2 < 2 ? 4 : 3;
+    const uint32_t j3adj = nb == 4 ? 0u : (uint32_t)-2048;
+
+    // ---------------------------------------------------------------- BatchNorm constants -> LDS (once per workgroup)
+    if (tid < 192) {
+        const float* src = tid < 16 ? p.s1 + tid * 4 : tid < 32 ? p.h1 + (tid - 16) * 4 : tid < 48 ? p.s2 + (tid - 32) * 4
+                         : tid < 64 ? p.h2 + (tid - 48) * 4 : tid < 128 ? p.s3 + (tid - 64) * 4 : p.h3 + (tid - 128) * 4;
+        const float4 v = *(const float4*)src;
+        u32x4 u;
+        u.x = __builtin_bit_cast(uint32_t, v.x); u.y = __builtin_bit_cast(uint32_t, v.y);
+        u.z = __builtin_bit_cast(uint32_t, v.z); u.w = __builtin_bit_cast(uint32_t, v.w);
+        wr128<0>(lds0 + P_CONST + tid * 16, u);
+    }
+    lgkm<0>();
+
+    // ---------------------------------------------------------------- DMA sources
+    const unsigned char* xg = (const unsigned char*)p.x;
+    // x waves: piece i of a step covers halo rows (8*wq + i)*8 + prow = halo pixel (4*wq + (i >> 1), (i & 1)*8 + prow);
+    // its byte offset is xoff0 + (i >> 1)*W*512 + (i & 1)*4096 (32-bit: the launcher rejects tensors of 4 GiB and more)
+    uint32_t xoff0 = 0, xlive = 0;
+    uint32_t xrc = (uint32_t)(prow << 8 | pchunk);           // laundered per tile, see wrc below
+    auto setup_x = [&](int tile) {
+        const int n = tile / p.tiles_per_img, trem = tile - n * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        xlive = 0;
+        asm volatile("" : "+v"(xrc));
+        const int prow = xrc >> 8, pchunk = xrc & 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int h = (8 * wq + i) * 8 + prow;
+            const int yy = ty * TS - 1 + (h >> 4), xx = tx * TS - 1 + (h & 15);
+            const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            xlive |= ok ? (1u << i) : 0u;
+        }
+        xoff0 = (uint32_t)((((n * p.H + ty * TS - 1 + 4 * wq) * p.W + tx * TS - 1 + prow) * CIN + pchunk * 8) * 2);   // may wrap below 0: only used when live
+    };
+    const int wrow = 2 * wq * 8 + prow;                      // weight waves: rows wrow and wrow + 8 of a 64-row chunk
+    // packed (row, chunk) of this lane's weight pieces.  Offsets are rebuilt at every issue from this one register,
+    // which is laundered through an empty asm once per tile: hoisted out of the tile loop the 17 chunk addresses and
+    // the per-piece x offsets spill, and scratch traffic would break the hand-counted vmcnt bookkeeping
+    uint32_t wrc = (uint32_t)(wrow << 8 | pchunk);
+    auto dma = [&](const unsigned char* src, int lds_off) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+    };
+    auto issue_x = [&](int kc, int base) {                   // 8 pieces per x wave: channels [64kc, 64kc+64) of the halo
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            dma(((xlive >> i) & 1u) ? xg + (uint32_t)(xoff0 + (i >> 1) * p.W * 512 + (i & 1) * 4096 + kc * 128) : (const unsigned char*)p.zero,
+                base + (8 * wq + i) * 1024);
+    };
+    auto issue_w = [&](const void* w, uint32_t row_bytes, uint32_t col_bytes, int slot) {   // 2 pieces per weight wave
+        const unsigned char* src = (const unsigned char*)w + (uint32_t)((wrc >> 8) * row_bytes + (wrc & 7) * 16 + col_bytes);
+        dma(src, P_WR + slot * 8192 + 2 * wq * 1024);
+        dma(src + 8 * row_bytes, P_WR + slot * 8192 + (2 * wq + 1) * 1024);
+    };
+    auto issue_w1 = [&](int kc, int slot) { issue_w(p.w1, CIN * 2, kc * 128, slot); };
+    auto issue_tap = [&](int t, int slot) { issue_w(p.w2, 576 * 2, t * 128, slot); };
+    auto issue_w3 = [&](int nc, int slot) { issue_w(p.w3, 64 * 2, nc * 8192, slot); };
+
+    // ---------------------------------------------------------------- fragment / epilogue addresses (tile independent)
+    // second 32-deep half of a 64-deep step: chunk index + 4, i.e. address ^ 64 (bases are 128-byte aligned)
+    const uint32_t sw0 = (uint32_t)((g4 ^ (lr & 7)) << 4);
+    const uint32_t wrow2 = (uint32_t)((32 * wm2 + lr) * 128);
+    const uint32_t p1row = (uint32_t)((wn2 * 64 + lr) * 128);  // phase 1: halo rows (4*wn2 + j)*16 + lr
+    uint32_t m1a[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) m1a[kx] = lds0 + P_M1 + (rb * 16 + lr + kx) * 128 + (uint32_t)((g4 ^ ((lr + kx) & 7)) << 4);
+    uint32_t eoff[2], e1off[2], roff[2];                     // accumulator-layout byte offsets (8 B at channel 32*wm2+16*i+4*g4)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int chunk = 4 * wm2 + 2 * i + (g4 >> 1);
+        eoff[i] = (uint32_t)((rb * 16 + lr) * 128 + ((chunk ^ (lr & 7)) << 4) + (g4 & 1) * 8);            // output grid
+        e1off[i] = (uint32_t)((wn2 * 64 + lr) * 128 + ((chunk ^ (lr & 7)) << 4) + (g4 & 1) * 8);          // halo grid
+        roff[i] = (uint32_t)(((rb + 1) * 16 + lr + 1) * 128 + ((chunk ^ ((lr + 1) & 7)) << 4) + (g4 & 1) * 8);   // centre px of the halo
+    }
+    const uint32_t cch = lds0 + P_CONST + (uint32_t)((32 * wm2 + 4 * g4) * 4);   // + 64*i bytes per channel block
+    u32x2 rv[4][2][4];                                       // identity values of the tile, one set per 64-channel pass
+    f32x4 acc[2][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    auto p1_compute = [&](auto KC, int xbase, int slot) {
+        constexpr int kc = decltype(KC)::value;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const uint32_t ra = lds0 + xbase + roff[i];
+            rv[kc][i][0] = rd64<0>(ra);
+            rv[kc][i][1] = rd64<2048>(ra);
+            rv[kc][i][2] = rd64<4096>(ra);
+            rv[kc][i][3] = rd64<6144>(ra + j3adj);
+        }
+        const uint32_t wa = lds0 + P_WR + slot * 8192 + wrow2, xa = lds0 + xbase + p1row;
+        step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, acc);
+    };
+    auto tap = [&](auto KY, auto KX, int slot) {
+        constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value;
+        const uint32_t wa = lds0 + P_WR + slot * 8192 + wrow2;
+        step_2x4<ky * 2048>(wa + sw0, (wa + sw0) ^ 64, m1a[kx], m1a[kx] ^ 64, m1a[kx] + j3adj, (m1a[kx] ^ 64) + j3adj, acc);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // ================================================================ prologue: the queue state a previous tile would leave
+    int tile = xcd_remap(blockIdx.x, G);
+    if (xw) { setup_x(tile); issue_x(0, P_XR0); issue_x(1, P_XR1); }
+    else { issue_w1(1, 1); issue_w1(0, 0); }
+
+    for (bool first = true;; first = false) {
+        const int n = tile / p.tiles_per_img, trem = tile - n * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int y0 = ty * TS, x0 = tx * TS;
+        unsigned char* const ybase = (unsigned char*)p.y + (((size_t)n * p.H + y0) * p.W + x0) * 512;
+        PSTAMP();
+        asm volatile("" : "+v"(wrc));
+        // ------------------------------------------------------------ phase 1
+        bar();                                               // previous tile: stage and mid2 reads complete
+        if (xw) { issue_x(2, P_M1); issue_x(3, P_M2); } else issue_w1(2, 2);
+        // vm<N>: N = operations this wave queued after the ones needed (x waves: 8 per step, 16 stores per tile;
+        // weight waves: 2 per chunk, 4 stores per pass)
+        if (first) vm<0>(); else if (xw) vmx<40>(); else vmw<6>();
+        bar();
+        PSTAMP();
+        zero_acc();
+        p1_compute(I0{}, P_XR0, 0);
+        if (xw) vmx<32>();
+        bar();
+        if (!xw) issue_w1(3, 0);
+        PSTAMP();
+        p1_compute(I1{}, P_XR1, 1);
+        if (xw) vmx<8>(); else vmw<2>();                       // x step 2 (after it: step 3) / W1 chunk 2 (after it: chunk 3)
+        bar();
+        if (!xw) issue_tap(0, 1);
+        PSTAMP();
+        p1_compute(I2{}, P_M1, 2);
+        if (xw) vmx<0>(); else vmw<2>();                       // x step 3 / W1 chunk 3 (after it: tap 0)
+        bar();
+        if (!xw) issue_tap(1, 2);
+        PSTAMP();
+        p1_compute(I3{}, P_M2, 0);
+        bar();
+        PSTAMP();
+        // the step ring is idle until the next tile: fetch its first two steps now (the last tile re-fetches its own)
+        const int next = tile + G;
+        const bool has_next = next < p.total;
+        if (xw) { setup_x(has_next ? next : tile); issue_x(0, P_XR0); issue_x(1, P_XR1); }
+        else issue_tap(2, 0);
+        {   // epilogue 1 -> mid1 (halo pixels outside the image are conv2's zero padding: exactly 0)
+            const bool xin = (unsigned)(x0 - 1 + lr) < (unsigned)p.W;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 sc = rd_f4<C_S1 * 4>(cch + 64 * i), sh = rd_f4<C_H1 * 4>(cch + 64 * i);
+                const uint32_t ea = lds0 + P_M1 + e1off[i];
+                const int yb = y0 - 1 + 4 * wn2;
+                wr64<0>(ea, bn_relu_pack(acc[i][0], sc, sh, xin && (unsigned)(yb + 0) < (unsigned)p.H));
+                wr64<2048>(ea, bn_relu_pack(acc[i][1], sc, sh, xin && (unsigned)(yb + 1) < (unsigned)p.H));
+                wr64<4096>(ea, bn_relu_pack(acc[i][2], sc, sh, xin && (unsigned)(yb + 2) < (unsigned)p.H));
+                wr64<6144>(ea, bn_relu_pack(acc[i][3], sc, sh, xin && (unsigned)(yb + 3) < (unsigned)p.H));
+            }
+        }
+        lgkm<0>();
+        PSTAMP();
+        // ------------------------------------------------------------ phase 2 (weight ring: tap t in slot (t+1)%3)
+        zero_acc();
+        if (!xw) vmw<4>(); bar(); tap(I0{}, I0{}, 1); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(3, 1); tap(I0{}, I1{}, 2); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(4, 2); tap(I0{}, I2{}, 0); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(5, 0); tap(I1{}, I0{}, 1); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(6, 1); tap(I1{}, I1{}, 2); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(7, 2); tap(I1{}, I2{}, 0); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(8, 0); tap(I2{}, I0{}, 1); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_w3(0, 1); tap(I2{}, I1{}, 2); PSTAMP();
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_w3(1, 2); tap(I2{}, I2{}, 0); PSTAMP();
+        {   // epilogue 2 -> mid2
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 sc = rd_f4<C_S2 * 4>(cch + 64 * i), sh = rd_f4<C_H2 * 4>(cch + 64 * i);
+                const uint32_t ea = lds0 + P_M2 + eoff[i];
+                wr64<0>(ea, bn_relu_pack(acc[i][0], sc, sh, true));
+                wr64<2048>(ea, bn_relu_pack(acc[i][1], sc, sh, true));
+                wr64<4096>(ea, bn_relu_pack(acc[i][2], sc, sh, true));
+                if (nb == 4) wr64<6144>(ea, bn_relu_pack(acc[i][3], sc, sh, true));
+            }
+        }
+        lgkm<0>();
+        PSTAMP();
+        // ------------------------------------------------------------ phase 3: 4 passes of 64 output channels
+        auto pass = [&](auto NC, int slot) {
+            constexpr int nc = decltype(NC)::value;
+            zero_acc();
+            const uint32_t wa = lds0 + P_WR + slot * 8192 + wrow2;
+            const uint32_t m2a = m1a[0] + (P_M2 - P_M1);
+            step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, m2a, m2a ^ 64, m2a + j3adj, (m2a ^ 64) + j3adj, acc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 sc = rd_f4<(C_S3 + 64 * nc) * 4>(cch + 64 * i), sh = rd_f4<(C_H3 + 64 * nc) * 4>(cch + 64 * i);
+                const uint32_t ea = lds0 + P_M1 + eoff[i];
+                auto out = [&](const f32x4& a, const u32x2& r) {
+                    float lo, hi;
+                    float v0 = a[0] * sc.x + sh.x, v1 = a[1] * sc.y + sh.y, v2 = a[2] * sc.z + sh.z, v3 = a[3] * sc.w + sh.w;
+                    unpack_bf16x2(r.x, lo, hi); v0 += lo; v1 += hi;
+                    unpack_bf16x2(r.y, lo, hi); v2 += lo; v3 += hi;
+                    u32x2 o;
+                    o.x = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
+                    o.y = pack_bf16x2(fmaxf(v2, 0.f), fmaxf(v3, 0.f));
+                    return o;
+                };
+                wr64<0>(ea, out(acc[i][0], rv[nc][i][0]));
+                wr64<2048>(ea, out(acc[i][1], rv[nc][i][1]));
+                wr64<4096>(ea, out(acc[i][2], rv[nc][i][2]));
+                if (nb == 4) wr64<6144>(ea, out(acc[i][3], rv[nc][i][3]));
+            }
+            lgkm<0>();
+            bar();                                           // stage complete
+            // coalesced stores: wave w owns the 196 valid 16-byte pieces w*196 .. w*196+195 of the [196 px][8 chunks]
+            // stage (exactly four store instructions per wave and pass)
+            u32x4 v[4];
+            uint32_t st_off[4];
+            int lane_v = lane;
+            asm volatile("" : "+v"(lane_v));                 // recompute per pass: hoisted out of the tile loop these 32 values spill
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int idx = wave * 196 + it * 64 + (it < 3 ? lane_v : (lane_v & 3));
+                const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
+                v[it] = rd128<0>(lds0 + P_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4));
+                st_off[it] = (uint32_t)(((oy * p.W + ox) * 256 + c * 8) * 2 + nc * 128);
+            }
+            lgkm<0>();
+#pragma unroll
+            for (int it = 0; it < 3; ++it) *(u32x4*)(ybase + st_off[it]) = v[it];
+            if (lane < 4) *(u32x4*)(ybase + st_off[3]) = v[3];
+        };
+        if (!xw) vmw<2>();  bar(); if (!xw) issue_w3(2, 0); pass(I0{}, 1); PSTAMP();   // after W3(0): W3(1)
+        if (!xw) vmw<6>();  bar(); if (!xw) issue_w1(1, 1); pass(I1{}, 2); PSTAMP();   // after W3(1): W3(2), 4 stores
+        if (!xw) vmw<10>(); bar(); if (!xw) issue_w3(3, 2); pass(I2{}, 0); PSTAMP();   // after W3(2): 4 st, W1'(1), 4 st
+        if (!xw) vmw<4>();  bar(); if (!xw) issue_w1(0, 0); pass(I3{}, 2); PSTAMP();   // after W3(3): 4 stores
+#ifdef AP_TRACE
+        stamp_i = 0; ++tile_no;
+#endif
+        if (!has_next) break;
+        tile = next;
+    }
+    vm<0>();                                                 // no LDS-DMA may be in flight when the LDS is released
+}
+
+hipError_t launch256(const BneckArgs& a, hipStream_t st) {
+    static int n_cu = 0;
+    if (!n_cu) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)bneck256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_TOTAL);
+        if (e != hipSuccess) return e;
+    }
+    if ((size_t)a.N * a.H * a.W * 512 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit x offsets
+    const int grid = a.total < n_cu ? a.total : n_cu;
+    hipLaunchKernelGGL(bneck256_kernel, dim3(grid), dim3(512), P_TOTAL, st, a);
+    return hipGetLastError();
+}
+
+template <int CIN, bool DS> hipError_t launch(const BneckArgs& a, hipStream_t st) {
+    static bool attr_set = false;
+    auto kern = bneck64_kernel<CIN, DS>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+        if (e != hipSuccess) return e;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(a.total), dim3(512), L_TOTAL, st, a);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+int g_bneck_legacy = 0;   // testing knob: 1 = one-tile-per-workgroup kernel for the identity blocks too
+
+// Fused layer1 bottleneck.  cin = 256 (identity blocks) or 64 with ds = 1 (block 0, downsample folded into W3).
+hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st) {
+    if (!a.zero || a.H % TS || a.W % TS || a.N <= 0) return hipErrorInvalidValue;
+    a.tiles_x = a.W / TS;
+    a.tiles_per_img = a.tiles_x * (a.H / TS);
+    a.total = a.N * a.tiles_per_img;
+    if (cin == 256 && !ds) return g_bneck_legacy ? launch<256, false>(a, st) : launch256(a, st);
+    if (cin == 64 && ds) return launch<64, true>(a, st);
+    return hipErrorInvalidValue;
+}

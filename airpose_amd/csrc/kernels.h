@@ -31,6 +31,19 @@ hipError_t ap_launch_conv(const ConvArgs& a, int is_bf16, hipStream_t st);
 // software-pipelined (LDS-DMA ring) variant; cfg: 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 256x64
 hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStream_t st);
 
+// ---- fused layer1 bottleneck (bottleneck.hip); bf16 only
+struct BneckArgs {
+    const void* x;                // [N][H][W][cin] bf16 (cin = 256, or 64 for the downsample block)
+    void* y;                      // [N][H][W][256] bf16
+    const void *w1, *w2, *w3;     // packed bf16 rows: [64..][cin], [64..][9*64], [256][64 | 128]
+    const float *s1, *h1, *s2, *h2, *s3, *h3;   // BatchNorm scale / shift per conv
+    const void* zero;             // >= 16 bytes of zeros
+    unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
+    int N, H, W;                  // H, W multiples of 14
+    int tiles_x, tiles_per_img, total;   // filled by the launcher
+};
+hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st);
+
 // ---- stem / pooling (stem.hip)
 // conv 7x7/2 p3 (3->64) + BN + ReLU from NCHW fp32 into NHWC T [N][112][112][64]
 hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, const float* scale, const float* shift,

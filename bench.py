@@ -163,7 +163,8 @@ def main():
         conv_flops_step = conv_stack_flops_per_image() * n_img
         conv_ms_step = tm["conv_ms"] / max(tm["passes"], 1)
         chunk = args.chunk or 512
-        launches = 48 * ((2 * B + chunk - 1) // chunk)   # 52 convs, 4 downsample convs folded into conv3
+        # 52 convs: 4 downsample convs folded into conv3, layer1's 3 bottlenecks are one fused kernel each (bf16)
+        launches = (42 if args.precision == "bf16" else 48) * ((2 * B + chunk - 1) // chunk)
         peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
         res = {
@@ -180,8 +181,9 @@ def main():
                        "pairs_per_gpu": B, "global_pairs": world * B, "image": "224x224", "ief_iters": 3,
                        "trunk_chunk_images": chunk, "sharding": "whole pairs per GPU, no data-path collective"},
             "roofline": {"bound": "mfma",
-                         "kernel": "conv_pipe_kernel / conv_igemm_kernel: the 52 fused conv+BN(+residual)+ReLU launches "
-                                   "of one trunk pass, 48 launches (dominant instance conv_pipe_kernel<bf16,128,128,2,4,2>, 42 of 48)",
+                         "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of one trunk pass in %d launches: conv_pipe_kernel "
+                                   "(dominant instance <bf16,128,128,2,4,2>: 39 launches) + 3 fused layer1 bottlenecks "
+                                   "(bneck64_kernel / bneck256_kernel)" % launches,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(),
                          "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,

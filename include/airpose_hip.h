@@ -98,6 +98,17 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
                    const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
                    int relu, void* stream);
 
+/* Fused 64-plane bottleneck (layer1 of the trunk, bf16 only): Bottleneck.forward, model_copenet.py:27-47, as ONE
+ * kernel with both intermediates resident in LDS.  x [N][H][W][Cin] bf16, y [N][H][W][256] bf16; H, W multiples of 14.
+ *   downsample = 0: Cin = 256, w1 [64..][256], w2 [64..][3][3][64], w3 [256][64];  y = relu(bn3(conv3(..)) + x)
+ *   downsample = 1: Cin = 64,  w1 [64..][64],  w3 [256][128] = [conv3 | downsample conv] (K-concatenated, BN scales
+ *                   folded into the weights, s3 = 1, h3 = shift3 + shift_ds);           y = relu(W3 . [mid2 | x] + h3)
+ * Weight rows are K-contiguous bf16 as for ap_conv2d_nhwc; s*, h* are fp32 BatchNorm scale / shift.  Matches the
+ * three-convolution path to bf16 rounding of the fp32 accumulations. */
+int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
+                         const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
+                         int N, int H, int W, int Cin, int downsample, void* stream);
+
 /* Tuning/testing knob (process-wide): tile configuration of the convolution kernels.  -1 = automatic,
  * 0..3 = software-pipelined LDS-DMA kernel with 256x128 / 128x128 / 128x64 / 256x64 tiles,
  * 100 = register-staged 2-stage kernel.  Results are identical for every setting. */
@@ -125,6 +136,9 @@ int ap_net_set_fuse_ds(ap_net* h, int on);
 /* bf16 mode: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool kernels
  * (bit-identical results; kept for A/B measurement). */
 int ap_net_set_fuse_stem(ap_net* h, int on);
+/* bf16 mode: on = 1 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
+ * intermediates never leave LDS), on = 0 as its three (two + folded-downsample) convolutions.  Parity-tested. */
+int ap_net_set_fuse_block(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);
 

@@ -144,6 +144,105 @@ def test_conv_configs_agree_bitwise(dev):
         assert torch.equal(o, outs[0])
 
 
+# ------------------------------------------------------------------------------------------------ fused bottleneck
+def _bneck_case(dev, N, H, ds, seed):
+    """Bottleneck.forward (model_copenet.py:27-47) for planes = 64 on bf16 operands: fp64 oracle that rounds the two
+    64-channel intermediates to bf16 exactly where the kernel (and the three-convolution path) does."""
+    from airpose_amd import _native as Nn
+    g = torch.Generator().manual_seed(seed)
+    cin = 64 if ds else 256
+    bf = torch.bfloat16
+    x = torch.randn(N, cin, H, H, generator=g).to(bf)
+    w1 = (torch.randn(64, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(bf)
+    w2 = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).to(bf)
+    w3 = (torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5).to(bf)
+    wd = (torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5).to(bf)       # folded downsample columns
+    sc = [torch.rand(c, generator=g) + 0.5 for c in (64, 64, 256)]
+    sh = [torch.randn(c, generator=g) * 0.1 for c in (64, 64, 256)]
+    if ds:
+        sc[2] = torch.ones(256)                 # pack_c3_ds folds the BN scales into the weights
+    bn = lambda t, i: t * sc[i].double().view(1, -1, 1, 1) + sh[i].double().view(1, -1, 1, 1)
+    m1 = bn(F.conv2d(x.double(), w1.double()), 0).clamp_min(0).to(bf)
+    m2 = bn(F.conv2d(m1.double(), w2.double(), padding=1), 1).clamp_min(0).to(bf)
+    t = F.conv2d(m2.double(), w3.double())
+    ref = (bn(t + F.conv2d(x.double(), wd.double()), 2) if ds else bn(t, 2) + x.double()).clamp_min(0)
+
+    def rows(w, rows_pad):                      # OIHW -> [O..][kh][kw][I] bf16, rows zero-padded
+        o = torch.zeros(rows_pad, w.shape[2], w.shape[3], w.shape[1], dtype=bf)
+        o[:w.shape[0]] = w.permute(0, 2, 3, 1)
+        return o.contiguous().to(dev)
+    w3p = torch.cat([w3, wd], 1) if ds else w3
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    y = torch.full((N, H, H, 256), float("nan"), dtype=bf, device=dev)
+    dv = [rows(w1, 128), rows(w2, 128), rows(w3p, 256)] + [t.to(dev) for t in sc + sh]
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    rc = Nn.lib().ap_bottleneck64_nhwc(p(xd), p(dv[0]), p(dv[3]), p(dv[6]), p(dv[1]), p(dv[4]), p(dv[7]), p(dv[2]),
+                                       p(dv[5]), p(dv[8]), p(y), N, H, H, cin, int(ds), Nn.stream_ptr(dev))
+    Nn.check(rc, "ap_bottleneck64_nhwc")
+    torch.cuda.synchronize()
+    return y.float().cpu().permute(0, 3, 1, 2).double(), ref
+
+
+@pytest.mark.parametrize("ds", [0, 1])
+@pytest.mark.parametrize("N,H", [(2, 56), (3, 14), (1, 28), (5, 56)])
+def test_fused_bottleneck_primitive(dev, N, H, ds):
+    got, ref = _bneck_case(dev, N, H, ds, seed=100 * N + H + ds)
+    assert torch.isfinite(got).all()
+    # same operands and the same bf16 rounding points: what differs is the fp32 accumulation order (an intermediate
+    # may round to the neighbouring bf16 value) and the bf16 rounding of the output
+    assert rel_err(got.numpy(), ref.numpy()) < 8e-3
+
+
+def test_fused_bottleneck_persistent_loop_equals_three_convs(dev):
+    """More tiles than CUs (and not a multiple): every workgroup of the persistent kernel walks several tiles, the
+    last round is partial.  The fused block must equal conv1 -> conv2 -> conv3(+identity) bit for bit (same operands,
+    same bf16 rounding points, same K order per output element)."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(77)
+    N, H = 37, 56                                           # 592 tiles on 256 CUs
+    x = torch.randn(N, H, H, 256, generator=g).to(bf).to(dev)
+    w1 = (torch.randn(128, 256, generator=g) * (2.0 / 256) ** 0.5).to(bf).to(dev)
+    w2 = (torch.randn(128, 576, generator=g) * (2.0 / 576) ** 0.5).to(bf).to(dev)
+    w3 = (torch.randn(256, 64, generator=g) * (2.0 / 64) ** 0.5).to(bf).to(dev)
+    sc = [(torch.rand(c, generator=g) + 0.5).to(dev) for c in (128, 128, 256)]
+    sh = [(torch.randn(c, generator=g) * 0.1).to(dev) for c in (128, 128, 256)]
+    y = torch.full((N, H, H, 256), float("nan"), dtype=bf, device=dev)
+    y2 = torch.empty_like(y)
+    t1 = torch.empty(N, H, H, 64, dtype=bf, device=dev)
+    t2 = torch.empty_like(t1)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    Nn.check(L.ap_bottleneck64_nhwc(p(x), p(w1), p(sc[0]), p(sh[0]), p(w2), p(sc[1]), p(sh[1]), p(w3), p(sc[2]), p(sh[2]),
+                                    p(y), N, H, H, 256, 0, st), "ap_bottleneck64_nhwc")
+    B = Nn.PRECISIONS["bf16"]
+    Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w1), p(sc[0]), p(sh[0]), None, p(t1), N, H, H, 256, 64, 1, 1, 0, 1, st), "c1")
+    Nn.check(L.ap_conv2d_nhwc(B, p(t1), p(w2), p(sc[1]), p(sh[1]), None, p(t2), N, H, H, 64, 64, 3, 1, 1, 1, st), "c2")
+    Nn.check(L.ap_conv2d_nhwc(B, p(t2), p(w3), p(sc[2]), p(sh[2]), p(x), p(y2), N, H, H, 64, 256, 1, 1, 0, 1, st), "c3")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
+
+
+def test_fused_bottleneck_is_deterministic(dev):
+    a, _ = _bneck_case(dev, 4, 56, 0, seed=9)
+    b, _ = _bneck_case(dev, 4, 56, 0, seed=9)
+    assert torch.equal(a, b)
+
+
+def test_fused_layer1_matches_separate_convs(netbf, golden, copenet_inputs, dev):
+    """Whole-bottleneck fusion of layer1 (default) vs its separate convolutions, through the trunk."""
+    x = copenet_inputs["im0"].to(dev)
+    netbf.set_fuse_block(1)
+    a = netbf.forward_feat_ext(x)
+    netbf.set_fuse_block(0)
+    b = netbf.forward_feat_ext(x)
+    netbf.set_fuse_block(1)
+    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-2
+    assert rel_err(a.cpu().numpy(), golden["copenet_b2"]["xf0"]) < 3e-2
+
+
 # ------------------------------------------------------------------------------------------------ trunk / IEF / forward
 def test_trunk_fp32_matches_golden(golden, net32, copenet_inputs, dev):
     g = golden["copenet_b2"]
