@@ -20,7 +20,13 @@
 // global_load_lds with the swizzle on the SOURCE address.  Pixel rows are indexed on a 16-wide grid (row = y*16 + x)
 // so a 16-pixel MFMA column block is one tile row (columns 14, 15 are junk that is never stored).
 // All LDS traffic is inline asm and every s_waitcnt is counted by hand (a compiler-visible LDS access after an LDS-DMA
-// would be answered with vmcnt(0)); -DAP_BNECK_SAFE turns every counted wait into vmcnt(0) for cross-checking.
+// would be answered with vmcnt(0)); -DAP_BNECK_SAFE (-DAP_BNECK_SAFE_X / _W for the persistent kernel's two DMA roles)
+// turns every counted wait into vmcnt(0) for cross-checking: results must be bit-identical.
+//
+// Two kernels: bneck64_kernel<64, true> below (one tile per workgroup; the downsample block, whose x tile is only
+// 32 KiB and stays resident) and bneck256_kernel further down (persistent, wave-specialised DMA; the identity blocks).
+// The <256, false> paths of the first kernel are the first version of the identity block, kept as the readable
+// reference of the phase structure; they are not instantiated.
 #include <type_traits>
 
 #include "ap_common.h"
@@ -100,9 +106,11 @@ template <int N, int OFF0> __device__ __forceinline__ void rd_blocks(uint32_t ad
 // one 64-deep contraction step of a [2 channel blocks] x [4 pixel blocks] wave tile.
 // wa0/wa1: weight fragment addresses of the two 32-deep halves; xa0/xa1: pixel fragment addresses (blocks 0..2 at
 // OFF + j*2048), xb0/xb1: the same for block 3 (a clamped duplicate of block 2 in the 3-row waves)
-template <int OFF>
+struct NoHook { __device__ __forceinline__ void operator()(int) const {} };
+// hook(0) runs once the fragment reads are queued, hook(1) between the two MFMA groups (slots for global stores)
+template <int OFF, typename F = NoHook>
 __device__ __forceinline__ void step_2x4(uint32_t wa0, uint32_t wa1, uint32_t xa0, uint32_t xa1, uint32_t xb0, uint32_t xb1,
-                                         f32x4 (&acc)[2][4]) {
+                                         f32x4 (&acc)[2][4], F&& hook = NoHook{}) {
     u32x4 a0[2], a1[2], b0[4], b1[4];
     rd_blocks<2, 0>(wa0, a0);
     { u32x4 t[3]; rd_blocks<3, OFF>(xa0, t); b0[0] = t[0]; b0[1] = t[1]; b0[2] = t[2]; }
@@ -110,11 +118,14 @@ __device__ __forceinline__ void step_2x4(uint32_t wa0, uint32_t wa1, uint32_t xa
     rd_blocks<2, 0>(wa1, a1);
     { u32x4 t[3]; rd_blocks<3, OFF>(xa1, t); b1[0] = t[0]; b1[1] = t[1]; b1[2] = t[2]; }
     b1[3] = rd128<OFF + 6144>(xb1);
+    hook(0);
     lgkm<6>();
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) mma(acc[i][j], a0[i], b0[j]);
+    __builtin_amdgcn_sched_barrier(0);
+    hook(1);
     __builtin_amdgcn_sched_barrier(0);
     lgkm<0>();
 #pragma unroll
@@ -465,6 +476,11 @@ constexpr int C_S1 = 0, C_H1 = 64, C_S2 = 128, C_H2 = 192, C_S3 = 256, C_H3 = 51
 template <int OFF> __device__ __forceinline__ void wr128(uint32_t addr, u32x4 v) {
     asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
 }
+__device__ __forceinline__ float4 as_f4(const u32x4& r) {
+    const uint32_t a = r.x, b = r.y, c = r.z, d = r.w;       // (copy the lanes out first: bit_cast on a vector element mis-compiles)
+    return make_float4(__builtin_bit_cast(float, a), __builtin_bit_cast(float, b), __builtin_bit_cast(float, c),
+                       __builtin_bit_cast(float, d));
+}
 template <int OFF> __device__ __forceinline__ float4 rd_f4(uint32_t addr) {
     const u32x4 r = rd128<OFF>(addr);
     lgkm<0>();
@@ -488,8 +504,11 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
     int stamp_i = 0, tile_no = 0;
 #define PSTAMP() do { if (p.dbg && blockIdx.x == 0 && tile_no == 2 && (tid == 0 || tid == 256)) \
         p.dbg[(tid ? 40 : 0) + stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
+#define FSTAMP(k) do { if (nc == 1 && p.dbg && blockIdx.x == 0 && tile_no == 2 && (tid == 0 || tid == 256)) \
+        p.dbg[(tid ? 40 : 0) + 26 + (k)] = __builtin_readcyclecounter(); } while (0)
 #else
 #define PSTAMP() do {} while (0)
+#define FSTAMP(k) do {} while (0)
 #endif
 
     // compute roles: 2 channel-block pairs x 4 pixel-block groups.  Phase 1: halo rows 4*wn2 .. +3;
@@ -541,11 +560,13 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
     };
-    auto issue_x = [&](int kc, int base) {                   // 8 pieces per x wave: channels [64kc, 64kc+64) of the halo
+    auto issue_x1 = [&](int kc, int base, int i) {           // piece i (of 8 per x wave) of channels [64kc, 64kc+64) of the halo
+        dma(((xlive >> i) & 1u) ? xg + (uint32_t)(xoff0 + (i >> 1) * p.W * 512 + (i & 1) * 4096 + kc * 128) : (const unsigned char*)p.zero,
+            base + (8 * wq + i) * 1024);
+    };
+    auto issue_x = [&](int kc, int base) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
-            dma(((xlive >> i) & 1u) ? xg + (uint32_t)(xoff0 + (i >> 1) * p.W * 512 + (i & 1) * 4096 + kc * 128) : (const unsigned char*)p.zero,
-                base + (8 * wq + i) * 1024);
+        for (int i = 0; i < 8; ++i) issue_x1(kc, base, i);
     };
     auto issue_w = [&](const void* w, uint32_t row_bytes, uint32_t col_bytes, int slot) {   // 2 pieces per weight wave
         const unsigned char* src = (const unsigned char*)w + (uint32_t)((wrc >> 8) * row_bytes + (wrc & 7) * 16 + col_bytes);
@@ -573,6 +594,29 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
         roff[i] = (uint32_t)(((rb + 1) * 16 + lr + 1) * 128 + ((chunk ^ ((lr + 1) & 7)) << 4) + (g4 & 1) * 8);   // centre px of the halo
     }
     const uint32_t cch = lds0 + P_CONST + (uint32_t)((32 * wm2 + 4 * g4) * 4);   // + 64*i bytes per channel block
+    // coalesced store geometry: wave w owns the 196 valid 16-byte pieces w*196 .. w*196+195 of the [196 px][8 chunks]
+    // stage (exactly four store instructions per wave and pass; the fourth carries 4 lanes)
+    uint32_t st_lds[4], st_off[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = wave * 196 + it * 64 + (it < 3 ? lane : (lane & 3));
+        const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
+        st_lds[it] = lds0 + P_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4);
+        st_off[it] = (uint32_t)(((oy * p.W + ox) * 256 + c * 8) * 2);
+    }
+    // A pass leaves its 64-channel output slice in sv (read back from the stage); the four global stores are issued
+    // inside the NEXT compute step (a burst of stores right behind the stage blocks the wave: the write path drains
+    // at the CU's HBM share, ~230 cycles per store instruction measured)
+    u32x4 sv[4];
+    auto put_stores = [&](int half, unsigned char* base) {
+        if (half == 0) {
+            *(u32x4*)(base + st_off[0]) = sv[0];
+            *(u32x4*)(base + st_off[1]) = sv[1];
+        } else {
+            *(u32x4*)(base + st_off[2]) = sv[2];
+            if (lane < 4) *(u32x4*)(base + st_off[3]) = sv[3];
+        }
+    };
     u32x2 rv[4][2][4];                                       // identity values of the tile, one set per 64-channel pass
     f32x4 acc[2][4];
     auto zero_acc = [&]() {
@@ -581,7 +625,7 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     };
-    auto p1_compute = [&](auto KC, int xbase, int slot) {
+    auto p1_compute = [&](auto KC, int xbase, int slot, unsigned char* st_base = nullptr) {
         constexpr int kc = decltype(KC)::value;
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -592,12 +636,25 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
             rv[kc][i][3] = rd64<6144>(ra + j3adj);
         }
         const uint32_t wa = lds0 + P_WR + slot * 8192 + wrow2, xa = lds0 + xbase + p1row;
-        step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, acc);
+        if (kc == 0 && st_base)                              // the previous tile's last slice leaves under this step
+            step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, acc,
+                        [&](int half) { put_stores(half, st_base); });
+        else
+            step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, acc);
     };
+    // The next tile's first two x steps (16 pieces per x wave) ride along with taps 0..8 and passes 0..2, at most two
+    // per compute step: a CU keeps only ~32 LDS-DMA pieces in flight (tools/probes/dma_depth_probe.hip), so a burst
+    // parks the issuing waves in the issue slot at the CU's share of the HBM rate.
+    //   taps 0..7: step 0, piece t (between the MFMA groups);  tap 8, passes 0..2: step 1, two pieces each
     auto tap = [&](auto KY, auto KX, int slot) {
-        constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value;
+        constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value, t = ky * 3 + kx;
         const uint32_t wa = lds0 + P_WR + slot * 8192 + wrow2;
-        step_2x4<ky * 2048>(wa + sw0, (wa + sw0) ^ 64, m1a[kx], m1a[kx] ^ 64, m1a[kx] + j3adj, (m1a[kx] ^ 64) + j3adj, acc);
+        step_2x4<ky * 2048>(wa + sw0, (wa + sw0) ^ 64, m1a[kx], m1a[kx] ^ 64, m1a[kx] + j3adj, (m1a[kx] ^ 64) + j3adj, acc,
+                            [&](int half) {
+                                if (!xw) return;
+                                if (t < 8) { if (half) issue_x1(0, P_XR0, t); }
+                                else issue_x1(1, P_XR1, half);
+                            });
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
@@ -609,6 +666,7 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
     if (xw) { setup_x(tile); issue_x(0, P_XR0); issue_x(1, P_XR1); }
     else { issue_w1(1, 1); issue_w1(0, 0); }
 
+    unsigned char* yprev = nullptr;                          // tile whose last output slice is still in sv
     for (bool first = true;; first = false) {
         const int n = tile / p.tiles_per_img, trem = tile - n * p.tiles_per_img;
         const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
@@ -618,35 +676,35 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
         asm volatile("" : "+v"(wrc));
         // ------------------------------------------------------------ phase 1
         bar();                                               // previous tile: stage and mid2 reads complete
-        if (xw) { issue_x(2, P_M1); issue_x(3, P_M2); } else issue_w1(2, 2);
-        // vm<N>: N = operations this wave queued after the ones needed (x waves: 8 per step, 16 stores per tile;
-        // weight waves: 2 per chunk, 4 stores per pass)
-        if (first) vm<0>(); else if (xw) vmx<40>(); else vmw<6>();
+        if (xw) { if (first) issue_x(2, P_M1); issue_x(3, P_M2); } else issue_w1(2, 2);   // (step 2 came in under pass 3)
+        // vm<N>: N = operations this wave queued after the ones needed (x waves: 8 per step; weight waves: 2 per
+        // chunk; everybody: 4 stores inside passes 1-3 and inside the next tile's first step)
+        if (first) vm<0>(); else if (xw) vmx<36>(); else vmw<6>();
         bar();
         PSTAMP();
         zero_acc();
-        p1_compute(I0{}, P_XR0, 0);
-        if (xw) vmx<32>();
+        p1_compute(I0{}, P_XR0, 0, yprev);
+        if (xw) vmx<24>();                                   // x step 1 (its last piece left under pass 2)
         bar();
         if (!xw) issue_w1(3, 0);
         PSTAMP();
         p1_compute(I1{}, P_XR1, 1);
-        if (xw) vmx<8>(); else vmw<2>();                       // x step 2 (after it: step 3) / W1 chunk 2 (after it: chunk 3)
+        if (xw) vmx<12>(); else vmw<6>();                      // x step 2, queued under the previous pass 3 (after it: step 3, 4 stores) / W1 chunk 2 (after it: 4 stores, chunk 3)
         bar();
         if (!xw) issue_tap(0, 1);
         PSTAMP();
         p1_compute(I2{}, P_M1, 2);
-        if (xw) vmx<0>(); else vmw<2>();                       // x step 3 / W1 chunk 3 (after it: tap 0)
+        if (xw) vmx<4>(); else vmw<2>();                       // x step 3 (after it: 4 stores) / W1 chunk 3 (after it: tap 0)
         bar();
         if (!xw) issue_tap(1, 2);
         PSTAMP();
         p1_compute(I3{}, P_M2, 0);
         bar();
         PSTAMP();
-        // the step ring is idle until the next tile: fetch its first two steps now (the last tile re-fetches its own)
+        // from here on the x waves fetch for the next tile (the last tile re-fetches its own: the queue bookkeeping stays)
         const int next = tile + G;
         const bool has_next = next < p.total;
-        if (xw) { setup_x(has_next ? next : tile); issue_x(0, P_XR0); issue_x(1, P_XR1); }
+        if (xw) setup_x(has_next ? next : tile);
         else issue_tap(2, 0);
         {   // epilogue 1 -> mid1 (halo pixels outside the image are conv2's zero padding: exactly 0)
             const bool xin = (unsigned)(x0 - 1 + lr) < (unsigned)p.W;
@@ -690,14 +748,40 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
         // ------------------------------------------------------------ phase 3: 4 passes of 64 output channels
         auto pass = [&](auto NC, int slot) {
             constexpr int nc = decltype(NC)::value;
+            FSTAMP(0);
             zero_acc();
-            const uint32_t wa = lds0 + P_WR + slot * 8192 + wrow2;
-            const uint32_t m2a = m1a[0] + (P_M2 - P_M1);
-            step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, m2a, m2a ^ 64, m2a + j3adj, (m2a ^ 64) + j3adj, acc);
+            u32x4 cs[2], ch[2];                              // BatchNorm scale / shift of this slice (ready with the fragments)
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                const float4 sc = rd_f4<(C_S3 + 64 * nc) * 4>(cch + 64 * i), sh = rd_f4<(C_H3 + 64 * nc) * 4>(cch + 64 * i);
-                const uint32_t ea = lds0 + P_M1 + eoff[i];
+                cs[i] = rd128<(C_S3 + 64 * nc) * 4>(cch + 64 * i);
+                ch[i] = rd128<(C_H3 + 64 * nc) * 4>(cch + 64 * i);
+            }
+            const uint32_t wa = lds0 + P_WR + slot * 8192 + wrow2;
+            const uint32_t m2a = m1a[0] + (P_M2 - P_M1);
+            // stage of this pass: mid1's buffer, except for the last pass, which reuses mid2's (after one more barrier)
+            // so that mid1's buffer can take x step 2 of the next tile a whole pass before the tile ends
+            constexpr int STG = nc == 3 ? P_M2 - P_M1 : 0;
+            if constexpr (nc > 0)                            // the previous slice leaves under this step's MFMAs
+                step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, m2a, m2a ^ 64, m2a + j3adj, (m2a ^ 64) + j3adj, acc,
+                            [&](int half) {
+                                put_stores(half, ybase + (nc - 1) * 128);
+                                if (!xw) return;
+                                if (nc == 3) {
+#pragma unroll
+                                    for (int i = 0; i < 4; ++i) issue_x1(2, P_M1, 4 * half + i);
+                                } else {
+                                    issue_x1(1, P_XR1, 2 + 2 * nc + half);
+                                }
+                            });
+            else
+                step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, m2a, m2a ^ 64, m2a + j3adj, (m2a ^ 64) + j3adj, acc,
+                            [&](int half) { if (xw) issue_x1(1, P_XR1, 2 + half); });
+            FSTAMP(1);
+            if constexpr (nc == 3) bar();                    // every wave is done with mid2
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 sc = as_f4(cs[i]), sh = as_f4(ch[i]);
+                const uint32_t ea = lds0 + P_M1 + STG + eoff[i];
                 auto out = [&](const f32x4& a, const u32x2& r) {
                     float lo, hi;
                     float v0 = a[0] * sc.x + sh.x, v1 = a[1] * sc.y + sh.y, v2 = a[2] * sc.z + sh.z, v3 = a[3] * sc.w + sh.w;
@@ -714,35 +798,27 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
                 if (nb == 4) wr64<6144>(ea, out(acc[i][3], rv[nc][i][3]));
             }
             lgkm<0>();
+            FSTAMP(2);
             bar();                                           // stage complete
-            // coalesced stores: wave w owns the 196 valid 16-byte pieces w*196 .. w*196+195 of the [196 px][8 chunks]
-            // stage (exactly four store instructions per wave and pass)
-            u32x4 v[4];
-            uint32_t st_off[4];
-            int lane_v = lane;
-            asm volatile("" : "+v"(lane_v));                 // recompute per pass: hoisted out of the tile loop these 32 values spill
+            FSTAMP(3);
 #pragma unroll
-            for (int it = 0; it < 4; ++it) {
-                const int idx = wave * 196 + it * 64 + (it < 3 ? lane_v : (lane_v & 3));
-                const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
-                v[it] = rd128<0>(lds0 + P_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4));
-                st_off[it] = (uint32_t)(((oy * p.W + ox) * 256 + c * 8) * 2 + nc * 128);
-            }
+            for (int it = 0; it < 4; ++it) sv[it] = rd128<STG>(st_lds[it]);
             lgkm<0>();
-#pragma unroll
-            for (int it = 0; it < 3; ++it) *(u32x4*)(ybase + st_off[it]) = v[it];
-            if (lane < 4) *(u32x4*)(ybase + st_off[3]) = v[3];
+            FSTAMP(4);
         };
-        if (!xw) vmw<2>();  bar(); if (!xw) issue_w3(2, 0); pass(I0{}, 1); PSTAMP();   // after W3(0): W3(1)
-        if (!xw) vmw<6>();  bar(); if (!xw) issue_w1(1, 1); pass(I1{}, 2); PSTAMP();   // after W3(1): W3(2), 4 stores
-        if (!xw) vmw<10>(); bar(); if (!xw) issue_w3(3, 2); pass(I2{}, 0); PSTAMP();   // after W3(2): 4 st, W1'(1), 4 st
-        if (!xw) vmw<4>();  bar(); if (!xw) issue_w1(0, 0); pass(I3{}, 2); PSTAMP();   // after W3(3): 4 stores
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_w3(2, 0); pass(I0{}, 1); PSTAMP();    // after W3(0): W3(1)
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_w1(1, 1); pass(I1{}, 2); PSTAMP();    // after W3(1): W3(2)
+        if (!xw) vmw<6>(); bar(); if (!xw) issue_w3(3, 2); pass(I2{}, 0); PSTAMP();    // after W3(2): W1'(1), 4 stores
+        if (!xw) vmw<4>(); bar(); if (!xw) issue_w1(0, 0); pass(I3{}, 2); PSTAMP();    // after W3(3): 4 stores
+        yprev = ybase + 3 * 128;
 #ifdef AP_TRACE
         stamp_i = 0; ++tile_no;
 #endif
         if (!has_next) break;
         tile = next;
     }
+    put_stores(0, yprev);
+    put_stores(1, yprev);
     vm<0>();                                                 // no LDS-DMA may be in flight when the LDS is released
 }
 
@@ -777,15 +853,13 @@ template <int CIN, bool DS> hipError_t launch(const BneckArgs& a, hipStream_t st
 
 }  // namespace
 
-int g_bneck_legacy = 0;   // testing knob: 1 = one-tile-per-workgroup kernel for the identity blocks too
-
 // Fused layer1 bottleneck.  cin = 256 (identity blocks) or 64 with ds = 1 (block 0, downsample folded into W3).
 hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st) {
     if (!a.zero || a.H % TS || a.W % TS || a.N <= 0) return hipErrorInvalidValue;
     a.tiles_x = a.W / TS;
     a.tiles_per_img = a.tiles_x * (a.H / TS);
     a.total = a.N * a.tiles_per_img;
-    if (cin == 256 && !ds) return g_bneck_legacy ? launch<256, false>(a, st) : launch256(a, st);
+    if (cin == 256 && !ds) return launch256(a, st);
     if (cin == 64 && ds) return launch<64, true>(a, st);
     return hipErrorInvalidValue;
 }

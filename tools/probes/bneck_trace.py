@@ -31,4 +31,7 @@ for ds in (0, 1):
     for wg in (0, 1):
         t = b[wg * 40: wg * 40 + len(names) + 1]
         d = [int(t[i + 1] - t[i]) for i in range(len(names))]
+        if not ds:
+            f = b[wg * 40 + 26: wg * 40 + 32]
+            print("      pass 1 detail: mfma step=%d epilogue=%d stage barrier=%d stage read=%d store issue=%d" % tuple(int(f[i + 1] - f[i]) for i in range(5)))
         print("ds=%d slot %d total %6d cycles: " % (ds, wg, int(t[len(names)] - t[0])) + "  ".join("%s=%d" % (names[i], d[i]) for i in range(len(names))))
