@@ -4,29 +4,25 @@
 //   out = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + (downsample(x) | x))
 // At 56x56 the three convs of a layer1 block are HBM-bound when run as separate GEMMs (the 64-channel
 // intermediates and the 256-channel block input are written and re-read: 3.3 GB per block at 512 images).
-// This kernel keeps both intermediates in LDS: one workgroup owns a 14x14 output tile of one image and runs
+// These kernels keep both intermediates in LDS: a workgroup owns a 14x14 output tile of one image and runs
 //
-//   phase 1  mid1[16x16 halo px][64] = relu(bn1(W1 . x))         K = CIN, streamed in 64-channel steps (LDS-DMA ring)
+//   phase 1  mid1[16x16 halo px][64] = relu(bn1(W1 . x))         K = CIN in 64-channel steps
 //   phase 2  mid2[14x14 px][64]      = relu(bn2(W2 * mid1))      9 taps x K 64, weights streamed per tap
-//   phase 3  y[14x14 px][256]        = relu(bn3(W3 . mid2) + x)  4 passes of 64 output channels; the identity tile
-//                                                               arrives by LDS-DMA one pass ahead, stores are 16-byte
-//                                                               coalesced through an LDS stage
-//   (DS variant, block 0: K3 = 128 = [mid2 | x] with the downsample conv and both BN scales folded into W3,
+//   phase 3  y[14x14 px][256]        = relu(bn3(W3 . mid2) + x)  4 passes of 64 output channels through an LDS stage,
+//                                                               16-byte coalesced stores
+//   (downsample block: K3 = 128 = [mid2 | x] with the downsample conv and both BN scales folded into W3,
 //    pack_c3_ds in api.hip; x is the resident phase-1 tile, no identity add)
 //
-// so HBM sees the block input once (+ the 1.31x halo, which neighbouring tiles find in L2) and the output once.
+// so HBM sees the block input once (+ the 1.31x halo) and the output once.  The result equals the three-convolution
+// path bit for bit (same operands, same bf16 rounding points, same K order per output element).
 // MFMA operands as in conv_pipe.hip: weights are the A operand (rows = channels), pixels the B operand; every LDS
 // image is rows of 128 B (64 bf16) with the 16-byte chunk index XOR-swizzled by (row & 7), written lane-linearly by
 // global_load_lds with the swizzle on the SOURCE address.  Pixel rows are indexed on a 16-wide grid (row = y*16 + x)
 // so a 16-pixel MFMA column block is one tile row (columns 14, 15 are junk that is never stored).
 // All LDS traffic is inline asm and every s_waitcnt is counted by hand (a compiler-visible LDS access after an LDS-DMA
-// would be answered with vmcnt(0)); -DAP_BNECK_SAFE (-DAP_BNECK_SAFE_X / _W for the persistent kernel's two DMA roles)
-// turns every counted wait into vmcnt(0) for cross-checking: results must be bit-identical.
-//
-// Two kernels: bneck64_kernel<64, true> below (one tile per workgroup; the downsample block, whose x tile is only
-// 32 KiB and stays resident) and bneck256_kernel further down (persistent, wave-specialised DMA; the identity blocks).
-// The <256, false> paths of the first kernel are the first version of the identity block, kept as the readable
-// reference of the phase structure; they are not instantiated.
+// would be answered with vmcnt(0)); -DAP_BNECK_SAFE_X -DAP_BNECK_SAFE_W turn the counted waits of the two DMA roles
+// into vmcnt(0) for cross-checking: results must be bit-identical.
+// Two kernels: bneck256_kernel (identity blocks) and bneck64ds_kernel (the downsample block), both persistent.
 #include <type_traits>
 
 #include "ap_common.h"
@@ -37,20 +33,9 @@ namespace {
 typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
 
 constexpr int TS = 14;                                       // output tile edge
-// LDS map (bytes)
-constexpr int L_XR0 = 0;                                     // 256 rows: x step ring slot 0 | identity chunk (even pass) | DS: resident x tile
-constexpr int L_XR1 = 32768;                                 // 256 rows: x step ring slot 1 | identity chunk (odd pass)  | DS: W3 double buffer
-constexpr int L_WR = 65536;                                  // 4 x 64 rows: W1 steps / W2 taps / W3 chunks
-constexpr int L_M1 = 98304;                                  // 264 rows: mid1 on the 16-wide halo grid; phase 3: output stage
-constexpr int L_M2 = 132096;                                 // 224 rows: mid2 on the 16-wide grid
-constexpr int L_TOTAL = 160768;
 
 template <int N> __device__ __forceinline__ void vm() {
-#ifdef AP_BNECK_SAFE
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#else
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-#endif
 }
 template <int N> __device__ __forceinline__ void vmx() {   // x-wave / weight-wave waits of the persistent kernel (debug switches)
 #ifdef AP_BNECK_SAFE_X
@@ -144,322 +129,12 @@ __device__ __forceinline__ u32x2 bn_relu_pack(const f32x4& a, const float4& sc, 
     return o;
 }
 
-template <int CIN, bool DS>
-__global__ void __launch_bounds__(512) bneck64_kernel(const BneckArgs p) {
-    static_assert(DS ? CIN == 64 : CIN == 256, "layer1 shapes");
-    constexpr int KC = CIN / 64;                             // phase-1 steps
-    constexpr int K3 = DS ? 128 : 64;                        // conv3 contraction ([mid2 | x] when the downsample is folded in)
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-#ifdef AP_TRACE   // cycle stamps of wave 0 of workgroups 0 and 4096 (40 slots each)
-    int stamp_i = 0;
-    const bool tracing = p.dbg && (blockIdx.x == 0 || blockIdx.x == 4096) && tid == 0;
-#define BSTAMP() do { if (tracing) p.dbg[(blockIdx.x ? 40 : 0) + stamp_i] = __builtin_readcyclecounter(); ++stamp_i; } while (0)
-#else
-#define BSTAMP() do {} while (0)
-#endif
-    BSTAMP();
-    const int lr = lane & 15, g4 = lane >> 4;
-    const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;  // DMA piece geometry: 8 rows x 8 chunks, swizzled source
-    const int tile = xcd_remap(blockIdx.x, p.total);
-    const int n = tile / p.tiles_per_img, trem = tile - n * p.tiles_per_img;
-    const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
-    const int y0 = ty * TS, x0 = tx * TS;
-    const unsigned char* xg = (const unsigned char*)p.x;
-    const unsigned char* zg = (const unsigned char*)p.zero;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-
-    // wave roles.  phase 1: 4 channel blocks x 2 halves of the halo (8 pixel blocks each);
-    // phases 2/3: 2 channel-block pairs x 4 row groups of the 14 output rows (4, 4, 3, 3 rows)
-    const int wm = wave & 3, wn = wave >> 2;
-    const int wm2 = wave & 1, wn2 = wave >> 1;
-    const int rb = wn2 < 2 ? wn2 * 4 : 8 + (wn2 - 2) * 3;
-    const int nb = wn2 < 2 ? 4 : 3;
-    const uint32_t j3adj = nb == 4 ? 0u : (uint32_t)-2048;   // block 3 of a 3-row wave re-reads block 2
-
-    // ---------------------------------------------------------------- DMA sources (4 activation pieces per wave)
-    const unsigned char* xsrc[4];                            // phase 1: halo rows (wave*4+i)*8 + prow
-    const unsigned char* rsrc[4];                            // phase 3: identity rows on the 16-wide output grid
-    uint32_t xlive = 0, rlive = 0;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int h = (wave * 4 + i) * 8 + prow;
-        const int yy = y0 - 1 + (h >> 4), xx = x0 - 1 + (h & 15);
-        const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
-        xsrc[i] = ok ? xg + ((((size_t)n * p.H + yy) * p.W + xx) * CIN + pchunk * 8) * 2 : zg;
-        xlive |= ok ? (1u << i) : 0u;
-        const int oy = h >> 4, ox = h & 15;
-        const bool rok = (wave * 4 + i) < 28 && ox < TS;
-        rsrc[i] = rok ? xg + ((((size_t)n * p.H + y0 + oy) * p.W + x0 + ox) * CIN + pchunk * 8) * 2 : zg;
-        rlive |= rok ? (1u << i) : 0u;
-    }
-    const unsigned char* w1src = (const unsigned char*)p.w1 + ((size_t)(wave * 8 + prow) * CIN + pchunk * 8) * 2;
-    const unsigned char* w2src = (const unsigned char*)p.w2 + ((size_t)(wave * 8 + prow) * 576 + pchunk * 8) * 2;
-    const unsigned char* w3src = (const unsigned char*)p.w3 + ((size_t)(wave * 8 + prow) * K3 + pchunk * 8) * 2;
-
-    auto dma = [&](const unsigned char* src, int lds_off) {
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
-    };
-    auto issue_p1 = [&](int kc, int slot) {                  // 5 pieces: x channels [64kc, 64kc+64) of the halo + W1 columns
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dma(xsrc[i] + (((xlive >> i) & 1u) ? kc * 128 : 0), L_XR0 + slot * 32768 + (wave * 4 + i) * 1024);
-        dma(w1src + kc * 128, L_WR + slot * 8192 + wave * 1024);
-    };
-    auto issue_tap = [&](int t) {                            // 1 piece: W2[:, tap t, :] -> ring slot (t+2)&3
-        dma(w2src + t * 128, L_WR + ((t + 2) & 3) * 8192 + wave * 1024);
-    };
-    auto w3_buf = [&](int nc) { return DS ? L_XR1 + (nc & 1) * 16384 : L_WR + ((nc & 1) ? 0 : 3) * 8192; };
-    auto issue_w3 = [&](int nc) {                            // K3/64 pieces: W3 rows [64nc, 64nc+64)
-#pragma unroll
-        for (int u = 0; u < K3 / 64; ++u)
-            dma(w3src + (size_t)nc * 64 * K3 * 2 + u * 128, w3_buf(nc) + u * 8192 + wave * 1024);
-    };
-    auto issue_res = [&](int nc) {                           // 4 pieces: identity channels [64nc, 64nc+64) of the tile
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            dma(rsrc[i] + (((rlive >> i) & 1u) ? nc * 128 : 0), ((nc & 1) ? L_XR1 : L_XR0) + (wave * 4 + i) * 1024);
-    };
-
-    // ---------------------------------------------------------------- fragment addresses
-    const uint32_t sw0 = (uint32_t)((g4 ^ (lr & 7)) << 4), sw1 = (uint32_t)(((4 + g4) ^ (lr & 7)) << 4);
-    // mid1 / resident-x fragment bases for the three horizontal tap shifts (row = (rb + j + ky)*16 + lr + kx)
-    uint32_t m1a[3][2];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx)
-#pragma unroll
-        for (int s = 0; s < 2; ++s)
-            m1a[kx][s] = lds0 + L_M1 + (rb * 16 + lr + kx) * 128 + (uint32_t)(((g4 + 4 * s) ^ ((lr + kx) & 7)) << 4);
-    const uint32_t m2a0 = lds0 + L_M2 + (rb * 16 + lr) * 128 + sw0, m2a1 = lds0 + L_M2 + (rb * 16 + lr) * 128 + sw1;
-    const uint32_t wrow2 = (uint32_t)((32 * wm2 + lr) * 128);   // weight rows of this wave's channel-block pair
-
-    // ================================================================ prologue: fill the pipes
-    issue_p1(0, 0);
-    if constexpr (KC > 1) issue_p1(1, 1);
-    issue_tap(0);
-    issue_tap(1);
-    if constexpr (DS) { issue_w3(0); issue_w3(1); }
-    BSTAMP();
-
-    // BatchNorm constants in accumulator layout (4 consecutive channels per lane).  Queued behind the
-    // prologue DMA and pinned (empty asm) so that the compiler's own wait for them sits at the first pipeline wait
-    // instead of draining the DMA queue in front of epilogue 1
-    float4 s1 = *(const float4*)(p.s1 + 16 * wm + 4 * g4), h1 = *(const float4*)(p.h1 + 16 * wm + 4 * g4);
-    float4 s2[2], h2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        s2[i] = *(const float4*)(p.s2 + 32 * wm2 + 16 * i + 4 * g4);
-        h2[i] = *(const float4*)(p.h2 + 32 * wm2 + 16 * i + 4 * g4);
-    }
-    float4 s3[4][2], h3[4][2];
-#pragma unroll
-    for (int nc = 0; nc < 4; ++nc)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            s3[nc][i] = *(const float4*)(p.s3 + 64 * nc + 32 * wm2 + 16 * i + 4 * g4);
-            h3[nc][i] = *(const float4*)(p.h3 + 64 * nc + 32 * wm2 + 16 * i + 4 * g4);
-        }
-
-    auto pin = [](float4& v) { asm volatile("" : "+v"(v.x), "+v"(v.y), "+v"(v.z), "+v"(v.w)); };
-    pin(s1); pin(h1);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) { pin(s2[i]); pin(h2[i]); }
-#pragma unroll
-    for (int nc = 0; nc < 4; ++nc)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { pin(s3[nc][i]); pin(h3[nc][i]); }
-
-    // ================================================================ phase 1: mid1 = relu(bn1(W1 . x)) on the halo
-    f32x4 acc1[8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) acc1[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto p1_compute = [&](int slot) {
-        const uint32_t wa = lds0 + L_WR + slot * 8192 + (16 * wm + lr) * 128;
-        const uint32_t xa = lds0 + L_XR0 + slot * 32768 + (wn * 128 + lr) * 128;
-        u32x4 b0[8], b1[8];
-        const u32x4 a0 = rd128<0>(wa + sw0);
-        rd_blocks<8, 0>(xa + sw0, b0);
-        const u32x4 a1 = rd128<0>(wa + sw1);
-        rd_blocks<8, 0>(xa + sw1, b1);
-        lgkm<9>();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) mma(acc1[j], a0, b0[j]);
-        __builtin_amdgcn_sched_barrier(0);
-        lgkm<0>();
-#pragma unroll
-        for (int j = 0; j < 8; ++j) mma(acc1[j], a1, b1[j]);
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    // vm<N>: N = DMA pieces this wave queued AFTER the ones needed now (the queue retires in order)
-    if constexpr (!DS) {
-        vm<7>(); bar(); p1_compute(0); bar(); BSTAMP(); issue_p1(2, 0);                       // after: P1(1) T0 T1
-        vm<7>(); bar(); p1_compute(1); bar(); BSTAMP(); issue_p1(3, 1);                       // after: T0 T1 P1(2)
-        vm<5>(); bar(); p1_compute(0); bar(); BSTAMP(); issue_tap(2);                         // after: P1(3)
-        vm<1>(); bar(); p1_compute(1); bar(); BSTAMP(); issue_tap(3); issue_res(0); issue_res(1);   // after: T2
-    } else {
-        vm<6>(); bar(); p1_compute(0); bar(); BSTAMP(); issue_tap(2); issue_tap(3);           // after: T0 T1 W3(0)x2 W3(1)x2
-    }
-    {   // epilogue 1: halo pixels outside the image are conv2's zero padding -> exactly 0, not relu(shift)
-        const uint32_t ea = lds0 + L_M1 + (wn * 128 + lr) * 128 + (uint32_t)(((2 * wm + (g4 >> 1)) ^ (lr & 7)) << 4) + (g4 & 1) * 8;
-        const bool xin = (unsigned)(x0 - 1 + lr) < (unsigned)p.W;
-        auto put = [&](auto J) {
-            constexpr int j = decltype(J)::value;
-            const bool ok = xin && (unsigned)(y0 - 1 + 8 * wn + j) < (unsigned)p.H;
-            wr64<j * 2048>(ea, bn_relu_pack(acc1[j], s1, h1, ok));
-        };
-        put(std::integral_constant<int, 0>{}); put(std::integral_constant<int, 1>{});
-        put(std::integral_constant<int, 2>{}); put(std::integral_constant<int, 3>{});
-        put(std::integral_constant<int, 4>{}); put(std::integral_constant<int, 5>{});
-        put(std::integral_constant<int, 6>{}); put(std::integral_constant<int, 7>{});
-    }
-    lgkm<0>();
-    BSTAMP();
-
-    // ================================================================ phase 2: mid2 = relu(bn2(W2 * mid1))
-    f32x4 acc2[2][4];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) acc2[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    auto tap = [&](auto KY, auto KX, int slot) {
-        constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value;
-        const uint32_t wa = lds0 + L_WR + slot * 8192 + wrow2;
-        step_2x4<ky * 2048>(wa + sw0, wa + sw1, m1a[kx][0], m1a[kx][1], m1a[kx][0] + j3adj, m1a[kx][1] + j3adj, acc2);
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    using I2 = std::integral_constant<int, 2>;
-    if constexpr (!DS) {
-        bar(); tap(I0{}, I0{}, 2); BSTAMP();                                                  // T0, T1 retired before P1(2)
-        tap(I0{}, I1{}, 3); BSTAMP();
-        vm<9>(); bar(); issue_tap(4); issue_tap(5); tap(I0{}, I2{}, 0); BSTAMP();             // after T2: T3 R0x4 R1x4
-        vm<10>(); bar(); tap(I1{}, I0{}, 1); BSTAMP();                                        // after T3: R0 R1 T4 T5
-        vm<1>(); bar(); issue_tap(6); issue_tap(7); tap(I1{}, I1{}, 2); BSTAMP();             // after T4: T5
-        vm<2>(); bar(); tap(I1{}, I2{}, 3); BSTAMP();                                         // after T5: T6 T7
-        vm<1>(); bar(); issue_tap(8); issue_w3(0); tap(I2{}, I0{}, 0); BSTAMP();              // after T6: T7
-        vm<2>(); bar(); tap(I2{}, I1{}, 1); BSTAMP();                                         // after T7: T8 W3(0)
-        vm<1>(); bar(); tap(I2{}, I2{}, 2); BSTAMP();                                         // after T8: W3(0)
-    } else {
-        vm<7>(); bar(); tap(I0{}, I0{}, 2); BSTAMP();                                         // after T0: T1 W3(0)x2 W3(1)x2 T2 T3
-        vm<6>(); bar(); tap(I0{}, I1{}, 3); BSTAMP();
-        vm<1>(); bar(); issue_tap(4); issue_tap(5); tap(I0{}, I2{}, 0); BSTAMP();             // after T2: T3
-        vm<2>(); bar(); tap(I1{}, I0{}, 1); BSTAMP();                                         // after T3: T4 T5
-        vm<1>(); bar(); issue_tap(6); issue_tap(7); tap(I1{}, I1{}, 2); BSTAMP();
-        vm<2>(); bar(); tap(I1{}, I2{}, 3); BSTAMP();
-        vm<1>(); bar(); issue_tap(8); tap(I2{}, I0{}, 0); BSTAMP();
-        vm<1>(); bar(); tap(I2{}, I1{}, 1); BSTAMP();
-        vm<0>(); bar(); tap(I2{}, I2{}, 2); BSTAMP();
-    }
-    // accumulator-layout addresses on the 16-wide output grid (mid2, identity, stage): row (rb + j)*16 + lr,
-    // 8 bytes at channel 32*wm2 + 16*i + 4*g4
-    uint32_t eoff[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-        eoff[i] = (uint32_t)((rb * 16 + lr) * 128 + (((4 * wm2 + 2 * i + (g4 >> 1)) ^ (lr & 7)) << 4) + (g4 & 1) * 8);
-    {   // epilogue 2
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint32_t ea = lds0 + L_M2 + eoff[i];
-            wr64<0>(ea, bn_relu_pack(acc2[i][0], s2[i], h2[i], true));
-            wr64<2048>(ea, bn_relu_pack(acc2[i][1], s2[i], h2[i], true));
-            wr64<4096>(ea, bn_relu_pack(acc2[i][2], s2[i], h2[i], true));
-            if (nb == 4) wr64<6144>(ea, bn_relu_pack(acc2[i][3], s2[i], h2[i], true));
-        }
-    }
-    lgkm<0>();
-    BSTAMP();
-
-    // ================================================================ phase 3: y = relu(bn3(W3 . [mid2 | x]) (+ x))
-    // coalesced store geometry: wave w stores the 196 valid 16-byte pieces w*196 .. w*196+195 of the
-    // [196 px][8 chunks] stage; every wave executes exactly four store instructions per pass
-    uint32_t st_lds[4];
-    unsigned char* st_dst[4];
-#pragma unroll
-    for (int it = 0; it < 4; ++it) {
-        const int idx = wave * 196 + it * 64 + (it < 3 ? lane : (lane & 3));
-        const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
-        st_lds[it] = lds0 + L_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4);
-        st_dst[it] = (unsigned char*)p.y + ((((size_t)n * p.H + y0 + oy) * p.W + x0 + ox) * 256 + c * 8) * 2;
-    }
-    auto pass = [&](auto NC) {
-        constexpr int nc = decltype(NC)::value;
-        // identity values in accumulator layout (landed one pass ago; read now so the latency hides under the MFMAs)
-        u32x2 rv[2][4];
-        if constexpr (!DS) {
-            const uint32_t rbase = lds0 + ((nc & 1) ? L_XR1 : L_XR0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                rv[i][0] = rd64<0>(rbase + eoff[i]);
-                rv[i][1] = rd64<2048>(rbase + eoff[i]);
-                rv[i][2] = rd64<4096>(rbase + eoff[i]);
-                rv[i][3] = rd64<6144>(rbase + eoff[i] + j3adj);
-            }
-        }
-        f32x4 acc[2][4];
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const uint32_t wa = lds0 + w3_buf(nc) + wrow2;
-        step_2x4<0>(wa + sw0, wa + sw1, m2a0, m2a1, m2a0 + j3adj, m2a1 + j3adj, acc);
-        if constexpr (DS) {                                  // second K segment: the resident x tile at the centre pixels
-            const uint32_t xa0 = m1a[1][0] - L_M1 + L_XR0, xa1 = m1a[1][1] - L_M1 + L_XR0;
-            step_2x4<2048>(wa + 8192 + sw0, wa + 8192 + sw1, xa0, xa1, xa0 + j3adj, xa1 + j3adj, acc);
-        }
-        lgkm<0>();                                           // (identity reads; already retired in order)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const uint32_t ea = lds0 + L_M1 + eoff[i];
-            auto out = [&](const f32x4& a, const u32x2& r) {
-                float v0 = a[0] * s3[nc][i].x + h3[nc][i].x, v1 = a[1] * s3[nc][i].y + h3[nc][i].y;
-                float v2 = a[2] * s3[nc][i].z + h3[nc][i].z, v3 = a[3] * s3[nc][i].w + h3[nc][i].w;
-                if constexpr (!DS) {
-                    float lo, hi;
-                    unpack_bf16x2(r.x, lo, hi); v0 += lo; v1 += hi;
-                    unpack_bf16x2(r.y, lo, hi); v2 += lo; v3 += hi;
-                }
-                u32x2 o;
-                o.x = pack_bf16x2(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
-                o.y = pack_bf16x2(fmaxf(v2, 0.f), fmaxf(v3, 0.f));
-                return o;
-            };
-            wr64<0>(ea, out(acc[i][0], rv[i][0]));
-            wr64<2048>(ea, out(acc[i][1], rv[i][1]));
-            wr64<4096>(ea, out(acc[i][2], rv[i][2]));
-            if (nb == 4) wr64<6144>(ea, out(acc[i][3], rv[i][3]));
-        }
-        lgkm<0>();
-        bar();                                               // stage complete
-        u32x4 v[4];
-#pragma unroll
-        for (int it = 0; it < 4; ++it) v[it] = rd128<0>(st_lds[it]);
-        lgkm<0>();
-#pragma unroll
-        for (int it = 0; it < 3; ++it) *(u32x4*)(st_dst[it] + nc * 128) = v[it];
-        if (lane < 4) *(u32x4*)(st_dst[3] + nc * 128) = v[3];
-    };
-    using I3 = std::integral_constant<int, 3>;
-    if constexpr (!DS) {
-        vm<0>(); bar(); issue_w3(1); pass(I0{}); BSTAMP();                                    // W3(0), R0, R1 landed; mid2 visible
-        vm<4>(); bar(); issue_w3(2); issue_res(2); pass(I1{}); BSTAMP();                      // after W3(1): 4 stores
-        vm<4>(); bar(); issue_w3(3); issue_res(3); pass(I2{}); BSTAMP();                      // after W3(2) R2: 4 stores
-        vm<4>(); bar(); pass(I3{}); BSTAMP();
-    } else {
-        bar(); pass(I0{}); BSTAMP();                                                          // W3(0), W3(1) retired before T2
-        bar(); issue_w3(2); pass(I1{}); BSTAMP();
-        vm<4>(); bar(); issue_w3(3); pass(I2{}); BSTAMP();                                    // after W3(2): 4 stores
-        vm<4>(); bar(); pass(I3{}); BSTAMP();
-    }
-}
-
 // =====================================================================================================================
-// Identity blocks (CIN = 256): persistent, wave-specialised version.
+// Identity blocks (CIN = 256): persistent, wave-specialised.
 //
-// In-kernel cycle stamps of the one-tile-per-workgroup kernel above showed a workgroup waiting ~10k cycles for its
-// first operands and ~1.5k cycles per pass for the identity tile, with one workgroup per CU (LDS) nothing covers them.
-// Here a workgroup loops over tiles (grid = #CUs) and
+// In-kernel cycle stamps of a first, one-tile-per-workgroup version showed a workgroup waiting ~10k cycles for its
+// first operands and ~1.5k cycles per pass for an identity tile fetched a second time; with one workgroup per CU
+// (LDS) nothing covers them.  Here a workgroup loops over tiles (grid = #CUs) and
 //   * the first two 64-channel steps of the NEXT tile's x halo are fetched into the (then idle) step ring during
 //     phases 2-3; steps 2 and 3 land in the mid1 / mid2 buffers, which are idle during phase 1;
 //   * the identity values are captured from the x steps in LDS during phase 1 (chunk kc of x is exactly what pass
@@ -822,32 +497,269 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
     vm<0>();                                                 // no LDS-DMA may be in flight when the LDS is released
 }
 
-hipError_t launch256(const BneckArgs& a, hipStream_t st) {
+// =====================================================================================================================
+// Downsample block (CIN = 64, K3 = 128 = [mid2 | x]): the same persistent, wave-specialised scheme.  The x halo tile
+// is one 32 KiB step that stays resident (it is conv3's second K segment), so two tile buffers alternate and the
+// next tile's x rides along with taps 0..7; the weight ring has 4 slots (W1 | taps cycle through three | the 16 KiB
+// W3 chunks take two).  LDS map: x tile A | x tile B | mid1 / stage | mid2 | weight ring 4 x 8 KiB | constants.
+constexpr int D_XA = 0, D_XB = 32768, D_M1 = 65536, D_M2 = 98304, D_WR = 126976, D_CONST = 159744, D_TOTAL = 162816;
+
+__global__ void __launch_bounds__(512) bneck64ds_kernel(const BneckArgs p) {
+    constexpr int CIN = 64;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g4 = lane >> 4;
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    const bool xw = wave >= 4;                               // DMA role: x tiles (waves 4-7) or weight chunks (0-3)
+    const int wq = wave & 3;
+    const int G = gridDim.x;
+    const int wm2 = wave & 1, wn2 = wave >> 1;
+    const int rb = wn2 < 2 ? wn2 * 4 : 8 + (wn2 - 2) * 3;
+    const int nb = wn2 < 2 ? 4 : 3;
+    const uint32_t j3adj = nb == 4 ? 0u : (uint32_t)-2048;
+
+    if (tid < 192) {                                         // BatchNorm constants -> LDS (once per workgroup)
+        const float* src = tid < 16 ? p.s1 + tid * 4 : tid < 32 ? p.h1 + (tid - 16) * 4 : tid < 48 ? p.s2 + (tid - 32) * 4
+                         : tid < 64 ? p.h2 + (tid - 48) * 4 : tid < 128 ? p.s3 + (tid - 64) * 4 : p.h3 + (tid - 128) * 4;
+        const float4 v = *(const float4*)src;
+        u32x4 u;
+        u.x = __builtin_bit_cast(uint32_t, v.x); u.y = __builtin_bit_cast(uint32_t, v.y);
+        u.z = __builtin_bit_cast(uint32_t, v.z); u.w = __builtin_bit_cast(uint32_t, v.w);
+        wr128<0>(lds0 + D_CONST + tid * 16, u);
+    }
+    lgkm<0>();
+
+    // ---------------------------------------------------------------- DMA sources (see bneck256_kernel)
+    const unsigned char* xg = (const unsigned char*)p.x;
+    uint32_t xoff0 = 0, xlive = 0;
+    uint32_t xrc = (uint32_t)(prow << 8 | pchunk);
+    auto setup_x = [&](int tile) {
+        const int n = tile / p.tiles_per_img, trem = tile - n * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        xlive = 0;
+        asm volatile("" : "+v"(xrc));
+        const int prow = xrc >> 8, pchunk = xrc & 7;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int h = (8 * wq + i) * 8 + prow;
+            const int yy = ty * TS - 1 + (h >> 4), xx = tx * TS - 1 + (h & 15);
+            const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+            xlive |= ok ? (1u << i) : 0u;
+        }
+        xoff0 = (uint32_t)((((n * p.H + ty * TS - 1 + 4 * wq) * p.W + tx * TS - 1 + prow) * CIN + pchunk * 8) * 2);
+    };
+    const int wrow = 2 * wq * 8 + prow;
+    uint32_t wrc = (uint32_t)(wrow << 8 | pchunk);
+    auto dma = [&](const unsigned char* src, int lds_off) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
+    };
+    auto issue_x1 = [&](int base, int i) {                   // piece i (of 8 per x wave) of the 64-channel halo tile
+        dma(((xlive >> i) & 1u) ? xg + (uint32_t)(xoff0 + (i >> 1) * p.W * (CIN * 2) + (i & 1) * (8 * CIN * 2)) : (const unsigned char*)p.zero,
+            base + (8 * wq + i) * 1024);
+    };
+    auto issue_w = [&](const void* w, uint32_t row_bytes, uint32_t col_bytes, int slot) {   // 2 pieces per weight wave
+        const unsigned char* src = (const unsigned char*)w + (uint32_t)((wrc >> 8) * row_bytes + (wrc & 7) * 16 + col_bytes);
+        dma(src, D_WR + slot * 8192 + 2 * wq * 1024);
+        dma(src + 8 * row_bytes, D_WR + slot * 8192 + (2 * wq + 1) * 1024);
+    };
+    auto issue_w1 = [&]() { issue_w(p.w1, CIN * 2, 0, 0); };
+    auto issue_tap = [&](int t) { issue_w(p.w2, 576 * 2, t * 128, 1 + t % 3); };
+    auto issue_w3 = [&](int nc, int u) { issue_w(p.w3, 128 * 2, nc * 64 * 256 + u * 128, ((nc & 1) ? 2 : 0) + u); };
+
+    // ---------------------------------------------------------------- fragment / epilogue addresses
+    const uint32_t sw0 = (uint32_t)((g4 ^ (lr & 7)) << 4);
+    const uint32_t wrow2 = (uint32_t)((32 * wm2 + lr) * 128);
+    const uint32_t p1row = (uint32_t)((wn2 * 64 + lr) * 128);
+    uint32_t m1a[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) m1a[kx] = lds0 + D_M1 + (rb * 16 + lr + kx) * 128 + (uint32_t)((g4 ^ ((lr + kx) & 7)) << 4);
+    uint32_t eoff[2], e1off[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int chunk = 4 * wm2 + 2 * i + (g4 >> 1);
+        eoff[i] = (uint32_t)((rb * 16 + lr) * 128 + ((chunk ^ (lr & 7)) << 4) + (g4 & 1) * 8);
+        e1off[i] = (uint32_t)((wn2 * 64 + lr) * 128 + ((chunk ^ (lr & 7)) << 4) + (g4 & 1) * 8);
+    }
+    const uint32_t cch = lds0 + D_CONST + (uint32_t)((32 * wm2 + 4 * g4) * 4);
+    uint32_t st_lds[4], st_off[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) {
+        const int idx = wave * 196 + it * 64 + (it < 3 ? lane : (lane & 3));
+        const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
+        st_lds[it] = lds0 + D_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4);
+        st_off[it] = (uint32_t)(((oy * p.W + ox) * 256 + c * 8) * 2);
+    }
+    u32x4 sv[4];
+    auto put_stores = [&](int half, unsigned char* base) {
+        if (half == 0) {
+            *(u32x4*)(base + st_off[0]) = sv[0];
+            *(u32x4*)(base + st_off[1]) = sv[1];
+        } else {
+            *(u32x4*)(base + st_off[2]) = sv[2];
+            if (lane < 4) *(u32x4*)(base + st_off[3]) = sv[3];
+        }
+    };
+    f32x4 acc[2][4];
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    using I3 = std::integral_constant<int, 3>;
+
+    // ================================================================ prologue: the queue state a previous tile would leave
+    int tile = xcd_remap(blockIdx.x, G);
+    int xcur = D_XA;                                         // buffer of the current tile's x halo; the other one takes the next
+    if (xw) {
+        setup_x(tile);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) issue_x1(D_XA, i);
+    } else { issue_w1(); issue_tap(0); }
+
+    unsigned char* yprev = nullptr;
+    for (bool first = true;; first = false) {
+        const int n = tile / p.tiles_per_img, trem = tile - n * p.tiles_per_img;
+        const int ty = trem / p.tiles_x, tx = trem - ty * p.tiles_x;
+        const int y0 = ty * TS, x0 = tx * TS;
+        unsigned char* const ybase = (unsigned char*)p.y + (((size_t)n * p.H + y0) * p.W + x0) * 512;
+        const int xnext = xcur ^ (D_XA ^ D_XB);
+        asm volatile("" : "+v"(wrc));
+        // ------------------------------------------------------------ phase 1 (one 64-deep step)
+        bar();                                               // previous tile: stage / mid2 / W3 reads complete
+        if (!xw) { issue_tap(1); issue_tap(2); }
+        // vm<N>: N = operations this wave queued after the ones needed
+        if (first) vm<0>(); else if (xw) vmx<12>(); else vmw<10>();      // x tile (then: 12 stores) / W1 (then: T0, 4 stores, T1, T2)
+        bar();
+        zero_acc();
+        {
+            const uint32_t wa = lds0 + D_WR + wrow2, xa = lds0 + xcur + p1row;
+            if (yprev)                                       // the previous tile's last slice leaves under this step
+                step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, acc,
+                            [&](int half) { put_stores(half, yprev); });
+            else
+                step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, xa + sw0, (xa + sw0) ^ 64, acc);
+        }
+        bar();
+        const int next = tile + G;
+        const bool has_next = next < p.total;
+        if (xw) setup_x(has_next ? next : tile);             // (the last tile re-fetches its own: the bookkeeping stays)
+        else issue_w3(0, 0);                                 // W1's slot
+        {   // epilogue 1 -> mid1
+            const bool xin = (unsigned)(x0 - 1 + lr) < (unsigned)p.W;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 sc = rd_f4<C_S1 * 4>(cch + 64 * i), sh = rd_f4<C_H1 * 4>(cch + 64 * i);
+                const uint32_t ea = lds0 + D_M1 + e1off[i];
+                const int yb = y0 - 1 + 4 * wn2;
+                wr64<0>(ea, bn_relu_pack(acc[i][0], sc, sh, xin && (unsigned)(yb + 0) < (unsigned)p.H));
+                wr64<2048>(ea, bn_relu_pack(acc[i][1], sc, sh, xin && (unsigned)(yb + 1) < (unsigned)p.H));
+                wr64<4096>(ea, bn_relu_pack(acc[i][2], sc, sh, xin && (unsigned)(yb + 2) < (unsigned)p.H));
+                wr64<6144>(ea, bn_relu_pack(acc[i][3], sc, sh, xin && (unsigned)(yb + 3) < (unsigned)p.H));
+            }
+        }
+        lgkm<0>();
+        // ------------------------------------------------------------ phase 2 (tap t in ring slot 1 + t % 3)
+        zero_acc();
+        auto tap = [&](auto KY, auto KX) {
+            constexpr int ky = decltype(KY)::value, kx = decltype(KX)::value, t = ky * 3 + kx;
+            const uint32_t wa = lds0 + D_WR + (1 + t % 3) * 8192 + wrow2;
+            step_2x4<ky * 2048>(wa + sw0, (wa + sw0) ^ 64, m1a[kx], m1a[kx] ^ 64, m1a[kx] + j3adj, (m1a[kx] ^ 64) + j3adj, acc,
+                                [&](int half) { if (xw && t < 8 && half) issue_x1(xnext, t); });   // next tile's x, a piece per tap
+        };
+        if (!xw) vmw<14>(); bar(); tap(I0{}, I0{});                                   // after T0: 4 st, T1, T2, 4 st, W3(0)a
+        if (!xw) vmw<8>(); bar(); if (!xw) issue_tap(3); tap(I0{}, I1{});             // after T1: T2, 4 st, W3(0)a
+        if (!xw) vmw<8>(); bar(); if (!xw) issue_tap(4); tap(I0{}, I2{});             // after T2: 4 st, W3(0)a, T3
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(5); tap(I1{}, I0{});
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(6); tap(I1{}, I1{});
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(7); tap(I1{}, I2{});
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_tap(8); tap(I2{}, I0{});
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_w3(0, 1); tap(I2{}, I1{});           // slot 1: tap 6 is done
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_w3(1, 0); tap(I2{}, I2{});           // slot 2: tap 7 is done
+        {   // epilogue 2 -> mid2
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 sc = rd_f4<C_S2 * 4>(cch + 64 * i), sh = rd_f4<C_H2 * 4>(cch + 64 * i);
+                const uint32_t ea = lds0 + D_M2 + eoff[i];
+                wr64<0>(ea, bn_relu_pack(acc[i][0], sc, sh, true));
+                wr64<2048>(ea, bn_relu_pack(acc[i][1], sc, sh, true));
+                wr64<4096>(ea, bn_relu_pack(acc[i][2], sc, sh, true));
+                if (nb == 4) wr64<6144>(ea, bn_relu_pack(acc[i][3], sc, sh, true));
+            }
+        }
+        lgkm<0>();
+        // ------------------------------------------------------------ phase 3: y = relu(W3 . [mid2 | x] + h3), 4 slices
+        auto pass = [&](auto NC) {
+            constexpr int nc = decltype(NC)::value;
+            zero_acc();
+            u32x4 cs[2], ch[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                cs[i] = rd128<(C_S3 + 64 * nc) * 4>(cch + 64 * i);
+                ch[i] = rd128<(C_H3 + 64 * nc) * 4>(cch + 64 * i);
+            }
+            const uint32_t wa = lds0 + D_WR + ((nc & 1) ? 2 : 0) * 8192 + wrow2;
+            const uint32_t m2a = m1a[0] + (D_M2 - D_M1);
+            const uint32_t xa = m1a[1] - D_M1 + xcur;        // centre pixels of the resident x halo tile (row + 1, column + 1)
+            if constexpr (nc > 0)
+                step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, m2a, m2a ^ 64, m2a + j3adj, (m2a ^ 64) + j3adj, acc,
+                            [&](int half) { put_stores(half, ybase + (nc - 1) * 128); });
+            else
+                step_2x4<0>(wa + sw0, (wa + sw0) ^ 64, m2a, m2a ^ 64, m2a + j3adj, (m2a ^ 64) + j3adj, acc);
+            step_2x4<2048>(wa + 8192 + sw0, (wa + 8192 + sw0) ^ 64, xa, xa ^ 64, xa + j3adj, (xa ^ 64) + j3adj, acc);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const float4 sc = as_f4(cs[i]), sh = as_f4(ch[i]);
+                const uint32_t ea = lds0 + D_M1 + eoff[i];
+                wr64<0>(ea, bn_relu_pack(acc[i][0], sc, sh, true));
+                wr64<2048>(ea, bn_relu_pack(acc[i][1], sc, sh, true));
+                wr64<4096>(ea, bn_relu_pack(acc[i][2], sc, sh, true));
+                if (nb == 4) wr64<6144>(ea, bn_relu_pack(acc[i][3], sc, sh, true));
+            }
+            lgkm<0>();
+            bar();                                           // stage complete
+#pragma unroll
+            for (int it = 0; it < 4; ++it) sv[it] = rd128<0>(st_lds[it]);
+            lgkm<0>();
+        };
+        if (!xw) vmw<2>(); bar(); if (!xw) issue_w3(1, 1); pass(I0{});                               // after W3(0)b: W3(1)a; slot 3: tap 8 is done
+        if (!xw) vmw<0>(); bar(); if (!xw) { issue_w3(2, 0); issue_w3(2, 1); } pass(I1{});
+        if (!xw) vmw<4>(); bar(); if (!xw) { issue_w3(3, 0); issue_w3(3, 1); } pass(I2{});          // after W3(2): 4 stores
+        if (!xw) vmw<4>(); bar(); if (!xw) { issue_w1(); issue_tap(0); } pass(I3{});                 // after W3(3): 4 stores
+        yprev = ybase + 3 * 128;
+        if (!has_next) break;
+        tile = next;
+        xcur = xnext;
+    }
+    put_stores(0, yprev);
+    put_stores(1, yprev);
+    vm<0>();                                                 // no LDS-DMA may be in flight when the LDS is released
+}
+
+hipError_t launch_persistent(const BneckArgs& a, bool ds, hipStream_t st) {
     static int n_cu = 0;
     if (!n_cu) {
-        int dev = 0;
+        int dev = 0, n = 0;
         hipError_t e = hipGetDevice(&dev);
         if (e != hipSuccess) return e;
-        e = hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev);
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)bneck256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_TOTAL);
         if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)bneck64ds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, D_TOTAL);
+        if (e != hipSuccess) return e;
+        n_cu = n;
     }
     if ((size_t)a.N * a.H * a.W * 512 >= ((size_t)1 << 32)) return hipErrorInvalidValue;   // 32-bit x offsets
     const int grid = a.total < n_cu ? a.total : n_cu;
-    hipLaunchKernelGGL(bneck256_kernel, dim3(grid), dim3(512), P_TOTAL, st, a);
-    return hipGetLastError();
-}
-
-template <int CIN, bool DS> hipError_t launch(const BneckArgs& a, hipStream_t st) {
-    static bool attr_set = false;
-    auto kern = bneck64_kernel<CIN, DS>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
-        if (e != hipSuccess) return e;
-        attr_set = true;
-    }
-    hipLaunchKernelGGL(kern, dim3(a.total), dim3(512), L_TOTAL, st, a);
+    if (ds) hipLaunchKernelGGL(bneck64ds_kernel, dim3(grid), dim3(512), D_TOTAL, st, a);
+    else hipLaunchKernelGGL(bneck256_kernel, dim3(grid), dim3(512), P_TOTAL, st, a);
     return hipGetLastError();
 }
 
@@ -859,7 +771,7 @@ hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st) {
     a.tiles_x = a.W / TS;
     a.tiles_per_img = a.tiles_x * (a.H / TS);
     a.total = a.N * a.tiles_per_img;
-    if (cin == 256 && !ds) return launch256(a, st);
-    if (cin == 64 && ds) return launch<64, true>(a, st);
+    if (cin == 256 && !ds) return launch_persistent(a, false, st);
+    if (cin == 64 && ds) return launch_persistent(a, true, st);
     return hipErrorInvalidValue;
 }
