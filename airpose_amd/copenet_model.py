@@ -254,6 +254,11 @@ class copenet(nn.Module):
         N.check(N.lib().ap_net_set_fold(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_fold")
 
+    def set_fuse_ief(self, on):
+        """Folded map: all IEF iterations in one kernel (default) or one GEMM per iteration."""
+        N.check(N.lib().ap_net_set_fuse_ief(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+                "ap_net_set_fuse_ief")
+
     def set_fuse_ds(self, on):
         N.check(N.lib().ap_net_set_fuse_ds(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_fuse_ds")

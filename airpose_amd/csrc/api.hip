@@ -169,6 +169,8 @@ struct ap_net {
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
     Layer fold_feat, fold_state;   // dec o fc2 o fc1 folded into one 145 x 2332 map (no activation between them)
+    DevBuf foldT_feat, foldT_state, fold_bias;   // the same map k-major ([k][148]) for the fused IEF kernel (copenet head)
+    bool fuse_ief = true;          // folded map: one split-K feature kernel + one kernel for all IEF iterations
     bool fold = true;
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
     bool fuse_block = true;        // bf16: layer1 bottlenecks as one kernel each (bottleneck.hip)
@@ -516,6 +518,17 @@ int finalize_regressor(ap_net* h) {
         }
         if ((rc = pack_linear(wf.data(), 2332, 0, 2048, 145, bfv.data(), h->fold_feat))) return rc;
         if ((rc = pack_linear(wf.data(), 2332, 2048, 284, 145, nullptr, h->fold_state))) return rc;
+        {   // k-major copies for the fused IEF kernel
+            std::vector<float> tf((size_t)2048 * 148, 0.f), ts((size_t)288 * 148, 0.f), tb(148, 0.f);   // (k padded to 288 with zero rows)
+            for (int o = 0; o < 145; ++o) {
+                for (int k = 0; k < 2048; ++k) tf[(size_t)k * 148 + o] = wf[(size_t)o * 2332 + k];
+                for (int k = 0; k < 284; ++k) ts[(size_t)k * 148 + o] = wf[(size_t)o * 2332 + 2048 + k];
+                tb[o] = bfv[o];
+            }
+            HIP_TRY(upload(h->foldT_feat, tf.data(), tf.size() * 4));
+            HIP_TRY(upload(h->foldT_state, ts.data(), ts.size() * 4));
+            HIP_TRY(upload(h->fold_bias, tb.data(), tb.size() * 4));
+        }
     }
     std::vector<float> mp(144, 0.f);
     memcpy(mp.data(), ip->data.data(), std::min<size_t>(144, ip->numel()) * 4);
@@ -631,6 +644,23 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
     HIP_TRY(h->ws_state.reserve((size_t)rows * ST * 4));
     size_t e0 = 0, e1 = 0;
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e0));
+    if (h->fold && h->fuse_ief) {
+        HIP_TRY(h->ws_H.reserve((size_t)ap_reg_fold_part_floats(rows) * 4));
+        RegInitArgs ia{};
+        ia.pos0 = in.pos0; ia.pos1 = in.pos1; ia.theta0 = in.th0; ia.theta1 = in.th1; ia.shape0 = in.sh0; ia.shape1 = in.sh1;
+        ia.theta0_bs = in.th0_bs; ia.theta1_bs = in.th1_bs; ia.shape0_bs = in.sh0_bs; ia.shape1_bs = in.sh1_bs;
+        ia.pos_bs = pos_bs; ia.rows = rows;
+        ia.mean_pose = h->mean_pose.as<float>(); ia.mean_shape = h->mean_shape.as<float>();
+        ia.state = nullptr; ia.B = B;
+        HIP_TRY(ap_launch_reg_fold_ief(ia, in.xf0, two_view ? in.xf1 : in.xf0, in.bb0, in.bb1, partner, partner_ld,
+                                       h->foldT_feat.as<float>(), h->foldT_state.as<float>(), h->fold_bias.as<float>(),
+                                       h->ws_H.as<float>(), iters, two_view, pose0, betas0, pose1, betas1, st));
+        if (h->tm.on) {
+            HIP_TRY(h->tm.rec(st, &e1));
+            h->tm.marks[3].push_back(e0); h->tm.marks[3].push_back(e1);
+        }
+        return AP_OK;
+    }
     float *Hb = h->ws_H.as<float>(), *T1 = h->ws_T1.as<float>(), *T2 = h->ws_T2.as<float>(), *S = h->ws_S.as<float>(),
           *D = h->ws_D.as<float>(), *state = h->ws_state.as<float>();
     int rc;
@@ -701,6 +731,7 @@ void ap_net_destroy(ap_net* h) {
     auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
     for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); rel(B.c3ds); }
     rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec); rel(h->fold_feat); rel(h->fold_state);
+    h->foldT_feat.release(); h->foldT_state.release(); h->fold_bias.release();
     h->tm.destroy();
     delete h;
 }
@@ -871,6 +902,12 @@ int ap_net_set_fuse_ds(ap_net* h, int on) {
 int ap_net_set_fuse_block(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_block = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_fuse_ief(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fuse_ief = on != 0;
     return AP_OK;
 }
 

@@ -74,6 +74,13 @@ struct RegInitArgs {
     int B;
 };
 hipError_t ap_launch_reg_init(const RegInitArgs& a, hipStream_t st);
+// folded IEF fast path: feature GEMM (split-K partial sums into `part`, ap_reg_fold_part_floats(rows) floats) and ONE
+// kernel for initialisation + all iterations + output.  wt_feat [2048][148], wt_state [284][148] (k-major), bias [148]
+hipError_t ap_launch_reg_fold_ief(const RegInitArgs& a, const float* xf0, const float* xf1, const float* bb0,
+                                  const float* bb1, const float* partner, int partner_ld, const float* wt_feat,
+                                  const float* wt_state, const float* bias, float* part, int iters, int two_view,
+                                  float* pose0, float* betas0, float* pose1, float* betas1, hipStream_t st);
+int ap_reg_fold_part_floats(int rows);
 // state (+= delta[:, :145] if delta) ; S[row] = [bb3 pos3 orient6 art126 shape10 art_other126 shape_other10 0 0 0 0]
 hipError_t ap_launch_reg_update_assemble(float* state, const float* delta, int ldd, const float* bb0, const float* bb1,
                                          const float* partner, int partner_ld,

@@ -77,6 +77,130 @@ __global__ void reg_output_kernel(const float* __restrict__ state, float* __rest
     }
 }
 
+// ---- folded IEF fast path ------------------------------------------------------------------------------------------
+// forward_reg is one affine map (api.hip: Wf = Wd W2 W1, 145 x 2332), so a whole IEF forward is
+//   H[row]   = bf + Wf[:, :2048] xf[row]                                  (once; split-K, reg_feat_splitk_kernel)
+//   state   += H + Wf[:, 2048:] [bb | state | partner's art, shape]       (iters times; reg_fold_ief_kernel)
+// and the cross-view swap only couples the two views of ONE pair: a workgroup owns a pair and runs all the iterations,
+// initialisation (model_copenet.py:119-137) and the pose / betas split without leaving the kernel.  Weights are
+// k-major ([k][148], coalesced over the output index) and stay in L2.
+constexpr int OLD = 148;   // padded output count (145)
+constexpr int KSPLIT = 8, KCH = 2048 / KSPLIT, FROWS = 8;
+
+constexpr int KQ = 4;      // k-quarters of a thread block: thread = (output o, quarter q), partial sums meet in LDS
+
+__global__ void __launch_bounds__(OLD * KQ) reg_feat_splitk_kernel(const float* __restrict__ xf0, const float* __restrict__ xf1,
+                                                                   int B, int rows, const float* __restrict__ wt,
+                                                                   float* __restrict__ part) {
+    __shared__ float xs[FROWS][KCH];
+    __shared__ float red[KQ][FROWS][OLD];
+    const int r0 = blockIdx.x * FROWS, ks = blockIdx.y, o = threadIdx.x % OLD, q = threadIdx.x / OLD;
+    for (int i = threadIdx.x; i < FROWS * KCH; i += blockDim.x) {
+        const int r = i / KCH, k = i - r * KCH, row = r0 + r;
+        float v = 0.f;
+        if (row < rows) v = (row < B ? xf0 + (size_t)row * 2048 : xf1 + (size_t)(row - B) * 2048)[ks * KCH + k];
+        xs[r][k] = v;
+    }
+    __syncthreads();
+    float acc[FROWS];
+#pragma unroll
+    for (int r = 0; r < FROWS; ++r) acc[r] = 0.f;
+    constexpr int KPT = KCH / KQ;                            // 64 k per thread
+    const float* w = wt + ((size_t)ks * KCH + q * KPT) * OLD + o;
+    for (int k0 = 0; k0 < KPT; k0 += 8) {
+        float wv[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k0 + u) * OLD];
+#pragma unroll
+        for (int u = 0; u < 8; ++u)
+#pragma unroll
+            for (int r = 0; r < FROWS; ++r) acc[r] = fmaf(wv[u], xs[r][q * KPT + k0 + u], acc[r]);
+    }
+#pragma unroll
+    for (int r = 0; r < FROWS; ++r) red[q][r][o] = acc[r];
+    __syncthreads();
+    for (int i = threadIdx.x; i < FROWS * OLD; i += blockDim.x) {
+        const int r = i / OLD, oo = i - r * OLD;
+        if (r0 + r < rows)
+            part[((size_t)ks * rows + r0 + r) * OLD + oo] = (red[0][r][oo] + red[1][r][oo]) + (red[2][r][oo] + red[3][r][oo]);
+    }
+}
+
+__global__ void __launch_bounds__(OLD * KQ) reg_fold_ief_kernel(const RegInitArgs a, const float* __restrict__ bb0,
+                                                                const float* __restrict__ bb1, const float* __restrict__ partner,
+                                                                int partner_ld, const float* __restrict__ part, int rows,
+                                                                const float* __restrict__ bias, const float* __restrict__ wst,
+                                                                int iters, int two_view, float* __restrict__ pose0,
+                                                                float* __restrict__ betas0, float* __restrict__ pose1,
+                                                                float* __restrict__ betas1) {
+    __shared__ float st[2][ST];        // state of the pair's views
+    __shared__ float S[2][SLD];        // assembled state input rows
+    __shared__ float H[2][OLD];        // feature part + bias
+    __shared__ float red[KQ][2][OLD];
+    const int b = blockIdx.x, nv = two_view ? 2 : 1, o = threadIdx.x % OLD, q = threadIdx.x / OLD;
+    for (int i = threadIdx.x; i < nv * ST; i += blockDim.x) {           // reg_init_kernel
+        const int v = i / ST, e = i - v * ST;
+        const float* pos = (v ? a.pos1 : a.pos0) + (size_t)b * a.pos_bs;
+        const float* theta = v ? a.theta1 : a.theta0;
+        const float* shape = v ? a.shape1 : a.shape0;
+        const float* th = theta ? theta + (size_t)b * (v ? a.theta1_bs : a.theta0_bs) : a.mean_pose;
+        const float* sh = shape ? shape + (size_t)b * (v ? a.shape1_bs : a.shape0_bs) : a.mean_shape;
+        st[v][e] = e < 3 ? pos[e] : e < 135 ? th[e - 3] : e < 145 ? sh[e - 135] : 0.f;
+    }
+    for (int i = threadIdx.x; i < nv * OLD; i += blockDim.x) {
+        const int v = i / OLD, oo = i - v * OLD;
+        const size_t row = (size_t)v * a.B + b;
+        float h = oo < 145 ? bias[oo] : 0.f;
+        for (int ks = 0; ks < KSPLIT; ++ks) h += part[((size_t)ks * rows + row) * OLD + oo];
+        H[v][oo] = h;
+    }
+    constexpr int KPT = 72;                                  // 4 x 72 = 288 >= 284 (the k-major weights are zero-padded)
+    const float* w = wst + (size_t)q * KPT * OLD + o;
+    for (int it = 0; it < iters; ++it) {
+        __syncthreads();
+        for (int i = threadIdx.x; i < nv * SLD; i += blockDim.x) {      // reg_update_assemble_kernel
+            const int v = i / SLD, e = i - v * SLD;
+            float val = 0.f;
+            if (e < 3) val = (v ? bb1 : bb0)[(size_t)b * 3 + e];
+            else if (e < 148) val = st[v][e - 3];
+            else if (e < 284) {
+                const int k = e - 148;
+                if (two_view) val = st[1 - v][k < 126 ? 9 + k : 135 + (k - 126)];
+                else val = partner[(size_t)b * partner_ld + k];
+            }
+            S[v][e] = val;
+        }
+        if (!two_view) for (int i = threadIdx.x; i < SLD; i += blockDim.x) S[1][i] = 0.f;
+        __syncthreads();
+        float d0 = 0.f, d1 = 0.f;
+        for (int k0 = 0; k0 < KPT; k0 += 8) {
+            float wv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(k0 + u) * OLD];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                d0 = fmaf(wv[u], S[0][q * KPT + k0 + u], d0);
+                d1 = fmaf(wv[u], S[1][q * KPT + k0 + u], d1);
+            }
+        }
+        red[q][0][o] = d0;
+        red[q][1][o] = d1;
+        __syncthreads();
+        for (int i = threadIdx.x; i < nv * 145; i += blockDim.x) {
+            const int v = i / 145, oo = i - v * 145;
+            st[v][oo] += H[v][oo] + ((red[0][v][oo] + red[1][v][oo]) + (red[2][v][oo] + red[3][v][oo]));
+        }
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nv * 145; i += blockDim.x) {          // reg_output_kernel
+        const int v = i / 145, e = i - v * 145;
+        float* pose = (v ? pose1 : pose0) + (size_t)b * 135;
+        float* betas = (v ? betas1 : betas0) + (size_t)b * 10;
+        if (e < 135) pose[e] = st[v][e];
+        else betas[e - 135] = st[v][e];
+    }
+}
+
 // ---- single-view HMR head (model_hmr.py:112-172): state = pose132 | shape10 | cam3 (145), row stride 160
 __global__ void hmr_init_kernel(const float* __restrict__ theta, int theta_bs, const float* __restrict__ shape,
                                 int shape_bs, const float* __restrict__ cam, int cam_bs,
@@ -140,6 +264,21 @@ hipError_t ap_launch_hmr_output(const float* state, float* rotmat, float* betas,
     hipLaunchKernelGGL(hmr_output_kernel, dim3(B), dim3(64), 0, st, state, rotmat, betas, cam);
     return hipGetLastError();
 }
+
+hipError_t ap_launch_reg_fold_ief(const RegInitArgs& a, const float* xf0, const float* xf1, const float* bb0,
+                                  const float* bb1, const float* partner, int partner_ld, const float* wt_feat,
+                                  const float* wt_state, const float* bias, float* part, int iters, int two_view,
+                                  float* pose0, float* betas0, float* pose1, float* betas1, hipStream_t st) {
+    const int rows = a.rows;
+    hipLaunchKernelGGL(reg_feat_splitk_kernel, dim3((rows + FROWS - 1) / FROWS, KSPLIT), dim3(OLD * KQ), 0, st, xf0, xf1, a.B,
+                       rows, wt_feat, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reg_fold_ief_kernel, dim3(a.B), dim3(OLD * KQ), 0, st, a, bb0, bb1, partner, partner_ld, part, rows, bias,
+                       wt_state, iters, two_view, pose0, betas0, pose1, betas1);
+    return hipGetLastError();
+}
+int ap_reg_fold_part_floats(int rows) { return KSPLIT * rows * OLD; }
 
 hipError_t ap_launch_reg_init(const RegInitArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(reg_init_kernel, dim3(a.rows), dim3(64), 0, st, a);

@@ -128,6 +128,10 @@ int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset);
  * (like the BatchNorm fold).  on = 1 (default) evaluates the folded map, on = 0 the literal three-GEMM chain;
  * both are parity-tested against the reference. */
 int ap_net_set_fold(ap_net* h, int on);
+/* With the folded map (ap_net_set_fold(1)): on = 1 (default) runs a whole IEF forward as two launches (split-K feature
+ * GEMM + ONE kernel for initialisation, all iterations with the cross-view swap, and the pose/betas split: the swap only
+ * couples the two views of a pair, which one workgroup owns); on = 0 as one GEMM per iteration plus glue kernels. */
+int ap_net_set_fuse_ief(ap_net* h, int on);
 /* First block of a stage: on = 1 (default) folds the downsample branch into conv3 as a second K segment
  * (relu(bn3(conv3(t)) + bn_ds(conv_ds(x))) as ONE GEMM over [t | x]: both BN scales folded into the weights in
  * fp64, no downsample tensor written or re-read); on = 0 runs the two convolutions of Bottleneck.forward

@@ -324,6 +324,23 @@ def test_ief_fp32_matches_golden(golden, net32, copenet_inputs, dev, fold):
     net32.set_fold(1)
 
 
+def test_fused_ief_kernel_matches_gemm_chain(golden, net32, copenet_inputs, dev):
+    """One-kernel IEF (split-K feature GEMM + all iterations in a workgroup per pair) vs one GEMM per iteration;
+    the golden comparison of the fused path itself is test_ief_fp32_matches_golden[fold=1]."""
+    g = golden["copenet_b2"]
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    pos = t("init_position")
+    outs = []
+    for on in (1, 0):
+        net32.set_fuse_ief(on)
+        outs.append(net32.forward_ief(t("xf0"), t("xf1"), copenet_inputs["bb0"].to(dev), copenet_inputs["bb1"].to(dev),
+                                      pos, pos, init_theta0=t("ci_theta0"), init_theta1=t("ci_theta1"),
+                                      init_shape0=t("ci_shape0"), init_shape1=t("ci_shape1"), iters=3))
+    net32.set_fuse_ief(1)
+    for a, b in zip(*outs):
+        assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 1e-5
+
+
 def test_forward_fp32_matches_golden(golden, net32, copenet_inputs, dev):
     g = golden["copenet_b2"]
     gin = {k: v.to(dev) for k, v in copenet_inputs.items()}
