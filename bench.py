@@ -53,10 +53,11 @@ REG_FLOPS_PER_PAIR = 2 * 3 * 2 * (2332 * 1024 + 1024 * 1024 + 1024 * 145)
 
 
 def pmc_traffic():
-    """HBM bytes per conv launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
-    profiles/r01_d_pmc_hbm_traffic.csv): counters cannot be collected inside the timed run itself."""
+    """HBM bytes per conv launch from the latest committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+    profiles/r*_pmc_hbm_traffic.csv via tools/collect_profiles.sh): counters cannot be collected inside the timed run."""
     try:
-        with open(os.path.join(REPO, "profiles", "r01_d_pmc_traffic.json")) as f:
+        import glob
+        with open(sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
             return json.load(f)["traffic_bytes_per_launch"]
     except Exception:
         return None

@@ -5,7 +5,7 @@ import sqlite3
 import sys
 
 db, n = sys.argv[1], int(sys.argv[2])
-FUSED_DS = len(sys.argv) > 3 and sys.argv[3] == "fused_ds"
+FUSED_DS = True   # (the downsample branch is always folded into conv3 now)
 c = sqlite3.connect(db)
 rows = list(c.execute("select name, start, end, duration, grid_x from kernels order by start"))
 idx = [i for i, r in enumerate(rows) if "stem" in r[0]]
@@ -27,12 +27,30 @@ for li, (pl, nb) in enumerate(zip(planes, layers)):
             shapes.append(("l%d.%d.c3" % (li + 1, bi), n * Ho * Ho, pl * 4, pl, n * Ho * Ho * pl, 1))
         inpl, H = pl * 4, Ho
 k = i0 + 1
-while "conv_" not in rows[k][0]:
+while "conv_" not in rows[k][0] and "bneck" not in rows[k][0]:
     print("%-40s %8.1f us" % (rows[k][0][:40], rows[k][3] / 1e3))
     k += 1
 print("%-40s %8.1f us" % (rows[i0][0][:40], rows[i0][3] / 1e3))
 tot = 0
 bylayer = {}
+if "bneck" in rows[k][0]:        # layer1 as three fused bottleneck kernels: fold its 9 shape rows into 3
+    fused, rest = [], []
+    for sh in shapes:
+        (fused if sh[0].startswith("l1.") else rest).append(sh)
+    for bi in range(3):
+        blk = [sh for sh in fused if sh[0].startswith("l1.%d." % bi)]
+        fl = sum(2.0 * M * N * K for (_, M, N, K, _, _) in blk)
+        M = blk[0][1]
+        by = (M * blk[0][3] + M * 256) * 2          # block input + output, once each
+        r = rows[k]
+        k += 1
+        dur = r[3] / 1e3
+        tot += dur
+        bylayer["l1"] = bylayer.get("l1", 0) + dur
+        print("l1.%d.fused M=%7d (conv1+conv2+conv3%s) %-22s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
+            bi, M, "+ds" if bi == 0 else "+id", r[0].split("::")[-1].split("(")[0], r[4] // 512, dur, fl / dur / 1e6,
+            by / 1e6, by / dur / 1e3))
+    shapes = rest
 for (nm, M, N, K, inel, res) in shapes:
     r = rows[k]
     k += 1
