@@ -1146,6 +1146,13 @@ int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset) {
     return AP_OK;
 }
 
+int ap_rotmat_to_angle_axis(const float* rotmat, int n, int cols, float* angle_axis, void* stream) {
+    if (!rotmat || !angle_axis || n <= 0 || (cols != 3 && cols != 4))
+        return fail(AP_EINVAL, "ap_rotmat_to_angle_axis: bad argument (cols must be 3 or 4)");
+    HIP_TRY(ap_launch_rotmat_to_angle_axis(rotmat, n, cols, angle_axis, (hipStream_t)stream));
+    return AP_OK;
+}
+
 int ap_rot6d_to_rotmat(const float* x6, int n, float* rotmat, void* stream) {
     if (!x6 || !rotmat || n <= 0) return fail(AP_EINVAL, "ap_rot6d_to_rotmat: bad argument");
     HIP_TRY(ap_launch_rot6d(x6, n, rotmat, (hipStream_t)stream));

@@ -270,6 +270,33 @@ __global__ void rot6d_kernel(const float* __restrict__ x6, int n, float* __restr
     for (int e = 0; e < 9; ++e) R[(size_t)i * 9 + e] = r[e];
 }
 
+// rotation_matrix_to_angle_axis of torchgeometry 0.1.2 (rotation_matrix_to_quaternion on the TRANSPOSED matrix with its
+// four trace branches, eps = 1e-6, then quaternion_to_angle_axis), as called at copenet_twoview.py:323-324
+__global__ void rotmat_to_angle_axis_kernel(const float* __restrict__ R, int n, int ld, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* r = R + (size_t)i * ld * 3;                 // row stride ld (3 or 4)
+    // rt[a][b] = r[b][a]
+    const float t00 = r[0], t10 = r[1], t20 = r[2], t01 = r[ld], t11 = r[ld + 1], t21 = r[ld + 2],
+                t02 = r[2 * ld], t12 = r[2 * ld + 1], t22 = r[2 * ld + 2];
+    float q[4], t;
+    if (t22 < 1e-6f) {
+        if (t00 > t11) { t = 1 + t00 - t11 - t22; q[0] = t12 - t21; q[1] = t; q[2] = t01 + t10; q[3] = t20 + t02; }
+        else           { t = 1 - t00 + t11 - t22; q[0] = t20 - t02; q[1] = t01 + t10; q[2] = t; q[3] = t12 + t21; }
+    } else {
+        if (t00 < -t11) { t = 1 - t00 - t11 + t22; q[0] = t01 - t10; q[1] = t20 + t02; q[2] = t12 + t21; q[3] = t; }
+        else            { t = 1 + t00 + t11 + t22; q[0] = t; q[1] = t12 - t21; q[2] = t20 - t02; q[3] = t01 - t10; }
+    }
+    const float s = 0.5f / sqrtf(t);
+    const float w = q[0] * s, x = q[1] * s, y = q[2] * s, z = q[3] * s;
+    const float ss = x * x + y * y + z * z, sn = sqrtf(ss);
+    const float two_theta = 2.0f * (w < 0.f ? atan2f(-sn, -w) : atan2f(sn, w));
+    const float k = ss > 0.f ? two_theta / sn : 2.0f;
+    out[(size_t)i * 3 + 0] = x * k;
+    out[(size_t)i * 3 + 1] = y * k;
+    out[(size_t)i * 3 + 2] = z * k;
+}
+
 __global__ void transform_points_kernel(const float* __restrict__ rt, const float* __restrict__ pts, int B, int P,
                                         float* __restrict__ out) {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -315,6 +342,11 @@ hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, h
 
 hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(smplx_joints_kernel, dim3(a.n), dim3(128), 0, st, m, a);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_rotmat_to_angle_axis(const float* R, int n, int ld, float* out, hipStream_t st) {
+    hipLaunchKernelGGL(rotmat_to_angle_axis_kernel, dim3((n + 255) / 256), dim3(256), 0, st, R, n, ld, out);
     return hipGetLastError();
 }
 

@@ -22,6 +22,21 @@ def rot6d_to_rotmat(x):
     return out
 
 
+def rotation_matrix_to_angle_axis(rotation_matrix):
+    """tgm.rotation_matrix_to_angle_axis (torchgeometry 0.1.2): (N,3,4) -- or (N,3,3) -- -> (N,3), the conversion the
+    caller applies to pred_rotmat for pred_angles [copenet_twoview.py:323-324]."""
+    dev = _cuda(rotation_matrix, "rotation_matrix_to_angle_axis")
+    r = N.f32c(rotation_matrix)
+    if r.dim() != 3 or r.shape[1] != 3 or r.shape[2] not in (3, 4):
+        raise ValueError("rotation_matrix_to_angle_axis: expected (N,3,4) or (N,3,3), got %s" % (tuple(r.shape),))
+    out = torch.empty(r.shape[0], 3, device=dev, dtype=torch.float32)
+    if r.shape[0]:
+        with torch.cuda.device(dev):
+            N.check(N.lib().ap_rotmat_to_angle_axis(N.dptr(r), r.shape[0], r.shape[2], N.dptr(out), N.stream_ptr(dev)),
+                    "ap_rotmat_to_angle_axis")
+    return out
+
+
 def perspective_projection(points, rotation, translation, focal_length, camera_center):
     """(bs,N,3) -> (bs,N,2)   [geometry.py:63-91]; camera_center (bs,2) or the caller's (1,bs,2)."""
     dev = _cuda(points, "perspective_projection")

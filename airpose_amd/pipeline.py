@@ -28,7 +28,7 @@ class TwoViewInference(object):
         pos = self.init_position(B, dev)
         return self.model(x0=im0, x1=im1, bb0=bb0, bb1=bb1, init_position0=pos, init_position1=pos, iters=self.iters)
 
-    def __call__(self, batch, want_rotmat=True):
+    def __call__(self, batch, want_rotmat=True, want_angles=False):
         im0, im1 = batch["im0"], batch["im1"]
         B, dev = im0.shape[0], im0.device
         p0, b0, p1, b1 = self.forward_net(im0, im1, batch["bb0"], batch["bb1"])
@@ -49,4 +49,10 @@ class TwoViewInference(object):
             out["pred_j2d_cam%d" % v] = o["j2d_cam"][sl]
             if want_rotmat:
                 out["pred_rotmat%d" % v] = o["rotmat"][sl]
+        if want_angles:                                    # test-mode output of the caller, :323-324
+            if not want_rotmat:
+                raise ValueError("want_angles needs want_rotmat")
+            from .geometry import rotation_matrix_to_angle_axis
+            ang = rotation_matrix_to_angle_axis(o["rotmat"].reshape(-1, 3, 3)).view(2, B, 22, 3)
+            out["pred_angles0"], out["pred_angles1"] = ang[0], ang[1]
         return out

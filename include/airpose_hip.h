@@ -193,6 +193,9 @@ int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);
  * Stand-alone geometry helpers (copenet/src/copenet/utils/geometry.py:47-61, 63-91;
  * copenet/src/copenet/utils/utils.py:237-256). */
 int ap_rot6d_to_rotmat(const float* x6, int n, float* rotmat, void* stream);          /* [n][6] -> [n][3][3] */
+/* tgm.rotation_matrix_to_angle_axis (torchgeometry 0.1.2) as called for pred_angles at copenet_twoview.py:323-324:
+ * [n][3][cols] row-major (cols = 3, or 4 for the caller's zero-padded 3x4 input) -> [n][3] */
+int ap_rotmat_to_angle_axis(const float* rotmat, int n, int cols, float* angle_axis, void* stream);
 int ap_transform_points(const float* rt, const float* pts, int B, int P, float* out, void* stream); /* rt [B][3][4] */
 int ap_perspective_projection(const float* pts, int B, int P, const float* rotation, const float* translation,
                               float fx, float fy, const float* center, float* out, void* stream);

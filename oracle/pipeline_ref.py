@@ -51,4 +51,8 @@ def infer(sd, model, im0, im1, bb0, bb1, intr0, intr1, iters=3):
         out["pred_j2d_cam%d" % v] = o["j2d_cam"]
         out["pred_smpltrans%d" % v] = o["smpltrans"]
         out["pred_rotmat%d" % v] = o["rotmat"]
+        # :323-324 (test mode): tgm.rotation_matrix_to_angle_axis of the zero-padded (22B,3,4) rotation matrices
+        rm = o["rotmat"].reshape(-1, 3, 3)
+        out["pred_angles%d" % v] = geometry_ref.rotation_matrix_to_angle_axis(
+            torch.cat([rm, torch.zeros(rm.shape[0], 3, 1, dtype=rm.dtype)], 2)).view(B, 22, 3)
     return out

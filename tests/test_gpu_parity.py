@@ -467,6 +467,25 @@ def test_geometry_helpers_match_golden(golden, dev):
     assert rel_err(v.cpu().numpy(), g["tf_verts_out"]) < 1e-6 and rel_err(j.cpu().numpy(), g["tf_joints_out"]) < 1e-6
 
 
+def test_rotation_matrix_to_angle_axis_matches_oracle(dev):
+    """pred_angles conversion (tgm 0.1.2 semantics): all four trace branches, (N,3,3) and the caller's (N,3,4) form."""
+    from airpose_amd.geometry import rotation_matrix_to_angle_axis
+    from oracle import geometry_ref as G
+    g = torch.Generator().manual_seed(3)
+    aa = torch.randn(4000, 3, generator=g) * 1.6                       # angles up to ~2 pi: exercises every branch
+    R = G.batch_rodrigues_quat(aa.double()).float()
+    R = torch.cat([R, torch.eye(3).unsqueeze(0), torch.diag(torch.tensor([1.0, -1.0, -1.0])).unsqueeze(0)], 0)
+    ref = G.rotation_matrix_to_angle_axis(R.double())
+    got3 = rotation_matrix_to_angle_axis(R.to(dev)).cpu().double()
+    got4 = rotation_matrix_to_angle_axis(torch.cat([R, torch.zeros(R.shape[0], 3, 1)], 2).to(dev)).cpu().double()
+    assert torch.equal(got3, got4)
+    # angle-axis is discontinuous at |angle| = pi (axis sign): compare the rotations they encode there
+    err = (got3 - ref).abs().max(1).values
+    near_pi = (ref.norm(dim=1) > 3.13)
+    assert err[~near_pi].max() < 2e-5
+    assert (G.batch_rodrigues_quat(got3[near_pi]) - G.batch_rodrigues_quat(ref[near_pi])).abs().max() < 1e-4
+
+
 def test_whole_pipeline_fp32_matches_oracle(net32, body, copenet_sd, copenet_inputs, smplx_model, dev):
     """BASELINE config 2 at test size: regressed theta/beta, 3-D joints/vertices, 2-D projection within 1e-4."""
     from airpose_amd import pipeline
@@ -475,7 +494,7 @@ def test_whole_pipeline_fp32_matches_oracle(net32, body, copenet_sd, copenet_inp
     with torch.no_grad():
         want = pipeline_ref.infer(copenet_sd, smplx_model, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"],
                                   inp["intr0"], inp["intr1"])
-    got = pipeline.TwoViewInference(net32, body)({k: v.to(dev) for k, v in inp.items()})
+    got = pipeline.TwoViewInference(net32, body)({k: v.to(dev) for k, v in inp.items()}, want_angles=True)
     for k in sorted(want):
         e = rel_err(got[k].cpu().numpy(), want[k].numpy())
         print("%-22s rel err %.3e" % (k, e))

@@ -118,3 +118,25 @@ def test_ief_known_answers(copenet_sd):
         p0, s0, p1, s1 = copenet_ref.ief(sdz, xf0, xf1, bb0, bb1, pos0, pos1, iters=3)
     assert torch.allclose(p0[:, :3], pos0) and torch.allclose(s1, copenet_sd["init_shape"].expand(B, -1))
     assert torch.allclose(p0[:, 3:], copenet_sd["init_pose"][:, :132].expand(B, -1))
+
+
+def test_oracle_angle_axis_known_answers():
+    """rotation_matrix_to_angle_axis (torchgeometry 0.1.2 restatement, parity unpinned): inverse of the axis-angle ->
+    rotation map for angles below pi, identity -> 0, and the caller's zero-padded (N,3,4) input form."""
+    import torch
+    from oracle import geometry_ref as G
+    g = torch.Generator().manual_seed(11)
+    axis = torch.randn(500, 3, generator=g, dtype=torch.float64)
+    axis = axis / axis.norm(dim=1, keepdim=True)
+    ang = torch.rand(500, 1, generator=g, dtype=torch.float64) * 3.1
+    aa = axis * ang
+    K = torch.zeros(500, 3, 3, dtype=torch.float64)
+    K[:, 0, 1], K[:, 0, 2], K[:, 1, 0], K[:, 1, 2], K[:, 2, 0], K[:, 2, 1] = -axis[:, 2], axis[:, 1], axis[:, 2], -axis[:, 0], -axis[:, 1], axis[:, 0]
+    R = torch.eye(3, dtype=torch.float64) + torch.sin(ang).view(-1, 1, 1) * K + (1 - torch.cos(ang)).view(-1, 1, 1) * (K @ K)
+    got = G.rotation_matrix_to_angle_axis(torch.cat([R, torch.zeros(500, 3, 1, dtype=torch.float64)], 2))
+    assert (got - aa).abs().max() < 1e-9
+    assert G.rotation_matrix_to_angle_axis(torch.eye(3, dtype=torch.float64).unsqueeze(0)).abs().max() == 0
+    # 180 degrees about x (the mean pose's root joint): |angle| = pi, axis +-x
+    Rx = torch.diag(torch.tensor([1.0, -1.0, -1.0], dtype=torch.float64)).unsqueeze(0)
+    a = G.rotation_matrix_to_angle_axis(Rx)
+    assert abs(abs(a[0, 0].item()) - 3.141592653589793) < 1e-9 and a[0, 1:].abs().max() < 1e-9
