@@ -101,6 +101,33 @@ def ief(sd, xf0, xf1, bb0, bb1, init_position0, init_position1,
     return p0, b0, p1, b1
 
 
+def sep_forward_reg(sd0, sd1, xf0, xf1, bb0, bb1, pos0, pos1, orient0, orient1, art0, art1, shape0, shape1):
+    """copenet_real/models/model_copenet_sep.py:184-210 -- two weight sets; view 1's input is built AFTER `pred_shape0`
+    has been rebound to view 0's updated shape (:197-198, 202), so it sees [old art_pose0 | NEW shape0]."""
+    xc0 = torch.cat([xf0, bb0, pos0, orient0, art0, shape0, art1, shape1], 1)
+    xc0 = _lin(_lin(xc0, sd0, "fc1"), sd0, "fc2")
+    pshape0 = shape0 + _lin(xc0, sd0, "decshape")
+    ppose0 = torch.cat([pos0, orient0, art0], 1) + _lin(xc0, sd0, "decpose")
+    xc1 = torch.cat([xf1, bb1, pos1, orient1, art1, shape1, art0, pshape0], 1)
+    xc1 = _lin(_lin(xc1, sd1, "fc1"), sd1, "fc2")
+    pshape1 = shape1 + _lin(xc1, sd1, "decshape")
+    ppose1 = torch.cat([pos1, orient1, art1], 1) + _lin(xc1, sd1, "decpose")
+    return ppose0, pshape0, ppose1, pshape1
+
+
+def sep_ief(sd0, sd1, xf0, xf1, bb0, bb1, init_position0, init_position1, iters=3):
+    """IEF loop of model_copenet_sep.py:137-182 from trunk features (default initial state of each sub-model)."""
+    B = xf0.shape[0]
+    o0, a0 = sd0["init_pose"][:, :6].expand(B, -1), sd0["init_pose"][:, 6:132].expand(B, -1)
+    o1, a1 = sd1["init_pose"][:, :6].expand(B, -1), sd1["init_pose"][:, 6:132].expand(B, -1)
+    s0, s1 = sd0["init_shape"].expand(B, -1), sd1["init_shape"].expand(B, -1)
+    p0, b0, p1, b1 = sep_forward_reg(sd0, sd1, xf0, xf1, bb0, bb1, init_position0, init_position1, o0, o1, a0, a1, s0, s1)
+    for _ in range(int(iters) - 1):
+        p0, b0, p1, b1 = sep_forward_reg(sd0, sd1, xf0, xf1, bb0, bb1, p0[:, :3], p1[:, :3], p0[:, 3:9], p1[:, 3:9],
+                                         p0[:, 9:], p1[:, 9:], b0, b1)
+    return p0, b0, p1, b1
+
+
 def copenet_forward(sd, x0, x1, bb0, bb1, init_position0, init_position1,
                     init_theta0=None, init_theta1=None, init_shape0=None, init_shape1=None, iters=3):
     """model_copenet.py:112-159."""

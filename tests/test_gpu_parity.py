@@ -467,6 +467,23 @@ def test_geometry_helpers_match_golden(golden, dev):
     assert rel_err(v.cpu().numpy(), g["tf_verts_out"]) < 1e-6 and rel_err(j.cpu().numpy(), g["tf_joints_out"]) < 1e-6
 
 
+def test_copenet_sep_matches_reference(golden, dev):
+    """copenet_sep (two weight sets, asymmetric cross-view step) on the GPU vs the imported reference's forward."""
+    from airpose_amd import copenet_sep_model, weights as W
+    g, gs = golden["copenet_b2"], golden["copenet_sep_b2"]
+    net = copenet_sep_model.getcopenet_sep(MEAN_PARAMS, precision="fp32")
+    assert list(net.state_dict().keys()) == [str(k) for k in gs["state_dict_keys"]]
+    net.copenet0.load_state_dict(W.to_torch(W.copenet_state_dict(int(gs["weights_seed0"]), MEAN_PARAMS)))
+    net.copenet1.load_state_dict(W.to_torch(W.copenet_state_dict(int(gs["weights_seed1"]), MEAN_PARAMS)))
+    net.eval().to(dev)
+    t = lambda k: torch.from_numpy(g[k]).to(dev)
+    pos = t("init_position")
+    for it in (1, 3):
+        out = net.forward_ief(t("xf0"), t("xf1"), t("bb0"), t("bb1"), pos, pos, iters=it)
+        for got, key in zip(out, ("pose0", "betas0", "pose1", "betas1")):
+            assert rel_err(got.cpu().numpy(), gs["%s_it%d" % (key, it)]) < TOL32, (key, it)
+
+
 def test_rotation_matrix_to_angle_axis_matches_oracle(dev):
     """pred_angles conversion (tgm 0.1.2 semantics): all four trace branches, (N,3,3) and the caller's (N,3,4) form."""
     from airpose_amd.geometry import rotation_matrix_to_angle_axis

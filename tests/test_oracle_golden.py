@@ -140,3 +140,21 @@ def test_oracle_angle_axis_known_answers():
     Rx = torch.diag(torch.tensor([1.0, -1.0, -1.0], dtype=torch.float64)).unsqueeze(0)
     a = G.rotation_matrix_to_angle_axis(Rx)
     assert abs(abs(a[0, 0].item()) - 3.141592653589793) < 1e-9 and a[0, 1:].abs().max() < 1e-9
+
+
+def test_oracle_copenet_sep_matches_reference(golden):
+    """Two-weight-set model (copenet_real/models/model_copenet_sep.py): the oracle's sep IEF from the golden trunk
+    features equals the imported reference's forward (forward_feat_ext patched to those features)."""
+    import torch
+    from airpose_amd import weights as W
+    from oracle import copenet_ref
+    from conftest import MEAN_PARAMS
+    g, gs = golden["copenet_b2"], golden["copenet_sep_b2"]
+    sd0 = W.to_torch(W.copenet_state_dict(int(gs["weights_seed0"]), MEAN_PARAMS))
+    sd1 = W.to_torch(W.copenet_state_dict(int(gs["weights_seed1"]), MEAN_PARAMS))
+    t = lambda a: torch.from_numpy(a)
+    pos = t(g["init_position"])
+    for it in (1, 3):
+        out = copenet_ref.sep_ief(sd0, sd1, t(g["xf0"]), t(g["xf1"]), t(g["bb0"]), t(g["bb1"]), pos, pos, iters=it)
+        for got, key in zip(out, ("pose0", "betas0", "pose1", "betas1")):
+            assert rel_err(got.numpy(), gs["%s_it%d" % (key, it)]) < 2e-6, (key, it)

@@ -17,6 +17,7 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF_SRC = "/root/reference/copenet/src"
+REF_SRC_REAL = "/root/reference/copenet_real/src"
 sys.path.insert(0, REPO)
 OUT = os.path.join(REPO, "tests", "golden")
 MEAN = os.path.join(REPO, "airpose_amd", "data", "smpl_mean_params.npz")
@@ -40,7 +41,9 @@ def import_reference():
     tv.models, tvm.resnet = tvm, tvr
     _stub("cv2")
     _stub("torchgeometry")
+    _stub("pytorch_lightning", LightningModule=torch.nn.Module)     # model_copenet_sep.py subclasses pl.LightningModule
     sys.path.insert(0, REF_SRC)
+    sys.path.insert(0, REF_SRC_REAL)
     from copenet.models import model_copenet, model_hmr
     from copenet.utils import geometry
     from copenet.utils import utils as ref_utils
@@ -111,6 +114,25 @@ def main():
     np.savez_compressed(os.path.join(OUT, "hmr_b1.npz"), weights_seed=WSEED + 1, inputs_seed=ISEED + 1,
                         im_sum=x.double().sum().item(), rotmat=rotmat.numpy(), betas=betas.numpy(), cam=cam.numpy())
     print("hmr_b1: betas", betas.numpy()[0, :4])
+
+    # ------------------------------------------------------------------ copenet_sep (two weight sets; IEF from features)
+    # The two trunks are ordinary ResNet-50s (pinned above); the fixture pins the sep driver + its asymmetric
+    # forward_reg by feeding the golden trunk features through the reference model with forward_feat_ext patched out.
+    from copenet_real.models import model_copenet_sep
+    sep = model_copenet_sep.copenet_sep(model_copenet_sep.Bottleneck, [3, 4, 6, 3], MEAN).eval()
+    sep.copenet0.load_state_dict(W.to_torch(W.copenet_state_dict(WSEED + 2, MEAN)), strict=True)
+    sep.copenet1.load_state_dict(W.to_torch(W.copenet_state_dict(WSEED + 3, MEAN)), strict=True)
+    sep.copenet0.forward_feat_ext = lambda x: torch.from_numpy(g["xf0"])
+    sep.copenet1.forward_feat_ext = lambda x: torch.from_numpy(g["xf1"])
+    gs = {"weights_seed0": WSEED + 2, "weights_seed1": WSEED + 3,
+          "state_dict_keys": np.array(list(sep.state_dict().keys()))}
+    with torch.no_grad():
+        for it in (1, 3):
+            p0, b0, p1, b1 = sep(inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], pos, pos, iters=it)
+            gs["pose0_it%d" % it], gs["betas0_it%d" % it] = p0.numpy(), b0.numpy()
+            gs["pose1_it%d" % it], gs["betas1_it%d" % it] = p1.numpy(), b1.numpy()
+    np.savez_compressed(os.path.join(OUT, "copenet_sep_b2.npz"), **gs)
+    print("copenet_sep_b2: pose1", gs["pose1_it3"][0, :6])
 
     # ------------------------------------------------------------------ geometry helpers
     rs = np.random.RandomState(7)
