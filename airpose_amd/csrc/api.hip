@@ -477,6 +477,17 @@ int finalize_regressor(ap_net* h) {
         HIP_TRY(upload(h->mean_cam, ic->data.data(), 3 * 4));
         return AP_OK;
     }
+    // copenet_singleview (model_copenet_singleview.py:67,156-168): xc = [xf | bb | pose135 | shape10], i.e. the two-view
+    // layout without the partner's 136 columns -> the same code with those fc1 columns zero
+    HostTensor w1_padded;
+    if (h->variant == 2) {
+        if (w1->numel() != (size_t)1024 * 2196) return fail(AP_ESHAPE, "copenet_singleview: fc1.weight must be 1024 x 2196");
+        w1_padded.shape = {1024, 2332};
+        w1_padded.data.assign((size_t)1024 * 2332, 0.f);
+        for (int o = 0; o < 1024; ++o)
+            memcpy(&w1_padded.data[(size_t)o * 2332], &w1->data[(size_t)o * 2196], (size_t)2196 * 4);
+        w1 = &w1_padded;
+    }
     if (w1->numel() != (size_t)1024 * 2332 || w2->numel() != (size_t)1024 * 1024 || wp->numel() != (size_t)135 * 1024 ||
         wsh->numel() != (size_t)10 * 1024 || ip->numel() < 132 || is->numel() != 10)
         return fail(AP_ESHAPE, "regressor tensor shape mismatch");
@@ -633,7 +644,11 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
                   int partner_ld, int pos_bs, float* pose0, float* betas0, float* pose1, float* betas1,
                   hipStream_t st) {
     if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
-    if (h->variant != 0) return fail(AP_ESTATE, "regressor entry points need a copenet (variant 0) handle");
+    if (h->variant != 0 && h->variant != 2)
+        return fail(AP_ESTATE, "regressor entry points need a copenet (variant 0) or copenet_singleview (variant 2) handle");
+    if (h->variant == 2 && (two_view || partner))
+        return fail(AP_ESTATE, "a copenet_singleview handle has no cross-view inputs");
+    if (h->variant == 0 && !two_view && !partner) return fail(AP_EINVAL, "regressor step: partner state missing");
     if (B <= 0 || iters < 1) return fail(AP_EINVAL, "regressor: bad B / iters");
     const int rows = two_view ? 2 * B : B;
     HIP_TRY(h->ws_H.reserve((size_t)rows * 1024 * 4));
@@ -711,7 +726,7 @@ const char* ap_version(void) { return "airpose_hip 0.1 (gfx950)"; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
 int ap_net_create(ap_net** out, int device, int precision, int variant) {
-    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16) || (variant != 0 && variant != 1))
+    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16) || (variant < 0 || variant > 2))
         return fail(AP_EINVAL, "ap_net_create: bad arguments");
     HIP_TRY(hipSetDevice(device));
     ap_net* h = new ap_net();
@@ -787,6 +802,21 @@ int ap_regressor_step(ap_net* h, const float* xf, const float* bb, const float* 
     RegInputs in{xf, nullptr, bb, nullptr, pose_in, nullptr, pose_in + 3, nullptr, betas_in, nullptr, 135, 0, 10, 0};
     return regressor_run(h, in, B, 1, 0, partner, partner_ld, 135, pose_out, betas_out, nullptr, nullptr,
                          (hipStream_t)stream);
+}
+
+int ap_singleview_fwd(ap_net* h, const float* x, const float* bb, const float* pos, const float* init_theta,
+                      int theta_bs, const float* init_shape, int shape_bs, int B, int iters, float* pose, float* betas,
+                      void* stream) {
+    if (!h || !x || !bb || !pos || !pose || !betas) return fail(AP_EINVAL, "ap_singleview_fwd: null argument");
+    if (h->variant != 2) return fail(AP_ESTATE, "ap_singleview_fwd needs a copenet_singleview (variant 2) handle");
+    if (B <= 0) return fail(AP_EINVAL, "ap_singleview_fwd: bad batch");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(h->ws_feat.reserve((size_t)B * 2048 * 4));
+    float* f = h->ws_feat.as<float>();
+    int rc = trunk_fwd(h, x, B, nullptr, 0, f, st);
+    if (rc) return rc;
+    RegInputs in{f, nullptr, bb, nullptr, pos, nullptr, init_theta, nullptr, init_shape, nullptr, theta_bs, 0, shape_bs, 0};
+    return regressor_run(h, in, B, iters, 0, nullptr, 0, 3, pose, betas, nullptr, nullptr, st);
 }
 
 int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0, const float* bb1,

@@ -58,7 +58,7 @@ __global__ void reg_update_assemble_kernel(float* __restrict__ state, const floa
         else if (e < 284) {
             const int k = e - 148;                                 // partner art (126) | shape (10)
             if (two_view) val = st[1 - v][k < 126 ? 9 + k : 135 + (k - 126)];
-            else val = partner[(size_t)b * partner_ld + k];
+            else val = partner ? partner[(size_t)b * partner_ld + k] : 0.f;   // (no partner: single-view model)
         }
         S[row * SLD + e] = val;
     }
@@ -166,7 +166,7 @@ __global__ void __launch_bounds__(OLD * KQ) reg_fold_ief_kernel(const RegInitArg
             else if (e < 284) {
                 const int k = e - 148;
                 if (two_view) val = st[1 - v][k < 126 ? 9 + k : 135 + (k - 126)];
-                else val = partner[(size_t)b * partner_ld + k];
+                else val = partner ? partner[(size_t)b * partner_ld + k] : 0.f;   // (no partner: single-view model)
             }
             S[v][e] = val;
         }

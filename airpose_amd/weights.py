@@ -82,18 +82,24 @@ def load_mean_params(path):
 
 
 def copenet_state_dict(seed, mean_params_path, variant="copenet"):
-    """Full state_dict (numpy arrays) for the two-view ``copenet`` (or ``hmr``) module."""
+    """Full state_dict (numpy arrays) for the two-view ``copenet`` (or ``hmr`` / ``copenet_singleview``) module."""
     rs = np.random.RandomState(seed)
     sd = trunk_state_dict(rs)
-    fc1_in = FC1_IN if variant == "copenet" else HMR_FC1_IN
-    npose_out = 3 + 6 + NPOSE if variant == "copenet" else 22 * 6
+    if variant not in ("copenet", "hmr", "singleview"):
+        raise ValueError(variant)
+    fc1_in = {"copenet": FC1_IN, "hmr": HMR_FC1_IN, "singleview": 2048 + 3 + 135 + 10}[variant]
+    npose_out = 22 * 6 if variant == "hmr" else 3 + 6 + NPOSE
     _linear(rs, sd, "fc1", 1024, fc1_in)
     _linear(rs, sd, "fc2", 1024, 1024)
     _linear(rs, sd, "decpose", npose_out, 1024, xavier_gain=0.01)
     _linear(rs, sd, "decshape", 10, 1024, xavier_gain=0.01)
     _linear(rs, sd, "deccam", 3, 1024, xavier_gain=0.01)
     pose, shape, cam = load_mean_params(mean_params_path)
-    sd["init_pose"], sd["init_shape"], sd["init_cam"] = pose, shape, cam
+    if variant == "singleview":     # model_copenet_singleview.py:89-92 registers init_position instead of init_cam
+        sd["init_pose"], sd["init_shape"] = pose, shape
+        sd["init_position"] = np.array([[0.0, 0.0, 10.0 / 0.05]], np.float32)
+    else:
+        sd["init_pose"], sd["init_shape"], sd["init_cam"] = pose, shape, cam
     return sd
 
 

@@ -46,7 +46,8 @@ const char* ap_last_error(void);
  * (conv OIHW, linear [out][in]); ap_net_finalize folds BN into a per-channel scale/shift, repacks
  * the weights K-contiguous NHWC in the handle's precision and uploads them.  Calling set_tensor +
  * finalize again re-packs (fine-tuned weights).
- * variant: 0 = copenet two-view (fc1 in = 2332), 1 = hmr single-view head (fc1 in = 2193, ap_hmr_fwd). */
+ * variant: 0 = copenet two-view (fc1 in = 2332), 1 = hmr single-view head (fc1 in = 2193, ap_hmr_fwd),
+ *          2 = copenet_singleview (fc1 in = 2196, ap_singleview_fwd). */
 int ap_net_create(ap_net** out, int device, int precision, int variant);
 void ap_net_destroy(ap_net* h);
 int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
@@ -73,6 +74,14 @@ int ap_regressor_fwd(ap_net* h, const float* xf0, const float* xf1, const float*
  * the other view's art pose (126) | shape (10); outputs as above. */
 int ap_regressor_step(ap_net* h, const float* xf, const float* bb, const float* pose_in, const float* betas_in,
                       const float* partner, int partner_ld, int B, float* pose_out, float* betas_out, void* stream);
+
+/* copenet_singleview baseline (models/model_copenet_singleview.py:108-168; needs a variant-2 handle: fc1 is 1024 x 2196,
+ * xc = [xf | bb | pose135 | shape10]): trunk + `iters` regressor evaluations for ONE view, no cross-view input.
+ * x [B][3][224][224], bb/pos [B][3], init_theta [tb][>=132] / init_shape [sb][10] as for ap_regressor_fwd (NULL = model
+ * mean); outputs pose [B][135], betas [B][10]. */
+int ap_singleview_fwd(ap_net* h, const float* x, const float* bb, const float* pos, const float* init_theta,
+                      int theta_bs, const float* init_shape, int shape_bs, int B, int iters, float* pose, float* betas,
+                      void* stream);
 
 /* copenet.forward (model_copenet.py:112-159): both trunks (one batched 2B pass, shared weights) + IEF. */
 int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0, const float* bb1,

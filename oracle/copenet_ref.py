@@ -138,6 +138,19 @@ def copenet_forward(sd, x0, x1, bb0, bb1, init_position0, init_position1,
 
 
 # ------------------------------------------------------------------ hmr (Config 1, CPU plumbing)
+def singleview_forward(sd, x, bb, init_position, init_theta=None, init_shape=None, iters=3):
+    """models/model_copenet_singleview.py:108-138 (+ forward_reg :156-168): xc = [xf | bb | pose135 | shape10]."""
+    B = x.shape[0]
+    theta = sd["init_pose"][:, :132].expand(B, -1) if init_theta is None else init_theta
+    pose = torch.cat([init_position, theta], 1)
+    shape = sd["init_shape"].expand(B, -1) if init_shape is None else init_shape
+    xf = forward_feat_ext(x, sd)
+    for _ in range(int(iters)):
+        xc = _lin(_lin(torch.cat([xf, bb, pose, shape], 1), sd, "fc1"), sd, "fc2")
+        pose, shape = _lin(xc, sd, "decpose") + pose, _lin(xc, sd, "decshape") + shape
+    return pose, shape
+
+
 def hmr_forward_reg(sd, xf, pose, shape, cam):
     """model_hmr.py:160-172."""
     xc = _lin(_lin(torch.cat([xf, pose, shape, cam], 1), sd, "fc1"), sd, "fc2")

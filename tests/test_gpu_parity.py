@@ -467,6 +467,32 @@ def test_geometry_helpers_match_golden(golden, dev):
     assert rel_err(v.cpu().numpy(), g["tf_verts_out"]) < 1e-6 and rel_err(j.cpu().numpy(), g["tf_joints_out"]) < 1e-6
 
 
+def test_singleview_on_gpu_matches_reference(golden, dev):
+    """copenet_singleview baseline on the GPU (ap_singleview_fwd) vs the imported reference's forward."""
+    from airpose_amd import copenet_singleview_model, weights as W
+    g = golden["singleview_b1"]
+    sd = W.to_torch(W.copenet_state_dict(int(g["weights_seed"]), MEAN_PARAMS, variant="singleview"))
+    net = copenet_singleview_model.getcopenet(MEAN_PARAMS, precision="fp32").eval()
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    net.load_state_dict(sd)
+    net.to(dev)
+    inp = W.synthetic_inputs(int(g["inputs_seed"]), 1)
+    pos = torch.from_numpy(g["init_position"]).to(dev)
+    pose, betas = net(torch.from_numpy(inp["im0"]).to(dev), torch.from_numpy(inp["bb0"]).to(dev), pos, iters=3)
+    assert rel_err(pose.cpu().numpy(), g["pose"]) < TOL32 and rel_err(betas.cpu().numpy(), g["betas"]) < TOL32
+    netb = copenet_singleview_model.getcopenet(MEAN_PARAMS, precision="bf16").eval()
+    netb.load_state_dict(sd)
+    netb.to(dev)
+    pose_b, _ = netb(torch.from_numpy(inp["im0"]).to(dev), torch.from_numpy(inp["bb0"]).to(dev), pos, iters=3)
+    assert rel_err(pose_b.cpu().numpy(), g["pose"]) < TOLBF
+    with pytest.raises(RuntimeError):      # a two-view entry point on a single-view handle is an error, not a fallback
+        netb.forward_feat_ext(torch.zeros(1, 3, 224, 224, device=dev)) and None
+        from airpose_amd import _native as Nn
+        z = torch.zeros(1, 2048, device=dev)
+        Nn.check(Nn.lib().ap_regressor_fwd(netb._native(dev), *[ctypes.c_void_p(z.data_ptr())] * 6, None, 0, None, 0, None, 0,
+                                           None, 0, 1, 1, *[ctypes.c_void_p(z.data_ptr())] * 4, None), "ap_regressor_fwd")
+
+
 def test_copenet_sep_matches_reference(golden, dev):
     """copenet_sep (two weight sets, asymmetric cross-view step) on the GPU vs the imported reference's forward."""
     from airpose_amd import copenet_sep_model, weights as W

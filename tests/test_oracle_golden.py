@@ -158,3 +158,18 @@ def test_oracle_copenet_sep_matches_reference(golden):
         out = copenet_ref.sep_ief(sd0, sd1, t(g["xf0"]), t(g["xf1"]), t(g["bb0"]), t(g["bb1"]), pos, pos, iters=it)
         for got, key in zip(out, ("pose0", "betas0", "pose1", "betas1")):
             assert rel_err(got.numpy(), gs["%s_it%d" % (key, it)]) < 2e-6, (key, it)
+
+
+def test_oracle_singleview_matches_reference(golden):
+    """copenet_singleview baseline (models/model_copenet_singleview.py): oracle vs the imported reference's forward."""
+    import torch
+    from airpose_amd import weights as W
+    from oracle import copenet_ref
+    g = golden["singleview_b1"]
+    sd = W.to_torch(W.copenet_state_dict(int(g["weights_seed"]), MEAN_PARAMS, variant="singleview"))
+    assert sorted(sd.keys()) == sorted(str(k) for k in g["state_dict_keys"])
+    inp = W.synthetic_inputs(int(g["inputs_seed"]), 1)
+    with torch.no_grad():
+        pose, betas = copenet_ref.singleview_forward(sd, torch.from_numpy(inp["im0"]), torch.from_numpy(inp["bb0"]),
+                                                     torch.from_numpy(g["init_position"]), iters=3)
+    assert rel_err(pose.numpy(), g["pose"]) < 2e-6 and rel_err(betas.numpy(), g["betas"]) < 2e-6

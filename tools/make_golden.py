@@ -115,6 +115,19 @@ def main():
                         im_sum=x.double().sum().item(), rotmat=rotmat.numpy(), betas=betas.numpy(), cam=cam.numpy())
     print("hmr_b1: betas", betas.numpy()[0, :4])
 
+    # ------------------------------------------------------------------ copenet_singleview baseline, B=1
+    from copenet.models import model_copenet_singleview
+    sds = W.to_torch(W.copenet_state_dict(WSEED + 4, MEAN, variant="singleview"))
+    snet = model_copenet_singleview.copenet(model_copenet_singleview.Bottleneck, [3, 4, 6, 3], MEAN).eval()
+    snet.load_state_dict(sds, strict=True)
+    si = W.synthetic_inputs(ISEED + 4, 1)
+    with torch.no_grad():
+        sp, sb = snet(torch.from_numpy(si["im0"]), torch.from_numpy(si["bb0"]), pos[:1], iters=3)
+    np.savez_compressed(os.path.join(OUT, "singleview_b1.npz"), weights_seed=WSEED + 4, inputs_seed=ISEED + 4,
+                        state_dict_keys=np.array(list(snet.state_dict().keys())), pose=sp.numpy(), betas=sb.numpy(),
+                        init_position=pos[:1].numpy())
+    print("singleview_b1: pose", sp.numpy()[0, :6])
+
     # ------------------------------------------------------------------ copenet_sep (two weight sets; IEF from features)
     # The two trunks are ordinary ResNet-50s (pinned above); the fixture pins the sep driver + its asymmetric
     # forward_reg by feeding the golden trunk features through the reference model with forward_feat_ext patched out.
