@@ -488,6 +488,37 @@ int finalize_regressor(ap_net* h) {
             memcpy(&w1_padded.data[(size_t)o * 2332], &w1->data[(size_t)o * 2196], (size_t)2196 * 4);
         w1 = &w1_padded;
     }
+    // muhmr (model_muhmr.py:67-72,163-197): xc = [xf | cam3 | orient6 | art126 | shape10 | partner 136], decoders
+    // decpose (132) / decshape / deccam.  The weak-perspective camera takes the place of the two-view model's
+    // translation: cam goes into the `pos` slot (fc1 columns of bb are zero) and deccam's rows are stacked in front of
+    // decpose's, so the state row is [cam3 | pose132 | shape10] and the two-view code runs unchanged
+    HostTensor wp_stacked, bp_stacked;
+    if (h->variant == 3) {
+        const HostTensor *wc = find(h, "deccam.weight"), *bc = find(h, "deccam.bias");
+        if (!wc || !bc) return fail(AP_ESTATE, "muhmr: missing deccam tensors");
+        if (w1->numel() != (size_t)1024 * 2329 || wp->numel() != (size_t)132 * 1024 || wc->numel() != (size_t)3 * 1024 ||
+            bp->numel() != 132 || bc->numel() != 3)
+            return fail(AP_ESHAPE, "muhmr: fc1.weight must be 1024 x 2329, decpose 132 x 1024, deccam 3 x 1024");
+        w1_padded.shape = {1024, 2332};
+        w1_padded.data.assign((size_t)1024 * 2332, 0.f);
+        for (int o = 0; o < 1024; ++o) {
+            const float* src = &w1->data[(size_t)o * 2329];
+            float* dst = &w1_padded.data[(size_t)o * 2332];
+            memcpy(dst, src, (size_t)2048 * 4);                       // trunk features
+            memcpy(dst + 2051, src + 2048, (size_t)(2329 - 2048) * 4);   // cam -> pos slot, then orient .. partner
+        }
+        w1 = &w1_padded;
+        wp_stacked.shape = {135, 1024};
+        wp_stacked.data.resize((size_t)135 * 1024);
+        memcpy(wp_stacked.data.data(), wc->data.data(), (size_t)3 * 1024 * 4);
+        memcpy(wp_stacked.data.data() + (size_t)3 * 1024, wp->data.data(), (size_t)132 * 1024 * 4);
+        bp_stacked.shape = {135};
+        bp_stacked.data.resize(135);
+        memcpy(bp_stacked.data.data(), bc->data.data(), 3 * 4);
+        memcpy(bp_stacked.data.data() + 3, bp->data.data(), 132 * 4);
+        wp = &wp_stacked;
+        bp = &bp_stacked;
+    }
     if (w1->numel() != (size_t)1024 * 2332 || w2->numel() != (size_t)1024 * 1024 || wp->numel() != (size_t)135 * 1024 ||
         wsh->numel() != (size_t)10 * 1024 || ip->numel() < 132 || is->numel() != 10)
         return fail(AP_ESHAPE, "regressor tensor shape mismatch");
@@ -545,6 +576,11 @@ int finalize_regressor(ap_net* h) {
     memcpy(mp.data(), ip->data.data(), std::min<size_t>(144, ip->numel()) * 4);
     HIP_TRY(upload(h->mean_pose, mp.data(), 144 * 4));
     HIP_TRY(upload(h->mean_shape, is->data.data(), 10 * 4));
+    if (h->variant == 3) {
+        const HostTensor* ic = find(h, "init_cam");
+        if (!ic || ic->numel() != 3) return fail(AP_ESTATE, "muhmr: missing init_cam");
+        HIP_TRY(upload(h->mean_cam, ic->data.data(), 3 * 4));
+    }
     return AP_OK;
 }
 
@@ -644,11 +680,11 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
                   int partner_ld, int pos_bs, float* pose0, float* betas0, float* pose1, float* betas1,
                   hipStream_t st) {
     if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
-    if (h->variant != 0 && h->variant != 2)
-        return fail(AP_ESTATE, "regressor entry points need a copenet (variant 0) or copenet_singleview (variant 2) handle");
+    if (h->variant == 1)
+        return fail(AP_ESTATE, "regressor entry points need a copenet-layout handle (variants 0, 2, 3), not hmr");
     if (h->variant == 2 && (two_view || partner))
         return fail(AP_ESTATE, "a copenet_singleview handle has no cross-view inputs");
-    if (h->variant == 0 && !two_view && !partner) return fail(AP_EINVAL, "regressor step: partner state missing");
+    if (h->variant != 2 && !two_view && !partner) return fail(AP_EINVAL, "regressor step: partner state missing");
     if (B <= 0 || iters < 1) return fail(AP_EINVAL, "regressor: bad B / iters");
     const int rows = two_view ? 2 * B : B;
     HIP_TRY(h->ws_H.reserve((size_t)rows * 1024 * 4));
@@ -726,7 +762,7 @@ const char* ap_version(void) { return "airpose_hip 0.1 (gfx950)"; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
 int ap_net_create(ap_net** out, int device, int precision, int variant) {
-    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16) || (variant < 0 || variant > 2))
+    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16) || (variant < 0 || variant > 3))
         return fail(AP_EINVAL, "ap_net_create: bad arguments");
     HIP_TRY(hipSetDevice(device));
     ap_net* h = new ap_net();
@@ -817,6 +853,29 @@ int ap_singleview_fwd(ap_net* h, const float* x, const float* bb, const float* p
     if (rc) return rc;
     RegInputs in{f, nullptr, bb, nullptr, pos, nullptr, init_theta, nullptr, init_shape, nullptr, theta_bs, 0, shape_bs, 0};
     return regressor_run(h, in, B, iters, 0, nullptr, 0, 3, pose, betas, nullptr, nullptr, st);
+}
+
+int ap_muhmr_fwd(ap_net* h, const float* x0, const float* x1, const float* init_cam0, int cam0_bs, const float* init_cam1,
+                 int cam1_bs, const float* init_theta0, int theta0_bs, const float* init_theta1, int theta1_bs,
+                 const float* init_shape0, int shape0_bs, const float* init_shape1, int shape1_bs, int B, int iters,
+                 float* campose0, float* betas0, float* campose1, float* betas1, void* stream) {
+    if (!h || !x0 || !x1 || !campose0 || !betas0 || !campose1 || !betas1) return fail(AP_EINVAL, "ap_muhmr_fwd: null argument");
+    if (h->variant != 3) return fail(AP_ESTATE, "ap_muhmr_fwd needs a muhmr (variant 3) handle");
+    if (B <= 0) return fail(AP_EINVAL, "ap_muhmr_fwd: bad batch");
+    if (cam0_bs != cam1_bs) return fail(AP_EINVAL, "ap_muhmr_fwd: init_cam0 / init_cam1 must share their batch stride");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(h->ws_feat.reserve((size_t)2 * B * 2048 * 4));
+    float* f0 = h->ws_feat.as<float>();
+    float* f1 = f0 + (size_t)B * 2048;
+    int rc = trunk_fwd(h, x0, B, x1, B, f0, st);
+    if (rc) return rc;
+    const float* c0 = init_cam0 ? init_cam0 : h->mean_cam.as<float>();
+    const float* c1 = init_cam1 ? init_cam1 : h->mean_cam.as<float>();
+    const int cbs = init_cam0 ? cam0_bs : 0;
+    if (!!init_cam0 != !!init_cam1) return fail(AP_EINVAL, "ap_muhmr_fwd: give both initial cameras or neither");
+    // bb has zero weight in the re-mapped fc1: any finite [B][3] floats do (the head of the feature rows is at hand)
+    RegInputs in{f0, f1, f0, f1, c0, c1, init_theta0, init_theta1, init_shape0, init_shape1, theta0_bs, theta1_bs, shape0_bs, shape1_bs};
+    return regressor_run(h, in, B, iters, 1, nullptr, 0, cbs, campose0, betas0, campose1, betas1, st);
 }
 
 int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0, const float* bb1,

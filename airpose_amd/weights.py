@@ -85,10 +85,10 @@ def copenet_state_dict(seed, mean_params_path, variant="copenet"):
     """Full state_dict (numpy arrays) for the two-view ``copenet`` (or ``hmr`` / ``copenet_singleview``) module."""
     rs = np.random.RandomState(seed)
     sd = trunk_state_dict(rs)
-    if variant not in ("copenet", "hmr", "singleview"):
+    if variant not in ("copenet", "hmr", "singleview", "muhmr"):
         raise ValueError(variant)
-    fc1_in = {"copenet": FC1_IN, "hmr": HMR_FC1_IN, "singleview": 2048 + 3 + 135 + 10}[variant]
-    npose_out = 22 * 6 if variant == "hmr" else 3 + 6 + NPOSE
+    fc1_in = {"copenet": FC1_IN, "hmr": HMR_FC1_IN, "singleview": 2048 + 3 + 135 + 10, "muhmr": 2048 + 3 + 132 + 10 + 136}[variant]
+    npose_out = 22 * 6 if variant in ("hmr", "muhmr") else 3 + 6 + NPOSE
     _linear(rs, sd, "fc1", 1024, fc1_in)
     _linear(rs, sd, "fc2", 1024, 1024)
     _linear(rs, sd, "decpose", npose_out, 1024, xavier_gain=0.01)

@@ -47,7 +47,7 @@ const char* ap_last_error(void);
  * the weights K-contiguous NHWC in the handle's precision and uploads them.  Calling set_tensor +
  * finalize again re-packs (fine-tuned weights).
  * variant: 0 = copenet two-view (fc1 in = 2332), 1 = hmr single-view head (fc1 in = 2193, ap_hmr_fwd),
- *          2 = copenet_singleview (fc1 in = 2196, ap_singleview_fwd). */
+ *          2 = copenet_singleview (fc1 in = 2196, ap_singleview_fwd), 3 = muhmr (fc1 in = 2329, ap_muhmr_fwd). */
 int ap_net_create(ap_net** out, int device, int precision, int variant);
 void ap_net_destroy(ap_net* h);
 int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
@@ -82,6 +82,16 @@ int ap_regressor_step(ap_net* h, const float* xf, const float* bb, const float* 
 int ap_singleview_fwd(ap_net* h, const float* x, const float* bb, const float* pos, const float* init_theta,
                       int theta_bs, const float* init_shape, int shape_bs, int B, int iters, float* pose, float* betas,
                       void* stream);
+
+/* muhmr two-view baseline (models/model_muhmr.py:112-199; needs a variant-3 handle): both trunks + `iters` evaluations of
+ * forward_reg with xc = [xf | cam3 | orient6 | art126 | shape10 | partner's art126, shape10] and decoders decpose (132) /
+ * decshape / deccam.  init_cam* [cb][3] (batch stride cam*_bs floats, 0 broadcasts; both NULL = the model's init_cam),
+ * init_theta* / init_shape* as for ap_regressor_fwd.  Outputs campose* [B][135] = pred_cam (3) | pred_pose (132),
+ * betas* [B][10]. */
+int ap_muhmr_fwd(ap_net* h, const float* x0, const float* x1, const float* init_cam0, int cam0_bs, const float* init_cam1,
+                 int cam1_bs, const float* init_theta0, int theta0_bs, const float* init_theta1, int theta1_bs,
+                 const float* init_shape0, int shape0_bs, const float* init_shape1, int shape1_bs, int B, int iters,
+                 float* campose0, float* betas0, float* campose1, float* betas1, void* stream);
 
 /* copenet.forward (model_copenet.py:112-159): both trunks (one batched 2B pass, shared weights) + IEF. */
 int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0, const float* bb1,

@@ -151,6 +151,23 @@ def singleview_forward(sd, x, bb, init_position, init_theta=None, init_shape=Non
     return pose, shape
 
 
+def muhmr_forward(sd, x0, x1, iters=3):
+    """models/model_muhmr.py:112-199 with the default initial state: xc = [xf | cam | orient | art | shape | partner's
+    art, shape] (:168,174); both views are evaluated from the OLD state (symmetric swap)."""
+    B = x0.shape[0]
+    xf = [forward_feat_ext(x0, sd), forward_feat_ext(x1, sd)]
+    pose = [sd["init_pose"][:, :132].expand(B, -1)] * 2
+    shape = [sd["init_shape"].expand(B, -1)] * 2
+    cam = [sd["init_cam"].expand(B, -1)] * 2
+    for _ in range(int(iters)):
+        xc = [_lin(_lin(torch.cat([xf[v], cam[v], pose[v], shape[v], pose[1 - v][:, 6:], shape[1 - v]], 1), sd, "fc1"),
+                   sd, "fc2") for v in (0, 1)]
+        pose = [pose[v] + _lin(xc[v], sd, "decpose") for v in (0, 1)]
+        shape = [shape[v] + _lin(xc[v], sd, "decshape") for v in (0, 1)]
+        cam = [cam[v] + _lin(xc[v], sd, "deccam") for v in (0, 1)]
+    return pose[0], shape[0], cam[0], pose[1], shape[1], cam[1]
+
+
 def hmr_forward_reg(sd, xf, pose, shape, cam):
     """model_hmr.py:160-172."""
     xc = _lin(_lin(torch.cat([xf, pose, shape, cam], 1), sd, "fc1"), sd, "fc2")

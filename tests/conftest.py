@@ -26,7 +26,7 @@ def rel_err(a, b):
 @pytest.fixture(scope="session")
 def golden():
     return {n: np.load(os.path.join(GOLDEN, n + ".npz"), allow_pickle=False)
-            for n in ("copenet_b2", "hmr_b1", "geometry", "copenet_sep_b2", "singleview_b1")}
+            for n in ("copenet_b2", "hmr_b1", "geometry", "copenet_sep_b2", "singleview_b1", "muhmr_b1")}
 
 
 @pytest.fixture(scope="session")

@@ -493,6 +493,27 @@ def test_singleview_on_gpu_matches_reference(golden, dev):
                                            None, 0, 1, 1, *[ctypes.c_void_p(z.data_ptr())] * 4, None), "ap_regressor_fwd")
 
 
+def test_muhmr_on_gpu_matches_reference(golden, dev):
+    """muhmr two-view baseline on the GPU (ap_muhmr_fwd: camera in the translation slot of the two-view kernels) vs the
+    imported reference's forward; caller-supplied initial state vs the default one."""
+    from airpose_amd import muhmr_model, weights as W
+    g = golden["muhmr_b1"]
+    sd = W.to_torch(W.copenet_state_dict(int(g["weights_seed"]), MEAN_PARAMS, variant="muhmr"))
+    net = muhmr_model.getcopenet(MEAN_PARAMS, precision="fp32").eval()
+    assert list(net.state_dict().keys()) == [str(k) for k in g["state_dict_keys"]]
+    net.load_state_dict(sd)
+    net.to(dev)
+    inp = W.synthetic_inputs(int(g["inputs_seed"]), 1)
+    x0, x1 = torch.from_numpy(inp["im0"]).to(dev), torch.from_numpy(inp["im1"]).to(dev)
+    out = net(x0, x1, iters=3)
+    for got, key in zip(out, ("pose0", "betas0", "cam0", "pose1", "betas1", "cam1")):
+        assert rel_err(got.cpu().numpy(), g[key]) < TOL32, key
+    same = net(x0, x1, init_cam0=sd["init_cam"].to(dev), init_cam1=sd["init_cam"].to(dev),
+               init_theta0=sd["init_pose"][:, :132].to(dev), init_shape1=sd["init_shape"].to(dev), iters=3)
+    for a, b in zip(out, same):
+        assert torch.equal(a, b)
+
+
 def test_copenet_sep_matches_reference(golden, dev):
     """copenet_sep (two weight sets, asymmetric cross-view step) on the GPU vs the imported reference's forward."""
     from airpose_amd import copenet_sep_model, weights as W

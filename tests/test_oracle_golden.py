@@ -173,3 +173,18 @@ def test_oracle_singleview_matches_reference(golden):
         pose, betas = copenet_ref.singleview_forward(sd, torch.from_numpy(inp["im0"]), torch.from_numpy(inp["bb0"]),
                                                      torch.from_numpy(g["init_position"]), iters=3)
     assert rel_err(pose.numpy(), g["pose"]) < 2e-6 and rel_err(betas.numpy(), g["betas"]) < 2e-6
+
+
+def test_oracle_muhmr_matches_reference(golden):
+    """muhmr two-view baseline (models/model_muhmr.py): oracle vs the imported reference's forward."""
+    import torch
+    from airpose_amd import weights as W
+    from oracle import copenet_ref
+    g = golden["muhmr_b1"]
+    sd = W.to_torch(W.copenet_state_dict(int(g["weights_seed"]), MEAN_PARAMS, variant="muhmr"))
+    assert sorted(sd.keys()) == sorted(str(k) for k in g["state_dict_keys"])
+    inp = W.synthetic_inputs(int(g["inputs_seed"]), 1)
+    with torch.no_grad():
+        out = copenet_ref.muhmr_forward(sd, torch.from_numpy(inp["im0"]), torch.from_numpy(inp["im1"]), iters=3)
+    for got, key in zip(out, ("pose0", "betas0", "cam0", "pose1", "betas1", "cam1")):
+        assert rel_err(got.numpy(), g[key]) < 2e-6, key

@@ -128,6 +128,19 @@ def main():
                         init_position=pos[:1].numpy())
     print("singleview_b1: pose", sp.numpy()[0, :6])
 
+    # ------------------------------------------------------------------ muhmr two-view baseline, B=1
+    from copenet.models import model_muhmr
+    sdm = W.to_torch(W.copenet_state_dict(WSEED + 5, MEAN, variant="muhmr"))
+    mnet = model_muhmr.copenet(model_muhmr.Bottleneck, [3, 4, 6, 3], MEAN).eval()
+    mnet.load_state_dict(sdm, strict=True)
+    mi = W.synthetic_inputs(ISEED + 5, 1)
+    with torch.no_grad():
+        mo = mnet(torch.from_numpy(mi["im0"]), torch.from_numpy(mi["im1"]), iters=3)
+    np.savez_compressed(os.path.join(OUT, "muhmr_b1.npz"), weights_seed=WSEED + 5, inputs_seed=ISEED + 5,
+                        state_dict_keys=np.array(list(mnet.state_dict().keys())),
+                        **{k: v.numpy() for k, v in zip(("pose0", "betas0", "cam0", "pose1", "betas1", "cam1"), mo)})
+    print("muhmr_b1: cam0", mo[2].numpy()[0])
+
     # ------------------------------------------------------------------ copenet_sep (two weight sets; IEF from features)
     # The two trunks are ordinary ResNet-50s (pinned above); the fixture pins the sep driver + its asymmetric
     # forward_reg by feeding the golden trunk features through the reference model with forward_feat_ext patched out.
