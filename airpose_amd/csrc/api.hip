@@ -1254,6 +1254,16 @@ int ap_transform_points(const float* rt, const float* pts, int B, int P, float* 
     return AP_OK;
 }
 
+int ap_preprocess_crops(const unsigned char* frames, int64_t frame_stride_bytes, int n, int H, int W, int bgr,
+                        const int* crop_y0y1x0x1, float* out_nchw, float* scale_out, int* pad_left_top_out, void* stream) {
+    if (!frames || !crop_y0y1x0x1 || !out_nchw || !scale_out || !pad_left_top_out || n <= 0 || H <= 0 || W <= 0 ||
+        frame_stride_bytes < 0)
+        return fail(AP_EINVAL, "ap_preprocess_crops: bad argument");
+    HIP_TRY(ap_launch_preprocess(frames, (size_t)frame_stride_bytes, n, H, W, bgr, crop_y0y1x0x1, out_nchw, scale_out,
+                                 pad_left_top_out, (hipStream_t)stream));
+    return AP_OK;
+}
+
 int ap_perspective_projection(const float* pts, int B, int P, const float* rotation, const float* translation,
                               float fx, float fy, const float* center, float* out, void* stream) {
     if (!pts || !center || !out || B <= 0 || P <= 0) return fail(AP_EINVAL, "ap_perspective_projection: bad argument");

@@ -60,6 +60,10 @@ hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int is_bf16, hip
 // global 7x7 average: [N][49][C] T -> [N][C] fp32
 hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int is_bf16, hipStream_t st);
 
+// crop + letter-box resize + /255 + normalise: uint8 HWC frames -> [n][3][224][224] fp32 (stem.hip)
+hipError_t ap_launch_preprocess(const unsigned char* frames, size_t frame_stride, int n, int H, int W, int bgr,
+                                const int* crop, float* out, float* scale_out, int* pad_out, hipStream_t st);
+
 // ---- regressor glue (regressor.hip); all fp32
 struct RegInitArgs {
     const float *pos0, *pos1;          // [B][3]

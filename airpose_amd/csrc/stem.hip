@@ -361,7 +361,66 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, f
     for (int e = 0; e < EPC; ++e) dst[e] = s[e] / 49.0f;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Input contract of the network on the GPU: aerialpeople_crop.__getitem__
+// (copenet/src/copenet/dsets/aerialpeople.py:125-141,174) + resize_with_pad (utils/utils.py:214-235):
+//   img = frame[:, :, ::-1] / 255 -> crop -> cv2.resize (float image: INTER_LINEAR, half-pixel centres, float
+//   coefficients, border clamp) to int(scale*w) x int(scale*h), scale = 224 / max(h, w) -> zero padding to
+//   224x224, centred -> CHW float -> Normalize(mean, std).   One thread per output pixel, all three channels.
+__global__ void preprocess_kernel(const unsigned char* __restrict__ frames, size_t frame_stride, int H, int W, int bgr,
+                                  const int* __restrict__ crop, float* __restrict__ out, float* __restrict__ scale_out,
+                                  int* __restrict__ pad_out) {
+    const int i = blockIdx.y, px = blockIdx.x * blockDim.x + threadIdx.x;
+    const int y0 = crop[i * 4 + 0], y1 = crop[i * 4 + 1], x0 = crop[i * 4 + 2], x1 = crop[i * 4 + 3];
+    const int h = y1 - y0, w = x1 - x0;
+    const double scale = 224.0 / (double)(h > w ? h : w);
+    const int dw = (int)(scale * w), dh = (int)(scale * h);
+    const int pad_top = (224 - dh) / 2, pad_left = (224 - dw) / 2;
+    if (px == 0) {
+        scale_out[i] = (float)scale;
+        pad_out[i * 2 + 0] = pad_left;
+        pad_out[i * 2 + 1] = pad_top;
+    }
+    if (px >= 224 * 224) return;
+    const int oy = px / 224, ox = px - oy * 224, dy = oy - pad_top, dx = ox - pad_left;
+    const float mean[3] = {0.485f, 0.456f, 0.406f}, stdv[3] = {0.229f, 0.224f, 0.225f};
+    float v[3] = {0.f, 0.f, 0.f};
+    if (dy >= 0 && dy < dh && dx >= 0 && dx < dw) {
+        // cv::resize, INTER_LINEAR: scale_x = 1 / (dw / w) in double, fx = (float)((dx + 0.5) * scale_x - 0.5)
+        const double sxd = 1.0 / ((double)dw / (double)w), syd = 1.0 / ((double)dh / (double)h);
+        float fx = (float)((dx + 0.5) * sxd - 0.5), fy = (float)((dy + 0.5) * syd - 0.5);
+        int sx = (int)floorf(fx), sy = (int)floorf(fy);
+        fx -= sx; fy -= sy;
+        if (sx < 0) { fx = 0.f; sx = 0; }
+        if (sx >= w - 1) { fx = 0.f; sx = w - 1; }
+        if (sy < 0) { fy = 0.f; sy = 0; }
+        if (sy >= h - 1) { fy = 0.f; sy = h - 1; }
+        const int sx1 = sx + 1 < w ? sx + 1 : sx, sy1 = sy + 1 < h ? sy + 1 : sy;
+        const unsigned char* f = frames + (size_t)i * frame_stride;
+        const unsigned char* p00 = f + ((size_t)(y0 + sy) * W + x0 + sx) * 3;
+        const unsigned char* p01 = f + ((size_t)(y0 + sy) * W + x0 + sx1) * 3;
+        const unsigned char* p10 = f + ((size_t)(y0 + sy1) * W + x0 + sx) * 3;
+        const unsigned char* p11 = f + ((size_t)(y0 + sy1) * W + x0 + sx1) * 3;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            const int cs = bgr ? 2 - c : c;
+            const float a = p00[cs] / 255.f, b = p01[cs] / 255.f, cc = p10[cs] / 255.f, d = p11[cs] / 255.f;
+            const float top = a * (1.f - fx) + b * fx, bot = cc * (1.f - fx) + d * fx;
+            v[c] = top * (1.f - fy) + bot * fy;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[(((size_t)i * 3 + c) * 224 + oy) * 224 + ox] = (v[c] - mean[c]) / stdv[c];
+}
+
 }  // namespace
+
+hipError_t ap_launch_preprocess(const unsigned char* frames, size_t frame_stride, int n, int H, int W, int bgr,
+                                const int* crop, float* out, float* scale_out, int* pad_out, hipStream_t st) {
+    hipLaunchKernelGGL(preprocess_kernel, dim3((224 * 224 + 255) / 256, n), dim3(256), 0, st, frames, frame_stride, H, W,
+                       bgr, crop, out, scale_out, pad_out);
+    return hipGetLastError();
+}
 
 hipError_t ap_launch_stem_conv(const float* x, const float* w, const float* scale, const float* shift, void* y,
                                int n_img, int is_bf16, hipStream_t st) {

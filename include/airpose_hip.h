@@ -211,6 +211,16 @@ int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);
 /* ---------------------------------------------------------------------------------------------
  * Stand-alone geometry helpers (copenet/src/copenet/utils/geometry.py:47-61, 63-91;
  * copenet/src/copenet/utils/utils.py:237-256). */
+/* The network's input contract computed on the GPU (aerialpeople.py:125-141,174 + resize_with_pad,
+ * utils/utils.py:214-235): frame[:, :, ::-1] / 255 -> crop -> cv2.resize semantics for float images (INTER_LINEAR,
+ * half-pixel centres, border clamp) to int(scale*w) x int(scale*h), scale = 224 / max(h, w) -> centred zero padding to
+ * 224 x 224 -> CHW -> Normalize(ImageNet mean, std).
+ * frames: n uint8 HWC images [H][W][3] on the device, frame i at frames + i*frame_stride_bytes (0 = one shared frame);
+ * bgr = 1 reverses the channel order (cv2.imread frames).  crop [n][4] = y0, y1, x0, x1 (device ints; y1/x1 exclusive,
+ * inside the frame, non-empty).  out [n][3][224][224]; scale_out [n] = the resize scale (bb's third component),
+ * pad_left_top_out [n][2]. */
+int ap_preprocess_crops(const unsigned char* frames, int64_t frame_stride_bytes, int n, int H, int W, int bgr,
+                        const int* crop_y0y1x0x1, float* out_nchw, float* scale_out, int* pad_left_top_out, void* stream);
 int ap_rot6d_to_rotmat(const float* x6, int n, float* rotmat, void* stream);          /* [n][6] -> [n][3][3] */
 /* tgm.rotation_matrix_to_angle_axis (torchgeometry 0.1.2) as called for pred_angles at copenet_twoview.py:323-324:
  * [n][3][cols] row-major (cols = 3, or 4 for the caller's zero-padded 3x4 input) -> [n][3] */

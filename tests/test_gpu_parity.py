@@ -531,6 +531,27 @@ def test_copenet_sep_matches_reference(golden, dev):
             assert rel_err(got.cpu().numpy(), gs["%s_it%d" % (key, it)]) < TOL32, (key, it)
 
 
+def test_preprocess_crops_matches_oracle(dev):
+    """GPU input pipeline (crop, letter-box bilinear resize, /255, normalise) vs the oracle restatement: up- and
+    down-scaling, tall / wide / square crops, crops touching the frame border, per-sample and shared frames."""
+    from airpose_amd.utils import preprocess_crops
+    from oracle import preprocess_ref as P
+    rs = np.random.RandomState(9)
+    frames = (rs.rand(5, 270, 480, 3) * 255).astype(np.uint8)
+    crops = np.array([[0, 270, 0, 480], [10, 110, 30, 80], [100, 212, 200, 424], [5, 229, 7, 231], [200, 270, 400, 480]])
+    img, scale, pad = preprocess_crops(torch.from_numpy(frames).to(dev), torch.from_numpy(crops))
+    for i in range(5):
+        want, s, p = P.preprocess(frames[i], tuple(crops[i]))
+        assert abs(scale[i].item() - s) < 1e-6 and pad[i].tolist() == p
+        assert np.abs(img[i].cpu().numpy() - want).max() < 5e-5, i
+    img1, _, _ = preprocess_crops(torch.from_numpy(frames[2]).to(dev), torch.from_numpy(crops[2:3]))
+    assert torch.equal(img1[0], img[2])
+    with pytest.raises(RuntimeError):
+        preprocess_crops(torch.from_numpy(frames), torch.from_numpy(crops))                 # CPU tensor: no fallback
+    with pytest.raises(RuntimeError):
+        preprocess_crops(torch.from_numpy(frames).to(dev), torch.tensor([[0, 300, 0, 10]] * 5))   # outside the frame
+
+
 def test_rotation_matrix_to_angle_axis_matches_oracle(dev):
     """pred_angles conversion (tgm 0.1.2 semantics): all four trace branches, (N,3,3) and the caller's (N,3,4) form."""
     from airpose_amd.geometry import rotation_matrix_to_angle_axis

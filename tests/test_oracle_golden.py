@@ -188,3 +188,24 @@ def test_oracle_muhmr_matches_reference(golden):
         out = copenet_ref.muhmr_forward(sd, torch.from_numpy(inp["im0"]), torch.from_numpy(inp["im1"]), iters=3)
     for got, key in zip(out, ("pose0", "betas0", "cam0", "pose1", "betas1", "cam1")):
         assert rel_err(got.numpy(), g[key]) < 2e-6, key
+
+
+def test_oracle_preprocess_known_answers():
+    """Input pipeline restatement (parity unpinned: cv2 absent): identity size = pixel copy, constant stays constant,
+    the bilinear core equals torch's independent implementation of the same half-pixel / clamp rule."""
+    import torch
+    import torch.nn.functional as F
+    from oracle import preprocess_ref as P
+    rs = np.random.RandomState(5)
+    img = rs.rand(37, 61, 3)
+    assert np.array_equal(P.cv2_resize_linear(img, 61, 37), img)
+    assert np.allclose(P.cv2_resize_linear(np.full((20, 30, 3), 0.25), 77, 51), 0.25, atol=1e-12)
+    for (dw, dh) in ((224, 136), (100, 33), (122, 75)):
+        want = F.interpolate(torch.from_numpy(img).permute(2, 0, 1)[None], size=(dh, dw), mode="bilinear", align_corners=False)
+        got = P.cv2_resize_linear(img, dw, dh)
+        assert np.abs(got - want[0].permute(1, 2, 0).numpy()).max() < 1e-5      # (float32 taps in cv2's algorithm: ~4e-6 at source coordinate 60)
+    frame = (rs.rand(120, 200, 3) * 255).astype(np.uint8)
+    out, scale, pad = P.preprocess(frame, (10, 110, 30, 80))            # 100 x 50 crop -> 224 x 112, padded left/right
+    assert scale == 2.24 and pad == [56, 0] and out.shape == (3, 224, 224)
+    assert np.allclose(out[:, :, :56], (-P.MEAN / P.STD)[:, None, None], atol=1e-6)
+    assert np.allclose(out[0, 0, 56] * P.STD[0] + P.MEAN[0], frame[10, 30, 2] / 255.0, atol=1e-6)   # BGR -> RGB, corner clamp
