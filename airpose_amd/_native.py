@@ -63,6 +63,9 @@ SIGNATURES = {
     "ap_smplx_fwd_fused": (_i, [_vp, _i, _vp, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp]),
     "ap_smplx_enable_timing": (_i, [_vp, _i]),
     "ap_smplx_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
+    "ap_fit_create": (_i, [_c.POINTER(_vp), _vp] + [_vp] * 6 + [_i]),
+    "ap_fit_destroy": (None, [_vp]),
+    "ap_fit_run": (_i, [_vp, _i] + [_vp] * 8 + [_i, _i, _i, _f, _f, _f, _f, _vp, _vp, _vp]),
     "ap_preprocess_crops": (_i, [_vp, _c.c_int64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ap_rot6d_to_rotmat": (_i, [_vp, _i, _vp, _vp]),
     "ap_rotmat_to_angle_axis": (_i, [_vp, _i, _i, _vp, _vp]),

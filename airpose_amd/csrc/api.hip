@@ -194,6 +194,13 @@ struct ap_smplx {
     Timing tm;
 };
 
+struct ap_fit {                   // AirPose+ fitting loop state (fitting.hip)
+    int device = 0;
+    const ap_smplx* body = nullptr;
+    DevBuf w1t, w2t, w3t, w1, w2, w3, b1, b2, b3;     // VPoser decoder: k-major transposes (forward) / as stored (backward)
+    DevBuf H1, H2, O, dO, dH2, dH1, dz, aa, dphi, dtau, dbeta, loss, adam_m, adam_v, robust;
+};
+
 namespace {
 
 // ---------------------------------------------------------------------------------- packing
@@ -1261,6 +1268,98 @@ int ap_preprocess_crops(const unsigned char* frames, int64_t frame_stride_bytes,
         return fail(AP_EINVAL, "ap_preprocess_crops: bad argument");
     HIP_TRY(ap_launch_preprocess(frames, (size_t)frame_stride_bytes, n, H, W, bgr, crop_y0y1x0x1, out_nchw, scale_out,
                                  pad_left_top_out, (hipStream_t)stream));
+    return AP_OK;
+}
+
+// ---------------------------------------------------------------------------------- AirPose+ fitting loop
+int ap_fit_create(ap_fit** out, const ap_smplx* body, const float* w1, const float* b1, const float* w2, const float* b2,
+                  const float* w3, const float* b3, int device) {
+    if (!out || !body || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return fail(AP_EINVAL, "ap_fit_create: null argument");
+    HIP_TRY(hipSetDevice(device));
+    ap_fit* h = new ap_fit();
+    h->device = device; h->body = body;
+    auto tr = [](const float* w, int o, int i, int ldo) {      // [o][i] -> [i][ldo] (k-major, zero padded columns)
+        std::vector<float> t((size_t)i * ldo, 0.f);
+        for (int a = 0; a < o; ++a) for (int b = 0; b < i; ++b) t[(size_t)b * ldo + a] = w[(size_t)a * i + b];
+        return t;
+    };
+    hipError_t e = hipSuccess;
+    auto up = [&](DevBuf& b, const std::vector<float>& v) { if (e == hipSuccess) e = upload(b, v.data(), v.size() * 4); };
+    up(h->w1t, tr(w1, 512, 32, 512)); up(h->w2t, tr(w2, 512, 512, 512)); up(h->w3t, tr(w3, 126, 512, 128));
+    up(h->w1, std::vector<float>(w1, w1 + 512 * 32)); up(h->w2, std::vector<float>(w2, w2 + 512 * 512));
+    up(h->w3, std::vector<float>(w3, w3 + 126 * 512));
+    std::vector<float> b3p(128, 0.f);
+    memcpy(b3p.data(), b3, 126 * 4);
+    up(h->b1, std::vector<float>(b1, b1 + 512)); up(h->b2, std::vector<float>(b2, b2 + 512)); up(h->b3, b3p);
+    if (e != hipSuccess) { delete h; return fail((int)e, std::string("ap_fit_create: ") + hipGetErrorString(e)); }
+    *out = h;
+    return AP_OK;
+}
+
+void ap_fit_destroy(ap_fit* h) {
+    if (!h) return;
+    for (DevBuf* b : {&h->w1t, &h->w2t, &h->w3t, &h->w1, &h->w2, &h->w3, &h->b1, &h->b2, &h->b3, &h->H1, &h->H2, &h->O, &h->dO,
+                      &h->dH2, &h->dH1, &h->dz, &h->aa, &h->dphi, &h->dtau, &h->dbeta, &h->loss, &h->adam_m, &h->adam_v, &h->robust})
+        b->release();
+    delete h;
+}
+
+int ap_fit_run(ap_fit* h, int L, float* z, float* phi, float* tau, float* beta, const float* j2d, const int* robust_host,
+               const float* intr, const float* extr, int first_iter, int n_iters, int switch_iter, float lr, float sigma,
+               float w_vposer, float w_temporal, float* loss_hist, float* grad_out, void* stream) {
+    if (!h || !z || !phi || !tau || !beta || !j2d || !robust_host || !intr || !extr || L <= 0 || n_iters < 0 || first_iter < 0)
+        return fail(AP_EINVAL, "ap_fit_run: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    const int nprm = L * 32 + 2 * L * 9 + 10;
+    HIP_TRY(h->H1.reserve((size_t)L * 512 * 4)); HIP_TRY(h->H2.reserve((size_t)L * 512 * 4));
+    HIP_TRY(h->O.reserve((size_t)L * 128 * 4)); HIP_TRY(h->dO.reserve((size_t)L * 128 * 4));
+    HIP_TRY(h->dH2.reserve((size_t)L * 512 * 4)); HIP_TRY(h->dH1.reserve((size_t)L * 512 * 4));
+    HIP_TRY(h->dz.reserve((size_t)L * 32 * 4)); HIP_TRY(h->aa.reserve((size_t)L * 63 * 4));
+    HIP_TRY(h->dphi.reserve((size_t)2 * L * 6 * 4)); HIP_TRY(h->dtau.reserve((size_t)2 * L * 3 * 4));
+    HIP_TRY(h->dbeta.reserve((size_t)L * 10 * 4)); HIP_TRY(h->loss.reserve((size_t)L * 4 * 4));
+    HIP_TRY(h->adam_m.reserve((size_t)nprm * 4)); HIP_TRY(h->adam_v.reserve((size_t)nprm * 4));
+    HIP_TRY(h->robust.reserve((size_t)L * 4));
+    HIP_TRY(hipMemcpyAsync(h->robust.p, robust_host, (size_t)L * 4, hipMemcpyHostToDevice, st));
+    FitArgs a{};
+    a.L = L;
+    a.O = h->O.as<float>(); a.dO = h->dO.as<float>(); a.ldo = 128; a.aa_all = h->aa.as<float>();
+    a.z = z; a.phi = phi; a.tau = tau; a.beta = beta; a.dz = h->dz.as<float>(); a.ldz = 32;
+    a.dphi = h->dphi.as<float>(); a.dtau = h->dtau.as<float>(); a.dbeta_part = h->dbeta.as<float>();
+    a.loss_part = h->loss.as<float>();
+    a.j_template = h->body->m.j_template; a.j_shapedirs = h->body->m.j_shapedirs; a.jsd_ld = 20;
+    a.j2d = j2d; a.robust = h->robust.as<int>(); a.intr = intr; a.extr = extr;
+    for (int f = 0; f < L; ++f) {
+        a.n_robust += robust_host[f] != 0;
+        if (f + 1 < L) a.n_pairs += robust_host[f] != 0 && robust_host[f + 1] != 0;
+    }
+    a.sigma = sigma; a.w_temporal = w_temporal; a.w_vposer = w_vposer; a.lr = lr;
+    a.adam_m = h->adam_m.as<float>(); a.adam_v = h->adam_v.as<float>(); a.grad_out = grad_out;
+    auto decode = [&]() -> hipError_t {                     // VPoser decoder MLP
+        hipError_t e = ap_launch_fit_linear(z, 32, 32, h->w1t.as<float>(), 512, h->b1.as<float>(), nullptr, 0, h->H1.as<float>(), 512, L, 512, 1, st);
+        if (e == hipSuccess) e = ap_launch_fit_linear(h->H1.as<float>(), 512, 512, h->w2t.as<float>(), 512, h->b2.as<float>(), nullptr, 0, h->H2.as<float>(), 512, L, 512, 1, st);
+        if (e == hipSuccess) e = ap_launch_fit_linear(h->H2.as<float>(), 512, 512, h->w3t.as<float>(), 128, h->b3.as<float>(), nullptr, 0, h->O.as<float>(), 128, L, 128, 0, st);
+        if (e == hipSuccess) e = ap_launch_fit_aa(h->O.as<float>(), 128, h->aa.as<float>(), L, st);
+        return e;
+    };
+    bool decoded = false;
+    for (int j = first_iter; j < first_iter + n_iters; ++j) {
+        const bool with_z = j >= switch_iter;
+        if (j == first_iter || j == switch_iter) {          // a new torch.optim.Adam starts with empty state (:279-295)
+            HIP_TRY(hipMemsetAsync(h->adam_m.p, 0, (size_t)nprm * 4, st));
+            HIP_TRY(hipMemsetAsync(h->adam_v.p, 0, (size_t)nprm * 4, st));
+        }
+        if (with_z || !decoded) { HIP_TRY(decode()); decoded = true; }      // z is constant before the switch
+        HIP_TRY(ap_launch_fit_frame(a, j, st));
+        if (with_z) {                                       // decoder backward: dO -> dH2 -> dH1 -> dz
+            HIP_TRY(ap_launch_fit_linear(h->dO.as<float>(), 128, 126, h->w3.as<float>(), 512, nullptr, h->H2.as<float>(), 512, h->dH2.as<float>(), 512, L, 512, 0, st));
+            HIP_TRY(ap_launch_fit_linear(h->dH2.as<float>(), 512, 512, h->w2.as<float>(), 512, nullptr, h->H1.as<float>(), 512, h->dH1.as<float>(), 512, L, 512, 0, st));
+            HIP_TRY(ap_launch_fit_linear(h->dH1.as<float>(), 512, 512, h->w1.as<float>(), 32, nullptr, nullptr, 0, h->dz.as<float>(), 32, L, 32, 0, st));
+        }
+        const int step = j < switch_iter ? j - first_iter + 1 : j - std::max(switch_iter, first_iter) + 1;
+        HIP_TRY(ap_launch_fit_adam(a, step, with_z ? 1 : 0, st));
+        if (loss_hist)
+            HIP_TRY(hipMemcpyAsync(loss_hist + (size_t)(j - first_iter) * L * 4, h->loss.p, (size_t)L * 4 * 4, hipMemcpyDeviceToDevice, st));
+    }
     return AP_OK;
 }
 

@@ -156,3 +156,29 @@ hipError_t ap_launch_rotmat_to_angle_axis(const float* R, int n, int ld, float* 
 hipError_t ap_launch_transform_points(const float* rt, const float* pts, int B, int P, float* out, hipStream_t st);
 hipError_t ap_launch_projection(const float* pts, int B, int P, const float* R, const float* t, float fx, float fy,
                                 const float* center, float* out, hipStream_t st);
+
+// ---- AirPose+ fitting loop (fitting.hip); all fp32
+struct FitArgs {
+    int L;                        // frames of the sequence
+    // VPoser decoder output / its gradient, [L][ldo] (126 used), and pose_body of every frame [L][21][3]
+    const float* O; float* dO; int ldo;
+    const float* aa_all;
+    // optimised state: z [L][32], phi [2][L][6], tau [2][L][3], beta [10]; gradients alongside
+    float *z, *phi, *tau, *beta;
+    const float* dz; int ldz;
+    float *dphi, *dtau, *dbeta_part;   // dbeta_part [L][10] (summed by the Adam kernel)
+    float* loss_part;             // [L][4]: 2-D | temporal(pose_body) | temporal(phi, tau) | -
+    // body model: rest joints J = j_template + j_shapedirs beta (first 24 chain joints)
+    const float* j_template; const float* j_shapedirs; int jsd_ld;
+    // observations: j2d [2 views][L][2 detectors][24][3 = x, y, conf], robust [L], intr [2][4], extr [2][12]
+    const float* j2d; const int* robust; int n_robust, n_pairs;
+    const float* intr; const float* extr;
+    float sigma, w_temporal, w_vposer, lr;
+    float *adam_m, *adam_v;       // [L*32 + 2*L*9 + 10]
+    float* grad_out;              // optional copy of the gradient vector (tests)
+};
+hipError_t ap_launch_fit_linear(const float* X, int ldx, int K, const float* Wt, int ldw, const float* bias, const float* G,
+                                int ldg, float* Y, int ldy, int L, int N, int act, hipStream_t st);
+hipError_t ap_launch_fit_aa(const float* O, int ldo, float* aa, int L, hipStream_t st);
+hipError_t ap_launch_fit_frame(const FitArgs& a, int it, hipStream_t st);
+hipError_t ap_launch_fit_adam(const FitArgs& a, int step, int with_z, hipStream_t st);

@@ -1,0 +1,73 @@
+"""AirPose+ fitting loop on MI355X (BASELINE config 5): mirror of the optimisation of
+copenet_real_data/scripts/bundle_adj.py:262-401 -- 300 Adam steps on the VPoser latent, the per-view root pose and the
+shared shape against 2-D joint detections in both views.  All compute in libairpose_hip.so (ap_fit_run: hand-written
+adjoints, no autograd); there is no CPU path."""
+import ctypes
+
+import torch
+
+from . import _native as N
+
+W_VPOSER, W_TEMPORAL, GM_SIGMA, LR, SWITCH_ITER = 0.05, 1.0, 30.0, 0.01, 100      # bundle_adj.py:134,243-245,279-295
+
+
+class AirPosePlusFitter:
+    """vposer: dict with the decoder's Linear layers `w1,b1,w2,b2,w3,b3` (VPoser V02_05 `decoder_net.{0,3,5}`);
+    body: an airpose_amd.smplx.SMPLX (rest joints and their shape directions come from its native handle)."""
+
+    def __init__(self, vposer, body, device=None):
+        N.require_gpu()
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.body = body
+        f = lambda t: torch.as_tensor(t, dtype=torch.float32).contiguous().cpu()
+        w = [f(vposer[k]) for k in ("w1", "b1", "w2", "b2", "w3", "b3")]
+        if w[0].shape != (512, 32) or w[2].shape != (512, 512) or w[4].shape != (126, 512):
+            raise RuntimeError("VPoser decoder layers must be 512x32, 512x512, 126x512")
+        self._h = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            N.check(N.lib().ap_fit_create(ctypes.byref(self._h), body._native(self.device),
+                                          *[ctypes.c_void_p(t.data_ptr()) for t in w], self.device.index or 0), "ap_fit_create")
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                N.lib().ap_fit_destroy(h)
+            except Exception:
+                pass
+
+    def run(self, state, j2d, robust, intr, extr, n_iters=300, first_iter=0, switch_iter=SWITCH_ITER, lr=LR, sigma=GM_SIGMA,
+            w_vposer=W_VPOSER, w_temporal=W_TEMPORAL, want_loss=False, want_grad=False):
+        """state: dict z (L,32), phi0/phi1 (L,6), tau0/tau1 (L,3), beta (10,) -- returns the fitted copy (+ loss history
+        (n_iters,4) = [2-D, temporal pose, temporal rigid, VPoser prior] and the last gradient dict on request)."""
+        dev = self.device
+        L = state["z"].shape[0]
+        z = N.f32c(state["z"], dev).clone()
+        phi = torch.stack([N.f32c(state["phi0"], dev), N.f32c(state["phi1"], dev)]).contiguous()
+        tau = torch.stack([N.f32c(state["tau0"], dev), N.f32c(state["tau1"], dev)]).contiguous()
+        beta = N.f32c(state["beta"], dev).clone()
+        j2d, intr, extr = N.f32c(j2d, dev), N.f32c(intr, dev), N.f32c(extr, dev)
+        if j2d.shape != (2, L, 2, 24, 3) or intr.shape != (2, 4) or extr.shape != (2, 3, 4):
+            raise RuntimeError("j2d (2,L,2,24,3), intr (2,4), extr (2,3,4)")
+        rob = torch.as_tensor(robust).to(torch.int32).cpu().contiguous()
+        hist = torch.zeros(n_iters, L, 4, device=dev) if want_loss else None
+        grad = torch.zeros(L * 32 + 2 * L * 9 + 10, device=dev) if want_grad else None
+        with torch.cuda.device(dev):
+            N.check(N.lib().ap_fit_run(self._h, L, N.dptr(z), N.dptr(phi), N.dptr(tau), N.dptr(beta), N.dptr(j2d),
+                                       ctypes.c_void_p(rob.data_ptr()), N.dptr(intr), N.dptr(extr), int(first_iter), int(n_iters),
+                                       int(switch_iter), float(lr), float(sigma), float(w_vposer), float(w_temporal),
+                                       N.dptr(hist) if hist is not None else None, N.dptr(grad) if grad is not None else None,
+                                       N.stream_ptr(dev)), "ap_fit_run")
+        out = {"z": z, "phi0": phi[0], "phi1": phi[1], "tau0": tau[0], "tau1": tau[1], "beta": beta}
+        res = [out]
+        if want_loss:
+            lh = hist.sum(1)
+            lh[:, 3] = 0.0      # (the prior is a function of z alone; reported by the caller if needed)
+            res.append(lh)
+        if want_grad:
+            nz, nphi = L * 32, 2 * L * 6
+            g = {"z": grad[:nz].view(L, 32), "phi0": grad[nz:nz + L * 6].view(L, 6), "phi1": grad[nz + L * 6:nz + nphi].view(L, 6),
+                 "tau0": grad[nz + nphi:nz + nphi + L * 3].view(L, 3), "tau1": grad[nz + nphi + L * 3:nz + nphi + L * 6].view(L, 3),
+                 "beta": grad[nz + nphi + L * 6:]}
+            res.append(g)
+        return res[0] if len(res) == 1 else tuple(res)

@@ -211,6 +211,30 @@ int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);
 /* ---------------------------------------------------------------------------------------------
  * Stand-alone geometry helpers (copenet/src/copenet/utils/geometry.py:47-61, 63-91;
  * copenet/src/copenet/utils/utils.py:237-256). */
+/* ---------------------------------------------------------------------------------------------
+ * AirPose+ fitting loop (BASELINE config 5; copenet_real_data/scripts/bundle_adj.py:262-401): Adam over a sequence of L
+ * frames on z (VPoser latent, [L][32]), the per-view root 6-D rotation phi [2][L][6] (pytorch3d convention) and
+ * translation tau [2][L][3], and a shared beta [10]; objective = Geman-McClure 2-D reprojection of the first 24 SMPL-X
+ * chain joints in both views against two detectors + VPoser prior + temporal smoothness, gradients by hand-written
+ * adjoints (decoder MLP, 6-D, rotation matrix -> axis-angle -> rotation matrix, kinematic chain, projection).
+ * The third-party pieces of the script (human_body_prior, VPoser weights, pytorch3d) are absent upstream: parity
+ * unpinned, see oracle/fitting_ref.py.
+ * ap_fit_create: body = an ap_smplx handle (rest joints and their shape directions); w1 [512][32], b1 [512], w2 [512][512],
+ * b2 [512], w3 [126][512], b3 [126] = the VPoser decoder's Linear layers (host, PyTorch layout).
+ * ap_fit_run: iterations first_iter .. first_iter + n_iters - 1 of the loop (iteration index matters: the script halves
+ * the hip confidences every iteration; z joins the optimised set, with a fresh Adam, at switch_iter = 100).  State
+ * arrays are device pointers updated in place; j2d [2][L][2][24][3] (x, y, confidence), intr [2][4] = fx, fy, cx, cy,
+ * extr [2][3][4] device; robust_host [L] host ints (frame mask).  loss_hist (optional, device [n_iters][L][4]): per-frame
+ * loss parts before each step; grad_out (optional, device [L*32 + 2*L*9 + 10]): the last gradient vector
+ * [dz | dphi | dtau | dbeta] (with lr = 0 a gradient probe). */
+typedef struct ap_fit ap_fit;
+int ap_fit_create(ap_fit** out, const ap_smplx* body, const float* w1, const float* b1, const float* w2, const float* b2,
+                  const float* w3, const float* b3, int device);
+void ap_fit_destroy(ap_fit* h);
+int ap_fit_run(ap_fit* h, int L, float* z, float* phi, float* tau, float* beta, const float* j2d, const int* robust_host,
+               const float* intr, const float* extr, int first_iter, int n_iters, int switch_iter, float lr, float sigma,
+               float w_vposer, float w_temporal, float* loss_hist, float* grad_out, void* stream);
+
 /* The network's input contract computed on the GPU (aerialpeople.py:125-141,174 + resize_with_pad,
  * utils/utils.py:214-235): frame[:, :, ::-1] / 255 -> crop -> cv2.resize semantics for float images (INTER_LINEAR,
  * half-pixel centres, border clamp) to int(scale*w) x int(scale*h), scale = 224 / max(h, w) -> centred zero padding to
