@@ -261,7 +261,8 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
                                   fmaxf(fmaxf(v[2 * pr][1], v[2 * pr + 1][1]), v[2 * pr + 2][1]));
                 o.y = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][2], v[2 * pr + 1][2]), v[2 * pr + 2][2]),
                                   fmaxf(fmaxf(v[2 * pr][3], v[2 * pr + 1][3]), v[2 * pr + 2][3]));
-                *(uint2*)(vm + ((pr * SO + xo) * SC + ch)) = o;
+                // rows of 128 B: 16-byte chunk index XOR-swizzled by the pixel (a lane's 16 pixels would all hit one bank)
+                *(uint2*)(vm + ((pr * SO + xo) * SC + ((((ch >> 3) ^ (xo & 7)) << 3) | (ch & 7)))) = o;
             }
         }
     }
@@ -275,7 +276,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         for (int dx = -1; dx <= 1; ++dx) {
             const int cx = 2 * px + dx;
             if (cx < 0) continue;
-            const u32x4 q = *(const u32x4*)(vm + ((pr * SO + cx) * SC + c8 * 8));
+            const u32x4 q = *(const u32x4*)(vm + ((pr * SO + cx) * SC + ((c8 ^ (cx & 7)) << 3)));
             float lo, hi;
             unpack_bf16x2(q.x, lo, hi); m[0] = fmaxf(m[0], lo); m[1] = fmaxf(m[1], hi);
             unpack_bf16x2(q.y, lo, hi); m[2] = fmaxf(m[2], lo); m[3] = fmaxf(m[3], hi);

@@ -39,7 +39,6 @@ def main():
     ap.add_argument("--only", default="")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--precision", default="bf16")
-    ap.add_argument("--hack", type=int, default=0)
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     L = N.lib()
@@ -68,7 +67,7 @@ def main():
 
             def run():
                 N.check(L.ap_conv2d_nhwc(N.PRECISIONS[args.precision], p(x), p(w), p(sc), p(sh), p(r), p(y), n, H, H,
-                                         cin, cout, k, st, pad, int(relu) | args.hack, N.stream_ptr(dev)), "conv")
+                                         cin, cout, k, st, pad, int(relu), N.stream_ptr(dev)), "conv")
             for _ in range(3):
                 run()
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
