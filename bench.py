@@ -184,7 +184,7 @@ def main():
             "roofline": {"bound": "mfma",
                          "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of one trunk pass in %d launches: conv_pipe_kernel "
                                    "(dominant instance <bf16,128,128,2,4,2>: 39 launches) + 3 fused layer1 bottlenecks "
-                                   "(bneck64_kernel / bneck256_kernel)" % launches,
+                                   "(bneck64ds_kernel, bneck256_kernel)" % launches,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(),
                          "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,

@@ -304,6 +304,38 @@ def test_trunk_batch_and_chunk_invariance(net32, dev):
     assert rel_err(single.cpu().numpy(), full.cpu().numpy()) < 1e-6
 
 
+def test_bf16_trunk_batch_and_chunk_invariance_bitwise(netbf, dev):
+    """bf16 throughput path (fused stem+pool, persistent fused layer1 bottlenecks, ring convs): a ragged batch, a
+    chunked pass and single-image passes give bit-identical features -- every output element has a fixed accumulation
+    order whatever the grid (1 image = 16 bottleneck tiles on 16 workgroups; 37 images = 592 tiles on 256)."""
+    from airpose_amd import weights as W
+    x = torch.from_numpy(W.synthetic_inputs(98, 5)["im1"]).to(dev)
+    netbf.set_chunk(0)
+    full = netbf.forward_feat_ext(x)
+    netbf.set_chunk(3)
+    chunked = netbf.forward_feat_ext(x)
+    netbf.set_chunk(0)
+    single = torch.cat([netbf.forward_feat_ext(x[i:i + 1]) for i in range(5)])
+    big = netbf.forward_feat_ext(torch.cat([x] * 8)[:37])
+    assert torch.equal(chunked, full) and torch.equal(single, full)
+    assert torch.equal(big[:5], full) and torch.equal(big[35:37], full[:2])
+
+
+def test_ief_ragged_batches(net32, copenet_sd, dev):
+    """The one-workgroup-per-pair IEF kernel and its split-K feature kernel at batch sizes around their tile sizes
+    (8 rows per feature workgroup): rows must equal the same rows of a larger batch."""
+    g = torch.Generator().manual_seed(21)
+    B = 13
+    xf0, xf1 = torch.randn(B, 2048, generator=g).to(dev), torch.randn(B, 2048, generator=g).to(dev)
+    bb0, bb1 = torch.rand(B, 3, generator=g).to(dev), torch.rand(B, 3, generator=g).to(dev)
+    pos = (torch.tensor([0.0, 0.0, 10.0]) * 0.05).expand(B, -1).contiguous().to(dev)
+    full = net32.forward_ief(xf0, xf1, bb0, bb1, pos, pos, iters=3)
+    for n in (1, 3, 8, 9):
+        part = net32.forward_ief(xf0[:n], xf1[:n], bb0[:n], bb1[:n], pos[:n], pos[:n], iters=3)
+        for a, b in zip(part, full):
+            assert torch.equal(a, b[:n]), n
+
+
 @pytest.mark.parametrize("fold", [1, 0])
 def test_ief_fp32_matches_golden(golden, net32, copenet_inputs, dev, fold):
     """fold = 1: fc1 -> fc2 -> dec evaluated as the folded affine map; fold = 0: the literal chain."""
