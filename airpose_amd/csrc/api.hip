@@ -389,13 +389,13 @@ int finalize_trunk(ap_net* h) {
             for (int r = 0; r < 7; ++r)
                 for (int s = 0; s < 7; ++s) sw[((r * 7 + s) * 3 + c) * 64 + o] = w->data[((o * 3 + c) * 7 + r) * 7 + s];
     HIP_TRY(upload(h->stem_w, sw.data(), sw.size() * 4));
-    {   // MFMA stem operand: [64][200] bf16, k' = r*24 + s*3 + c (zero elsewhere)
-        std::vector<uint16_t> pk(64 * 200, 0);
+    {   // MFMA stem operand: [64][232] bf16, k' = r*32 + s*4 + c (zero elsewhere: 4th channel slot, 8th tap, row pad)
+        std::vector<uint16_t> pk(64 * 232, 0);
         for (int o = 0; o < 64; ++o)
             for (int c = 0; c < 3; ++c)
                 for (int r = 0; r < 7; ++r)
                     for (int s2 = 0; s2 < 7; ++s2)
-                        pk[o * 200 + r * 24 + s2 * 3 + c] = host_f32_to_bf16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
+                        pk[o * 232 + r * 32 + s2 * 4 + c] = host_f32_to_bf16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
         HIP_TRY(upload(h->stem_wpk, pk.data(), pk.size() * 2));
     }
     std::vector<float> sc, sh;

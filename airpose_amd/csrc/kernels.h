@@ -49,7 +49,7 @@ hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st);
 hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, const float* scale, const float* shift,
                                void* y, int n_img, int is_bf16, hipStream_t st);
 // bf16 MFMA stem: images [0, n_split) come from x0, the rest from x1 (both views in one pass);
-// w_packed: [64][200] bf16, k' = r*24 + s*3 + c
+// w_packed: [64][232] bf16, k' = r*32 + s*4 + c
 hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_split, const void* w_packed,
                                     const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
 // fused bf16 MFMA stem + maxpool: NCHW fp32 crops -> [N][56][56][64] bf16

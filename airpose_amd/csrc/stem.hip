@@ -73,21 +73,22 @@ __global__ void __launch_bounds__(256) stem_direct_kernel(const float* __restric
 
 // ------------------------------------------------------------------------------------------------
 // MFMA stem (bf16 throughput path).  One workgroup = 16x16 conv outputs x 64 channels.
-// GEMM view: M = pixels, N = 64, K' = 7 kernel rows x 24 (21 = 7 taps x 3 channels, 3 zero pad) = 168 -> 192.
-// The input patch sits in LDS as bf16 [iy][ix][c] (channel-interleaved), so the 8 consecutive k' a lane feeds
-// to v_mfma_f32_16x16x32_bf16 are 8 consecutive bf16 of one patch row: no im2col buffer.  k' >= 21 within a
-// kernel row reads the neighbouring pixels' (finite) data against zero weights.
+// GEMM view: M = pixels, N = 64, K' = 7 kernel rows x 32 (7 taps x 4 channel slots, the 4th slot and an 8th tap are
+// zero) = 224.  The input patch sits in LDS as bf16 [iy][ix][4] (channel-interleaved, 8 bytes per pixel), so the 8
+// consecutive k' a lane feeds to v_mfma_f32_16x16x32_bf16 are two neighbouring pixels = ONE aligned ds_read_b128
+// (with 3 channels per pixel the same operand was four unaligned ds_read_b32 and the kernel was LDS-bound: PMC showed
+// 65 % of its LDS cycles as bank conflicts).  No im2col buffer; k' slots without a tap meet zero weights.
 constexpr int SP = 37;                       // patch rows / cols for a 16x16 output tile
-constexpr int SPW = 38;                      // patch row stride in pixels (even: keeps every 8-run dword aligned)
-constexpr int SWLD = 200;                    // packed weight row stride (bf16): 400 B, conflict-free b128 reads
-constexpr int SKB = 6;                       // 6 x 32 = 192 padded K
+constexpr int SPW = 38;                      // patch row stride in pixels (even: every fragment 16-byte aligned)
+constexpr int SWLD = 232;                    // packed weight row stride (bf16): 464 B, conflict-free b128 reads
+constexpr int SKB = 7;                       // 7 x 32 = 224 padded K: one k-block per kernel row
 
 __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                         int n_split, const bf16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, bf16_t* __restrict__ y) {
     __shared__ __attribute__((aligned(16))) bf16_t wsm[64 * SWLD];
-    __shared__ __attribute__((aligned(16))) bf16_t patch[SP * SPW * 3 + 32];
+    __shared__ __attribute__((aligned(16))) bf16_t patch[SP * SPW * 4 + 32];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int n = blockIdx.z, ty0 = blockIdx.y * 16, tx0 = blockIdx.x * 16;
     {   // weights: 64 x 400 B
@@ -101,10 +102,11 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
         const int iy = 2 * ty0 - 3 + py, ix = 2 * tx0 - 3 + px;
         float v = 0.f;
         if ((unsigned)iy < (unsigned)IMG && (unsigned)ix < (unsigned)IMG) v = xin[(c * IMG + iy) * IMG + ix];
-        patch[(py * SPW + px) * 3 + c] = f32_to_bf16(v);
+        patch[(py * SPW + px) * 4 + c] = f32_to_bf16(v);
     }
-    if (tid < 32) patch[SP * SPW * 3 + tid] = 0;
-    if (tid < SP * 3) patch[((tid / 3) * SPW + SP) * 3 + tid % 3] = 0;       // pad column
+    for (int i = tid; i < SP * SPW; i += 256) patch[i * 4 + 3] = 0;          // 4th channel slot
+    if (tid < 32) patch[SP * SPW * 4 + tid] = 0;
+    if (tid < SP * 3) patch[((tid / 3) * SPW + SP) * 4 + tid % 3] = 0;       // pad column
     __syncthreads();
 
     const int lr = lane & 15, g = lane >> 4;
@@ -114,22 +116,14 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < SKB; ++kb) {
-        const int k0 = kb * 32 + g * 8;                     // first of this lane's 8 k'
-        const int r = k0 / 24, t0 = k0 - r * 24;            // kernel row, offset inside the 24-wide row slot
+    for (int kb = 0; kb < SKB; ++kb) {                      // k-block = kernel row; lane group g = taps 2g, 2g+1
         u32x4 wf[4], xf[4];
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) wf[fn] = *(const u32x4*)(wsm + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
-        if (r < 7) {
 #pragma unroll
-            for (int fm = 0; fm < 4; ++fm) {
-                const int ty = wave * 4 + fm;
-                const uint32_t* pp = (const uint32_t*)(patch + ((2 * ty + r) * SPW + 2 * lr) * 3 + t0);
-                xf[fm].x = pp[0]; xf[fm].y = pp[1]; xf[fm].z = pp[2]; xf[fm].w = pp[3];
-            }
-        } else {
-#pragma unroll
-            for (int fm = 0; fm < 4; ++fm) xf[fm] = u32x4{0u, 0u, 0u, 0u};
+        for (int fm = 0; fm < 4; ++fm) {
+            const int ty = wave * 4 + fm;
+            xf[fm] = *(const u32x4*)(patch + ((2 * ty + kb) * SPW + 2 * lr + 2 * g) * 4);
         }
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm)
@@ -171,12 +165,13 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
                                                         int n_split, const bf16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
                                                         const float* __restrict__ shift, bf16_t* __restrict__ y) {
-    constexpr int WBYTES = 64 * SWLD * 2, PBYTES = (FROWS * FPW * 3 + 32) * 2;
+    constexpr int WBYTES = 64 * SWLD * 2, PBYTES = (FROWS * FPW * 4 + 32) * 2;
     constexpr int VBYTES = 2 * SO * SC * 2;
-    __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + PBYTES + VBYTES];
+    constexpr int PVBYTES = PBYTES > VBYTES ? PBYTES : VBYTES;
+    __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + PVBYTES];   // 58 KB: two workgroups per CU
     bf16_t* wsm = (bf16_t*)lds;
     bf16_t* patch = (bf16_t*)(lds + WBYTES);
-    bf16_t* vm = (bf16_t*)(lds + WBYTES + PBYTES);           // [2][112][64] vertically pooled rows
+    bf16_t* vm = (bf16_t*)(lds + WBYTES);                    // [2][112][64] vertically pooled rows, over the dead patch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int strip = blockIdx.x, n = blockIdx.y, py0 = strip * 2;
     {
@@ -186,20 +181,28 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
     }
     const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
     const int iy0 = 4 * py0 - 5;
-    for (int i = tid; i < 3 * FROWS * 56; i += 448) {      // float4 granules: (c, row, x4)
-        const int x4 = i % 56, t = i / 56, row = t % FROWS, c = t / FROWS;
+    for (int i = tid; i < FROWS * 56; i += 448) {           // (row, 4 pixels): three channel planes -> 4 x [c0 c1 c2 0]
+        const int x4 = i % 56, row = i / 56;
         const int iy = iy0 + row;
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if ((unsigned)iy < (unsigned)IMG) v = *(const float4*)(xin + ((size_t)c * IMG + iy) * IMG + 4 * x4);
-        bf16_t* d = patch + (row * FPW + 4 * x4 + 3) * 3 + c;
-        d[0] = f32_to_bf16(v.x); d[3] = f32_to_bf16(v.y); d[6] = f32_to_bf16(v.z); d[9] = f32_to_bf16(v.w);
+        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0;
+        if ((unsigned)iy < (unsigned)IMG) {
+            const float* src = xin + (size_t)iy * IMG + 4 * x4;
+            v0 = *(const float4*)src;
+            v1 = *(const float4*)(src + (size_t)IMG * IMG);
+            v2 = *(const float4*)(src + (size_t)2 * IMG * IMG);
+        }
+        uint2* d = (uint2*)(patch + (row * FPW + 4 * x4 + 3) * 4);
+        d[0] = make_uint2(pack_bf16x2(v0.x, v1.x), pack_bf16x2(v2.x, 0.f));
+        d[1] = make_uint2(pack_bf16x2(v0.y, v1.y), pack_bf16x2(v2.y, 0.f));
+        d[2] = make_uint2(pack_bf16x2(v0.z, v1.z), pack_bf16x2(v2.z, 0.f));
+        d[3] = make_uint2(pack_bf16x2(v0.w, v1.w), pack_bf16x2(v2.w, 0.f));
     }
-    for (int i = tid; i < FROWS * 8 * 3; i += 448) {       // left 3 / right 5 pad pixels of every row
-        const int c = i % 3, t = i / 3, q = t % 8, row = t / 8;
+    for (int i = tid; i < FROWS * 8; i += 448) {           // left 3 / right 5 pad pixels of every row
+        const int q = i % 8, row = i / 8;
         const int px = q < 3 ? q : 227 + (q - 3);
-        patch[(row * FPW + px) * 3 + c] = 0;
+        *(uint2*)(patch + (row * FPW + px) * 4) = make_uint2(0u, 0u);
     }
-    if (tid < 32) patch[FROWS * FPW * 3 + tid] = 0;
+    if (tid < 32) patch[FROWS * FPW * 4 + tid] = 0;
     __syncthreads();
 
     const int lr = lane & 15, g = lane >> 4;
@@ -209,6 +212,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
     // spill as long as the K-block loop is NOT unrolled: unrolling makes hipcc pre-compute every fragment address
     // and spill accumulators to scratch).  = 2: two passes of 32 channels (79 VGPRs), measured 15 % slower.
     constexpr int NH = AP_STEM_PASSES, FNH = 4 / NH;
+    static_assert(NH == 1, "the pooled rows reuse the patch's LDS: a second pass would read a clobbered patch");
 #pragma unroll 1
     for (int half = 0; half < NH; ++half) {
         f32x4 acc[5][FNH];
@@ -217,23 +221,13 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
 #pragma unroll
             for (int fn = 0; fn < FNH; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
-        for (int kb = 0; kb < SKB; ++kb) {
-            const int k0 = kb * 32 + g * 8;
-            const int r = k0 / 24, t0 = k0 - r * 24;
+        for (int kb = 0; kb < SKB; ++kb) {                  // k-block = kernel row; lane group g = taps 2g, 2g+1
             u32x4 wf[FNH], xf[5];
 #pragma unroll
             for (int fn = 0; fn < FNH; ++fn)
                 wf[fn] = *(const u32x4*)(wsm + ((half * FNH + fn) * 16 + lr) * SWLD + kb * 32 + g * 8);
-            if (r < 7) {
 #pragma unroll
-                for (int fm = 0; fm < 5; ++fm) {
-                    const uint32_t* pp = (const uint32_t*)(patch + ((2 * fm + r) * FPW + 2 * xo) * 3 + t0);
-                    xf[fm].x = pp[0]; xf[fm].y = pp[1]; xf[fm].z = pp[2]; xf[fm].w = pp[3];
-                }
-            } else {
-#pragma unroll
-                for (int fm = 0; fm < 5; ++fm) xf[fm] = u32x4{0u, 0u, 0u, 0u};
-            }
+            for (int fm = 0; fm < 5; ++fm) xf[fm] = *(const u32x4*)(patch + ((2 * fm + kb) * FPW + 2 * xo + 2 * g) * 4);
 #pragma unroll
             for (int fm = 0; fm < 5; ++fm)
 #pragma unroll
@@ -241,6 +235,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
                     acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
         }
+        __syncthreads();                                     // every wave is done with the patch: vm may overwrite it
 #pragma unroll
         for (int fn = 0; fn < FNH; ++fn) {
             const int ch = (half * FNH + fn) * 16 + g * 4;
