@@ -239,7 +239,7 @@ def test_fused_layer1_matches_separate_convs(netbf, golden, copenet_inputs, dev)
     netbf.set_fuse_block(0)
     b = netbf.forward_feat_ext(x)
     netbf.set_fuse_block(1)
-    assert rel_err(a.cpu().numpy(), b.cpu().numpy()) < 2e-2
+    assert torch.equal(a, b)           # same operands, rounding points and K order per output element
     assert rel_err(a.cpu().numpy(), golden["copenet_b2"]["xf0"]) < 3e-2
 
 
@@ -645,6 +645,14 @@ def test_full_size_properties_bf16(netbf, body, dev):
                 "intr1": d(intr[:2])})
     assert rel_err(two["pred_pose0"].cpu().numpy(), out["pred_pose0"][:2].cpu().numpy()) < 1e-6
     assert rel_err(two["pred_vertices_cam1"].cpu().numpy(), out["pred_vertices_cam1"][:2].cpu().numpy()) < 1e-6
+    # the persistent fused layer1 kernels at full size (512 images = 32 tiles per workgroup, hand-counted waits under
+    # full memory load) against the separate-convolution path: bit-identical, on repeated runs
+    x = d(torch.cat([im0, im1]))
+    netbf.set_fuse_block(0)
+    ref = netbf.forward_feat_ext(x)
+    netbf.set_fuse_block(1)
+    for _ in range(3):
+        assert torch.equal(netbf.forward_feat_ext(x), ref)
 
 
 def test_hmr_config1_on_gpu_matches_reference(golden, dev):
