@@ -72,7 +72,7 @@ struct Layer {                  // a conv or linear layer in packed device form
 };
 
 struct Timing {
-    bool on = false;
+    int on = 0;                     // 0 off, 1 every stage, 2 conv stack only (two events per trunk pass)
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     std::vector<size_t> marks[4];   // pairs of event indices per stage
@@ -603,7 +603,7 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
     HIP_TRY(h->ws_t1.reserve((size_t)n * 401408 * es));
     HIP_TRY(h->ws_t2.reserve((size_t)n * 200704 * es));
     size_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
-    if (h->tm.on) HIP_TRY(h->tm.rec(st, &e0));
+    if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
         HIP_TRY(ap_launch_stem_pool(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
                                     h->ws_a.p, n, st));
@@ -649,10 +649,10 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
     }
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e2));
     HIP_TRY(ap_launch_avgpool(cur, feat, n, 2048, bf, st));
-    if (h->tm.on) {
+    if (h->tm.on) { h->tm.marks[1].push_back(e1); h->tm.marks[1].push_back(e2); }
+    if (h->tm.on == 1) {
         HIP_TRY(h->tm.rec(st, &e3));
         h->tm.marks[0].push_back(e0); h->tm.marks[0].push_back(e1);
-        h->tm.marks[1].push_back(e1); h->tm.marks[1].push_back(e2);
         h->tm.marks[2].push_back(e2); h->tm.marks[2].push_back(e3);
     }
     return AP_OK;
@@ -701,7 +701,7 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
     HIP_TRY(h->ws_D.reserve((size_t)rows * DLD * 4));
     HIP_TRY(h->ws_state.reserve((size_t)rows * ST * 4));
     size_t e0 = 0, e1 = 0;
-    if (h->tm.on) HIP_TRY(h->tm.rec(st, &e0));
+    if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (h->fold && h->fuse_ief) {
         HIP_TRY(h->ws_H.reserve((size_t)ap_reg_fold_part_floats(rows) * 4));
         RegInitArgs ia{};
@@ -713,7 +713,7 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
         HIP_TRY(ap_launch_reg_fold_ief(ia, in.xf0, two_view ? in.xf1 : in.xf0, in.bb0, in.bb1, partner, partner_ld,
                                        h->foldT_feat.as<float>(), h->foldT_state.as<float>(), h->fold_bias.as<float>(),
                                        h->ws_H.as<float>(), iters, two_view, pose0, betas0, pose1, betas1, st));
-        if (h->tm.on) {
+        if (h->tm.on == 1) {
             HIP_TRY(h->tm.rec(st, &e1));
             h->tm.marks[3].push_back(e0); h->tm.marks[3].push_back(e1);
         }
@@ -753,7 +753,7 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
     // fold the last delta into the state and emit
     HIP_TRY(ap_launch_reg_update_assemble(state, D, DLD, in.bb0, in.bb1, partner, partner_ld, S, B, two_view, st));
     HIP_TRY(ap_launch_reg_output(state, pose0, betas0, pose1, betas1, B, two_view, st));
-    if (h->tm.on) {
+    if (h->tm.on == 1) {
         HIP_TRY(h->tm.rec(st, &e1));
         h->tm.marks[3].push_back(e0); h->tm.marks[3].push_back(e1);
     }
@@ -978,8 +978,8 @@ int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_th
 }
 
 int ap_net_enable_timing(ap_net* h, int on) {
-    if (!h) return fail(AP_EINVAL, "null handle");
-    h->tm.on = on != 0;
+    if (!h || on < 0 || on > 2) return fail(AP_EINVAL, "ap_net_enable_timing: handle, on in {0, 1, 2}");
+    h->tm.on = on;
     return AP_OK;
 }
 

@@ -139,7 +139,9 @@ int ap_debug_set_trace(void* device_buf_160_u64);
 /* Stage timing for bench.py: when enabled, HIP events bracket the stem, the implicit-GEMM conv stack,
  * the pooling tail and the regressor on the caller's stream.  ap_net_timing synchronises on the last
  * recorded events and returns the ACCUMULATED milliseconds and the number of recorded passes since
- * the last reset.  ms[0]=stem+maxpool, ms[1]=conv stack (52 launches/pass), ms[2]=avgpool, ms[3]=regressor. */
+ * the last reset.  ms[0]=stem+maxpool, ms[1]=conv stack (the 52 conv layers of a pass), ms[2]=avgpool, ms[3]=regressor.
+ * on = 1: every stage; on = 2: the conv stack only (two events per trunk pass: an event record costs a ~5 us bubble on
+ * the stream, so the timed region of bench.py carries only the pair its roofline line needs); on = 0: off. */
 int ap_net_enable_timing(ap_net* h, int on);
 int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset);
 /* forward_reg has no activation between fc1, fc2 and the decoders (dropout is the identity in eval mode,
