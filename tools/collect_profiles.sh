@@ -8,8 +8,8 @@ python $R/bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_ben
 python $R/bench.py --steps 20 --warmup 5 --batch 64 --no-tail --cpu-sample 0 > $O/${TAG}_bench_b64.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --steps 5 --warmup 2 --precision fp32 --cpu-sample 0 > $O/${TAG}_bench_fp32.json 2>> $O/${TAG}_bench.err
 rm -rf $O/${TAG}_trace $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $R/bench.py --steps 5 --warmup 2 --cpu-sample 0 > $O/${TAG}_trace.log 2>&1
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $R/bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 > $O/${TAG}_trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -- python $R/bench.py --steps 2 --warmup 1 --cpu-sample 0 > $O/${TAG}_pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -- python $R/bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 > $O/${TAG}_pmc_$C.log 2>&1
 done
 python $R/tools/summarize_profiles.py $TAG
