@@ -271,13 +271,28 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
     const uint32_t cch = lds0 + P_CONST + (uint32_t)((32 * wm2 + 4 * g4) * 4);   // + 64*i bytes per channel block
     // coalesced store geometry: wave w owns the 196 valid 16-byte pieces w*196 .. w*196+195 of the [196 px][8 chunks]
     // stage (exactly four store instructions per wave and pass; the fourth carries 4 lanes)
+    // Output stage, WAVE-PRIVATE: a wave's 2 x 4 accumulator tiles are [<= 4 rows x 16 px] x 32 channels = 64 B per pixel;
+    // it transposes them through its own 4 KiB of the stage (rows of 64 B, 16-byte chunk index XOR (row >> 2) & 3) into
+    // 16 bytes per lane and stores 64-byte pixel segments (the sibling wave of the channel pair stores the other half of
+    // the 128-byte line).  No workgroup barrier between the accumulators and the stores.  Exactly four store
+    // instructions per wave and pass (the wait counts rely on it): lanes past the wave's nb*14*4 pieces are masked,
+    // lane 0 of an otherwise empty instruction repeats piece 0.
+    const uint32_t stg = lds0 + P_M1 + wave * 4096;
+    uint32_t sea[2];                                         // accumulator-layout write address of channel block i
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        sea[i] = stg + lr * 64 + (uint32_t)(((2 * i + (g4 >> 1)) ^ ((lr >> 2) & 3)) << 4) + (g4 & 1) * 8;
     uint32_t st_lds[4], st_off[4];
+    uint32_t st_ok = 0;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int idx = wave * 196 + it * 64 + (it < 3 ? lane : (lane & 3));
-        const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
-        st_lds[it] = lds0 + P_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4);
-        st_off[it] = (uint32_t)(((oy * p.W + ox) * 256 + c * 8) * 2);
+        int idx = it * 64 + lane;
+        const bool ok = idx < nb * TS * 4;
+        if (!ok) idx = 0;
+        st_ok |= (ok || lane == 0) ? (1u << it) : 0u;
+        const int q = idx >> 2, c = idx & 3, j = q / TS, ox = q - j * TS, r = j * 16 + ox;
+        st_lds[it] = stg + r * 64 + (uint32_t)((c ^ ((r >> 2) & 3)) << 4);
+        st_off[it] = (uint32_t)((((rb + j) * p.W + ox) * 256 + 32 * wm2 + c * 8) * 2);
     }
     // A pass leaves its 64-channel output slice in sv (read back from the stage); the four global stores are issued
     // inside the NEXT compute step (a burst of stores right behind the stage blocks the wave: the write path drains
@@ -288,8 +303,8 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
             *(u32x4*)(base + st_off[0]) = sv[0];
             *(u32x4*)(base + st_off[1]) = sv[1];
         } else {
-            *(u32x4*)(base + st_off[2]) = sv[2];
-            if (lane < 4) *(u32x4*)(base + st_off[3]) = sv[3];
+            if (st_ok & 4u) *(u32x4*)(base + st_off[2]) = sv[2];
+            if (st_ok & 8u) *(u32x4*)(base + st_off[3]) = sv[3];
         }
     };
     u32x2 rv[4][2][4];                                       // identity values of the tile, one set per 64-channel pass
@@ -456,7 +471,7 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float4 sc = as_f4(cs[i]), sh = as_f4(ch[i]);
-                const uint32_t ea = lds0 + P_M1 + STG + eoff[i];
+                const uint32_t ea = sea[i] + STG;
                 auto out = [&](const f32x4& a, const u32x2& r) {
                     float lo, hi;
                     float v0 = a[0] * sc.x + sh.x, v1 = a[1] * sc.y + sh.y, v2 = a[2] * sc.z + sh.z, v3 = a[3] * sc.w + sh.w;
@@ -468,13 +483,12 @@ __global__ void __launch_bounds__(512) bneck256_kernel(const BneckArgs p) {
                     return o;
                 };
                 wr64<0>(ea, out(acc[i][0], rv[nc][i][0]));
-                wr64<2048>(ea, out(acc[i][1], rv[nc][i][1]));
-                wr64<4096>(ea, out(acc[i][2], rv[nc][i][2]));
-                if (nb == 4) wr64<6144>(ea, out(acc[i][3], rv[nc][i][3]));
+                wr64<1024>(ea, out(acc[i][1], rv[nc][i][1]));
+                wr64<2048>(ea, out(acc[i][2], rv[nc][i][2]));
+                if (nb == 4) wr64<3072>(ea, out(acc[i][3], rv[nc][i][3]));
             }
-            lgkm<0>();
+            lgkm<0>();                                       // (own writes; the stage region is this wave's)
             FSTAMP(2);
-            bar();                                           // stage complete
             FSTAMP(3);
 #pragma unroll
             for (int it = 0; it < 4; ++it) sv[it] = rd128<STG>(st_lds[it]);
@@ -584,13 +598,28 @@ __global__ void __launch_bounds__(512) bneck64ds_kernel(const BneckArgs p) {
         e1off[i] = (uint32_t)((wn2 * 64 + lr) * 128 + ((chunk ^ (lr & 7)) << 4) + (g4 & 1) * 8);
     }
     const uint32_t cch = lds0 + D_CONST + (uint32_t)((32 * wm2 + 4 * g4) * 4);
+    // Output stage, WAVE-PRIVATE: a wave's 2 x 4 accumulator tiles are [<= 4 rows x 16 px] x 32 channels = 64 B per pixel;
+    // it transposes them through its own 4 KiB of the stage (rows of 64 B, 16-byte chunk index XOR (row >> 2) & 3) into
+    // 16 bytes per lane and stores 64-byte pixel segments (the sibling wave of the channel pair stores the other half of
+    // the 128-byte line).  No workgroup barrier between the accumulators and the stores.  Exactly four store
+    // instructions per wave and pass (the wait counts rely on it): lanes past the wave's nb*14*4 pieces are masked,
+    // lane 0 of an otherwise empty instruction repeats piece 0.
+    const uint32_t stg = lds0 + D_M1 + wave * 4096;
+    uint32_t sea[2];                                         // accumulator-layout write address of channel block i
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+        sea[i] = stg + lr * 64 + (uint32_t)(((2 * i + (g4 >> 1)) ^ ((lr >> 2) & 3)) << 4) + (g4 & 1) * 8;
     uint32_t st_lds[4], st_off[4];
+    uint32_t st_ok = 0;
 #pragma unroll
     for (int it = 0; it < 4; ++it) {
-        const int idx = wave * 196 + it * 64 + (it < 3 ? lane : (lane & 3));
-        const int px = idx >> 3, c = idx & 7, oy = px / TS, ox = px - oy * TS, q = oy * 16 + ox;
-        st_lds[it] = lds0 + D_M1 + q * 128 + (uint32_t)((c ^ (q & 7)) << 4);
-        st_off[it] = (uint32_t)(((oy * p.W + ox) * 256 + c * 8) * 2);
+        int idx = it * 64 + lane;
+        const bool ok = idx < nb * TS * 4;
+        if (!ok) idx = 0;
+        st_ok |= (ok || lane == 0) ? (1u << it) : 0u;
+        const int q = idx >> 2, c = idx & 3, j = q / TS, ox = q - j * TS, r = j * 16 + ox;
+        st_lds[it] = stg + r * 64 + (uint32_t)((c ^ ((r >> 2) & 3)) << 4);
+        st_off[it] = (uint32_t)((((rb + j) * p.W + ox) * 256 + 32 * wm2 + c * 8) * 2);
     }
     u32x4 sv[4];
     auto put_stores = [&](int half, unsigned char* base) {
@@ -598,8 +627,8 @@ __global__ void __launch_bounds__(512) bneck64ds_kernel(const BneckArgs p) {
             *(u32x4*)(base + st_off[0]) = sv[0];
             *(u32x4*)(base + st_off[1]) = sv[1];
         } else {
-            *(u32x4*)(base + st_off[2]) = sv[2];
-            if (lane < 4) *(u32x4*)(base + st_off[3]) = sv[3];
+            if (st_ok & 4u) *(u32x4*)(base + st_off[2]) = sv[2];
+            if (st_ok & 8u) *(u32x4*)(base + st_off[3]) = sv[3];
         }
     };
     f32x4 acc[2][4];
@@ -716,14 +745,13 @@ __global__ void __launch_bounds__(512) bneck64ds_kernel(const BneckArgs p) {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const float4 sc = as_f4(cs[i]), sh = as_f4(ch[i]);
-                const uint32_t ea = lds0 + D_M1 + eoff[i];
+                const uint32_t ea = sea[i];
                 wr64<0>(ea, bn_relu_pack(acc[i][0], sc, sh, true));
-                wr64<2048>(ea, bn_relu_pack(acc[i][1], sc, sh, true));
-                wr64<4096>(ea, bn_relu_pack(acc[i][2], sc, sh, true));
-                if (nb == 4) wr64<6144>(ea, bn_relu_pack(acc[i][3], sc, sh, true));
+                wr64<1024>(ea, bn_relu_pack(acc[i][1], sc, sh, true));
+                wr64<2048>(ea, bn_relu_pack(acc[i][2], sc, sh, true));
+                if (nb == 4) wr64<3072>(ea, bn_relu_pack(acc[i][3], sc, sh, true));
             }
-            lgkm<0>();
-            bar();                                           // stage complete
+            lgkm<0>();                                       // (own writes; the stage region is this wave's)
 #pragma unroll
             for (int it = 0; it < 4; ++it) sv[it] = rd128<0>(st_lds[it]);
             lgkm<0>();
