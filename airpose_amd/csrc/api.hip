@@ -147,8 +147,9 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
         //   grids below one workgroup per CU with 128x128 tiles (e.g. layer4 conv1/conv2 at 128 images: 196 tiles) take
         //   the 128x64 tiles (twice the workgroups; 46-48 us against 72-83 us for the register-staged kernel there)
         const long mt128 = (a.M + 127) / 128, nt128 = (a.Cout + 127) / 128, nt64 = (a.Cout + 63) / 64;
+        //   (a folded downsample = second K segment needs the 128-wide tiles or the register-staged kernel)
         if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : 11;
-        else if (mt128 * nt64 >= 128) cfg = 12;
+        else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
     }
     if (cfg == 100) return ap_launch_conv(a, is_bf16, st);

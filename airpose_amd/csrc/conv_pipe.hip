@@ -467,6 +467,7 @@ hipError_t launch_pipe(ConvArgs a, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set = true;
     }
+    if (a.x2 && BN < 128) return hipErrorInvalidValue;       // the 64-wide tiles carry no second K segment: refuse, never drop it
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(64 * WM * WN), lds, st, a);
