@@ -1338,12 +1338,10 @@ int ap_fit_run(ap_fit* h, int L, float* z, float* phi, float* tau, float* beta, 
     }
     a.sigma = sigma; a.w_temporal = w_temporal; a.w_vposer = w_vposer; a.lr = lr;
     a.adam_m = h->adam_m.as<float>(); a.adam_v = h->adam_v.as<float>(); a.grad_out = grad_out;
-    auto decode = [&]() -> hipError_t {                     // VPoser decoder MLP
-        hipError_t e = ap_launch_fit_linear(z, 32, 32, h->w1t.as<float>(), 512, h->b1.as<float>(), nullptr, 0, h->H1.as<float>(), 512, L, 512, 1, st);
-        if (e == hipSuccess) e = ap_launch_fit_linear(h->H1.as<float>(), 512, 512, h->w2t.as<float>(), 512, h->b2.as<float>(), nullptr, 0, h->H2.as<float>(), 512, L, 512, 1, st);
-        if (e == hipSuccess) e = ap_launch_fit_linear(h->H2.as<float>(), 512, 512, h->w3t.as<float>(), 128, h->b3.as<float>(), nullptr, 0, h->O.as<float>(), 128, L, 128, 0, st);
-        if (e == hipSuccess) e = ap_launch_fit_aa(h->O.as<float>(), 128, h->aa.as<float>(), L, st);
-        return e;
+    auto decode = [&]() -> hipError_t {                     // VPoser decoder MLP + matrot2aa, one launch
+        return ap_launch_fit_decode(z, L, h->w1t.as<float>(), h->b1.as<float>(), h->w2t.as<float>(), h->b2.as<float>(),
+                                    h->w3t.as<float>(), h->b3.as<float>(), h->H1.as<float>(), h->H2.as<float>(),
+                                    h->O.as<float>(), h->aa.as<float>(), st);
     };
     bool decoded = false;
     for (int j = first_iter; j < first_iter + n_iters; ++j) {
@@ -1353,16 +1351,14 @@ int ap_fit_run(ap_fit* h, int L, float* z, float* phi, float* tau, float* beta, 
             HIP_TRY(hipMemsetAsync(h->adam_v.p, 0, (size_t)nprm * 4, st));
         }
         if (with_z || !decoded) { HIP_TRY(decode()); decoded = true; }      // z is constant before the switch
+        if (loss_hist) a.loss_part = loss_hist + (size_t)(j - first_iter) * L * 4;      // the frame kernel writes the history row
         HIP_TRY(ap_launch_fit_frame(a, j, st));
-        if (with_z) {                                       // decoder backward: dO -> dH2 -> dH1 -> dz
-            HIP_TRY(ap_launch_fit_linear(h->dO.as<float>(), 128, 126, h->w3.as<float>(), 512, nullptr, h->H2.as<float>(), 512, h->dH2.as<float>(), 512, L, 512, 0, st));
-            HIP_TRY(ap_launch_fit_linear(h->dH2.as<float>(), 512, 512, h->w2.as<float>(), 512, nullptr, h->H1.as<float>(), 512, h->dH1.as<float>(), 512, L, 512, 0, st));
-            HIP_TRY(ap_launch_fit_linear(h->dH1.as<float>(), 512, 512, h->w1.as<float>(), 32, nullptr, nullptr, 0, h->dz.as<float>(), 32, L, 32, 0, st));
-        }
         const int step = j < switch_iter ? j - first_iter + 1 : j - std::max(switch_iter, first_iter) + 1;
-        HIP_TRY(ap_launch_fit_adam(a, step, with_z ? 1 : 0, st));
-        if (loss_hist)
-            HIP_TRY(hipMemcpyAsync(loss_hist + (size_t)(j - first_iter) * L * 4, h->loss.p, (size_t)L * 4 * 4, hipMemcpyDeviceToDevice, st));
+        if (with_z)                                          // decoder backward dO -> dz and Adam on everything, one launch
+            HIP_TRY(ap_launch_fit_backprop_adam(a, h->w3.as<float>(), h->w2.as<float>(), h->w1.as<float>(), h->H1.as<float>(),
+                                                h->H2.as<float>(), step, st));
+        else
+            HIP_TRY(ap_launch_fit_adam(a, step, 0, st));
     }
     return AP_OK;
 }

@@ -11,7 +11,8 @@
 // Script quirks reproduced (see oracle/fitting_ref.py): sigma = 30, hip confidences halved on every iteration,
 // loss_beta without gradient, two Adam instances switching at iteration 100.
 // One wave per frame runs the whole geometric forward + backward (fit_frame_kernel); per iteration:
-//   [decoder forward 3x] fit_aa_kernel, fit_frame_kernel, [decoder backward 3x] fit_adam_kernel.
+//   fit_decode_kernel (decoder + matrot2aa), fit_frame_kernel, fit_backprop_adam_kernel (decoder backward + Adam);
+// before the switch to the second optimiser only fit_frame_kernel + fit_adam_kernel.
 #include "ap_common.h"
 #include "kernels.h"
 
@@ -426,6 +427,164 @@ __global__ void fit_adam_kernel(const FitArgs a, int step, int with_z) {
     if (a.grad_out) a.grad_out[i] = gr;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Fused decoder passes (latency: one launch instead of three GEMM launches + glue; the sequence is only L = 64 rows, so
+// the per-iteration cost is launch-to-launch latency, not work).  A workgroup of 1024 threads owns DR rows and runs the
+// whole 32 -> 512 -> 512 -> 126 chain (resp. its transpose).  Every layer has the same shape of work: thread =
+// (group of 4 adjacent output columns, K range), weights k-major so that a wave reads whole 16-byte-per-lane rows
+// (dwordx4: the texture-address path takes the same time per instruction for 4 and for 16 bytes per lane), partial sums
+// reduced over the K ranges through a 64 KiB LDS array.  Weights stream from L2; the bound is one CU's L2 port.
+constexpr int DR = 4;
+constexpr int FIT_LDS_FLOATS = 16384 + DR * (32 + 512 + 512 + 128);          // red + the activations of the four rows
+__device__ __forceinline__ float lrelu(float v) { return v > 0.f ? v : 0.01f * v; }
+
+// partial[kq][r][c] = sum over this thread's K range of w[k][c] * x[r][k];  C columns (k-major rows of C floats), K
+// rows of w of which the first kmax are real; x rows in LDS with stride XLD
+template <int C, int K, int XLD>
+__device__ __forceinline__ void layer_partial(const float* __restrict__ w, const float* x, float* red, int kmax) {
+    constexpr int CG = C / 4, NKQ = 1024 / CG, KP = K / NKQ, U = KP < 8 ? KP : 8;
+    static_assert(K % NKQ == 0 && KP % U == 0, "K range split");
+    const int t = threadIdx.x, cg = t % CG, kq = t / CG;
+    float acc[DR][4] = {};
+    for (int k0 = kq * KP; k0 < kq * KP + KP; k0 += U) {
+        float4 wv[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            wv[u] = k0 + u < kmax ? *reinterpret_cast<const float4*>(w + (size_t)(k0 + u) * C + 4 * cg) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int r = 0; r < DR; ++r) {
+                const float xv = x[r * XLD + k0 + u];
+                acc[r][0] = fmaf(wv[u].x, xv, acc[r][0]); acc[r][1] = fmaf(wv[u].y, xv, acc[r][1]);
+                acc[r][2] = fmaf(wv[u].z, xv, acc[r][2]); acc[r][3] = fmaf(wv[u].w, xv, acc[r][3]);
+            }
+    }
+#pragma unroll
+    for (int r = 0; r < DR; ++r)
+        *reinterpret_cast<float4*>(red + (size_t)(kq * DR + r) * C + 4 * cg) = make_float4(acc[r][0], acc[r][1], acc[r][2], acc[r][3]);
+}
+template <int C>
+__device__ __forceinline__ float layer_sum(const float* red, int r, int o) {
+    constexpr int NKQ = 4096 / C;
+    float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll 4
+    for (int kq = 0; kq < NKQ; kq += 4) {
+        v0 += red[((kq + 0) * DR + r) * C + o]; v1 += red[((kq + 1) * DR + r) * C + o];
+        v2 += red[((kq + 2) * DR + r) * C + o]; v3 += red[((kq + 3) * DR + r) * C + o];
+    }
+    return (v0 + v1) + (v2 + v3);
+}
+
+// z -> H1, H2 (kept for the backward pass), O, and pose_body axis-angle
+__global__ void __launch_bounds__(1024) fit_decode_kernel(const float* __restrict__ z, int L, const float* __restrict__ w1t,
+                                                          const float* __restrict__ b1, const float* __restrict__ w2t,
+                                                          const float* __restrict__ b2, const float* __restrict__ w3t,
+                                                          const float* __restrict__ b3, float* __restrict__ H1,
+                                                          float* __restrict__ H2, float* __restrict__ O, float* __restrict__ aa_out) {
+    extern __shared__ float lds[];
+    float* red = lds; float* xs = red + 16384; float* h1 = xs + DR * 32; float* h2 = h1 + DR * 512; float* os = h2 + DR * 512;
+    const int t = threadIdx.x, r0 = blockIdx.x * DR;
+    if (t < DR * 32) { const int r = t >> 5, c = t & 31; xs[r * 32 + c] = r0 + r < L ? z[(size_t)(r0 + r) * 32 + c] : 0.f; }
+    __syncthreads();
+    layer_partial<512, 32, 32>(w1t, xs, red, 32);
+    __syncthreads();
+    for (int i = t; i < DR * 512; i += 1024) {
+        const int r = i >> 9, o = i & 511;
+        const float v = lrelu(layer_sum<512>(red, r, o) + b1[o]);
+        h1[r * 512 + o] = v;
+        if (r0 + r < L) H1[(size_t)(r0 + r) * 512 + o] = v;
+    }
+    __syncthreads();
+    layer_partial<512, 512, 512>(w2t, h1, red, 512);
+    __syncthreads();
+    for (int i = t; i < DR * 512; i += 1024) {
+        const int r = i >> 9, o = i & 511;
+        const float v = lrelu(layer_sum<512>(red, r, o) + b2[o]);
+        h2[r * 512 + o] = v;
+        if (r0 + r < L) H2[(size_t)(r0 + r) * 512 + o] = v;
+    }
+    __syncthreads();
+    layer_partial<128, 512, 512>(w3t, h2, red, 512);
+    __syncthreads();
+    if (t < DR * 128) {
+        const int r = t >> 7, o = t & 127;
+        const float v = layer_sum<128>(red, r, o) + b3[o];
+        os[r * 128 + o] = v;
+        if (r0 + r < L) O[(size_t)(r0 + r) * 128 + o] = v;
+    }
+    __syncthreads();
+    if (t < DR * NB) {                                       // matrot2aa of the Gram-Schmidt rotations (fit_aa_kernel)
+        const int r = t / NB, j = t - r * NB;
+        if (r0 + r < L) {
+            const float* o = os + r * 128 + 6 * j;
+            const GS g = gs_fwd(v3(o[0], o[2], o[4]), v3(o[1], o[3], o[5]));
+            const float R[9] = {g.b1.x, g.b2.x, g.b3.x, g.b1.y, g.b2.y, g.b3.y, g.b1.z, g.b2.z, g.b3.z};
+            const AA a = aa_fwd(R);
+            float* dst = aa_out + ((size_t)(r0 + r) * NB + j) * 3;
+            dst[0] = a.aa.x; dst[1] = a.aa.y; dst[2] = a.aa.z;
+        }
+    }
+}
+
+// dO -> dH2 -> dH1 -> dz, then Adam on every optimised quantity of the workgroup's rows (and beta in workgroup 0).
+// Weights as torch stores them ([out][in]) ARE k-major for the transposed products.
+__global__ void __launch_bounds__(1024) fit_backprop_adam_kernel(const FitArgs a, const float* __restrict__ w3, const float* __restrict__ w2,
+                                                                 const float* __restrict__ w1, const float* __restrict__ H1,
+                                                                 const float* __restrict__ H2, int step) {
+    extern __shared__ float lds[];
+    float* red = lds; float* dzs = red + 16384; float* d2 = dzs + DR * 32; float* d1 = d2 + DR * 512; float* dos = d1 + DR * 512;
+    const int t = threadIdx.x, r0 = blockIdx.x * DR, L = a.L;
+    if (t < DR * 128) { const int r = t >> 7, c = t & 127; dos[r * 128 + c] = (r0 + r < L && c < 126) ? a.dO[(size_t)(r0 + r) * a.ldo + c] : 0.f; }
+    __syncthreads();
+    layer_partial<512, 128, 128>(w3, dos, red, 126);         // dH2 = (dO W3) * lrelu'(H2)
+    __syncthreads();
+    for (int i = t; i < DR * 512; i += 1024) {
+        const int r = i >> 9, o = i & 511;
+        const float hact = r0 + r < L ? H2[(size_t)(r0 + r) * 512 + o] : 0.f;
+        d2[r * 512 + o] = layer_sum<512>(red, r, o) * (hact > 0.f ? 1.f : 0.01f);
+    }
+    __syncthreads();
+    layer_partial<512, 512, 512>(w2, d2, red, 512);          // dH1 = (dH2 W2) * lrelu'(H1)
+    __syncthreads();
+    for (int i = t; i < DR * 512; i += 1024) {
+        const int r = i >> 9, o = i & 511;
+        const float hact = r0 + r < L ? H1[(size_t)(r0 + r) * 512 + o] : 0.f;
+        d1[r * 512 + o] = layer_sum<512>(red, r, o) * (hact > 0.f ? 1.f : 0.01f);
+    }
+    __syncthreads();
+    layer_partial<32, 512, 512>(w1, d1, red, 512);           // dz = dH1 W1
+    __syncthreads();
+    if (t < DR * 32) { const int r = t >> 5, c = t & 31; dzs[r * 32 + c] = layer_sum<32>(red, r, c); }
+    __syncthreads();
+    // ---- Adam (as fit_adam_kernel) on this workgroup's share: z, phi, tau of its rows; beta in workgroup 0
+    const int nz = L * 32, nphi = 2 * L * 6, ntau = 2 * L * 3;
+    int i = -1; float* p = nullptr; float gr = 0.f;
+    if (t < DR * 32) {
+        const int r = t >> 5, c = t & 31;
+        if (r0 + r < L) { i = (r0 + r) * 32 + c; p = a.z + i; gr = dzs[r * 32 + c] + a.w_vposer * 2.f * a.z[i] / (float)nz; }
+    } else if (t < DR * 32 + DR * 18) {
+        const int e = t - DR * 32, r = e / 18, q = e - r * 18, v = q / 9, d = q - v * 9;
+        if (r0 + r < L) {
+            if (d < 6) { const int j = (v * L + r0 + r) * 6 + d; i = nz + j; p = a.phi + j; gr = a.dphi[j]; }
+            else { const int j = (v * L + r0 + r) * 3 + d - 6; i = nz + nphi + j; p = a.tau + j; gr = a.dtau[j]; }
+        }
+    } else if (t < DR * 32 + DR * 18 + 10 && blockIdx.x == 0) {
+        const int k = t - DR * 32 - DR * 18;
+        i = nz + nphi + ntau + k; p = a.beta + k;
+        for (int f = 0; f < L; ++f) gr += a.dbeta_part[(size_t)f * 10 + k];
+    }
+    if (i >= 0) {
+        float m = a.adam_m[i], v = a.adam_v[i];
+        m = 0.9f * m + 0.1f * gr;
+        v = 0.999f * v + 0.001f * gr * gr;
+        a.adam_m[i] = m; a.adam_v[i] = v;
+        const float bc1 = 1.f - powf(0.9f, (float)step), bc2 = 1.f - powf(0.999f, (float)step);
+        *p -= (a.lr / bc1) * m / (sqrtf(v) / sqrtf(bc2) + 1e-8f);
+        if (a.grad_out) a.grad_out[i] = gr;
+    }
+}
+
 }  // namespace
 
 hipError_t ap_launch_fit_linear(const float* X, int ldx, int K, const float* Wt, int ldw, const float* bias, const float* G,
@@ -446,5 +605,20 @@ hipError_t ap_launch_fit_frame(const FitArgs& a, int it, hipStream_t st) {
 hipError_t ap_launch_fit_adam(const FitArgs& a, int step, int with_z, hipStream_t st) {
     const int total = a.L * 32 + 2 * a.L * 9 + 10;
     hipLaunchKernelGGL(fit_adam_kernel, dim3((total + 255) / 256), dim3(256), 0, st, a, step, with_z);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_fit_decode(const float* z, int L, const float* w1t, const float* b1, const float* w2t, const float* b2,
+                                const float* w3t, const float* b3, float* H1, float* H2, float* O, float* aa, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fit_decode_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FIT_LDS_FLOATS * 4);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(fit_decode_kernel, dim3((L + DR - 1) / DR), dim3(1024), FIT_LDS_FLOATS * 4, st, z, L, w1t, b1, w2t, b2, w3t, b3, H1, H2, O, aa);
+    return hipGetLastError();
+}
+hipError_t ap_launch_fit_backprop_adam(const FitArgs& a, const float* w3, const float* w2, const float* w1, const float* H1,
+                                       const float* H2, int step, hipStream_t st) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(fit_backprop_adam_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, FIT_LDS_FLOATS * 4);
+    if (attr != hipSuccess) return attr;
+    hipLaunchKernelGGL(fit_backprop_adam_kernel, dim3((a.L + DR - 1) / DR), dim3(1024), FIT_LDS_FLOATS * 4, st, a, w3, w2, w1, H1, H2, step);
     return hipGetLastError();
 }

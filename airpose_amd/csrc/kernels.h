@@ -182,3 +182,8 @@ hipError_t ap_launch_fit_linear(const float* X, int ldx, int K, const float* Wt,
 hipError_t ap_launch_fit_aa(const float* O, int ldo, float* aa, int L, hipStream_t st);
 hipError_t ap_launch_fit_frame(const FitArgs& a, int it, hipStream_t st);
 hipError_t ap_launch_fit_adam(const FitArgs& a, int step, int with_z, hipStream_t st);
+// fused decoder passes: one launch for z -> H1, H2, O, pose_body; one for dO -> dz followed by Adam on every quantity
+hipError_t ap_launch_fit_decode(const float* z, int L, const float* w1t, const float* b1, const float* w2t, const float* b2,
+                                const float* w3t, const float* b3, float* H1, float* H2, float* O, float* aa, hipStream_t st);
+hipError_t ap_launch_fit_backprop_adam(const FitArgs& a, const float* w3, const float* w2, const float* w1, const float* H1,
+                                       const float* H2, int step, hipStream_t st);
