@@ -12,4 +12,7 @@ rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $R/bench.py --step
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -- python $R/bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 > $O/${TAG}_pmc_$C.log 2>&1
 done
+# MFMA-busy pass (SQ + GRBM counters in one pass: independent blocks)
+rm -rf $O/${TAG}_pmc_MFMA
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_MFMA -- python $R/bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 > $O/${TAG}_pmc_MFMA.log 2>&1
 python $R/tools/summarize_profiles.py $TAG

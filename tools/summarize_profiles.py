@@ -63,6 +63,32 @@ if acc:
              "traffic_bytes_per_launch": (2 * fetch + write) * 1024 / steps / lp}
         json.dump(j, open(os.path.join(O, tag + "_pmc_traffic.json"), "w"), indent=1)
         print(json.dumps(j))
+# MFMA busy: SQ_VALU_MFMA_BUSY_CYCLES (cycles, summed over every SIMD of the chip) against GRBM_GUI_ACTIVE (cycles the
+# GPU was busy with the dispatch; one value per XCD, summed by rocprofv3 over the 8 XCDs) x 1024 SIMDs
+macc = collections.defaultdict(lambda: collections.defaultdict(float))
+mcnt = collections.Counter()
+for p in glob.glob(os.path.join(O, tag + "_pmc_MFMA", "**", "*counter_collection.csv"), recursive=True):
+    for r in csv.DictReader(open(p)):
+        macc[r["Kernel_Name"]][r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            mcnt[r["Kernel_Name"]] += 1
+if macc:
+    tb = tg = 0.0
+    with open(os.path.join(O, tag + "_pmc_mfma_busy.csv"), "w") as f:
+        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0  (%s)\n" % tag)
+        f.write("# mfma_busy_pct = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); 100 %% = every SIMD's matrix pipe busy for the whole dispatch\n")
+        f.write("kernel,launches,mfma_busy_cycles,insts_mfma,gui_active_cycles_per_xcd,mfma_busy_pct\n")
+        for k, d in sorted(macc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
+            g = d.get("GRBM_GUI_ACTIVE", 0.0) / 8
+            if g <= 0:
+                continue
+            b = d.get("SQ_VALU_MFMA_BUSY_CYCLES", 0.0)
+            f.write('"%s",%d,%.0f,%.0f,%.0f,%.2f\n' % (k[:90], mcnt[k], b, d.get("SQ_INSTS_MFMA", 0.0), g, 100 * b / (g * 1024)))
+            if is_trunk_conv(k):
+                tb += b; tg += g
+        if tg:
+            f.write('"conv stack (all bf16 conv kernels)",,%.0f,,%.0f,%.2f\n' % (tb, tg, 100 * tb / (tg * 1024)))
+            print("conv stack MFMA busy %.2f %%" % (100 * tb / (tg * 1024)))
 for f in ("bench", "bench_b64", "bench_fp32"):
     p = os.path.join(O, "%s_%s.json" % (tag, f))
     if os.path.exists(p) and os.path.getsize(p):
