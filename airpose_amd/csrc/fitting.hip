@@ -215,7 +215,38 @@ __global__ void fit_aa_kernel(const float* __restrict__ O, int ldo, float* __res
 __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) {
     const int f = blockIdx.x, lane = threadIdx.x, L = a.L;
     __shared__ float Rl[NJ][9], Jr[NJ][3], G[NJ][12], dG[NJ][12], dRl[NJ][9], dJ[NJ][3], red[32];
+    __shared__ float Sd[NJ * 3][10], PT[3][2][9], CAM[32];
+    // ---- every global input of the frame is requested up front (one memory latency instead of one per use: the
+    //      kernel is a chain of short dependent phases, and it runs 300 times back to back)
     const bool rob = a.robust[f] != 0;
+    const bool pair_prev = a.n_pairs > 0 && f > 0 && a.robust[f - 1] && rob;
+    const bool pair_next = a.n_pairs > 0 && f + 1 < L && rob && a.robust[f + 1];
+    for (int i = lane; i < NJ * 3 * 10; i += 64) Sd[i / 10][i % 10] = a.j_shapedirs[(i / 10) * a.jsd_ld + i % 10];
+    if (lane < 54) {                                         // phi | tau of this frame and of its neighbours, both views
+        const int which = lane / 18, v = (lane % 18) / 9, e = lane % 9;
+        const int ff = which == 0 ? f : which == 1 ? (f > 0 ? f - 1 : f) : (f + 1 < L ? f + 1 : f);
+        PT[which][v][e] = e < 6 ? a.phi[((size_t)v * L + ff) * 6 + e] : a.tau[((size_t)v * L + ff) * 3 + e - 6];
+    }
+    if (lane < 32) CAM[lane] = lane < 24 ? a.extr[lane] : a.intr[lane - 24];
+    float gtv[2][2][3] = {}, tmpl[3] = {0.f, 0.f, 0.f}, aprev[3] = {0.f, 0.f, 0.f}, anext[3] = {0.f, 0.f, 0.f}, betav[10];
+#pragma unroll
+    for (int k = 0; k < 10; ++k) betav[k] = a.beta[k];
+    if (lane < NJ) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) tmpl[c] = a.j_template[lane * 3 + c];
+#pragma unroll
+        for (int v = 0; v < 2; ++v)
+#pragma unroll
+            for (int det = 0; det < 2; ++det) {
+                const float* gt = a.j2d + ((((size_t)v * L + f) * 2 + det) * NJ + lane) * 3;
+                gtv[v][det][0] = gt[0]; gtv[v][det][1] = gt[1]; gtv[v][det][2] = gt[2];
+            }
+    }
+    if (lane < NB) {
+        const float* A = a.aa_all + ((size_t)f * NB + lane) * 3;
+        if (pair_prev) { aprev[0] = A[-NB * 3]; aprev[1] = A[-NB * 3 + 1]; aprev[2] = A[-NB * 3 + 2]; }
+        if (pair_next) { anext[0] = A[NB * 3]; anext[1] = A[NB * 3 + 1]; anext[2] = A[NB * 3 + 2]; }
+    }
     // ---- decoder tail: 6-D -> R -> axis-angle -> R' (lbs.batch_rodrigues), body joints 1..21
     GS g; AA q; RD rd;
     V3 a2 = v3(0, 0, 0), aav = v3(0, 0, 0);
@@ -234,14 +265,19 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
     }
     if (lane < NJ) {
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            float v = a.j_template[lane * 3 + c];
-            for (int k = 0; k < 10; ++k) v += a.j_shapedirs[(lane * 3 + c) * a.jsd_ld + k] * a.beta[k];
-            Jr[lane][c] = v;
-            dJ[lane][c] = 0.f;
-        }
+        for (int c = 0; c < 3; ++c) dJ[lane][c] = 0.f;
 #pragma unroll
         for (int e = 0; e < 12; ++e) dG[lane][e] = 0.f;
+    }
+    __syncthreads();                                         // Sd, PT, CAM staged
+    if (lane < NJ) {
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+            float v = tmpl[c];
+#pragma unroll
+            for (int k = 0; k < 10; ++k) v += Sd[lane * 3 + c][k] * betav[k];
+            Jr[lane][c] = v;
+        }
     }
     __syncthreads();
     // ---- kinematic chain (batch_rigid_transform), level by level
@@ -272,21 +308,21 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
     V3 pj = v3(0, 0, 0), dpj = v3(0, 0, 0);
     if (lane < NJ) pj = v3(G[lane][9], G[lane][10], G[lane][11]);
     for (int v = 0; v < 2; ++v) {
-        const float* ph = a.phi + ((size_t)v * L + f) * 6;
-        const float* ta = a.tau + ((size_t)v * L + f) * 3;
+        const float* ph = &PT[0][v][0];
+        const float* ta = &PT[0][v][6];
         const V3 pa2 = v3(ph[3], ph[4], ph[5]);
         const GS gv = gs_fwd(v3(ph[0], ph[1], ph[2]), pa2);  // rows of R_v
         V3 dX = v3(0, 0, 0);
         if (lane < NJ && rob) {
             const V3 X = v3(dot(gv.b1, pj) + ta[0], dot(gv.b2, pj) + ta[1], dot(gv.b3, pj) + ta[2]);
-            const float* E = a.extr + v * 12;
+            const float* E = &CAM[v * 12];
             const V3 Xc = v3(E[0] * X.x + E[1] * X.y + E[2] * X.z + E[3], E[4] * X.x + E[5] * X.y + E[6] * X.z + E[7],
                              E[8] * X.x + E[9] * X.y + E[10] * X.z + E[11]);
-            const float fx = a.intr[v * 4], fy = a.intr[v * 4 + 1], cx = a.intr[v * 4 + 2], cy = a.intr[v * 4 + 3];
+            const float fx = CAM[24 + v * 4], fy = CAM[25 + v * 4], cx = CAM[26 + v * 4], cy = CAM[27 + v * 4];
             const float u = fx * Xc.x / Xc.z + cx, w = fy * Xc.y / Xc.z + cy;
             float du = 0.f, dw = 0.f;
             for (int det = 0; det < 2; ++det) {
-                const float* gt = a.j2d + ((((size_t)v * L + f) * 2 + det) * NJ + lane) * 3;
+                const float* gt = gtv[v][det];
                 const float cf = gt[2] * hipw * inv_n, s2 = a.sigma * a.sigma;
                 const float ex = u - gt[0], ey = w - gt[1];
                 loss2d += cf * (ex * ex / (ex * ex + s2) + ey * ey / (ey * ey + s2));
@@ -310,13 +346,13 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
             // temporal terms on phi and tau: 100 * mean over (selected pairs x dim) of squared differences
             if (a.n_pairs > 0) {
                 const float cp = 2.f * 100.f * a.w_temporal / (6.f * a.n_pairs), ct = 2.f * 100.f * a.w_temporal / (3.f * a.n_pairs);
-                if (f > 0 && a.robust[f - 1] && a.robust[f]) {
-                    for (int e = 0; e < 6; ++e) dph[e] += cp * (ph[e] - ph[e - 6]);
-                    for (int e = 0; e < 3; ++e) dta[e] += ct * (ta[e] - ta[e - 3]);
+                if (pair_prev) {
+                    for (int e = 0; e < 6; ++e) dph[e] += cp * (ph[e] - PT[1][v][e]);
+                    for (int e = 0; e < 3; ++e) dta[e] += ct * (ta[e] - PT[1][v][6 + e]);
                 }
-                if (f + 1 < L && a.robust[f] && a.robust[f + 1]) {
-                    for (int e = 0; e < 6; ++e) dph[e] -= cp * (ph[e + 6] - ph[e]);
-                    for (int e = 0; e < 3; ++e) dta[e] -= ct * (ta[e + 3] - ta[e]);
+                if (pair_next) {
+                    for (int e = 0; e < 6; ++e) dph[e] -= cp * (PT[2][v][e] - ph[e]);
+                    for (int e = 0; e < 3; ++e) dta[e] -= ct * (PT[2][v][6 + e] - ta[e]);
                 }
             }
             for (int e = 0; e < 6; ++e) a.dphi[((size_t)v * L + f) * 6 + e] = dph[e];
@@ -363,14 +399,13 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
         V3 daa = rod_bwd(rd, aav, dRl[lane + 1]);
         if (a.n_pairs > 0) {
             const float ca = 2.f * 10.f * a.w_temporal / (63.f * a.n_pairs);
-            const float* A = a.aa_all + ((size_t)f * NB + lane) * 3;
-            if (f > 0 && a.robust[f - 1] && a.robust[f]) {
-                const V3 dprev = v3(aav.x - A[-NB * 3], aav.y - A[-NB * 3 + 1], aav.z - A[-NB * 3 + 2]);
+            if (pair_prev) {
+                const V3 dprev = v3(aav.x - aprev[0], aav.y - aprev[1], aav.z - aprev[2]);
                 daa = daa + ca * dprev;
                 ltemp += 10.f * a.w_temporal / (63.f * a.n_pairs) * dot(dprev, dprev);     // pair (f-1, f) accounted to frame f
             }
-            if (f + 1 < L && a.robust[f] && a.robust[f + 1])
-                daa = daa - ca * v3(A[NB * 3] - aav.x, A[NB * 3 + 1] - aav.y, A[NB * 3 + 2] - aav.z);
+            if (pair_next)
+                daa = daa - ca * v3(anext[0] - aav.x, anext[1] - aav.y, anext[2] - aav.z);
         }
         float dR[9];
         aa_bwd(q, daa, dR);
@@ -385,15 +420,15 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
     if (lane < 10) {
         float s = 0.f;
         for (int i = 0; i < NJ; ++i)
-            for (int c = 0; c < 3; ++c) s += a.j_shapedirs[(i * 3 + c) * a.jsd_ld + lane] * dJ[i][c];
+            for (int c = 0; c < 3; ++c) s += Sd[i * 3 + c][lane] * dJ[i][c];
         a.dbeta_part[(size_t)f * 10 + lane] = s;
     }
     // ---- loss bookkeeping (reporting only): 2-D | temporal on pose_body | on phi, tau (pairs accounted to frame f)
     float lrig = 0.f;
-    if (lane < 18 && a.n_pairs > 0 && f > 0 && a.robust[f - 1] && a.robust[f]) {
+    if (lane < 18 && pair_prev) {
         const int v = lane / 9, e = lane % 9;
-        if (e < 6) { const float* ph = a.phi + ((size_t)v * L + f) * 6; const float d = ph[e] - ph[e - 6]; lrig = 100.f * a.w_temporal / (6.f * a.n_pairs) * d * d; }
-        else { const float* ta = a.tau + ((size_t)v * L + f) * 3; const float d = ta[e - 6] - ta[e - 9]; lrig = 100.f * a.w_temporal / (3.f * a.n_pairs) * d * d; }
+        const float d = PT[0][v][e] - PT[1][v][e];
+        lrig = 100.f * a.w_temporal / ((e < 6 ? 6.f : 3.f) * a.n_pairs) * d * d;
     }
     const float l2 = wave_sum(loss2d), lt = wave_sum(ltemp), lr = wave_sum(lrig);
     if (lane == 0) { a.loss_part[(size_t)f * 4 + 0] = l2; a.loss_part[(size_t)f * 4 + 1] = lt; a.loss_part[(size_t)f * 4 + 2] = lr; a.loss_part[(size_t)f * 4 + 3] = 0.f; }
@@ -416,7 +451,13 @@ __global__ void fit_adam_kernel(const FitArgs a, int step, int with_z) {
         const int k = i - nz - nphi - ntau;
         p = a.beta + k;
         gr = 0.f;
-        for (int f = 0; f < L; ++f) gr += a.dbeta_part[(size_t)f * 10 + k];
+        for (int f0 = 0; f0 < L; f0 += 16) {                 // loads batched (independent), adds in frame order
+            float pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pv[u] = f0 + u < L ? a.dbeta_part[(size_t)(f0 + u) * 10 + k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gr += pv[u];
+        }
     }
     float m = a.adam_m[i], v = a.adam_v[i];
     m = 0.9f * m + 0.1f * gr;
@@ -572,7 +613,13 @@ __global__ void __launch_bounds__(1024) fit_backprop_adam_kernel(const FitArgs a
     } else if (t < DR * 32 + DR * 18 + 10 && blockIdx.x == 0) {
         const int k = t - DR * 32 - DR * 18;
         i = nz + nphi + ntau + k; p = a.beta + k;
-        for (int f = 0; f < L; ++f) gr += a.dbeta_part[(size_t)f * 10 + k];
+        for (int f0 = 0; f0 < L; f0 += 16) {                 // loads batched (independent), adds in frame order
+            float pv[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) pv[u] = f0 + u < L ? a.dbeta_part[(size_t)(f0 + u) * 10 + k] : 0.f;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) gr += pv[u];
+        }
     }
     if (i >= 0) {
         float m = a.adam_m[i], v = a.adam_v[i];
