@@ -179,6 +179,13 @@ class copenet(nn.Module):
 
     def _ief(self, entry, a0, a1, bb0, bb1, pos0, pos1, th0, th1, sh0, sh1, B, iters, dev):
         bb0, bb1, pos0, pos1 = (N.f32c(t, dev) for t in (bb0, bb1, pos0, pos1))
+        for name, t in (("bb0", bb0), ("bb1", bb1), ("init_position0", pos0), ("init_position1", pos1)):
+            if tuple(t.shape) != (B, 3):                     # torch.cat in forward_reg would raise on these
+                raise RuntimeError("%s must be (%d, 3), got %s" % (name, B, tuple(t.shape)))
+        if a0.shape[0] != B or a1.shape != a0.shape:
+            raise RuntimeError("the two views must hold the same number of samples")
+        if int(iters) < 1:
+            raise RuntimeError("iters must be >= 1 (forward always evaluates the regressor once)")
         th0, th0s = self._bs(N.f32c(th0, dev), B, 132, "init_theta0")
         th1, th1s = self._bs(N.f32c(th1, dev), B, 132, "init_theta1")
         sh0, sh0s = self._bs(N.f32c(sh0, dev), B, 10, "init_shape0")
@@ -209,6 +216,8 @@ class copenet(nn.Module):
         """The IEF loop of forward() from pre-computed trunk features (model_copenet.py:144-157)."""
         self._check_eval()
         dev = self._dev(xf0)
+        if xf0.dim() != 2 or xf0.shape[1] != 2048 or xf1.shape != xf0.shape:
+            raise RuntimeError("forward_ief expects two (B, 2048) feature tensors")
         return self._ief("ap_regressor_fwd", N.f32c(xf0), N.f32c(xf1, dev), bb0, bb1, init_position0, init_position1,
                          init_theta0, init_theta1, init_shape0, init_shape1, xf0.shape[0], iters, dev)
 
@@ -229,6 +238,8 @@ class copenet(nn.Module):
         xf, bb, pose, betas, partner = (N.f32c(t, dev) for t in (xf, bb, pose, betas, partner))
         if partner.shape != (B, 136) or pose.shape != (B, 135) or betas.shape != (B, 10):
             raise RuntimeError("regressor_step: pose (B,135), betas (B,10), partner (B,136)")
+        if xf.shape != (B, 2048) or bb.shape != (B, 3):
+            raise RuntimeError("regressor_step: xf (B,2048), bb (B,3)")
         pose_out = torch.empty(B, 135, device=dev, dtype=torch.float32)
         betas_out = torch.empty(B, 10, device=dev, dtype=torch.float32)
         with self._lock, torch.cuda.device(dev):

@@ -44,6 +44,7 @@ class SMPLX(nn.Module):
             model_data = SM.load_model_npz(p, num_betas, num_expression_coeffs)
         self.batch_size = batch_size
         self.gender = gender
+        self.num_betas, self.num_expression_coeffs = int(num_betas), int(num_expression_coeffs)
         self._md = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in model_data.items()}
         self.faces = self._md["faces"]                                   # ndarray, as upstream
         self.register_buffer("faces_tensor", torch.from_numpy(self._md["faces"].astype(np.int64)))
@@ -132,6 +133,12 @@ class SMPLX(nn.Module):
                                for p, n in zip(parts, sizes)], dim=1).contiguous()
         expression = N.f32c(expression, dev)
         transl = N.f32c(transl, dev)
+        if tuple(betas.shape) != (B, self.num_betas):
+            raise RuntimeError("betas must be (1|B, %d), got %s" % (self.num_betas, tuple(betas.shape)))
+        if expression is not None and tuple(expression.shape) != (B, self.num_expression_coeffs):
+            raise RuntimeError("expression must be (B, %d), got %s" % (self.num_expression_coeffs, tuple(expression.shape)))
+        if transl is not None and tuple(transl.shape) != (B, 3):
+            raise RuntimeError("transl must be (B, 3), got %s" % (tuple(transl.shape),))
         verts = torch.empty(B, self.num_verts, 3, device=dev, dtype=torch.float32)
         with self._lock, torch.cuda.device(dev):
             h = self._native(dev)

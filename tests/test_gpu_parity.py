@@ -686,6 +686,72 @@ def test_errors_are_loud(net32, dev):
     net32.eval()
 
 
+@pytest.mark.parametrize("iters", [1, 2, 5])
+@pytest.mark.parametrize("fuse", [1, 0])
+def test_ief_iteration_counts_and_caller_initialisation(net32, copenet_sd, dev, iters, fuse):
+    """forward(..., iters=k) for k other than 3, with caller-supplied init_theta / init_shape for one view only
+    (model_copenet.py:121-136 accepts either per view), against the oracle's IEF loop."""
+    from oracle import copenet_ref
+    g = torch.Generator().manual_seed(100 + iters)
+    B = 5
+    xf0, xf1 = torch.randn(B, 2048, generator=g), torch.randn(B, 2048, generator=g)
+    bb0, bb1 = torch.rand(B, 3, generator=g), torch.rand(B, 3, generator=g)
+    pos0, pos1 = torch.randn(B, 3, generator=g) * 0.3, torch.randn(B, 3, generator=g) * 0.3
+    theta1 = torch.randn(B, 144, generator=g) * 0.5          # caller-supplied for view 1 only; [:, :132] is used
+    shape0 = torch.randn(B, 10, generator=g) * 0.5           # caller-supplied for view 0 only
+    sd64 = {k: v.double() for k, v in copenet_sd.items() if v.is_floating_point()}
+    want = copenet_ref.ief(sd64, xf0.double(), xf1.double(), bb0.double(), bb1.double(), pos0.double(), pos1.double(),
+                           init_theta1=theta1.double(), init_shape0=shape0.double(), iters=iters)
+    d = lambda t: t.to(dev)
+    net32.set_fuse_ief(fuse)
+    try:
+        got = net32.forward_ief(d(xf0), d(xf1), d(bb0), d(bb1), d(pos0), d(pos1), init_theta1=d(theta1),
+                                init_shape0=d(shape0), iters=iters)
+    finally:
+        net32.set_fuse_ief(1)
+    for a, b in zip(got, want):
+        assert rel_err(a.cpu().numpy(), b.numpy()) < TOL32
+
+
+def test_trunk_across_the_chunk_boundary(netbf, dev):
+    """More images than one depth-first pass takes (512): 515 images run as passes of 512 + 3; every row must equal
+    the row of a small run (bf16 kernels are batch-invariant bit for bit)."""
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(6, 3, 224, 224, generator=g).to(dev)
+    big = torch.cat([x[:3], torch.zeros(509, 3, 224, 224, device=dev), x[3:]])      # rows 0-2 and 512-514 carry data
+    f_big = netbf.forward_feat_ext(big)
+    f_small = netbf.forward_feat_ext(x)
+    assert f_big.shape == (515, 2048)
+    assert torch.equal(f_big[:3], f_small[:3]) and torch.equal(f_big[512:], f_small[3:])
+    assert torch.equal(f_big[3], f_big[511])                 # two all-zero images
+
+
+def test_malformed_inputs_raise(net32, body, dev):
+    """Shape / dtype / device mistakes raise instead of computing on garbage (the reference would raise inside torch)."""
+    z = lambda *s: torch.zeros(*s, device=dev)
+    pos = z(2, 3)
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        net32(z(2, 3, 224, 224), z(3, 3, 224, 224), z(2, 3), z(2, 3), pos, pos)               # view batch mismatch
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        net32(z(2, 3, 224, 224), z(2, 3, 224, 224), z(2, 4), z(2, 3), pos, pos)               # bb is (B, 3)
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        net32(z(2, 3, 224, 224), z(2, 3, 224, 224), z(2, 3), z(2, 3), pos, pos, iters=0)      # at least one evaluation
+    # (other floating dtypes are accepted and converted to float32 on the way in: host-side plumbing)
+    assert net32.forward_feat_ext(torch.zeros(2, 3, 224, 224, device=dev, dtype=torch.float64)).dtype == torch.float32
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        body(betas=z(2, 10), body_pose=z(2, 20, 3, 3), global_orient=z(2, 1, 3, 3), pose2rot=False)   # 21 body joints
+    eye = torch.eye(3, device=dev)
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        body(betas=z(2, 11), body_pose=eye.expand(2, 21, 3, 3), global_orient=eye.expand(2, 1, 3, 3), pose2rot=False)
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        body(betas=z(2, 10), body_pose=eye.expand(2, 21, 3, 3), global_orient=eye.expand(2, 1, 3, 3), transl=z(2, 4),
+             pose2rot=False)
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        net32.forward_ief(z(2, 2047), z(2, 2047), z(2, 3), z(2, 3), pos, pos)
+    with pytest.raises((RuntimeError, ValueError, TypeError)):
+        net32.regressor_step(z(2, 2048), z(2, 2), z(2, 135), z(2, 10), z(2, 136))
+
+
 # ------------------------------------------------------------------------------------------------ AirPose+ fitting loop
 @pytest.fixture(scope="module")
 def fit_problem(smplx_model):
