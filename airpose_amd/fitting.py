@@ -49,7 +49,13 @@ class AirPosePlusFitter:
         j2d, intr, extr = N.f32c(j2d, dev), N.f32c(intr, dev), N.f32c(extr, dev)
         if j2d.shape != (2, L, 2, 24, 3) or intr.shape != (2, 4) or extr.shape != (2, 3, 4):
             raise RuntimeError("j2d (2,L,2,24,3), intr (2,4), extr (2,3,4)")
+        if z.shape != (L, 32) or phi.shape != (2, L, 6) or tau.shape != (2, L, 3) or beta.shape != (10,):
+            raise RuntimeError("state: z (L,32), phi0/phi1 (L,6), tau0/tau1 (L,3), beta (10,)")
         rob = torch.as_tensor(robust).to(torch.int32).cpu().contiguous()
+        if rob.shape != (L,):
+            raise RuntimeError("robust must hold one flag per frame")
+        if L < 1 or n_iters < 1:
+            raise RuntimeError("need at least one frame and one iteration")
         hist = torch.zeros(n_iters, L, 4, device=dev) if want_loss else None
         grad = torch.zeros(L * 32 + 2 * L * 9 + 10, device=dev) if want_grad else None
         with torch.cuda.device(dev):
