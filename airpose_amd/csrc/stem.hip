@@ -169,28 +169,50 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
     constexpr int VBYTES = 2 * SO * SC * 2;
     constexpr int PVBYTES = PBYTES > VBYTES ? PBYTES : VBYTES;
     __shared__ __attribute__((aligned(16))) unsigned char lds[WBYTES + PVBYTES];   // 58 KB: two workgroups per CU
+    __shared__ __attribute__((aligned(16))) float sbn[128];   // BatchNorm scale | shift (read from L2 with the prologue batch)
     bf16_t* wsm = (bf16_t*)lds;
     bf16_t* patch = (bf16_t*)(lds + WBYTES);
     bf16_t* vm = (bf16_t*)(lds + WBYTES);                    // [2][112][64] vertically pooled rows, over the dead patch
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int strip = blockIdx.x, n = blockIdx.y, py0 = strip * 2;
-    {
-        const u32x4* src = (const u32x4*)wpk;
-        u32x4* dst = (u32x4*)wsm;
-        for (int i = tid; i < WBYTES / 16; i += 448) dst[i] = src[i];
-    }
+    // Every global load of the prologue is issued before the first one is consumed (weights: 5 x 16 B per thread from
+    // L2; input strip: 2 x 3 float4 per thread from HBM): as rolled load -> wait -> store loops these were 4 + 2
+    // dependent memory round trips per workgroup, about half of its lifetime.
+    constexpr int WIT = (WBYTES / 16 + 447) / 448, XIT = (FROWS * 56 + 447) / 448;
     const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
     const int iy0 = 4 * py0 - 5;
-    for (int i = tid; i < FROWS * 56; i += 448) {           // (row, 4 pixels): three channel planes -> 4 x [c0 c1 c2 0]
-        const int x4 = i % 56, row = i / 56;
-        const int iy = iy0 + row;
-        float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0, v2 = v0;
-        if ((unsigned)iy < (unsigned)IMG) {
-            const float* src = xin + (size_t)iy * IMG + 4 * x4;
-            v0 = *(const float4*)src;
-            v1 = *(const float4*)(src + (size_t)IMG * IMG);
-            v2 = *(const float4*)(src + (size_t)2 * IMG * IMG);
-        }
+    u32x4 wreg[WIT];
+    float4 xin0[XIT], xin1[XIT], xin2[XIT];
+    const float bnv = tid < 64 ? scale[tid] : shift[tid & 63];
+    // (addresses are clamped instead of predicated: a load inside a divergent branch makes hipcc wait for it at the
+    //  branch's end, which re-serialises the round trips; out-of-range values are zeroed when they are consumed)
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) {
+        const int i = tid + k * 448;
+        wreg[k] = ((const u32x4*)wpk)[i < WBYTES / 16 ? i : WBYTES / 16 - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {                         // (row, 4 pixels) of the three channel planes
+        const int i0 = tid + k * 448, i = i0 < FROWS * 56 ? i0 : FROWS * 56 - 1;
+        const int x4 = i % 56, row = i / 56, iy = iy0 + row, iyc = iy < 0 ? 0 : iy > IMG - 1 ? IMG - 1 : iy;
+        const float* src = xin + (size_t)iyc * IMG + 4 * x4;
+        xin0[k] = *(const float4*)src;
+        xin1[k] = *(const float4*)(src + (size_t)IMG * IMG);
+        xin2[k] = *(const float4*)(src + (size_t)2 * IMG * IMG);
+    }
+    if (tid < 128) sbn[tid] = bnv;
+#pragma unroll
+    for (int k = 0; k < WIT; ++k) {
+        const int i = tid + k * 448;
+        if (i < WBYTES / 16) ((u32x4*)wsm)[i] = wreg[k];
+    }
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {                         // three channel planes -> 4 x [c0 c1 c2 0]
+        const int i = tid + k * 448, x4 = i % 56, row = i / 56;
+        if (i >= FROWS * 56) continue;
+        const bool inside = (unsigned)(iy0 + row) < (unsigned)IMG;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v0 = inside ? xin0[k] : zero4, v1 = inside ? xin1[k] : zero4, v2 = inside ? xin2[k] : zero4;
         uint2* d = (uint2*)(patch + (row * FPW + 4 * x4 + 3) * 4);
         d[0] = make_uint2(pack_bf16x2(v0.x, v1.x), pack_bf16x2(v2.x, 0.f));
         d[1] = make_uint2(pack_bf16x2(v0.y, v1.y), pack_bf16x2(v2.y, 0.f));
@@ -239,7 +261,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
 #pragma unroll
         for (int fn = 0; fn < FNH; ++fn) {
             const int ch = (half * FNH + fn) * 16 + g * 4;
-            const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
+            const float4 sc = *(const float4*)(sbn + ch), sh = *(const float4*)(sbn + 64 + ch);
             float v[5][4];
 #pragma unroll
             for (int fm = 0; fm < 5; ++fm) {
