@@ -221,7 +221,20 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
     const bool rob = a.robust[f] != 0;
     const bool pair_prev = a.n_pairs > 0 && f > 0 && a.robust[f - 1] && rob;
     const bool pair_next = a.n_pairs > 0 && f + 1 < L && rob && a.robust[f + 1];
-    for (int i = lane; i < NJ * 3 * 10; i += 64) Sd[i / 10][i % 10] = a.j_shapedirs[(i / 10) * a.jsd_ld + i % 10];
+    {
+        constexpr int SIT = (NJ * 3 * 10 + 63) / 64;         // 12 loads per lane, all issued before the first LDS write
+        float sv[SIT];
+#pragma unroll
+        for (int k = 0; k < SIT; ++k) {
+            const int i = min(lane + k * 64, NJ * 3 * 10 - 1);
+            sv[k] = a.j_shapedirs[(i / 10) * a.jsd_ld + i % 10];
+        }
+#pragma unroll
+        for (int k = 0; k < SIT; ++k) {
+            const int i = lane + k * 64;
+            if (i < NJ * 3 * 10) Sd[i / 10][i % 10] = sv[k];
+        }
+    }
     if (lane < 54) {                                         // phi | tau of this frame and of its neighbours, both views
         const int which = lane / 18, v = (lane % 18) / 9, e = lane % 9;
         const int ff = which == 0 ? f : which == 1 ? (f > 0 ? f - 1 : f) : (f + 1 < L ? f + 1 : f);

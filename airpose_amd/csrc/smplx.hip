@@ -176,12 +176,26 @@ constexpr int SKIN_MAXJ = 64;
 // thread = vertex, loops over SKIN_BPB bodies whose bone transforms sit in LDS
 template <int KB>
 __global__ void __launch_bounds__(256) smplx_skin_kernel(const SmplxModelDev m, const SmplxFwdArgs a) {
-    __shared__ float As[SKIN_BPB][SKIN_MAXJ * 12];
+    __shared__ __attribute__((aligned(16))) float As[SKIN_BPB][SKIN_MAXJ * 12];
     __shared__ float Ps[SKIN_BPB][16];
     const int b0 = blockIdx.y * SKIN_BPB, nb = min(SKIN_BPB, a.n - b0);
-    for (int i = threadIdx.x; i < nb * m.J * 12; i += 256) {
-        const int bb = i / (m.J * 12), e = i - bb * m.J * 12;
-        As[bb][e] = a.A[(size_t)(b0 + bb) * m.J * 12 + e];
+    {   // the block's bone transforms are one contiguous run of nb * J * 12 floats (48 J bytes per body: 16-byte aligned
+        // for every b0); all of a thread's loads are issued before the first LDS write (a rolled load -> wait -> store
+        // loop is ~20 dependent L2 round trips here)
+        const int n4 = nb * m.J * 3, J12 = m.J * 12;
+        const float4* src = (const float4*)(a.A + (size_t)b0 * J12);
+        constexpr int AIT = (SKIN_BPB * SKIN_MAXJ * 3 + 255) / 256;
+        float4 t4[AIT];
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) { const int i = threadIdx.x + k * 256; t4[k] = src[i < n4 ? i : n4 - 1]; }
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) {
+            const int i = threadIdx.x + k * 256;
+            if (i < n4) {
+                const int f = 4 * i, bb = f / J12, e = f - bb * J12;       // J12 is a multiple of 4: no straddling
+                *(float4*)&As[bb][e] = t4[k];
+            }
+        }
     }
     for (int i = threadIdx.x; i < nb * 16; i += 256) {
         const int bb = i >> 4, e = i & 15;
@@ -202,15 +216,23 @@ __global__ void __launch_bounds__(256) smplx_skin_kernel(const SmplxModelDev m, 
             w[k] = m.skin_w[(size_t)v * KB + k];
         }
     }
+    // running pointers (no 64-bit multiply per body) and the next body's point requested before this one is skinned:
+    // the counters showed 186 VALU instructions per vertex-body and waves parked on memory 61 % of their cycles
+    const float* vp = a.vposed + (size_t)b0 * m.ldv + 3 * (size_t)v;
+    float* dst = a.vertices + ((size_t)b0 * m.V + v) * 3;
+    const size_t dstep = (size_t)m.V * 3;
+    float nx = vp[0], ny = vp[1], nz = vp[2];
     for (int bb = 0; bb < nb; ++bb) {
-        const float* vp = a.vposed + (size_t)(b0 + bb) * m.ldv + 3 * (size_t)v;
+        const float x = nx, y = ny, z = nz;
+        vp += m.ldv;
+        if (bb + 1 < nb) { nx = vp[0]; ny = vp[1]; nz = vp[2]; }
         float o[3];
-        if constexpr (KB > 0) skin_point<KB>(As[bb], idx, w, vp[0], vp[1], vp[2], o);
-        else skin_point_dyn(As[bb], m.skin_idx + (size_t)v * m.K, m.skin_w + (size_t)v * m.K, m.K, vp[0], vp[1], vp[2], o);
+        if constexpr (KB > 0) skin_point<KB>(As[bb], idx, w, x, y, z, o);
+        else skin_point_dyn(As[bb], m.skin_idx + (size_t)v * m.K, m.skin_w + (size_t)v * m.K, m.K, x, y, z, o);
         o[0] += Ps[bb][12]; o[1] += Ps[bb][13]; o[2] += Ps[bb][14];        // + transl (upstream SMPLX.forward)
         if (a.post) apply_post(Ps[bb], o);                                 // transform_smpl
-        float* dst = a.vertices + ((size_t)(b0 + bb) * m.V + v) * 3;
         dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+        dst += dstep;
     }
 }
 
@@ -219,7 +241,15 @@ __global__ void __launch_bounds__(128) smplx_joints_kernel(const SmplxModelDev m
     __shared__ float As[SKIN_MAXJ * 12];
     __shared__ float Ps[16];
     const int b = blockIdx.x, t = threadIdx.x;
-    for (int i = t; i < m.J * 12; i += 128) As[i] = a.A[(size_t)b * m.J * 12 + i];
+    {
+        constexpr int AIT = (SKIN_MAXJ * 12 + 127) / 128;    // all of a thread's loads before its first LDS write
+        const int n = m.J * 12;
+        float av[AIT];
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) av[k] = a.A[(size_t)b * n + min(t + k * 128, n - 1)];
+#pragma unroll
+        for (int k = 0; k < AIT; ++k) if (t + k * 128 < n) As[t + k * 128] = av[k];
+    }
     if (t < 16) {
         float v = 0.f;
         if (t < 12) v = a.post ? a.post[(size_t)b * 12 + t] : ((t == 0 || t == 5 || t == 10) ? 1.f : 0.f);
