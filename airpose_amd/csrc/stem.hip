@@ -361,8 +361,13 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, f
 #pragma unroll
     for (int e = 0; e < EPC; ++e) s[e] = 0.f;
     const T* src = x + (size_t)n * 49 * C + cc * EPC;
-    for (int p = 0; p < 49; ++p) {
-        const uint4 v = *(const uint4*)(src + (size_t)p * C);
+    for (int p0 = 0; p0 < 49; p0 += 7) {                    // 7 loads in flight per thread, summed in pixel order
+      uint4 vv[7];
+#pragma unroll
+      for (int u = 0; u < 7; ++u) vv[u] = *(const uint4*)(src + (size_t)(p0 + u) * C);
+#pragma unroll
+      for (int u = 0; u < 7; ++u) {
+        const uint4 v = vv[u];
         if constexpr (sizeof(T) == 2) {
             float lo, hi;
             unpack_bf16x2(v.x, lo, hi); s[0] += lo; s[1] += hi;
@@ -373,6 +378,7 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, f
             s[0] += __builtin_bit_cast(float, v.x); s[1] += __builtin_bit_cast(float, v.y);
             s[2] += __builtin_bit_cast(float, v.z); s[3] += __builtin_bit_cast(float, v.w);
         }
+      }
     }
     float* dst = y + (size_t)n * C + cc * EPC;
 #pragma unroll
