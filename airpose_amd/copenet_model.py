@@ -105,12 +105,18 @@ class copenet(nn.Module):
 
     # ------------------------------------------------------------------ native handle
     def _signature(self):
-        ver = 0
-        for t in self.parameters():
-            ver += t._version + (id(t) & 0xffff)
-        for t in self.buffers():
-            ver += t._version + (id(t) & 0xffff)
-        return (self.precision, ver)
+        """Cheap change detector for the packed copy: per tensor the autograd version counter, the storage address
+        and the object identity.  It sees in-place ops, load_state_dict, .to() and re-assigned parameters; it CANNOT
+        see a write through ``.data`` / ``.detach()`` into the same storage (``p.data.copy_(w)``, the idiom of the
+        reference's own init, model_copenet.py:74-84) -- call ``repack()`` after such writes."""
+        sig = [self.precision]
+        for t in list(self.parameters()) + list(self.buffers()):
+            sig.append((t._version, t.data_ptr(), id(t)))
+        return hash(tuple(sig))
+
+    def repack(self):
+        """Force the next forward to re-pack every tensor into the native handle (after writes through ``.data``)."""
+        self._packed_sig = None
 
     def _native(self, device):
         """(Re)pack the current parameters into the library when they changed."""
@@ -119,11 +125,15 @@ class copenet(nn.Module):
         if self._handle is not None and sig == self._packed_sig:
             return self._handle
         L = N.lib()
+        if self._handle is not None and getattr(self, "_hdev", device.index) != device.index:
+            # the handle (packed weights, workspace, per-device launch state) belongs to the device of the first call
+            L.ap_net_destroy(self._handle)
+            self._handle = None
         if self._handle is None:
             h = ctypes.c_void_p()
             N.check(L.ap_net_create(ctypes.byref(h), device.index or 0, N.PRECISIONS[self.precision], self.variant),
                     "ap_net_create")
-            self._handle = h
+            self._handle, self._hdev = h, device.index
         for name, t in self.state_dict().items():
             if not t.dtype.is_floating_point:
                 continue                                   # num_batches_tracked

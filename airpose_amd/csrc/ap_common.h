@@ -32,6 +32,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     return start + i;
 }
 
+// hipFuncSetAttribute and the CU count are per DEVICE: launch-side caches are keyed by the current device id
+// (two nets of one process on two GPUs, e.g. copenet_sep, each get their >64 KiB dynamic-LDS opt-in).
+#define AP_MAX_DEVICES 16
+static inline hipError_t ap_current_device(int* dev) {
+    hipError_t e = hipGetDevice(dev);
+    if (e != hipSuccess) return e;
+    return (*dev < 0 || *dev >= AP_MAX_DEVICES) ? hipErrorInvalidDevice : hipSuccess;
+}
+
 // host-side bf16 helpers (weights packing)
 static inline uint16_t host_f32_to_bf16(float f) {
     uint32_t u = __builtin_bit_cast(uint32_t, f);

@@ -1025,6 +1025,9 @@ int ap_net_set_fold(ap_net* h, int on) {
 
 int ap_net_set_chunk(ap_net* h, int images_per_chunk) {
     if (!h || images_per_chunk < 0) return fail(AP_EINVAL, "ap_net_set_chunk: bad argument");
+    // kernels address an activation tensor of one chunk with 32-bit byte offsets in places (folded downsample segment,
+    // fused layer1 bottleneck): 1024 images keep every tensor of the pass below 4 GiB in both storage types
+    if (images_per_chunk > 1024) return fail(AP_EINVAL, "ap_net_set_chunk: at most 1024 images per chunk");
     h->chunk = images_per_chunk;
     return AP_OK;
 }

@@ -771,11 +771,13 @@ __global__ void __launch_bounds__(512) bneck64ds_kernel(const BneckArgs p) {
 }
 
 hipError_t launch_persistent(const BneckArgs& a, bool ds, hipStream_t st) {
-    static int n_cu = 0;
+    static int n_cu_dev[AP_MAX_DEVICES] = {};
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    int& n_cu = n_cu_dev[dev];
     if (!n_cu) {
-        int dev = 0, n = 0;
-        hipError_t e = hipGetDevice(&dev);
-        if (e != hipSuccess) return e;
+        int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)bneck256_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, P_TOTAL);

@@ -246,13 +246,16 @@ constexpr int lds_bytes() {
 
 template <typename T, int BM, int BN, int WM, int WN>
 hipError_t launch_cfg(ConvArgs a, hipStream_t st) {
-    static bool attr_set = false;
+    static bool attr_set[AP_MAX_DEVICES] = {};
     auto kern = conv_igemm_kernel<T, BM, BN, WM, WN>;
     constexpr int lds = lds_bytes<BM, BN>();
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;

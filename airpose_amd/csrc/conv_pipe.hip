@@ -458,16 +458,22 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
 
 template <typename T, int BM, int BN, int WM, int WN, int S, bool DIRECT>
 hipError_t launch_pipe(ConvArgs a, hipStream_t st) {
-    static bool attr_set = false;
+    static bool attr_set[AP_MAX_DEVICES] = {};
     auto kern = conv_pipe_kernel<T, BM, BN, WM, WN, S, DIRECT>;
     constexpr int ring = S * (BM + BN) * 128, epi = BM * (BN + 4) * 4;
     constexpr int lds = ring > epi ? ring : epi;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_set = true;
+        attr_set[dev] = true;
     }
     if (a.x2 && BN < 128) return hipErrorInvalidValue;       // the 64-wide tiles carry no second K segment: refuse, never drop it
+    // the second K segment addresses x2 with 32-bit byte offsets (0xffffffff = "row predicated off"): refuse a tensor
+    // that does not fit instead of wrapping (fp32 at >= 1338 images of layer2.0 would)
+    if (a.x2 && (size_t)a.N * a.H2 * a.W2 * a.ldx2 * sizeof(T) >= 0xffffffffull) return hipErrorInvalidValue;
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(a.mtiles * a.ntiles), dim3(64 * WM * WN), lds, st, a);

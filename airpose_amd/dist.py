@@ -47,18 +47,34 @@ class ViewSplitIEF(object):
         self.step_fn, self.group, self.ranks = step_fn, pair_group, tuple(pair_ranks)
         self.me = self.ranks.index(dist.get_rank())
 
+        self.n_exchanges = 0                                              # collectives issued so far (bench / tests)
+        # RCCL ("nccl") moves device buffers directly over xGMI; gloo (CPU tests, and the 2-process test that shares
+        # one GPU) takes host tensors, so the 544 B/sample message is staged through the host there
+        self._host_staged = dist.get_backend(pair_group) == "gloo"
+
     def exchange(self, pose, betas):
         mine = torch.cat([pose[:, 9:], betas], dim=1).contiguous()        # art_pose | shape
+        dev = mine.device
+        if self._host_staged and mine.is_cuda:
+            mine = mine.cpu()
         both = [torch.empty_like(mine), torch.empty_like(mine)]
         dist.all_gather(both, mine, group=self.group)
-        return both[1 - self.me]
+        self.n_exchanges += 1
+        return both[1 - self.me].to(dev)
 
-    def run(self, xf, bb, init_position, init_theta, init_shape, iters=3):
+    def run(self, xf, bb, init_position, init_theta, init_shape, iters=3, shared_init=True):
+        """shared_init: both ranks were handed the SAME init_theta / init_shape (the model's mean parameters
+        unless the caller supplies state, model_copenet.py:121-136).  The partner's initial [art_pose | shape]
+        is then this rank's own, so iteration 1 needs no exchange: iters - 1 collectives per forward.
+        With per-view caller state (init_theta0 != init_theta1) pass shared_init=False: one more exchange."""
         B = xf.shape[0]
         theta = init_theta[:, :132].expand(B, -1)
         pose = torch.cat([init_position, theta], dim=1).contiguous()
         betas = init_shape.expand(B, -1).contiguous()
-        for _ in range(int(iters)):
-            partner = self.exchange(pose, betas)
+        for it in range(int(iters)):
+            if it == 0 and shared_init:
+                partner = torch.cat([pose[:, 9:], betas], dim=1).contiguous()
+            else:
+                partner = self.exchange(pose, betas)
             pose, betas = self.step_fn(xf, bb, pose, betas, partner)
         return pose, betas

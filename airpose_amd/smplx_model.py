@@ -64,6 +64,18 @@ def make_synthetic_model(seed=4321, num_verts=NUM_VERTS, num_faces=NUM_FACES, ma
                 cand.append(PARENTS[PARENTS[j]])
         if children[j]:
             cand.append(children[j][rs.randint(len(children[j]))])
+        if max_bones > 4:
+            # more relatives (ancestors further up, every child, siblings) so that rows with 5 .. max_bones non-zero
+            # weights exist: these select the K = 8 / dynamic-K skinning kernels.  max_bones <= 4 draws exactly the
+            # random numbers it always did (the default model of the tests and the bench is unchanged).
+            a = cand[2] if len(cand) > 2 and PARENTS[j] >= 0 and PARENTS[PARENTS[j]] >= 0 else -1
+            while a >= 0 and PARENTS[a] >= 0:
+                a = PARENTS[a]
+                cand.append(a)
+            cand += [c for c in children[j] if c not in cand]
+            if PARENTS[j] >= 0:
+                cand += [c for c in children[PARENTS[j]] if c not in cand]
+            cand += [c for c in range(J) if c not in cand][:max(0, max_bones - len(cand))]
         k = rs.randint(1, min(max_bones, len(cand)) + 1)
         cand = cand[:k]
         w = rs.uniform(0.1, 1.0, size=k)
@@ -92,9 +104,20 @@ def load_model_npz(path, num_betas=NUM_BETAS, num_expr=NUM_EXPR):
     """Load a real SMPL-X ``.npz`` (keys as distributed: v_template, f, shapedirs, posedirs,
     J_regressor, kintree_table, weights, lmk_faces_idx, lmk_bary_coords)."""
     d = np.load(path, allow_pickle=True)
-    sd = np.asarray(d["shapedirs"], np.float32)                # (V,3,400): 300 shape + 100 expr
+    sd = np.asarray(d["shapedirs"], np.float32)                # (V,3,400): 300 shape + 100 expr; or (V,3,20): 10 + 10
+    if sd.ndim < 3:
+        sd = sd[:, :, None]
+    if sd.shape[2] < 400:
+        # the 10-shape / 10-expression model file: upstream smplx 0.1.28 (body_models.SMPLX.__init__) takes the
+        # expression directions from columns 10:20 in that case
+        num_betas, num_expr = min(num_betas, 10), min(num_expr, 10)
+        expr = sd[:, :, 10:10 + num_expr]
+    else:
+        expr = sd[:, :, 300:300 + num_expr]
     shape = sd[:, :, :num_betas]
-    expr = sd[:, :, 300:300 + num_expr] if sd.shape[2] > 300 else np.zeros(sd.shape[:2] + (num_expr,), np.float32)
+    if shape.shape[2] != NUM_BETAS or expr.shape[2] != NUM_EXPR:
+        raise ValueError("SMPL-X file %r yields %d shape / %d expression directions; this build packs %d / %d"
+                         % (path, shape.shape[2], expr.shape[2], NUM_BETAS, NUM_EXPR))
     pd = np.asarray(d["posedirs"], np.float32)                 # (V,3,486)
     posedirs = np.reshape(pd, [-1, pd.shape[-1]]).T.copy()     # (486, V*3)
     parents = np.asarray(d["kintree_table"])[0].astype(np.int64).copy()

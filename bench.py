@@ -9,11 +9,17 @@ copenet_twoview forward (ResNet-50 trunk on both views, 3 IEF iterations with cr
 projection, at 256 pairs per GPU in bf16 (BASELINE.json metric: "two-view frames/sec at batch 256").
 Pairs are independent units: every rank owns its own 256 pairs, no data-path collective (weak scaling).
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
   roofline      dominant kernel = the bf16 implicit-GEMM conv (52 launches per trunk chunk); algorithmic
                 FLOPs of those launches / their HIP-event time measured live in the timed region
   cpu_baseline  the CPU oracle (a torch restatement pinned to the reference) timed on this box's host
                 cores on a bounded sample -- a reported baseline, not the target
+  repeat_blocks the K-step block repeated (same fences) after the contract's block: median / min / max pairs/s
+  parity_mode   throughput of the mode that meets the 1e-4 bar + the measured per-slice error of both modes against
+                the CPU oracle on the first pairs of the batch
+  view_split    (N >= 2 ranks) BASELINE config 4: one view per rank, the 136-float partner state exchanged over
+                RCCL pair groups before IEF iterations 2 and 3
+Every `frac` recomputes from `stage_ms_per_step` and the byte / FLOP constants stated next to it.
 """
 import argparse
 import json
@@ -48,6 +54,9 @@ def conv_stack_flops_per_image():
     return 2 * macs
 
 
+TAIL_BYTES_PER_BODY = 129084         # beta 40 + 22 rotmats 792 + t 12 + vertices 125700 + joints 1524 + j2d 1016
+TAIL_CONST_BYTES = 25.5e6            # v_template + shapedirs[:, :, :10] + posedirs[:189] + sparse regressors, once per launch
+BLEND_K_ALGORITHMIC = 10 + 21 * 9    # = 199
 STEM_FLOPS_PER_IMAGE = 2 * 112 * 112 * 64 * 147
 REG_FLOPS_PER_PAIR = 2 * 3 * 2 * (2332 * 1024 + 1024 * 1024 + 1024 * 145)
 
@@ -74,6 +83,7 @@ def cpu_baseline(sd, md, sample_pairs):
     inp = {k: torch.from_numpy(v) for k, v in W.synthetic_inputs(4321, sample_pairs).items()}
     n_all = torch.get_num_threads()
     sweep = {}
+    want = None
     try:
         for n in sorted({t for t in (8, 16, 32, 64, n_all) if t <= n_all}):
             torch.set_num_threads(n)
@@ -81,7 +91,7 @@ def cpu_baseline(sd, md, sample_pairs):
             with torch.no_grad():
                 for i in range(3):                         # 1 warm-up + best of 2
                     t0 = time.perf_counter()
-                    pipeline_ref.infer(sd, md, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], inp["intr0"], inp["intr1"])
+                    want = pipeline_ref.infer(sd, md, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], inp["intr0"], inp["intr1"])
                     dt = time.perf_counter() - t0
                     if i and (best is None or dt < best):
                         best = dt
@@ -89,10 +99,115 @@ def cpu_baseline(sd, md, sample_pairs):
     finally:
         torch.set_num_threads(n_all)
     n_best = max(sweep, key=sweep.get)
-    return {"value": sweep[n_best], "unit": "pairs/s", "cores": n_best, "kind": "port",
-            "sample": "%d pairs (224x224, 3 IEF iterations, SMPL-X tail), fp32 torch CPU oracle, best of 2 after 1 warm-up, "
-                      "best of the thread-count sweep" % sample_pairs,
-            "host_cores": n_all, "threads_sweep_pairs_per_s": {str(k): v for k, v in sorted(sweep.items())}}
+    res = {"value": sweep[n_best], "unit": "pairs/s", "cores": n_best, "kind": "port",
+           "sample": "%d pairs (224x224, 3 IEF iterations, SMPL-X tail), fp32 torch CPU oracle, best of 2 after 1 warm-up, "
+                     "best of the thread-count sweep" % sample_pairs,
+           "host_cores": n_all, "threads_sweep_pairs_per_s": {str(k): v for k, v in sorted(sweep.items())}}
+    return res, inp, want                                  # the sample and the oracle's outputs on it: parity_block's checker
+
+
+def slice_errs(got, want):
+    """max |a-b| / max |b| per semantic slice of the output dict (a pose vector = translation | 6-D rotations)."""
+    import numpy as np
+    out = {}
+    for k in ("pred_pose0", "pred_pose1", "pred_betas0", "pred_betas1", "pred_j3d_cam0", "pred_j3d_cam1",
+              "pred_j2d_cam0", "pred_j2d_cam1", "pred_vertices_cam0", "pred_vertices_cam1"):
+        a, b = got[k].double().numpy(), want[k].double().numpy()
+        parts = {"theta.trans": (a[:, :3], b[:, :3]), "theta.rot6d": (a[:, 3:], b[:, 3:])} if "pose" in k else \
+                {k[5:-1].replace("_cam", ""): (a, b)}
+        for nm, (x, y) in parts.items():
+            e = float(np.abs(x - y).max() / max(np.abs(y).max(), 1e-30))
+            out[nm] = max(out.get(nm, 0.0), e)
+    return out
+
+
+def parity_block(args, sd, body, batch, net_bf, sample, want, dev):
+    """The mode that meets north_star's 1e-4 bar, timed on the same batch after the bf16 loop, and the measured
+    per-slice error of both modes on the CPU-baseline sample (the oracle outputs the cpu_baseline leg produced anyway are
+    the checker; the oracle is not run again here)."""
+    import torch
+    from airpose_amd import copenet_model, pipeline
+    if args.parity_steps <= 0 or args.precision != "bf16":
+        return None
+    net32 = copenet_model.getcopenet(MEAN, precision="fp32").eval()
+    net32.load_state_dict(sd)
+    if args.chunk:
+        net32.set_chunk(args.chunk)
+    pipe32 = pipeline.TwoViewInference(net32, body, iters=3)
+    out = pipe32(batch, want_rotmat=True)                      # warm-up (packs the weights)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.parity_steps):
+        out = pipe32(batch, want_rotmat=True)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    del out
+    res = {"dtype": "fp32", "arithmetic": "fp32 storage, v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain)",
+           "pairs_per_s": args.batch * args.parity_steps / dt, "ms_per_step": 1e3 * dt / args.parity_steps,
+           "steps": args.parity_steps, "bar": 1e-4}
+    if want is not None:
+        gin = {k: v.to(dev) for k, v in sample.items()}
+        got32 = {k: v.float().cpu() for k, v in pipe32(gin, want_rotmat=True).items()}
+        gotbf = {k: v.float().cpu() for k, v in pipeline.TwoViewInference(net_bf, body, iters=3)(gin, want_rotmat=True).items()}
+        e32, ebf = slice_errs(got32, want), slice_errs(gotbf, want)
+        res.update({"max_rel_err": max(e32.values()), "rel_err_by_slice": e32,
+                    "throughput_mode_rel_err_by_slice": ebf, "throughput_mode_max_rel_err": max(ebf.values()),
+                    "checked_pairs": int(sample["im0"].shape[0]),
+                    "error_measure": "max|a-b| / max|b| per semantic slice (translation, 6-D rotations, betas, 3-D "
+                                     "joints, vertices, 2-D projection) vs the fp32 CPU oracle on the cpu_baseline sample"})
+    del pipe32, net32
+    torch.cuda.empty_cache()
+    return res
+
+
+def view_split_block(args, net, batch, dev, rank, world):
+    """BASELINE config 4 on RCCL: ranks (2k, 2k+1) hold view 0 / view 1 of the same B pairs.  One step = the trunk on
+    this rank's view + the IEF loop with the partner's [art_pose | shape] (136 floats per sample) all-gathered on the
+    pair group before iterations 2 and 3 (model_copenet.py:185,192).  Odd world sizes cannot pair up: skipped."""
+    import torch
+    import torch.distributed as dist
+    from airpose_amd import dist as D
+    if world % 2:
+        return None
+    groups = D.make_pair_groups(world)
+    ief = D.ViewSplitIEF(net.regressor_step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
+    v = rank % 2
+    im, bb = batch["im%d" % v], batch["bb%d" % v]
+    B = im.shape[0]
+    pos = torch.tensor([0.0, 0.0, 10.0], device=dev).expand(B, -1).contiguous() * 0.05
+    th, sh = net.init_pose.to(dev), net.init_shape.to(dev)
+
+    def vstep():
+        return ief.run(net.forward_feat_ext(im), bb, pos, th, sh, iters=3)
+
+    def fence():
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(2):
+        vstep()
+    n0 = ief.n_exchanges
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        vstep()
+    fence()
+    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    n_ex = (ief.n_exchanges - n0) // args.steps
+    pose, betas = vstep()
+    fence()
+    t1 = time.perf_counter()
+    for _ in range(50):
+        ief.exchange(pose, betas)
+    fence()
+    tx = torch.tensor([(time.perf_counter() - t1) / 50], device=dev, dtype=torch.float64)
+    dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+    return {"pairs_per_s": (world // 2) * B * args.steps / float(t.item()), "ms_per_step": 1e3 * float(t.item()) / args.steps,
+            "exchange_us": 1e6 * float(tx.item()), "n_exchanges": n_ex, "bytes_per_exchange": B * 136 * 4,
+            "topology": "%d pair groups of 2 ranks, one view per rank, %d pairs per group" % (world // 2, B),
+            "collective": "2-rank all_gather on RCCL (torch.distributed backend nccl)"}
 
 
 def main():
@@ -107,6 +222,8 @@ def main():
     ap.add_argument("--no-tail", action="store_true", help="time the network only (BASELINE config 2 shape)")
     ap.add_argument("--stage-steps", type=int, default=5, help="extra untimed steps with per-stage HIP events")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test aid)")
+    ap.add_argument("--repeat-blocks", type=int, default=4, help="extra K-step blocks after the contract's one (spread)")
+    ap.add_argument("--parity-steps", type=int, default=3, help="steps of the parity-grade mode after the main loop (0 = skip)")
     args = ap.parse_args()
 
     import torch
@@ -169,6 +286,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = net.timing(reset=True)
+    # the same block again, a few times: spread of the headline inside one process (the contract's `value` stays the
+    # first block; the timed region of 20 steps is only ~0.14 s)
+    blocks = [world * B * args.steps / elapsed]
+    for _ in range(max(args.repeat_blocks, 0)):
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            out = step()
+        fence()
+        dt = time.perf_counter() - t1
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        blocks.append(world * B * args.steps / dt)
+    net.timing(reset=True)
     # stage breakdown: a few more steps, fully instrumented, outside the timed region
     net.enable_timing(1)
     if not args.no_tail:
@@ -181,6 +314,11 @@ def main():
     tb = body.timing(reset=True) if not args.no_tail else None
     net.enable_timing(0)
     del out
+    cpu, sample, want = (None, None, None)
+    if rank == 0 and world == 1 and args.cpu_sample > 0:
+        cpu, sample, want = cpu_baseline(sd, md, args.cpu_sample)
+    parity = parity_block(args, sd, body, batch, net, sample, want, dev) if (rank == 0 and world == 1 and not args.no_tail) else None
+    vs = view_split_block(args, net, batch, dev, rank, world) if world >= 2 else None
 
     if rank == 0:
         n_img = 2 * B
@@ -192,7 +330,7 @@ def main():
         peak = PEAK_BF16_DENSE_TFLOPS if args.precision == "bf16" else PEAK_FP32_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
         res = {
-            "metric": "two-view frames/sec at batch 256 (224x224)",
+            "metric": "two-view frames/sec at batch %d (224x224)" % B,
             "value": world * B * args.steps / elapsed,
             "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -220,20 +358,38 @@ def main():
             "path_tflops": (conv_flops_step + STEM_FLOPS_PER_IMAGE * n_img + REG_FLOPS_PER_PAIR * B) * args.steps
                            / elapsed / 1e12,
         }
+        srt = sorted(blocks)
+        res["repeat_blocks"] = {"n": len(blocks), "steps_each": args.steps, "median": srt[len(srt) // 2], "min": srt[0],
+                                "max": srt[-1], "unit": "pairs/s", "note": "block 0 is `value`"}
         if tb is not None:
             p = max(tb["passes"], 1)
-            tail_ms = (tb["prep_ms"] + tb["skin_ms"] + tb["joints_ms"]) / p
-            tail_bytes = n_img * 129084 + 25.5e6
-            res["stage_ms_per_step"].update({"smplx_prep": tb["prep_ms"] / p, "smplx_blend_gemm": tb["blend_gemm_ms"] / p,
-                                             "smplx_skin": tb["skin_ms"] / p, "smplx_joints": tb["joints_ms"] / p})
+            st = {"smplx_prep": tb["prep_ms"] / p, "smplx_blend_gemm": tb["blend_gemm_ms"] / p,
+                  "smplx_skin": tb["skin_ms"] / p, "smplx_joints": tb["joints_ms"] / p}
+            res["stage_ms_per_step"].update(st)
+            # the WHOLE tail (prep + blend-shape contraction + skinning + joints/projection: every kernel that
+            # touches the bytes below) against 129 084 B per body + 25.5 MB of model constants per launch
+            tail_ms = sum(st.values())
+            tail_bytes = n_img * TAIL_BYTES_PER_BODY + TAIL_CONST_BYTES
             res["smplx_tail_roofline"] = {"bound": "hbm", "achieved": tail_bytes / (tail_ms * 1e-3) / 1e9,
                                           "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                                          "frac": tail_bytes / (tail_ms * 1e-3) / 1e9 / PEAK_HBM_GBS}
-            gemm_flops = 2.0 * 224 * 31425 * n_img
-            res["smplx_blend_roofline"] = {"bound": "mfma-fp32", "achieved": gemm_flops / (tb["blend_gemm_ms"] / p * 1e-3) / 1e12,
-                                           "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s"}
-        if world == 1 and args.cpu_sample > 0:
-            res["cpu_baseline"] = cpu_baseline(sd, md, args.cpu_sample)
+                                          "frac": tail_bytes / (tail_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
+                                          "bytes": tail_bytes, "ms": tail_ms,
+                                          "kernels": "smplx_prep + smplx_blend_gemm + smplx_skin + smplx_joints "
+                                                     "(sum of their stage_ms_per_step)",
+                                          "formula": "n_bodies * 129084 B + 25.5e6 B, n_bodies = 2 * pairs"}
+            # algorithmic contraction length: 10 shape + 21 body joints x 9 pose-feature entries, not the
+            # zero-padded operand width the kernel runs
+            gemm_flops = 2.0 * BLEND_K_ALGORITHMIC * 31425 * n_img
+            res["smplx_blend_roofline"] = {"bound": "mfma-fp32", "achieved": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12,
+                                           "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
+                                           "frac": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
+                                           "flops": gemm_flops, "formula": "2 * 199 * 31425 * n_bodies"}
+        if parity is not None:
+            res["parity_mode"] = parity
+        if vs is not None:
+            res["view_split"] = vs
+        if cpu is not None:
+            res["cpu_baseline"] = cpu
         print(json.dumps(res))
     if use_dist:
         dist.barrier()

@@ -17,10 +17,33 @@ def pytest_configure(config):
 
 
 def rel_err(a, b):
-    """max |a-b| / max |b|  (per-tensor normalised max error; the 1e-4 bar of north_star is on this)."""
+    """max |a-b| / max |b| over ONE semantic tensor (all entries of the same physical kind and scale).
+    Do not pass a pred_pose (B,135) whole: its un-scaled translation (z ~ 10) would set the denominator for the
+    O(1) 6-D rotation entries -- use pose_rel_errs, which normalises translation and rotation separately."""
     a = np.asarray(a, np.float64)
     b = np.asarray(b, np.float64)
     return float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+def pose_rel_errs(a, b):
+    """rel_err of a pose vector (..,135) per semantic slice: translation [:3] and the 132 6-D rotation entries [3:]."""
+    a, b = np.asarray(a), np.asarray(b)
+    return {"trans": rel_err(a[..., :3], b[..., :3]), "rot6d": rel_err(a[..., 3:], b[..., 3:])}
+
+
+def elem_err(a, b, atol):
+    """element-wise max |a-b| / (atol + |b|): the like-for-like form of a '1e-4 relative' bar (atol = the scale below
+    which an entry counts as zero, e.g. 1e-2 for O(1) rotation entries)."""
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float((np.abs(a - b) / (atol + np.abs(b))).max())
+
+
+def key_errs(name, a, b):
+    """per-slice errors of one output-dict entry: pose tensors are split, everything else is one slice"""
+    if name.startswith("pred_pose") or name.startswith("pose"):
+        return {name + "." + k: v for k, v in pose_rel_errs(a, b).items()}
+    return {name: rel_err(a, b)}
 
 
 @pytest.fixture(scope="session")

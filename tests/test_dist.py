@@ -66,9 +66,19 @@ def _worker(rank, world, port, out_dir):
     ief = D.ViewSplitIEF(step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
     with torch.no_grad():
         pose, betas = ief.run(xf[rank], bb[rank], pos[rank], sd["init_pose"], sd["init_shape"], iters=3)
+        assert ief.n_exchanges == 2            # both views start from the model's mean state: none before iteration 1
         want = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], iters=3)
+        # caller-supplied per-view initial state (model_copenet.py:121-136): the first exchange is needed
+        th = [torch.randn(B, 132, generator=g) * 0.3, torch.randn(B, 132, generator=g) * 0.3]
+        sh = [torch.randn(B, 10, generator=g) * 0.3, torch.randn(B, 10, generator=g) * 0.3]
+        pose_c, betas_c = ief.run(xf[rank], bb[rank], pos[rank], th[rank], sh[rank], iters=2, shared_init=False)
+        assert ief.n_exchanges == 4
+        want_c = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], init_theta0=th[0], init_theta1=th[1],
+                                 init_shape0=sh[0], init_shape1=sh[1], iters=2)
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), pose=pose.numpy(), betas=betas.numpy(),
-             want_pose=want[2 * rank].numpy(), want_betas=want[2 * rank + 1].numpy())
+             want_pose=want[2 * rank].numpy(), want_betas=want[2 * rank + 1].numpy(),
+             pose_c=pose_c.numpy(), betas_c=betas_c.numpy(),
+             want_pose_c=want_c[2 * rank].numpy(), want_betas_c=want_c[2 * rank + 1].numpy())
     # default sharding: no collective on the data path -- only the bench's barrier / max-reduce
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -84,3 +94,5 @@ def test_view_split_ief_matches_two_view_oracle(tmp_path):
         d = np.load(str(tmp_path / ("r%d.npz" % r)))
         assert np.allclose(d["pose"], d["want_pose"], rtol=0, atol=2e-6)
         assert np.allclose(d["betas"], d["want_betas"], rtol=0, atol=2e-6)
+        assert np.allclose(d["pose_c"], d["want_pose_c"], rtol=0, atol=2e-6)
+        assert np.allclose(d["betas_c"], d["want_betas_c"], rtol=0, atol=2e-6)

@@ -13,12 +13,19 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import MEAN_PARAMS, rel_err
+from conftest import MEAN_PARAMS, elem_err, key_errs, pose_rel_errs, rel_err
 
 pytestmark = pytest.mark.gpu
 
 TOL32 = 1e-4
 TOLBF = 5e-2
+
+
+def pose_err(a, b):
+    """worst per-slice error of a pose vector (translation and 6-D rotation normalised separately)"""
+    a = a.detach().cpu().numpy() if hasattr(a, "detach") else a
+    b = b.detach().cpu().numpy() if hasattr(b, "detach") else b
+    return max(pose_rel_errs(a, b).values())
 
 
 @pytest.fixture(scope="module")
@@ -351,7 +358,7 @@ def test_ief_fp32_matches_golden(golden, net32, copenet_inputs, dev, fold):
     p0, b0, p1, b1 = net32.forward_ief(t("xf0"), t("xf1"), copenet_inputs["bb0"].to(dev), copenet_inputs["bb1"].to(dev),
                                        pos, pos, init_theta0=t("ci_theta0"), init_theta1=t("ci_theta1"),
                                        init_shape0=t("ci_shape0"), init_shape1=t("ci_shape1"), iters=2)
-    assert rel_err(p0.cpu().numpy(), g["ci_pose0"]) < TOL32 and rel_err(p1.cpu().numpy(), g["ci_pose1"]) < TOL32
+    assert pose_err(p0, g["ci_pose0"]) < TOL32 and pose_err(p1, g["ci_pose1"]) < TOL32
     assert rel_err(b0.cpu().numpy(), g["ci_betas0"]) < TOL32 and rel_err(b1.cpu().numpy(), g["ci_betas1"]) < TOL32
     net32.set_fold(1)
 
@@ -378,8 +385,8 @@ def test_forward_fp32_matches_golden(golden, net32, copenet_inputs, dev):
     gin = {k: v.to(dev) for k, v in copenet_inputs.items()}
     pos = torch.from_numpy(g["init_position"]).to(dev)
     p0, b0, p1, b1 = net32(gin["im0"], gin["im1"], gin["bb0"], gin["bb1"], pos, pos, iters=3)
-    errs = [rel_err(p0.cpu().numpy(), g["pose0_it3"]), rel_err(b0.cpu().numpy(), g["betas0_it3"]),
-            rel_err(p1.cpu().numpy(), g["pose1_it3"]), rel_err(b1.cpu().numpy(), g["betas1_it3"])]
+    errs = [pose_err(p0, g["pose0_it3"]), rel_err(b0.cpu().numpy(), g["betas0_it3"]),
+            pose_err(p1, g["pose1_it3"]), rel_err(b1.cpu().numpy(), g["betas1_it3"])]
     print("forward fp32 rel errs", errs)
     assert max(errs) < TOL32
 
@@ -389,9 +396,10 @@ def test_forward_bf16_tolerance(golden, netbf, copenet_inputs, dev):
     gin = {k: v.to(dev) for k, v in copenet_inputs.items()}
     pos = torch.from_numpy(g["init_position"]).to(dev)
     p0, b0, p1, b1 = netbf(gin["im0"], gin["im1"], gin["bb0"], gin["bb1"], pos, pos, iters=3)
-    errs = [rel_err(p0.cpu().numpy(), g["pose0_it3"]), rel_err(b1.cpu().numpy(), g["betas1_it3"])]
-    print("forward bf16 rel errs", errs)
-    assert max(errs) < TOLBF
+    slices = dict(pose_rel_errs(p0.cpu().numpy(), g["pose0_it3"]), betas=rel_err(b1.cpu().numpy(), g["betas1_it3"]))
+    slices["rot6d_elementwise(atol 1e-2)"] = elem_err(p0[:, 3:].cpu().numpy(), g["pose0_it3"][:, 3:], 1e-2)
+    print("forward bf16 per-slice rel errs", slices)
+    assert max(slices["trans"], slices["rot6d"], slices["betas"]) < TOLBF
 
 
 def test_view_swap_symmetry_and_zero_decoder(net32, copenet_sd, dev):
@@ -422,11 +430,11 @@ def test_forward_reg_and_step_match_oracle(net32, copenet_sd, dev):
     got = net32.forward_reg(d(xf0), d(xf1), d(bb0), d(bb1), d(pose0[:, :3]), d(pose1[:, :3]), d(pose0[:, 3:9]),
                             d(pose1[:, 3:9]), d(pose0[:, 9:]), d(pose1[:, 9:]), d(s0), d(s1))
     for g_, w_ in zip(got, want):
-        assert rel_err(g_.cpu().numpy(), w_.numpy()) < TOL32
+        assert (pose_err(g_, w_) if g_.shape[1] == 135 else rel_err(g_.cpu().numpy(), w_.numpy())) < TOL32
     # single-view step with the partner state supplied by the caller == the same numbers
     partner0 = torch.cat([pose1[:, 9:], s1], 1)
     p, s = net32.regressor_step(d(xf0), d(bb0), d(pose0), d(s0), d(partner0))
-    assert rel_err(p.cpu().numpy(), want[0].numpy()) < TOL32 and rel_err(s.cpu().numpy(), want[1].numpy()) < TOL32
+    assert pose_err(p, want[0]) < TOL32 and rel_err(s.cpu().numpy(), want[1].numpy()) < TOL32
 
 
 # ------------------------------------------------------------------------------------------------ SMPL-X + geometry
@@ -511,12 +519,12 @@ def test_singleview_on_gpu_matches_reference(golden, dev):
     inp = W.synthetic_inputs(int(g["inputs_seed"]), 1)
     pos = torch.from_numpy(g["init_position"]).to(dev)
     pose, betas = net(torch.from_numpy(inp["im0"]).to(dev), torch.from_numpy(inp["bb0"]).to(dev), pos, iters=3)
-    assert rel_err(pose.cpu().numpy(), g["pose"]) < TOL32 and rel_err(betas.cpu().numpy(), g["betas"]) < TOL32
+    assert pose_err(pose, g["pose"]) < TOL32 and rel_err(betas.cpu().numpy(), g["betas"]) < TOL32
     netb = copenet_singleview_model.getcopenet(MEAN_PARAMS, precision="bf16").eval()
     netb.load_state_dict(sd)
     netb.to(dev)
     pose_b, _ = netb(torch.from_numpy(inp["im0"]).to(dev), torch.from_numpy(inp["bb0"]).to(dev), pos, iters=3)
-    assert rel_err(pose_b.cpu().numpy(), g["pose"]) < TOLBF
+    assert pose_err(pose_b, g["pose"]) < TOLBF
     with pytest.raises(RuntimeError):      # a two-view entry point on a single-view handle is an error, not a fallback
         netb.forward_feat_ext(torch.zeros(1, 3, 224, 224, device=dev)) and None
         from airpose_amd import _native as Nn
@@ -613,9 +621,9 @@ def test_whole_pipeline_fp32_matches_oracle(net32, body, copenet_sd, copenet_inp
                                   inp["intr0"], inp["intr1"])
     got = pipeline.TwoViewInference(net32, body)({k: v.to(dev) for k, v in inp.items()}, want_angles=True)
     for k in sorted(want):
-        e = rel_err(got[k].cpu().numpy(), want[k].numpy())
-        print("%-22s rel err %.3e" % (k, e))
-        assert e < TOL32, k
+        for nm, e in key_errs(k, got[k].cpu().numpy(), want[k].numpy()).items():
+            print("%-28s rel err %.3e" % (nm, e))
+            assert e < TOL32, nm
 
 
 def test_full_size_properties_bf16(netbf, body, dev):
@@ -643,7 +651,7 @@ def test_full_size_properties_bf16(netbf, body, dev):
     assert torch.equal(out["pred_j3d_cam0"], swp["pred_j3d_cam1"])
     two = pipe({"im0": d(im0[:2]), "im1": d(im1[:2]), "bb0": d(bb0[:2]), "bb1": d(bb1[:2]), "intr0": d(intr[:2]),
                 "intr1": d(intr[:2])})
-    assert rel_err(two["pred_pose0"].cpu().numpy(), out["pred_pose0"][:2].cpu().numpy()) < 1e-6
+    assert pose_err(two["pred_pose0"], out["pred_pose0"][:2]) < 1e-6
     assert rel_err(two["pred_vertices_cam1"].cpu().numpy(), out["pred_vertices_cam1"][:2].cpu().numpy()) < 1e-6
     # the persistent fused layer1 kernels at full size (512 images = 32 tiles per workgroup, hand-counted waits under
     # full memory load) against the separate-convolution path: bit-identical, on repeated runs
@@ -797,3 +805,105 @@ def test_fitting_trajectory_follows_oracle(fit_problem, body, smplx_model, dev):
         print("after 40 steps %-5s rel err %.3e" % (k, e))
         assert e < 5e-3, k
     assert hist[-1, :3].sum().item() < hist[0, :3].sum().item()
+
+
+# ------------------------------------------------------------------------------------------------ K > 4 bones per vertex
+@pytest.mark.parametrize("max_bones", [6, 9])
+def test_smplx_more_than_four_bones_per_vertex(max_bones, dev):
+    """A real SMPL-X weight matrix may carry more than 4 non-zeros per vertex: max_bones = 6 selects
+    smplx_skin_kernel<8>, max_bones = 9 the dynamic-K instantiation (api.hip picks K from the packed model).
+    Both the plain SMPLX.forward and the fused pose6d -> LBS -> transform -> projection entry are checked."""
+    from airpose_amd import smplx, smplx_model as SM
+    from oracle import geometry_ref, smplx_ref
+    md = SM.make_synthetic_model(4321, max_bones=max_bones)
+    assert (md["lbs_weights"] != 0).sum(1).max() == max_bones
+    b = smplx.SMPLX(model_data=md).to(dev)
+    gen = torch.Generator().manual_seed(40 + max_bones)
+    B = 3
+    betas = torch.randn(B, 10, generator=gen)
+    bp = _rand_rot(B * 21, gen).view(B, 21, 3, 3)
+    go = _rand_rot(B, gen).view(B, 1, 3, 3)
+    tr = torch.randn(B, 3, generator=gen)
+    lh = _rand_rot(B * 15, gen).view(B, 15, 3, 3)
+    want_v, want_j = smplx_ref.smplx_forward(md, betas, bp, global_orient=go, transl=tr, left_hand_pose=lh)
+    out = b.forward(betas=betas.to(dev), body_pose=bp.to(dev), global_orient=go.to(dev), transl=tr.to(dev),
+                    left_hand_pose=lh.to(dev), pose2rot=False)
+    ev, ej = rel_err(out.vertices.cpu().numpy(), want_v.numpy()), rel_err(out.joints.cpu().numpy(), want_j.numpy())
+    print("K=%d smplx rel err verts %.3e joints %.3e" % (max_bones, ev, ej))
+    assert ev < TOL32 and ej < TOL32
+    # fused entry (the caller slice of copenet_twoview.py:222-223,237-246,307-311)
+    pose = torch.randn(B, 135, generator=gen)
+    pose[:, 2] += 10.0
+    cc = torch.tensor([[960.0, 540.0]]).expand(B, 2).contiguous()
+    R = geometry_ref.rot6d_to_rotmat(pose[:, 3:].reshape(-1, 6)).view(B, 22, 3, 3)
+    v, j = smplx_ref.smplx_forward(md, betas, R[:, 1:], global_orient=torch.eye(3).expand(B, 1, 3, 3),
+                                   transl=torch.zeros(B, 3))
+    want_vc = torch.einsum("bij,bvj->bvi", R[:, 0], v) + pose[:, None, :3]
+    want_jc = torch.einsum("bij,bvj->bvi", R[:, 0], j) + pose[:, None, :3]
+    want_2d = geometry_ref.perspective_projection(want_jc, torch.eye(3).expand(B, 3, 3), torch.zeros(B, 3),
+                                                  [1475.0, 1475.0], cc.unsqueeze(0))
+    o = b.forward_fused(pose.to(dev), betas.to(dev), cc.to(dev))
+    for nm, got, want in (("vertices_cam", o["vertices_cam"], want_vc), ("j3d_cam", o["j3d_cam"], want_jc),
+                          ("j2d_cam", o["j2d_cam"], want_2d)):
+        e = rel_err(got.cpu().numpy(), want.numpy())
+        print("K=%d fused %s rel err %.3e" % (max_bones, nm, e))
+        assert e < TOL32, nm
+
+
+# ------------------------------------------------------------------------------------------------ BASELINE config 4
+def _view_split_worker(rank, world, port, out_dir):
+    """One rank of the view-split topology (view `rank` of every pair) on the ONE leased GPU: 2-rank gloo group,
+    host-staged all_gather of the 136-float partner state, the real ap_regressor_step on cuda:0."""
+    import os
+    import sys
+    from conftest import MEAN_PARAMS as MP, REPO
+    sys.path.insert(0, REPO)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from airpose_amd import copenet_model, dist as D
+    from airpose_amd import weights as W
+    g = np.load(os.path.join(REPO, "tests", "golden", "copenet_b2.npz"))
+    d = torch.device("cuda", 0)
+    sd = W.to_torch(W.copenet_state_dict(int(g["weights_seed"]), MP))
+    net = copenet_model.getcopenet(MP, precision="fp32").eval()
+    net.load_state_dict(sd)
+    inp = W.synthetic_inputs(int(g["inputs_seed"]), int(g["batch"]))
+    im = torch.from_numpy(inp["im%d" % rank]).to(d)
+    bb = torch.from_numpy(inp["bb%d" % rank]).to(d)
+    pos = torch.from_numpy(g["init_position"]).to(d)
+    xf = net.forward_feat_ext(im)                               # this rank's view only
+    groups = D.make_pair_groups(world)
+    ief = D.ViewSplitIEF(net.regressor_step, groups[0], (0, 1))
+    pose, betas = ief.run(xf, bb, pos, sd["init_pose"].to(d), sd["init_shape"].to(d), iters=3)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, "vs%d.npz" % rank), pose=pose.cpu().numpy(), betas=betas.cpu().numpy(),
+             xf=xf.cpu().numpy(), n_exchanges=ief.n_exchanges)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_view_split_two_processes_on_one_gpu_match_golden(golden, net32, copenet_inputs, dev, tmp_path):
+    """BASELINE config 4 / SURVEY 8e at what a 1-GPU lease can reach: the two views of every pair live in two
+    PROCESSES (ranks 0, 1; both on cuda:0), each runs the trunk on its own view and the IEF loop through
+    dist.ViewSplitIEF with the real ap_regressor_step, exchanging [art_pose | shape] before iterations 2 and 3.
+    Result = the single-process forward (golden `copenet_b2`, made by the imported reference)."""
+    import torch.multiprocessing as mp
+    from test_dist import _free_port
+    world, port = 2, _free_port()
+    mp.spawn(_view_split_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    g = golden["copenet_b2"]
+    gin = {k: v.to(dev) for k, v in copenet_inputs.items()}
+    pos = torch.from_numpy(g["init_position"]).to(dev)
+    xf = [net32.forward_feat_ext(gin["im0"]), net32.forward_feat_ext(gin["im1"])]
+    one = net32.forward_ief(xf[0], xf[1], gin["bb0"], gin["bb1"], pos, pos, iters=3)
+    for r in range(world):
+        d = np.load(str(tmp_path / ("vs%d.npz" % r)))
+        assert int(d["n_exchanges"]) == 2
+        assert np.array_equal(d["xf"], xf[r].cpu().numpy())                      # same trunk kernels, same bits
+        ep = pose_err(d["pose"], g["pose%d_it3" % r])
+        eb = rel_err(d["betas"], g["betas%d_it3" % r])
+        print("view-split rank %d vs golden: pose %.3e betas %.3e" % (r, ep, eb))
+        assert ep < TOL32 and eb < TOL32
+        # and against the fused single-process IEF on the same GPU (different kernels: step chain vs fused loop)
+        assert pose_err(d["pose"], one[2 * r]) < 1e-5 and rel_err(d["betas"], one[2 * r + 1].cpu().numpy()) < 1e-5

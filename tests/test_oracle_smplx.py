@@ -1,6 +1,7 @@
 """Known-answer tests for the SMPL-X oracle (the only pin available: the upstream submodule and
 model files are absent from the reference checkout — PARITY UNPINNED).  CPU only."""
 import numpy as np
+import pytest
 import torch
 
 from airpose_amd import smplx_model as SM
@@ -95,3 +96,69 @@ def test_sparse_skin_weights_roundtrip(smplx_model):
     assert np.array_equal(dense, smplx_model["lbs_weights"])
     nz = w != 0
     assert (np.diff(np.where(nz, idx, 1000), axis=1) >= 0).all()    # ascending bone order, padding last
+
+
+# ------------------------------------------------------------------------------------------------ model-file loader
+def _write_upstream_npz(path, md, wide):
+    """An npz in the key layout of the distributed SMPLX_{GENDER}.npz (upstream smplx 0.1.28 reads exactly these keys):
+    posedirs (V,3,486), shapedirs (V,3,400) = 300 shape + 100 expression  (or (V,3,20) = 10 + 10 for the small file),
+    kintree_table (2,J) with the root's parent stored as a large unsigned value."""
+    V = md["v_template"].shape[0]
+    rs = np.random.RandomState(5)
+    if wide:
+        sd = (rs.standard_normal((V, 3, 400)) * 0.01).astype(np.float32)
+        sd[:, :, :10] = md["shapedirs"][:, :, :10]
+        sd[:, :, 300:310] = md["shapedirs"][:, :, 10:]
+    else:
+        sd = md["shapedirs"].copy()
+    kt = np.stack([md["parents"].copy(), np.arange(55)]).astype(np.int64)
+    kt[0, 0] = 4294967295
+    np.savez(path, v_template=md["v_template"], f=md["faces"].astype(np.uint32), shapedirs=sd,
+             posedirs=md["posedirs"].T.reshape(V, 3, 486).copy(), J_regressor=md["J_regressor"],
+             kintree_table=kt, weights=md["lbs_weights"], lmk_faces_idx=md["lmk_faces_idx"].astype(np.int32),
+             lmk_bary_coords=md["lmk_bary_coords"].astype(np.float64))
+
+
+@pytest.mark.parametrize("wide", [True, False])
+def test_load_model_npz_round_trip(tmp_path, wide):
+    """load_model_npz is the only route to a real SMPL-X file: an npz written in the upstream key layout must come
+    back as the dict it was made from (both the 400-column and the 10+10-column shapedirs files; in the small file
+    the expression directions are columns 10:20, as upstream's SMPLX.__init__ takes them)."""
+    from airpose_amd import smplx_model as SM
+    from oracle import smplx_ref
+    md = SM.make_synthetic_model(99, num_verts=64, num_faces=40, max_bones=6)
+    p = str(tmp_path / "SMPLX_NEUTRAL.npz")
+    _write_upstream_npz(p, md, wide)
+    assert SM.find_model(str(tmp_path), "neutral") == p and SM.find_model(p) == p
+    got = SM.load_model_npz(p)
+    for k in ("v_template", "shapedirs", "posedirs", "J_regressor", "parents", "lbs_weights", "faces", "lmk_faces_idx",
+              "lmk_bary_coords"):
+        assert got[k].shape == md[k].shape, k
+        assert np.array_equal(got[k], md[k].astype(got[k].dtype)), k
+    assert got["parents"][0] == -1 and got["synthetic"] is False
+    # expression inputs must act through the loaded file exactly as through the source dict
+    got["extra_joint_verts"] = md["extra_joint_verts"]        # (the 64-vertex toy has no vertex 9120)
+    gen = torch.Generator().manual_seed(3)
+    betas, expr = torch.randn(2, 10, generator=gen), torch.randn(2, 10, generator=gen)
+    bp = torch.eye(3).expand(2, 21, 3, 3)
+    v0, j0 = smplx_ref.smplx_forward(md, betas, bp, expression=expr)
+    v1, j1 = smplx_ref.smplx_forward(got, betas, bp, expression=expr)
+    assert torch.equal(v0, v1) and torch.equal(j0, j1)
+    vz, _ = smplx_ref.smplx_forward(got, betas, bp)
+    assert (v1 - vz).abs().max() > 1e-3                        # ... and they do act
+
+
+def test_sparse_skin_weights_keep_every_bone():
+    """K = max non-zeros per row (>= 4): rows with 5..9 bones must survive the top-K packing un-truncated."""
+    from airpose_amd import smplx_model as SM
+    for mb in (4, 6, 9):
+        md = SM.make_synthetic_model(7, num_verts=300, num_faces=60, max_bones=mb)
+        W = md["lbs_weights"]
+        idx, w = SM.sparse_skin_weights(W)
+        assert idx.shape[1] == max(mb, 4) and (W != 0).sum(1).max() == mb
+        dense = np.zeros_like(W)
+        for k in range(idx.shape[1]):
+            np.add.at(dense, (np.arange(W.shape[0]), idx[:, k]), w[:, k])
+        assert np.array_equal(dense, W)
+        live = np.where(w != 0, idx, 10 ** 6)
+        assert (np.diff(live, axis=1) >= 0).all()              # ascending bone order, padding last
