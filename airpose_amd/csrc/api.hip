@@ -116,7 +116,11 @@ struct Timing {
 constexpr double BN_EPS = 1e-5;
 
 unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_trace)
-int g_conv_cfg = -1;            // -1 auto, 0..3 conv_pipe config, 100 = legacy register-staged kernel
+int g_conv_cfg = -1;            // -1 auto, 0..13 conv_pipe config, 20/24..28 conv_phase, 100 = register-staged kernel
+// auto mode may pick the phase-interleaved 256-channel tiles (ap_set_conv_config(-3)).  OFF by default: measured inside the
+// trunk at 512 images (profiles/r02_phase_*) the one-workgroup-per-CU kernel is slower than the two-workgroups-per-CU ring
+// kernel on 7 of the 10 layer shapes it can run and equal on the rest, although it wins 15-20 % on layer4 in isolation
+bool g_conv_phase = false;
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -134,9 +138,31 @@ hipError_t zero_line(const void** out) {
     return hipSuccess;
 }
 
+hipError_t device_cus(int* n) {
+    static int cus[AP_MAX_DEVICES] = {};
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!cus[dev]) {
+        e = hipDeviceGetAttribute(&cus[dev], hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+    }
+    *n = cus[dev];
+    return hipSuccess;
+}
+
 // choose the tile configuration: large tiles need enough tiles to fill 256 CUs (1 workgroup per CU)
 hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
     int cfg = g_conv_cfg;
+    if (cfg < 0 && g_conv_phase && ap_conv_phase_supported(a, is_bf16) && a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0) >= 256) {
+        // deep contractions with >= 256 output channels and no residual: one 8-wave workgroup per CU on 256-channel
+        // tiles whose heights the planner fits to the CU count -- once there are enough rows for at least four
+        // pixel fragments per wave and CU (below that the small tiles of the ring kernel fill the chip better)
+        int n_cu = 0;
+        hipError_t e = device_cus(&n_cu);
+        if (e != hipSuccess) return e;
+        if ((long)a.M * (a.Cout / 256) >= (long)n_cu * 100) cfg = 20;
+    }
     if (cfg < 0) {
         // Measured on MI355X at 512 images (tools/conv_bench.py, profiles/r01_d_conv_configs.txt): the 2-stage
         // LDS-DMA ring with 8 waves per 128-row tile wins on every trunk layer -- two workgroups (16 waves) per CU
@@ -156,6 +182,15 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
     hipError_t e = zero_line(&a.zero);
     if (e != hipSuccess) return e;
     a.dbg = g_conv_dbg;
+    if (cfg >= 20) {                                         // 20: planner; 24..28: one height (4..8 fragments) for all rows
+        if (!ap_conv_phase_supported(a, is_bf16)) return hipErrorInvalidValue;
+        int n_cu = 0;
+        e = device_cus(&n_cu);
+        if (e != hipSuccess) return e;
+        if (cfg == 20) return ap_conv_phase_auto(a, n_cu, st);
+        const int fmw = cfg - 20;
+        return ap_launch_conv_phase(a, fmw, 0, (a.M + 32 * fmw - 1) / (32 * fmw), st);
+    }
     return ap_launch_conv_pipe(a, is_bf16, cfg, st);
 }
 constexpr int ST = 148, SLD = 288, DLD = 148;
@@ -952,8 +987,10 @@ int ap_debug_set_trace(void* device_buf_160_u64) {
 }
 
 int ap_set_conv_config(int cfg) {
-    if (cfg != -1 && cfg != 100 && (cfg < 0 || cfg > 13)) return fail(AP_EINVAL, "ap_set_conv_config: -1, 0..13 or 100");
-    g_conv_cfg = cfg;
+    if (cfg != -1 && cfg != -3 && cfg != 100 && cfg != 20 && !(cfg >= 24 && cfg <= 28) && (cfg < 0 || cfg > 13))
+        return fail(AP_EINVAL, "ap_set_conv_config: -1, -3, 0..13, 20, 24..28 or 100");
+    g_conv_phase = cfg == -3;
+    g_conv_cfg = cfg == -3 ? -1 : cfg;
     return AP_OK;
 }
 

@@ -129,8 +129,11 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
                          int N, int H, int W, int Cin, int downsample, void* stream);
 
 /* Tuning/testing knob (process-wide): tile configuration of the convolution kernels.  -1 = automatic,
- * 0..3 = software-pipelined LDS-DMA kernel with 256x128 / 128x128 / 128x64 / 256x64 tiles,
- * 100 = register-staged 2-stage kernel.  Results are identical for every setting. */
+ * -3 = automatic with the phase-interleaved kernel where it applies (experimental, see conv_phase.hip), 0..13 = software-pipelined LDS-DMA ring kernel (tile / wave /
+ * ring-depth variants, conv_pipe.hip), 20 = phase-interleaved 256-channel tiles with the planner that fits tile heights
+ * to the CU count, 24..28 = the same with one fixed height of 4..8 pixel fragments per wave (conv_phase.hip; bf16,
+ * C_out % 256 == 0, no residual: anything else is refused), 100 = register-staged 2-stage kernel.
+ * Results are identical (bitwise) for every setting. */
 int ap_set_conv_config(int cfg);
 /* Profiling aid: device buffer of 160 uint64 receiving per-phase cycle stamps of workgroup 0 of the pipelined
  * convolution kernel (2 waves x 8 K steps x 10 stamps); NULL (default) disables it. */

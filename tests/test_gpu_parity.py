@@ -136,6 +136,95 @@ def test_conv_primitive(dev, prec, case, cfg):
     assert rel_err(got.numpy(), ref.numpy()) < tol
 
 
+PHASE_CASES = [
+    # N, H, Cin, Cout, k, stride, pad, relu   (conv_phase.hip: bf16, Cout % 256 == 0, no residual)
+    (3, 14, 256, 256, 3, 1, 1, True),       # ragged M (588 rows), 3x3 halo, 36 K-tiles
+    (5, 7, 512, 512, 3, 1, 1, True),        # K = 4608, two channel tiles
+    (2, 28, 256, 256, 3, 2, 1, True),       # stride-2 3x3 (layer3.0 conv2)
+    (2, 56, 256, 512, 1, 2, 0, False),      # stride-2 1x1 through the tap path, no relu
+    (4, 14, 1024, 256, 1, 1, 0, True),      # pointwise, K = 1024 (layer3 conv1)
+    (9, 14, 256, 1024, 1, 1, 0, True),      # pointwise, K = 256: four K-tiles, wide N
+    (1, 14, 64, 256, 1, 1, 0, True),        # a single K-tile (prologue-only pipeline)
+    (1, 14, 128, 256, 1, 1, 0, False),      # two K-tiles
+    (7, 14, 192, 256, 1, 1, 0, True),       # three K-tiles, 1372 rows
+]
+
+
+@pytest.mark.parametrize("cfg", [20, 24, 25, 26, 27, 28])
+@pytest.mark.parametrize("case", PHASE_CASES)
+def test_conv_phase_primitive(dev, case, cfg):
+    """The phase-interleaved 256-channel kernel at every tile height against the fp64 oracle on identical operands,
+    and bit-for-bit against the ring kernel (same K order, same MFMA, same epilogue expression)."""
+    from airpose_amd import _native as Nn
+    N, H, Cin, Cout, k, stride, pad, relu = case
+    outs = []
+    for c in (cfg, 11):
+        Nn.check(Nn.lib().ap_set_conv_config(c), "ap_set_conv_config")
+        try:
+            got, ref = _conv_case(dev, "bf16", N, H, Cin, Cout, k, stride, pad, relu, False, seed=hash(case) % 10000)
+        finally:
+            Nn.lib().ap_set_conv_config(-1)
+        outs.append(got)
+    assert torch.isfinite(outs[0]).all()
+    assert rel_err(outs[0].numpy(), ref.numpy()) < 6e-3
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_conv_phase_refuses_what_it_cannot_do(dev):
+    from airpose_amd import _native as Nn
+    for case in ((2, 56, 64, 256, 1, 1, 0, True, True),      # residual
+                 (1, 56, 256, 128, 1, 1, 0, True, False)):   # 128 output channels
+        Nn.lib().ap_set_conv_config(20)
+        try:
+            with pytest.raises(RuntimeError):
+                _conv_case(dev, "bf16", *case, seed=1)
+        finally:
+            Nn.lib().ap_set_conv_config(-1)
+
+
+def test_conv_phase_full_size_is_deterministic_and_matches_ring(dev):
+    """BASELINE-size layer3 conv2 (512 images: 100 352 rows = one round of 224-row tiles + one of 192-row tiles on 256
+    CUs, hand-counted waits under full memory load): repeated runs identical, and identical to the ring kernel."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    g = torch.Generator(device="cpu").manual_seed(3)
+    n, H, C = 512, 14, 256
+    x = torch.randn(n, H, H, C, generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).to(torch.bfloat16).to(dev)
+    sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for cfg in (20, 20, 20, 11):
+        L.ap_set_conv_config(cfg)
+        try:
+            y = torch.full((n, H, H, C), float("nan"), dtype=torch.bfloat16, device=dev)
+            Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(x), p(w), p(sc), p(sh), None, p(y), n, H, H, C, C, 3, 1, 1, 1,
+                                      Nn.stream_ptr(dev)), "conv")
+            torch.cuda.synchronize()
+        finally:
+            L.ap_set_conv_config(-1)
+        outs.append(y)
+    assert torch.isfinite(outs[0].float()).all()
+    for o in outs[1:]:
+        assert torch.equal(o, outs[0])
+
+
+def test_trunk_with_and_without_phase_kernel_bitwise(netbf, dev):
+    """The automatic choice with the phase kernel enabled (layer2.0 conv3+downsample, layer3/4 conv1, conv2,
+    conv3+downsample at this size: pointwise, 3x3, strided and two-segment contractions) against the ring kernel
+    everywhere: identical trunk features, bit for bit.  128 images put layer3 over the planner's threshold."""
+    from airpose_amd import _native as Nn
+    gen = torch.Generator(device="cpu").manual_seed(21)
+    x = torch.randn(128, 3, 224, 224, generator=gen).to(dev)
+    a = netbf.forward_feat_ext(x)
+    Nn.check(Nn.lib().ap_set_conv_config(-3), "ap_set_conv_config")
+    try:
+        b = netbf.forward_feat_ext(x)
+    finally:
+        Nn.lib().ap_set_conv_config(-1)
+    assert torch.equal(a, b)
+
+
 def test_conv_configs_agree_bitwise(dev):
     """Every tile configuration accumulates each output element in the same K order."""
     from airpose_amd import _native as Nn
