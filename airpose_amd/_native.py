@@ -13,8 +13,9 @@ import torch  # noqa: F401  (must be imported first so that libamdhip64 is the o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIRPOSE_HIP_LIB", os.path.join(_HERE, "libairpose_hip.so"))   # override: profiling builds
 
-AP_PREC_FP32, AP_PREC_BF16 = 0, 1
-PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16}
+AP_PREC_FP32, AP_PREC_BF16, AP_PREC_BF16X2 = 0, 1, 2
+# fp32: exact fp32 MFMA chain | bf16: throughput mode | bf16x2: split-bf16 pairs, the fast parity mode
+PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16, "bf16x2": AP_PREC_BF16X2}
 
 _c = ctypes
 _vp, _i, _f, _i64p = _c.c_void_p, _c.c_int, _c.c_float, _c.POINTER(_c.c_int64)

@@ -50,7 +50,8 @@ class copenet(nn.Module):
         if tuple(layers) != (3, 4, 6, 3):
             raise ValueError("only the ResNet-50 layout [3, 4, 6, 3] of the reference is supported")
         if precision not in N.PRECISIONS:
-            raise ValueError("precision must be 'bf16' (throughput) or 'fp32' (parity)")
+            raise ValueError("precision must be 'bf16' (throughput), 'bf16x2' (split-bf16: fast parity mode) or "
+                             "'fp32' (exact fp32 MFMA chain)")
         self.precision = precision
         self.inplanes = 64
         npose = 21 * 6

@@ -152,9 +152,9 @@ hipError_t device_cus(int* n) {
 }
 
 // choose the tile configuration: large tiles need enough tiles to fill 256 CUs (1 workgroup per CU)
-hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
+hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipStream_t st) {
     int cfg = g_conv_cfg;
-    if (cfg < 0 && g_conv_phase && ap_conv_phase_supported(a, is_bf16) && a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0) >= 256) {
+    if (cfg < 0 && g_conv_phase && ap_conv_phase_supported(a, is_bf16 == AP_PREC_BF16) && a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0) >= 256) {
         // deep contractions with >= 256 output channels and no residual: one 8-wave workgroup per CU on 256-channel
         // tiles whose heights the planner fits to the CU count -- once there are enough rows for at least four
         // pixel fragments per wave and CU (below that the small tiles of the ring kernel fill the chip better)
@@ -183,7 +183,7 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16, hipStream_t st) {
     if (e != hipSuccess) return e;
     a.dbg = g_conv_dbg;
     if (cfg >= 20) {                                         // 20: planner; 24..28: one height (4..8 fragments) for all rows
-        if (!ap_conv_phase_supported(a, is_bf16)) return hipErrorInvalidValue;
+        if (!ap_conv_phase_supported(a, is_bf16 == AP_PREC_BF16)) return hipErrorInvalidValue;
         int n_cu = 0;
         e = device_cus(&n_cu);
         if (e != hipSuccess) return e;
@@ -220,7 +220,7 @@ struct ap_net {
     DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds, ws_feat;
     DevBuf ws_H, ws_S, ws_T1, ws_T2, ws_D, ws_state;
     Timing tm;
-    size_t esize() const { return prec == AP_PREC_BF16 ? 2 : 4; }
+    size_t esize() const { return prec == AP_PREC_BF16 ? 2 : 4; }   // fp32 and split-bf16 pairs: 4 bytes
 };
 
 struct ap_smplx {
@@ -295,7 +295,13 @@ int pack_conv(ap_net* h, const std::string& wname, const std::string& bnname, in
                 for (int r = 0; r < k; ++r)
                     for (int s = 0; s < k; ++s)
                         pk[(size_t)o * L.wld + (r * k + s) * cin + c] = w->data[(((size_t)o * cin + c) * k + r) * k + s];
-        HIP_TRY(upload(L.w, pk.data(), n * 4));
+        if (h->prec == AP_PREC_BF16X2) {
+            std::vector<uint32_t> ps(n);
+            for (size_t i = 0; i < n; ++i) ps[i] = host_split_pack(pk[i]);
+            HIP_TRY(upload(L.w, ps.data(), n * 4));
+        } else {
+            HIP_TRY(upload(L.w, pk.data(), n * 4));
+        }
     }
     HIP_TRY(upload(L.scale, scale.data(), scale.size() * 4));
     HIP_TRY(upload(L.shift, shift.data(), shift.size() * 4));
@@ -329,6 +335,10 @@ int pack_c3_ds(ap_net* h, const std::string& P, int planes, int inplanes, int st
         std::vector<uint16_t> pb(n);
         for (size_t i = 0; i < n; ++i) pb[i] = host_f32_to_bf16(pk[i]);
         HIP_TRY(upload(L.w, pb.data(), n * 2));
+    } else if (h->prec == AP_PREC_BF16X2) {
+        std::vector<uint32_t> ps(n);
+        for (size_t i = 0; i < n; ++i) ps[i] = host_split_pack(pk[i]);
+        HIP_TRY(upload(L.w, ps.data(), n * 4));
     } else {
         HIP_TRY(upload(L.w, pk.data(), n * 4));
     }
@@ -632,7 +642,8 @@ int finalize_regressor(ap_net* h) {
 
 // one depth-first pass over n = n0 + n1 images: the first n0 from x0, the rest from x1 (two views, one pass)
 int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
-    const int bf = h->prec == AP_PREC_BF16;
+    const int bf = h->prec == AP_PREC_BF16;                  // gates the bf16-only fused kernels
+    const int kind = h->prec;                                // storage kind of every generic kernel
     const size_t es = h->esize();
     const int n = n0 + n1;
     if (!(bf && h->fuse_stem)) HIP_TRY(h->ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
@@ -652,12 +663,12 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
     } else {
         if (n0)
             HIP_TRY(ap_launch_stem_conv(x0, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                        h->ws_stem.p, n0, 0, st));
+                                        h->ws_stem.p, n0, kind, st));
         if (n1)
             HIP_TRY(ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                        (char*)h->ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, 0, st));
+                                        (char*)h->ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, kind, st));
     }
-    if (!(bf && h->fuse_stem)) HIP_TRY(ap_launch_maxpool(h->ws_stem.p, h->ws_a.p, n, bf, st));
+    if (!(bf && h->fuse_stem)) HIP_TRY(ap_launch_maxpool(h->ws_stem.p, h->ws_a.p, n, kind, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
     void *cur = h->ws_a.p, *nxt = h->ws_b.p;
     int H = 56;
@@ -671,23 +682,23 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
             std::swap(cur, nxt);
             continue;
         }
-        if ((rc = run_conv(B.c1, cur, n, H, H, h->ws_t1.p, nullptr, 1, bf, st))) return rc;
-        if ((rc = run_conv(B.c2, h->ws_t1.p, n, H, H, h->ws_t2.p, nullptr, 1, bf, st))) return rc;
+        if ((rc = run_conv(B.c1, cur, n, H, H, h->ws_t1.p, nullptr, 1, kind, st))) return rc;
+        if ((rc = run_conv(B.c2, h->ws_t1.p, n, H, H, h->ws_t2.p, nullptr, 1, kind, st))) return rc;
         if (B.has_down && h->fuse_ds) {
-            if ((rc = run_c3_ds(B.c3ds, h->ws_t2.p, cur, n, Ho, H, nxt, bf, st))) return rc;
+            if ((rc = run_c3_ds(B.c3ds, h->ws_t2.p, cur, n, Ho, H, nxt, kind, st))) return rc;
         } else {
             const void* res = cur;
             if (B.has_down) {
-                if ((rc = run_conv(B.down, cur, n, H, H, h->ws_ds.p, nullptr, 0, bf, st))) return rc;
+                if ((rc = run_conv(B.down, cur, n, H, H, h->ws_ds.p, nullptr, 0, kind, st))) return rc;
                 res = h->ws_ds.p;
             }
-            if ((rc = run_conv(B.c3, h->ws_t2.p, n, Ho, Ho, nxt, res, 1, bf, st))) return rc;
+            if ((rc = run_conv(B.c3, h->ws_t2.p, n, Ho, Ho, nxt, res, 1, kind, st))) return rc;
         }
         std::swap(cur, nxt);
         H = Ho;
     }
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e2));
-    HIP_TRY(ap_launch_avgpool(cur, feat, n, 2048, bf, st));
+    HIP_TRY(ap_launch_avgpool(cur, feat, n, 2048, kind, st));
     if (h->tm.on) { h->tm.marks[1].push_back(e1); h->tm.marks[1].push_back(e2); }
     if (h->tm.on == 1) {
         HIP_TRY(h->tm.rec(st, &e3));
@@ -808,7 +819,7 @@ const char* ap_version(void) { return "airpose_hip 0.1 (gfx950)"; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
 int ap_net_create(ap_net** out, int device, int precision, int variant) {
-    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16) || (variant < 0 || variant > 3))
+    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16 && precision != AP_PREC_BF16X2) || (variant < 0 || variant > 3))
         return fail(AP_EINVAL, "ap_net_create: bad arguments");
     HIP_TRY(hipSetDevice(device));
     ap_net* h = new ap_net();
@@ -946,7 +957,8 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
                    const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
                    int relu, void* stream) {
     const int bf = precision == AP_PREC_BF16;
-    if ((precision != AP_PREC_BF16 && precision != AP_PREC_FP32) || !x || !w || !scale || !shift || !y || N <= 0 ||
+    if ((precision != AP_PREC_BF16 && precision != AP_PREC_FP32 && precision != AP_PREC_BF16X2) || !x || !w || !scale ||
+        !shift || !y || N <= 0 ||
         H <= 0 || W <= 0 || ksize <= 0 || stride <= 0 || pad < 0)
         return fail(AP_EINVAL, "ap_conv2d_nhwc: bad argument");
     if (Cin % (bf ? 64 : 32) || Cout % (bf ? 8 : 4) || Cin <= 0 || Cout <= 0)
@@ -960,7 +972,7 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
     a.Cout = Cout; a.KH = a.KW = ksize; a.stride = stride; a.pad = pad;
     a.M = N * a.Ho * a.Wo;
     a.ldx = Cin; a.ldy = Cout; a.ldr = Cout; a.wld = ksize * ksize * Cin; a.relu = relu;
-    HIP_TRY(dispatch_conv(a, bf, (hipStream_t)stream));
+    HIP_TRY(dispatch_conv(a, precision, (hipStream_t)stream));
     return AP_OK;
 }
 

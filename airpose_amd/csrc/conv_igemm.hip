@@ -25,19 +25,31 @@
 
 namespace {
 
-template <typename T> struct Elem;
-template <> struct Elem<bf16_t> { static constexpr int EPC = 8; };
-template <> struct Elem<float>  { static constexpr int EPC = 4; };
+template <typename T> using Elem = ElemKind<T>;
 
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void mma_chunk(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN]) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (Elem<T>::KIND == K_BF16) {
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
                 acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+    } else if constexpr (Elem<T>::KIND == K_SPLIT) {
+        // (hi, lo) pairs: straight = hi*hi + lo*lo, against the 16-bit rotated activations = the two cross terms
+        u32x4 xr[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xr[fm]), acc[fm][fn], 0, 0, 0);
+            }
     } else {
         // lane group g holds k = 4g..4g+3 of a 16-deep slab; MFMA t contracts {4g'+t : g'=0..3}
 #pragma unroll
@@ -229,11 +241,22 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         } else {
             float4 a = *(const float4*)src;
             if (rg) {
-                const float4 rv = *(const float4*)(rg + (size_t)m * p.ldr + ch);
-                a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
+                if constexpr (Elem<T>::KIND == K_SPLIT) {
+                    const u32x4 rv = *(const u32x4*)(rg + (size_t)m * p.ldr + ch);
+                    a.x += split_unpack(rv.x); a.y += split_unpack(rv.y); a.z += split_unpack(rv.z); a.w += split_unpack(rv.w);
+                } else {
+                    const float4 rv = *(const float4*)(rg + (size_t)m * p.ldr + ch);
+                    a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
+                }
             }
             if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-            *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
+            if constexpr (Elem<T>::KIND == K_SPLIT) {
+                u32x4 o;
+                o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
+                *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
+            } else {
+                *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
+            }
         }
     }
 }
@@ -280,6 +303,8 @@ hipError_t launch_T(const ConvArgs& a, hipStream_t st) {
 // Rows of the packed weight matrix must be padded (zero rows) to this multiple.
 int ap_conv_cout_pad(void) { return 128; }
 
-hipError_t ap_launch_conv(const ConvArgs& a, int is_bf16, hipStream_t st) {
-    return is_bf16 ? launch_T<bf16_t>(a, st) : launch_T<float>(a, st);
+hipError_t ap_launch_conv(const ConvArgs& a, int kind, hipStream_t st) {
+    if (kind == K_BF16) return launch_T<bf16_t>(a, st);
+    if (kind == K_SPLIT) return launch_T<bsplit_t>(a, st);
+    return kind == K_F32 ? launch_T<float>(a, st) : hipErrorInvalidValue;
 }

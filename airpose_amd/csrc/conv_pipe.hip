@@ -20,9 +20,7 @@
 
 namespace {
 
-template <typename T> struct Elem2;
-template <> struct Elem2<bf16_t> { static constexpr int EPC = 8; };
-template <> struct Elem2<float>  { static constexpr int EPC = 4; };
+template <typename T> using Elem2 = ElemKind<T>;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -42,13 +40,26 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr)
 
 template <typename T, int FM, int FN>
 __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN]) {
-    if constexpr (sizeof(T) == 2) {
+    if constexpr (Elem2<T>::KIND == K_BF16) {
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
                 acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+    } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
+        u32x4 xr[FM];
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xr[fm]), acc[fm][fn], 0, 0, 0);
+            }
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -69,12 +80,22 @@ template <typename T, int FM, int FN, int NP, typename F>
 __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN], F&& piece) {
     constexpr int NM = FM * FN;
     static_assert(NM >= NP + 1, "need more MFMAs than DMA pieces per cluster");
+    u32x4 xr[Elem2<T>::KIND == K_SPLIT ? FM : 1];
+    if constexpr (Elem2<T>::KIND == K_SPLIT) {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
+    }
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
         const int fm = j / FN, fn = j % FN;
-        if constexpr (sizeof(T) == 2) {
+        if constexpr (Elem2<T>::KIND == K_BF16) {
             acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+        } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xr[fm]), acc[fm][fn], 0, 0, 0);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -358,6 +379,11 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                         float lo, hi;
                         unpack_bf16x2(rpre[(fm * FN + fn) * 2], lo, hi); v0 += lo; v1 += hi;
                         unpack_bf16x2(rpre[(fm * FN + fn) * 2 + 1], lo, hi); v2 += lo; v3 += hi;
+                    } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
+                        v0 += split_unpack(rpre[(fm * FN + fn) * 4]);
+                        v1 += split_unpack(rpre[(fm * FN + fn) * 4 + 1]);
+                        v2 += split_unpack(rpre[(fm * FN + fn) * 4 + 2]);
+                        v3 += split_unpack(rpre[(fm * FN + fn) * 4 + 3]);
                     } else {
                         v0 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4]);
                         v1 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4 + 1]);
@@ -371,6 +397,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                         uint2 o;
                         o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
                         *(uint2*)(yg + (size_t)m * p.ldy + ch) = o;
+                    } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
+                        u32x4 o;
+                        o.x = split_pack(v0); o.y = split_pack(v1); o.z = split_pack(v2); o.w = split_pack(v3);
+                        *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
                     } else {
                         *(float4*)(yg + (size_t)m * p.ldy + ch) = make_float4(v0, v1, v2, v3);
                     }
@@ -446,11 +476,21 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             if (rg) {
                 // (copy the lanes out first: bit_cast applied directly to a vector element mis-compiles)
                 const uint32_t r0 = rv[it].x, r1 = rv[it].y, r2 = rv[it].z, r3 = rv[it].w;
-                a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
-                a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
+                if constexpr (Elem2<T>::KIND == K_SPLIT) {
+                    a.x += split_unpack(r0); a.y += split_unpack(r1); a.z += split_unpack(r2); a.w += split_unpack(r3);
+                } else {
+                    a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
+                    a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
+                }
             }
             if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-            *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
+            if constexpr (Elem2<T>::KIND == K_SPLIT) {
+                u32x4 o;
+                o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
+                *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
+            } else {
+                *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
+            }
         }
     }
     AP_BSTAMP(7);
@@ -480,47 +520,41 @@ hipError_t launch_pipe(ConvArgs a, hipStream_t st) {
     return hipGetLastError();
 }
 
-}  // namespace
-
 // cfg: 0 = 256x128 (8 waves, 3 stages), 1 = 128x128 (4 waves, 4 stages), 2 = 128x64 (4 waves, 4 stages),
 //      3 = 256x64 (8 waves, 3 stages); +4 = same tiles with the register (LDS-free) epilogue;
 //      8 = 128x128 / 9 = 128x64, 4 waves, 2 stages: small LDS footprint, 2-3 workgroups per CU
-hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStream_t st) {
+template <typename T>
+hipError_t launch_pipe_cfg(const ConvArgs& a, int cfg, hipStream_t st) {
+    switch (cfg) {
+        case 0: return launch_pipe<T, 256, 128, 4, 2, 3, false>(a, st);
+        case 1: return launch_pipe<T, 128, 128, 2, 2, 4, false>(a, st);
+        case 2: return launch_pipe<T, 128, 64, 2, 2, 4, false>(a, st);
+        case 3: return launch_pipe<T, 256, 64, 4, 2, 3, false>(a, st);
+        case 4: return launch_pipe<T, 256, 128, 4, 2, 3, true>(a, st);
+        case 5: return launch_pipe<T, 128, 128, 2, 2, 4, true>(a, st);
+        case 6: return launch_pipe<T, 128, 64, 2, 2, 4, true>(a, st);
+        case 7: return launch_pipe<T, 256, 64, 4, 2, 3, true>(a, st);
+        case 8: return launch_pipe<T, 128, 128, 2, 2, 2, false>(a, st);
+        case 9: return launch_pipe<T, 128, 64, 2, 2, 2, false>(a, st);
+        case 10: return launch_pipe<T, 128, 128, 4, 2, 2, false>(a, st);
+        case 11: return launch_pipe<T, 128, 128, 2, 4, 2, false>(a, st);
+        case 12: return launch_pipe<T, 128, 64, 4, 2, 2, false>(a, st);
+        case 13: return launch_pipe<T, 128, 64, 8, 1, 2, false>(a, st);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace
+
+// kind: K_F32 / K_BF16 / K_SPLIT (= AP_PREC_*).  The split-bf16 kind ships the two configurations the automatic choice
+// uses (11, 12); every configuration exists for the other two.
+hipError_t ap_launch_conv_pipe(const ConvArgs& a, int kind, int cfg, hipStream_t st) {
     if (!a.zero) return hipErrorInvalidValue;
-    if (is_bf16) {
-        switch (cfg) {
-            case 0: return launch_pipe<bf16_t, 256, 128, 4, 2, 3, false>(a, st);
-            case 1: return launch_pipe<bf16_t, 128, 128, 2, 2, 4, false>(a, st);
-            case 2: return launch_pipe<bf16_t, 128, 64, 2, 2, 4, false>(a, st);
-            case 3: return launch_pipe<bf16_t, 256, 64, 4, 2, 3, false>(a, st);
-            case 4: return launch_pipe<bf16_t, 256, 128, 4, 2, 3, true>(a, st);
-            case 5: return launch_pipe<bf16_t, 128, 128, 2, 2, 4, true>(a, st);
-            case 6: return launch_pipe<bf16_t, 128, 64, 2, 2, 4, true>(a, st);
-            case 7: return launch_pipe<bf16_t, 256, 64, 4, 2, 3, true>(a, st);
-            case 8: return launch_pipe<bf16_t, 128, 128, 2, 2, 2, false>(a, st);
-            case 9: return launch_pipe<bf16_t, 128, 64, 2, 2, 2, false>(a, st);
-            case 10: return launch_pipe<bf16_t, 128, 128, 4, 2, 2, false>(a, st);
-            case 11: return launch_pipe<bf16_t, 128, 128, 2, 4, 2, false>(a, st);
-            case 12: return launch_pipe<bf16_t, 128, 64, 4, 2, 2, false>(a, st);
-            case 13: return launch_pipe<bf16_t, 128, 64, 8, 1, 2, false>(a, st);
-        }
-    } else {
-        switch (cfg) {
-            case 0: return launch_pipe<float, 256, 128, 4, 2, 3, false>(a, st);
-            case 1: return launch_pipe<float, 128, 128, 2, 2, 4, false>(a, st);
-            case 2: return launch_pipe<float, 128, 64, 2, 2, 4, false>(a, st);
-            case 3: return launch_pipe<float, 256, 64, 4, 2, 3, false>(a, st);
-            case 4: return launch_pipe<float, 256, 128, 4, 2, 3, true>(a, st);
-            case 5: return launch_pipe<float, 128, 128, 2, 2, 4, true>(a, st);
-            case 6: return launch_pipe<float, 128, 64, 2, 2, 4, true>(a, st);
-            case 7: return launch_pipe<float, 256, 64, 4, 2, 3, true>(a, st);
-            case 8: return launch_pipe<float, 128, 128, 2, 2, 2, false>(a, st);
-            case 9: return launch_pipe<float, 128, 64, 2, 2, 2, false>(a, st);
-            case 10: return launch_pipe<float, 128, 128, 4, 2, 2, false>(a, st);
-            case 11: return launch_pipe<float, 128, 128, 2, 4, 2, false>(a, st);
-            case 12: return launch_pipe<float, 128, 64, 4, 2, 2, false>(a, st);
-            case 13: return launch_pipe<float, 128, 64, 8, 1, 2, false>(a, st);
-        }
+    if (kind == K_BF16) return launch_pipe_cfg<bf16_t>(a, cfg, st);
+    if (kind == K_F32) return launch_pipe_cfg<float>(a, cfg, st);
+    if (kind == K_SPLIT) {
+        if (cfg == 11) return launch_pipe<bsplit_t, 128, 128, 2, 4, 2, false>(a, st);
+        if (cfg == 12) return launch_pipe<bsplit_t, 128, 64, 4, 2, 2, false>(a, st);
     }
     return hipErrorInvalidValue;
 }

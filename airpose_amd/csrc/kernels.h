@@ -28,9 +28,9 @@ struct ConvArgs {
 };
 
 int ap_conv_cout_pad(void);
-hipError_t ap_launch_conv(const ConvArgs& a, int is_bf16, hipStream_t st);
+hipError_t ap_launch_conv(const ConvArgs& a, int kind, hipStream_t st);   // kind = AP_PREC_*: 0 fp32, 1 bf16, 2 split-bf16
 // software-pipelined (LDS-DMA ring) variant; cfg: 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 256x64
-hipError_t ap_launch_conv_pipe(const ConvArgs& a, int is_bf16, int cfg, hipStream_t st);
+hipError_t ap_launch_conv_pipe(const ConvArgs& a, int kind, int cfg, hipStream_t st);
 
 // phase-interleaved 256-channel tiles, one 8-wave workgroup per CU (conv_phase.hip); bf16, no residual, Cout % 256 == 0
 bool ap_conv_phase_supported(const ConvArgs& a, int is_bf16);
@@ -53,7 +53,7 @@ hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st);
 // ---- stem / pooling (stem.hip)
 // conv 7x7/2 p3 (3->64) + BN + ReLU from NCHW fp32 into NHWC T [N][112][112][64]
 hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, const float* scale, const float* shift,
-                               void* y, int n_img, int is_bf16, hipStream_t st);
+                               void* y, int n_img, int kind, hipStream_t st);
 // bf16 MFMA stem: images [0, n_split) come from x0, the rest from x1 (both views in one pass);
 // w_packed: [64][232] bf16, k' = r*32 + s*4 + c
 hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_split, const void* w_packed,
@@ -62,9 +62,9 @@ hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_spli
 hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
                                 const float* shift, void* y_pooled, int n_img, hipStream_t st);
 // maxpool 3x3/2 p1: [N][112][112][64] -> [N][56][56][64]
-hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int is_bf16, hipStream_t st);
+hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStream_t st);
 // global 7x7 average: [N][49][C] T -> [N][C] fp32
-hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int is_bf16, hipStream_t st);
+hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int kind, hipStream_t st);
 
 // crop + letter-box resize + /255 + normalise: uint8 HWC frames -> [n][3][224][224] fp32 (stem.hip)
 hipError_t ap_launch_preprocess(const unsigned char* frames, size_t frame_stride, int n, int H, int W, int bgr,

@@ -65,6 +65,10 @@ __global__ void __launch_bounds__(256) stem_direct_kernel(const float* __restric
             o.x = pack_bf16x2(v[0], v[1]);
             o.y = pack_bf16x2(v[2], v[3]);
             *(uint2*)(dst + 4 * q) = o;
+        } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
+            u32x4 o;
+            o.x = split_pack(v[0]); o.y = split_pack(v[1]); o.z = split_pack(v[2]); o.w = split_pack(v[3]);
+            *(u32x4*)(dst + 4 * q) = o;
         } else {
             *(float4*)(dst + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -331,6 +335,9 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T
                 unpack_bf16x2(v.y, lo, hi); m[2] = fmaxf(m[2], lo); m[3] = fmaxf(m[3], hi);
                 unpack_bf16x2(v.z, lo, hi); m[4] = fmaxf(m[4], lo); m[5] = fmaxf(m[5], hi);
                 unpack_bf16x2(v.w, lo, hi); m[6] = fmaxf(m[6], lo); m[7] = fmaxf(m[7], hi);
+            } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
+                m[0] = fmaxf(m[0], split_unpack(v.x)); m[1] = fmaxf(m[1], split_unpack(v.y));
+                m[2] = fmaxf(m[2], split_unpack(v.z)); m[3] = fmaxf(m[3], split_unpack(v.w));
             } else {
                 m[0] = fmaxf(m[0], __builtin_bit_cast(float, v.x));
                 m[1] = fmaxf(m[1], __builtin_bit_cast(float, v.y));
@@ -343,6 +350,9 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T
     if constexpr (sizeof(T) == 2) {
         o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
         o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
+    } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
+        // (hi + lo is exact in fp32 and split_pack of it returns the same word: the maximum is one of the inputs, bit for bit)
+        o.x = split_pack(m[0]); o.y = split_pack(m[1]); o.z = split_pack(m[2]); o.w = split_pack(m[3]);
     } else {
         o.x = __builtin_bit_cast(uint32_t, m[0]); o.y = __builtin_bit_cast(uint32_t, m[1]);
         o.z = __builtin_bit_cast(uint32_t, m[2]); o.w = __builtin_bit_cast(uint32_t, m[3]);
@@ -374,6 +384,8 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, f
             unpack_bf16x2(v.y, lo, hi); s[2] += lo; s[3] += hi;
             unpack_bf16x2(v.z, lo, hi); s[4] += lo; s[5] += hi;
             unpack_bf16x2(v.w, lo, hi); s[6] += lo; s[7] += hi;
+        } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
+            s[0] += split_unpack(v.x); s[1] += split_unpack(v.y); s[2] += split_unpack(v.z); s[3] += split_unpack(v.w);
         } else {
             s[0] += __builtin_bit_cast(float, v.x); s[1] += __builtin_bit_cast(float, v.y);
             s[2] += __builtin_bit_cast(float, v.z); s[3] += __builtin_bit_cast(float, v.w);
@@ -447,10 +459,12 @@ hipError_t ap_launch_preprocess(const unsigned char* frames, size_t frame_stride
 }
 
 hipError_t ap_launch_stem_conv(const float* x, const float* w, const float* scale, const float* shift, void* y,
-                               int n_img, int is_bf16, hipStream_t st) {
+                               int n_img, int kind, hipStream_t st) {
     dim3 grid(SO / 16, SO / 16, n_img);
-    if (is_bf16)
+    if (kind == K_BF16)
         hipLaunchKernelGGL(stem_direct_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, scale, shift, (bf16_t*)y);
+    else if (kind == K_SPLIT)
+        hipLaunchKernelGGL(stem_direct_kernel<bsplit_t>, grid, dim3(256), 0, st, x, w, scale, shift, (bsplit_t*)y);
     else
         hipLaunchKernelGGL(stem_direct_kernel<float>, grid, dim3(256), 0, st, x, w, scale, shift, (float*)y);
     return hipGetLastError();
@@ -470,8 +484,12 @@ hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, co
     return hipGetLastError();
 }
 
-hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int is_bf16, hipStream_t st) {
-    if (is_bf16) {
+hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStream_t st) {
+    if (kind == K_SPLIT) {
+        const int total = n_img * PO * PO * (SC / 4);
+        hipLaunchKernelGGL(maxpool_kernel<bsplit_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x,
+                           (bsplit_t*)y, total);
+    } else if (kind == K_BF16) {
         const int total = n_img * PO * PO * (SC / 8);
         hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)x,
                            (bf16_t*)y, total);
@@ -483,8 +501,12 @@ hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int is_bf16, hip
     return hipGetLastError();
 }
 
-hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int is_bf16, hipStream_t st) {
-    if (is_bf16) {
+hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int kind, hipStream_t st) {
+    if (kind == K_SPLIT) {
+        const int total = n_img * (C / 4);
+        hipLaunchKernelGGL(avgpool_kernel<bsplit_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x, y,
+                           C, total);
+    } else if (kind == K_BF16) {
         const int total = n_img * (C / 8);
         hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, y, C,
                            total);

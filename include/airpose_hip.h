@@ -31,6 +31,9 @@ extern "C" {
 
 #define AP_PREC_FP32 0 /* fp32 storage, v_mfma_f32_16x16x4_f32: parity mode (1e-4 vs the CPU reference) */
 #define AP_PREC_BF16 1 /* bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate: throughput mode */
+#define AP_PREC_BF16X2 2 /* split-bf16 storage (hi + lo bf16 pair per value, 16 mantissa bits, fp32 bytes): every product as
+                          * hi*hi + hi*lo + lo*hi + lo*lo on the bf16 matrix pipe (two MFMAs per 4 K elements), fp32
+                          * accumulate: the fast parity mode (meets the 1e-4 bar at ~4x the fp32-MFMA rate) */
 
 typedef struct ap_net ap_net;     /* ResNet-50 trunk + IEF regressor */
 typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
@@ -112,7 +115,8 @@ int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_th
  * Bottleneck.forward (model_copenet.py:27-47: conv -> BN -> [+ residual] -> ReLU).  Exposed so the kernel can be
  * unit-tested and reused.  NHWC activations x [N][H][W][Cin], y/res [N][Ho][Wo][Cout]; w [Cout_pad][k][k][Cin]
  * with Cout_pad = Cout rounded up to 128 (zero rows), scale/shift [Cout_pad]; element type of x/w/res/y is
- * bf16 (AP_PREC_BF16) or float (AP_PREC_FP32); Cin a multiple of 64 (bf16) / 32 (fp32), Cout of 8 / 4. */
+ * bf16 (AP_PREC_BF16), float (AP_PREC_FP32) or split-bf16 pairs (AP_PREC_BF16X2, 4 bytes per element like float);
+ * Cin a multiple of 64 (bf16) / 32 (fp32, bf16x2), Cout of 8 / 4. */
 int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* scale, const float* shift,
                    const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
                    int relu, void* stream);
