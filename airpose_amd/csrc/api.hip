@@ -202,7 +202,7 @@ struct ap_net {
     bool finalized = false;
     std::map<std::string, HostTensor> tensors;
     // trunk
-    DevBuf stem_w, stem_wpk, stem_scale, stem_shift;
+    DevBuf stem_w, stem_wpk, stem_wpk_lo, stem_scale, stem_shift;   // stem_wpk_lo: low plane of the split-bf16 stem weights
     struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false; };
     std::vector<Block> blocks;
     // regressor (fp32)
@@ -446,6 +446,17 @@ int finalize_trunk(ap_net* h) {
                     for (int s2 = 0; s2 < 7; ++s2)
                         pk[o * 232 + r * 32 + s2 * 4 + c] = host_f32_to_bf16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
         HIP_TRY(upload(h->stem_wpk, pk.data(), pk.size() * 2));
+        if (h->prec == AP_PREC_BF16X2) {                    // low plane: bf16(w - hi) at the same positions
+            std::vector<uint16_t> pl(64 * 232, 0);
+            for (int o = 0; o < 64; ++o)
+                for (int c = 0; c < 3; ++c)
+                    for (int r = 0; r < 7; ++r)
+                        for (int s2 = 0; s2 < 7; ++s2) {
+                            const float wv = w->data[((o * 3 + c) * 7 + r) * 7 + s2];
+                            pl[o * 232 + r * 32 + s2 * 4 + c] = (uint16_t)(host_split_pack(wv) >> 16);
+                        }
+            HIP_TRY(upload(h->stem_wpk_lo, pl.data(), pl.size() * 2));
+        }
     }
     std::vector<float> sc, sh;
     int rc = bn_fold(h, "bn1", 64, sc, sh);
@@ -660,6 +671,9 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
     } else if (bf) {
         HIP_TRY(ap_launch_stem_conv_mfma(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
                                          h->stem_shift.as<float>(), h->ws_stem.p, n, st));
+    } else if (kind == AP_PREC_BF16X2) {
+        HIP_TRY(ap_launch_stem_conv_mfma_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
+                                               h->stem_shift.as<float>(), h->ws_stem.p, n, st));
     } else {
         if (n0)
             HIP_TRY(ap_launch_stem_conv(x0, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
@@ -832,7 +846,7 @@ void ap_net_destroy(ap_net* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->mean_cam, &h->ws_stem, &h->ws_a,
+    for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_wpk_lo, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->mean_cam, &h->ws_stem, &h->ws_a,
                       &h->ws_b, &h->ws_t1, &h->ws_t2, &h->ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
                       &h->ws_D, &h->ws_state})
         b->release();

@@ -42,14 +42,13 @@ __device__ __forceinline__ void mma_chunk(const u32x4 (&xf)[FM], const u32x4 (&w
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
+        for (int pass = 0; pass < 2; ++pass)          // (the two MFMAs of one accumulator FM*FN instructions apart)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn) {
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xr[fm]), acc[fm][fn], 0, 0, 0);
-            }
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, pass ? xr[fm] : xf[fm]), acc[fm][fn], 0, 0, 0);
     } else {
         // lane group g holds k = 4g..4g+3 of a 16-deep slab; MFMA t contracts {4g'+t : g'=0..3}
 #pragma unroll

@@ -52,14 +52,13 @@ __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm)
+        for (int pass = 0; pass < 2; ++pass)
 #pragma unroll
-            for (int fn = 0; fn < FN; ++fn) {
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xr[fm]), acc[fm][fn], 0, 0, 0);
-            }
+            for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FN; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, pass ? xr[fm] : xf[fm]), acc[fm][fn], 0, 0, 0);
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -75,27 +74,28 @@ __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&
     }
 }
 
-// MFMA cluster with NP callbacks (one LDS-DMA piece each) spread evenly between the MFMAs
+// MFMA cluster with NP callbacks (one LDS-DMA piece each) spread evenly between the MFMAs.  Split-bf16: the FM*FN
+// straight products first, then the FM*FN products against the rotated activations, so that the two MFMAs of one
+// accumulator are FM*FN instructions apart (back to back they would wait for each other).
 template <typename T, int FM, int FN, int NP, typename F>
 __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN], F&& piece) {
-    constexpr int NM = FM * FN;
+    constexpr int KIND = Elem2<T>::KIND;
+    constexpr int NM = FM * FN * (KIND == K_SPLIT ? 2 : 1);
     static_assert(NM >= NP + 1, "need more MFMAs than DMA pieces per cluster");
-    u32x4 xr[Elem2<T>::KIND == K_SPLIT ? FM : 1];
-    if constexpr (Elem2<T>::KIND == K_SPLIT) {
+    u32x4 xr[KIND == K_SPLIT ? FM : 1];
+    if constexpr (KIND == K_SPLIT) {
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
     }
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
-        const int fm = j / FN, fn = j % FN;
-        if constexpr (Elem2<T>::KIND == K_BF16) {
+        const int jj = j % (FM * FN), fm = jj / FN, fn = jj % FN;
+        if constexpr (KIND == K_BF16) {
             acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                 __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
-        } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
+        } else if constexpr (KIND == K_SPLIT) {
             acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
-            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xr[fm]), acc[fm][fn], 0, 0, 0);
+                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, j < FM * FN ? xf[fm] : xr[fm]), acc[fm][fn], 0, 0, 0);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {

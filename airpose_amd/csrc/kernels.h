@@ -58,6 +58,9 @@ hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, cons
 // w_packed: [64][232] bf16, k' = r*32 + s*4 + c
 hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_split, const void* w_packed,
                                     const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
+// split-bf16 MFMA stem (bf16x2 mode): w_hi / w_lo: [64][232] bf16 planes of the packed weights; y: split pairs
+hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
+                                          const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
 // fused bf16 MFMA stem + maxpool: NCHW fp32 crops -> [N][56][56][64] bf16
 hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
                                 const float* shift, void* y_pooled, int n_img, hipStream_t st);

@@ -153,6 +153,98 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
 }
 
 // ------------------------------------------------------------------------------------------------
+// Split-bf16 MFMA stem (bf16x2 parity mode): the same tile program as stem_mfma_kernel with every operand as a
+// (hi, lo) bf16 pair held in two planes -- two weight images [64][232] and two input patches -- and each product as
+// hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (the lo*lo term, 2^-18 relative, is dropped: the planes are separate
+// fragments here, so the three MFMAs are explicit).  Output: split-bf16 pairs, NHWC.
+__global__ void __launch_bounds__(256) stem_mfma_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                              int n_split, const bf16_t* __restrict__ wpk_hi,
+                                                              const bf16_t* __restrict__ wpk_lo,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, bsplit_t* __restrict__ y) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char stem_lds[];
+    constexpr int WEL = 64 * SWLD, PEL = SP * SPW * 4 + 32;
+    bf16_t* wsm_hi = (bf16_t*)stem_lds;
+    bf16_t* wsm_lo = wsm_hi + WEL;
+    bf16_t* patch_hi = wsm_lo + WEL;
+    bf16_t* patch_lo = patch_hi + PEL;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // one workgroup = one column of 7 tiles of an image: the 58 KB of weights are fetched once per 7 tiles
+    const int n = blockIdx.z, tx0 = blockIdx.x * 16;
+    {
+        const u32x4 *sh_ = (const u32x4*)wpk_hi, *sl_ = (const u32x4*)wpk_lo;
+        u32x4 *dh = (u32x4*)wsm_hi, *dl = (u32x4*)wsm_lo;
+        for (int i = tid; i < WEL * 2 / 16; i += 256) { dh[i] = sh_[i]; dl[i] = sl_[i]; }
+    }
+    const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
+    const int lr = lane & 15, g = lane >> 4;
+  for (int ty0 = 0; ty0 < SO; ty0 += 16) {
+    if (ty0) __syncthreads();                               // every wave is done with the previous tile's patch
+    for (int i = tid; i < 3 * SP * SP; i += 256) {
+        const int c = i / (SP * SP), rem = i - c * SP * SP, py = rem / SP, px = rem - py * SP;
+        const int iy = 2 * ty0 - 3 + py, ix = 2 * tx0 - 3 + px;
+        float v = 0.f;
+        if ((unsigned)iy < (unsigned)IMG && (unsigned)ix < (unsigned)IMG) v = xin[(c * IMG + iy) * IMG + ix];
+        const bf16_t hi = f32_to_bf16(v);
+        patch_hi[(py * SPW + px) * 4 + c] = hi;
+        patch_lo[(py * SPW + px) * 4 + c] = f32_to_bf16(v - bf16_to_f32(hi));
+    }
+    for (int i = tid; i < SP * SPW; i += 256) { patch_hi[i * 4 + 3] = 0; patch_lo[i * 4 + 3] = 0; }
+    if (tid < 32) { patch_hi[SP * SPW * 4 + tid] = 0; patch_lo[SP * SPW * 4 + tid] = 0; }
+    if (tid < SP * 3) {
+        patch_hi[((tid / 3) * SPW + SP) * 4 + tid % 3] = 0;
+        patch_lo[((tid / 3) * SPW + SP) * 4 + tid % 3] = 0;
+    }
+    __syncthreads();
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < SKB; ++kb) {
+        u32x4 wh[4], wl[4], xh[4], xl[4];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            wh[fn] = *(const u32x4*)(wsm_hi + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
+            wl[fn] = *(const u32x4*)(wsm_lo + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
+        }
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+            const int ty = wave * 4 + fm;
+            xh[fm] = *(const u32x4*)(patch_hi + ((2 * ty + kb) * SPW + 2 * lr + 2 * g) * 4);
+            xl[fm] = *(const u32x4*)(patch_lo + ((2 * ty + kb) * SPW + 2 * lr + 2 * g) * 4);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, pass == 2 ? wl[fn] : wh[fn]),
+                        __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn], 0, 0, 0);
+    }
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        const int ch = fn * 16 + g * 4;
+        const float4 sc = *(const float4*)(scale + ch), sh = *(const float4*)(shift + ch);
+#pragma unroll
+        for (int fm = 0; fm < 4; ++fm) {
+            const int oy = ty0 + wave * 4 + fm, ox = tx0 + lr;
+            u32x4 o;
+            o.x = split_pack(fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f));
+            o.y = split_pack(fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f));
+            o.z = split_pack(fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f));
+            o.w = split_pack(fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f));
+            *(u32x4*)(y + (((size_t)n * SO + oy) * SO + ox) * SC + ch) = o;
+        }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Fused MFMA stem + 3x3/2 max-pool (bf16 throughput path): conv1 -> bn1 -> relu -> maxpool in one kernel,
 // the 112x112x64 stem activation (1.6 MB/image) never touches HBM.
 // One workgroup = 7 waves = one image x a strip of 2 pooled rows (5 conv rows, 15 input rows); wave w owns the
@@ -474,6 +566,23 @@ hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_spli
                                     const float* scale, const float* shift, void* y, int n_img, hipStream_t st) {
     hipLaunchKernelGGL(stem_mfma_kernel, dim3(SO / 16, SO / 16, n_img), dim3(256), 0, st, x0, x1, n_split,
                        (const bf16_t*)w_packed, scale, shift, (bf16_t*)y);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
+                                          const float* scale, const float* shift, void* y, int n_img, hipStream_t st) {
+    static bool attr_set[AP_MAX_DEVICES] = {};
+    constexpr int lds = (2 * 64 * SWLD + 2 * (SP * SPW * 4 + 32)) * 2;
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)stem_mfma_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(stem_mfma_split_kernel, dim3(SO / 16, 1, n_img), dim3(256), lds, st, x0, x1, n_split,
+                       (const bf16_t*)w_hi, (const bf16_t*)w_lo, scale, shift, (bsplit_t*)y);
     return hipGetLastError();
 }
 
