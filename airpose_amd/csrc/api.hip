@@ -226,9 +226,11 @@ struct ap_net {
 struct ap_smplx {
     int device = 0;
     SmplxModelDev m{};
-    Layer dirs;                 // blend-shape GEMM operand: rows = 3V, K = 512
+    Layer dirs;                 // blend-shape GEMM operand: rows = 3V, K = 512 (fp32: exact fp32 MFMA chain)
+    DevBuf dirs_split;          // the same operand as split-bf16 pairs: four-term products on the bf16 matrix pipe (default)
+    bool blend_split = true;
     DevBuf j_template, j_shapedirs, parents, depth, skin_idx, skin_w, extra_verts, lmk_tri, lmk_bary;
-    DevBuf ws_coef, ws_A, ws_jposed, ws_post, ws_vposed;
+    DevBuf ws_coef, ws_A, ws_jposed, ws_post, ws_vposed, ws_cc;
     int n_out_joints = 0;
     Timing tm;
 };
@@ -1179,6 +1181,11 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
             for (int n = 0; n < rows; ++n) pk[(size_t)n * L.wld + 20 + p] = src[n];
         }
         hipError_t e = upload(L.w, pk.data(), pk.size() * 4);
+        if (e == hipSuccess) {
+            std::vector<uint32_t> ps(pk.size());
+            for (size_t i = 0; i < pk.size(); ++i) ps[i] = host_split_pack(pk[i]);
+            e = upload(h->dirs_split, ps.data(), ps.size() * 4);
+        }
         if (e == hipSuccess) e = upload(L.scale, scale.data(), scale.size() * 4);
         if (e == hipSuccess) e = upload(L.shift, shift.data(), shift.size() * 4);
         if (e != hipSuccess) { ap_smplx_destroy(h); return fail((int)e, std::string("upload: ") + hipGetErrorString(e)); }
@@ -1222,9 +1229,9 @@ void ap_smplx_destroy(ap_smplx* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&h->dirs.w, &h->dirs.scale, &h->dirs.shift, &h->j_template, &h->j_shapedirs, &h->parents, &h->depth,
+    for (DevBuf* b : {&h->dirs.w, &h->dirs_split, &h->dirs.scale, &h->dirs.shift, &h->j_template, &h->j_shapedirs, &h->parents, &h->depth,
                       &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A,
-                      &h->ws_jposed, &h->ws_post, &h->ws_vposed})
+                      &h->ws_jposed, &h->ws_post, &h->ws_vposed, &h->ws_cc})
         b->release();
     h->tm.destroy();
     delete h;
@@ -1236,6 +1243,7 @@ int ap_smplx_num_joints_out(const ap_smplx* h) { return h ? h->n_out_joints : AP
 
 namespace {
 int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
+    h->m.coef_split = h->blend_split ? 1 : 0;
     const SmplxModelDev& m = h->m;
     const int n = a.n;
     HIP_TRY(h->ws_coef.reserve((size_t)n * m.ncoef * 4));
@@ -1246,6 +1254,11 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     a.coef = h->ws_coef.as<float>(); a.A = h->ws_A.as<float>(); a.jposed = h->ws_jposed.as<float>();
     a.post = (a.pose6d || a.post_rt) ? h->ws_post.as<float>() : nullptr;
     a.vposed = h->ws_vposed.as<float>();
+    if (a.n_main > 0 && a.intr0) {                           // camera centres resolved by the prep kernel
+        HIP_TRY(h->ws_cc.reserve((size_t)a.n_main * 2 * 4));
+        a.cc_ws = h->ws_cc.as<float>();
+        a.cam_center = a.cc_ws;
+    }
     size_t ev[5] = {0, 0, 0, 0, 0};
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[0]));
     HIP_TRY(ap_launch_smplx_prep(m, a, st));
@@ -1255,11 +1268,13 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     int K = body_only ? 20 + 21 * 9 : 20 + (m.J - 1) * 9;
     K = ((K + 31) / 32) * 32;
     ConvArgs g{};
-    g.x = a.coef; g.w = h->dirs.w.p; g.scale = h->dirs.scale.as<float>(); g.shift = h->dirs.shift.as<float>();
+    g.x = a.coef; g.w = h->blend_split ? h->dirs_split.p : h->dirs.w.p;
+    g.scale = h->dirs.scale.as<float>(); g.shift = h->dirs.shift.as<float>();
+    g.out_f32 = 1;                                           // v_posed stays fp32 (only the split kind reads the flag)
     g.res = nullptr; g.y = h->ws_vposed.p;
     g.N = n; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = K; g.Cout = h->dirs.cout; g.KH = g.KW = 1; g.stride = 1; g.pad = 0;
     g.M = n; g.ldx = m.ncoef; g.ldy = m.ldv; g.ldr = 0; g.wld = h->dirs.wld; g.relu = 0;
-    HIP_TRY(dispatch_conv(g, 0, st));
+    HIP_TRY(dispatch_conv(g, h->blend_split ? AP_PREC_BF16X2 : AP_PREC_FP32, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[2]));
     HIP_TRY(ap_launch_smplx_skin(m, a, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[3]));
@@ -1298,6 +1313,33 @@ int ap_smplx_fwd_fused(ap_smplx* h, int n, const float* pred_pose, int pose_ld, 
     a.vertices = vertices_cam; a.joints = joints_cam; a.joints2d = cam_center ? joints2d : nullptr;
     a.rotmat_out = rotmat;
     return smplx_run(h, a, true, (hipStream_t)stream);
+}
+
+int ap_smplx_fwd_twoview(ap_smplx* h, int B, float* pred_pose, int pose_ld, float trans_scale, const float* betas,
+                         const float* intr0, const float* intr1, float fx, float fy, const float* in_smpltrans,
+                         float* vertices, float* joints_cam, float* joints2d, float* rotmat, void* stream) {
+    if (!h || B <= 0 || !pred_pose || pose_ld < 135 || !betas || !vertices || !joints_cam || (!intr0) != (!intr1) ||
+        trans_scale < 0.f)
+        return fail(AP_EINVAL, "ap_smplx_fwd_twoview: bad argument");
+    SmplxFwdArgs a{};
+    a.n_main = 2 * B;
+    a.n = in_smpltrans ? 4 * B : 2 * B;
+    a.in_trans = in_smpltrans;
+    a.betas = betas;
+    a.pose6d = pred_pose + 3; a.pose6d_ld = pose_ld;
+    a.post_t = pred_pose; a.post_t_ld = pose_ld;
+    if (trans_scale > 0.f) { a.pose_rw = pred_pose; a.trans_scale = trans_scale; }
+    a.intr0 = intr0; a.intr1 = intr1; a.fx = fx; a.fy = fy;
+    a.vertices = vertices; a.joints = joints_cam; a.joints2d = intr0 ? joints2d : nullptr;
+    a.rotmat_out = rotmat;
+    return smplx_run(h, a, true, (hipStream_t)stream);
+}
+
+int ap_smplx_set_blend_precision(ap_smplx* h, int precision) {
+    if (!h || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16X2))
+        return fail(AP_EINVAL, "ap_smplx_set_blend_precision: AP_PREC_FP32 or AP_PREC_BF16X2");
+    h->blend_split = precision == AP_PREC_BF16X2;
+    return AP_OK;
 }
 
 int ap_smplx_enable_timing(ap_smplx* h, int on) {

@@ -242,7 +242,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             if (rg) {
                 if constexpr (Elem<T>::KIND == K_SPLIT) {
                     const u32x4 rv = *(const u32x4*)(rg + (size_t)m * p.ldr + ch);
-                    a.x += split_unpack(rv.x); a.y += split_unpack(rv.y); a.z += split_unpack(rv.z); a.w += split_unpack(rv.w);
+                    if (p.out_f32) {
+                        a.x += __builtin_bit_cast(float, rv.x); a.y += __builtin_bit_cast(float, rv.y);
+                        a.z += __builtin_bit_cast(float, rv.z); a.w += __builtin_bit_cast(float, rv.w);
+                    } else {
+                        a.x += split_unpack(rv.x); a.y += split_unpack(rv.y); a.z += split_unpack(rv.z); a.w += split_unpack(rv.w);
+                    }
                 } else {
                     const float4 rv = *(const float4*)(rg + (size_t)m * p.ldr + ch);
                     a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
@@ -251,7 +256,12 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             if constexpr (Elem<T>::KIND == K_SPLIT) {
                 u32x4 o;
-                o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
+                if (p.out_f32) {
+                    o.x = __builtin_bit_cast(uint32_t, a.x); o.y = __builtin_bit_cast(uint32_t, a.y);
+                    o.z = __builtin_bit_cast(uint32_t, a.z); o.w = __builtin_bit_cast(uint32_t, a.w);
+                } else {
+                    o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
+                }
                 *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
             } else {
                 *(float4*)(yg + (size_t)m * p.ldy + ch) = a;

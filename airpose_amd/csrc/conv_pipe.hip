@@ -477,7 +477,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                 // (copy the lanes out first: bit_cast applied directly to a vector element mis-compiles)
                 const uint32_t r0 = rv[it].x, r1 = rv[it].y, r2 = rv[it].z, r3 = rv[it].w;
                 if constexpr (Elem2<T>::KIND == K_SPLIT) {
-                    a.x += split_unpack(r0); a.y += split_unpack(r1); a.z += split_unpack(r2); a.w += split_unpack(r3);
+                    if (p.out_f32) {
+                        a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
+                        a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
+                    } else {
+                        a.x += split_unpack(r0); a.y += split_unpack(r1); a.z += split_unpack(r2); a.w += split_unpack(r3);
+                    }
                 } else {
                     a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
                     a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
@@ -486,7 +491,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
             if constexpr (Elem2<T>::KIND == K_SPLIT) {
                 u32x4 o;
-                o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
+                if (p.out_f32) {
+                    o.x = __builtin_bit_cast(uint32_t, a.x); o.y = __builtin_bit_cast(uint32_t, a.y);
+                    o.z = __builtin_bit_cast(uint32_t, a.z); o.w = __builtin_bit_cast(uint32_t, a.w);
+                } else {
+                    o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
+                }
                 *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
             } else {
                 *(float4*)(yg + (size_t)m * p.ldy + ch) = a;

@@ -25,6 +25,7 @@ struct ConvArgs {
     int relu;
     int mtiles, ntiles;   // filled by the launcher
     int row0;             // first pixel row of this launch (conv_phase only; 0 elsewhere)
+    int out_f32;          // split-bf16 kind only: y (and res) are plain fp32 [M][ldy] instead of split pairs
 };
 
 int ap_conv_cout_pad(void);
@@ -112,6 +113,7 @@ hipError_t ap_launch_hmr_output(const float* state, float* rotmat, float* betas,
 struct SmplxModelDev {
     int V, J, K;                  // vertices, joints (55), bones per vertex
     int ncoef;                    // columns of the coefficient matrix (512)
+    int coef_split;               // coefficient rows / blend-shape operand held as split-bf16 pairs (default) or fp32
     int ldv;                      // row stride of v_posed workspace (floats)
     const float* j_template;      // [J][3]
     const float* j_shapedirs;     // [J][3][20]
@@ -136,6 +138,14 @@ struct SmplxFwdArgs {
     const float* body_pose;       // [n][21][9]
     const float* extra_pose;      // [n][33][9] or NULL (identity)
     const float* transl;          // [n][3] or NULL
+    // two-view pipeline entry (ap_smplx_fwd_twoview): bodies [0, n_main) are the regressed ones; bodies [n_main, n) are
+    // the test-mode "input" meshes = body (b - n_main) with betas = 0, identity root and translation in_trans
+    int n_main;                   // 0 = all bodies are regular
+    const float* in_trans;        // [n - n_main][3]
+    float* pose_rw;               // pred_pose base for the in-place translation un-scale, or NULL
+    float trans_scale;
+    const float *intr0, *intr1;   // [n_main / 2][9] each: camera centre = intr[:, :2, 2] of the body's view, or NULL
+    float* cc_ws;                 // [n][2] resolved camera centres (workspace)
     // post transform (transform_smpl): X' = R X + t
     const float* post_rt;         // [n][12] (3x4 row-major) or NULL
     const float* post_t;          // with pose6d: translation [n][post_t_ld]

@@ -36,10 +36,17 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
     __shared__ float Jr[64][3];
     __shared__ float cf[20];
     float* coef = a.coef + (size_t)b * m.ncoef;
+    // test-mode input mesh (copenet_twoview.py:258-279): body sb's rotations, zero betas, [I | in_smpltrans]
+    const bool inmesh = a.n_main > 0 && b >= a.n_main;
+    const int sb = inmesh ? b - a.n_main : b;
+    // the blend-shape contraction runs on the bf16 matrix pipe in split-bf16 form (m.coef_split): the coefficient row is
+    // written as (hi, lo) pairs, 4 bytes per coefficient like the fp32 it replaces
+    auto put = [&](int i, float v) { coef[i] = m.coef_split ? __builtin_bit_cast(float, split_pack(v)) : v; };
     if (j < 20) {
-        const float c = j < 10 ? a.betas[(size_t)b * 10 + j] : (a.expression ? a.expression[(size_t)b * 10 + j - 10] : 0.f);
+        float c = j < 10 ? a.betas[(size_t)sb * 10 + j] : (a.expression ? a.expression[(size_t)sb * 10 + j - 10] : 0.f);
+        if (inmesh) c = 0.f;
         cf[j] = c;
-        coef[j] = c;
+        put(j, c);
     }
     for (int i = 20 + (m.J - 1) * 9 + j; i < m.ncoef; i += 64) coef[i] = 0.f;
 
@@ -47,15 +54,33 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
     if (a.pose6d) {
         if (j < 22) {
             float Rj[9];
-            rot6d_dev(a.pose6d + (size_t)b * a.pose6d_ld + 6 * j, Rj);
-            if (a.rotmat_out)
+            rot6d_dev(a.pose6d + (size_t)sb * a.pose6d_ld + 6 * j, Rj);
+            if (a.rotmat_out && !inmesh)
                 for (int e = 0; e < 9; ++e) a.rotmat_out[((size_t)b * 22 + j) * 9 + e] = Rj[e];
             if (j == 0) {
                 // root 6D is the transform_smpl rotation; the chain root stays identity (copenet_twoview.py:237-243)
                 float* P = a.post + (size_t)b * 12;
                 for (int rr = 0; rr < 3; ++rr) {
-                    P[rr * 4 + 0] = Rj[rr * 3 + 0]; P[rr * 4 + 1] = Rj[rr * 3 + 1]; P[rr * 4 + 2] = Rj[rr * 3 + 2];
-                    P[rr * 4 + 3] = a.post_t ? a.post_t[(size_t)b * a.post_t_ld + rr] : 0.f;
+                    float t = 0.f;
+                    if (inmesh) {
+                        t = a.in_trans[(size_t)sb * 3 + rr];
+                    } else if (a.post_t) {
+                        t = a.post_t[(size_t)b * a.post_t_ld + rr];
+                        if (a.pose_rw) {                    // pred_smpltrans /= trans_scale, in place on pred_pose (:214-218)
+                            t = t / a.trans_scale;
+                            a.pose_rw[(size_t)b * a.post_t_ld + rr] = t;
+                        }
+                    }
+                    P[rr * 4 + 0] = inmesh ? (rr == 0 ? 1.f : 0.f) : Rj[rr * 3 + 0];
+                    P[rr * 4 + 1] = inmesh ? (rr == 1 ? 1.f : 0.f) : Rj[rr * 3 + 1];
+                    P[rr * 4 + 2] = inmesh ? (rr == 2 ? 1.f : 0.f) : Rj[rr * 3 + 2];
+                    P[rr * 4 + 3] = t;
+                }
+                if (a.cc_ws && !inmesh) {                   // camera_center = intr[:, :2, 2] of this body's view (:311,317)
+                    const int half = a.n_main / 2;
+                    const float* K = (b < half ? a.intr0 + (size_t)b * 9 : a.intr1 + (size_t)(b - half) * 9);
+                    a.cc_ws[(size_t)b * 2 + 0] = K[2];
+                    a.cc_ws[(size_t)b * 2 + 1] = K[5];
                 }
             } else {
                 for (int e = 0; e < 9; ++e) R[e] = Rj[e];
@@ -75,8 +100,7 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
         }
     }
     if (j >= 1 && j < m.J) {
-        float* pf = coef + 20 + (j - 1) * 9;
-        for (int e = 0; e < 9; ++e) pf[e] = R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f);
+        for (int e = 0; e < 9; ++e) put(20 + (j - 1) * 9 + e, R[e] - ((e == 0 || e == 4 || e == 8) ? 1.f : 0.f));
     }
     __syncthreads();
     if (j < m.J) {
@@ -371,7 +395,7 @@ hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, h
 }
 
 hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st) {
-    hipLaunchKernelGGL(smplx_joints_kernel, dim3(a.n), dim3(128), 0, st, m, a);
+    hipLaunchKernelGGL(smplx_joints_kernel, dim3(a.n_main > 0 ? a.n_main : a.n), dim3(128), 0, st, m, a);
     return hipGetLastError();
 }
 

@@ -1,8 +1,9 @@
 """Host mirror of the inference branch of ``copenet_twoview.fwd_pass_and_loss``
-(copenet/src/copenet/copenet_twoview.py:166-223, 236-257, 307-350): batch dict in, the reference's
-test-mode output dict out.  Python only orchestrates: four C-ABI calls per forward
-(ap_copenet_fwd, one torch in-place un-scale of the translation exactly as the reference does it,
-ap_smplx_fwd_fused for both views at once)."""
+(copenet/src/copenet/copenet_twoview.py:166-223, 236-279, 307-350): batch dict in, the reference's
+test-mode output dict out.  Python only orchestrates: TWO C-ABI calls per forward -- ap_copenet_fwd and
+ap_smplx_fwd_twoview (translation un-scale in place on pred_pose, rot6d, SMPL-X for both views, root transform,
+projection with the camera centres read from the intrinsics, optionally the test-mode input meshes) -- and no
+torch kernel in between."""
 import torch
 
 from . import _native as N
@@ -28,27 +29,38 @@ class TwoViewInference(object):
         pos = self.init_position(B, dev)
         return self.model(x0=im0, x1=im1, bb0=bb0, bb1=bb1, init_position0=pos, init_position1=pos, iters=self.iters)
 
-    def __call__(self, batch, want_rotmat=True, want_angles=False):
+    def __call__(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False):
         im0, im1 = batch["im0"], batch["im1"]
         B, dev = im0.shape[0], im0.device
         p0, b0, p1, b1 = self.forward_net(im0, im1, batch["bb0"], batch["bb1"])
-        # pred_pose0/1 and betas0/1 are the two halves of one (2,B,.) buffer: run both views as 2B bodies
+        # pred_pose0/1 and betas0/1 are the two halves of one (2,B,.) buffer: both views run as 2B bodies
         pose = p0._base if p0._base is not None and p0._base.shape == (2, B, 135) else torch.stack([p0, p1])
         betas = b0._base if b0._base is not None and b0._base.shape == (2, B, 10) else torch.stack([b0, b1])
-        pose[:, :, :3] /= TRANS_SCALE                      # :214-218, in place: pred_pose itself is un-scaled
-        cc = torch.cat([N.f32c(batch["intr0"], dev)[:, :2, 2], N.f32c(batch["intr1"], dev)[:, :2, 2]], 0).contiguous()
-        o = self.smplx.forward_fused(pose.view(2 * B, 135), betas.view(2 * B, 10), cc, self.focal_length, want_rotmat)
+        in_trans = None
+        if want_input_mesh:
+            # in_smpltrans after the reference's ``*= trans_scale`` ... ``/= trans_scale`` round trip (:199-203,216-218)
+            key = ("in", B, dev)
+            if key not in self._pos:
+                t = self.init_position(B, dev) / TRANS_SCALE
+                self._pos[key] = torch.stack([t, t]).contiguous()
+            in_trans = self._pos[key]
+        # ``pred_smpltrans /= trans_scale`` happens inside the native call, in place on pose (so the returned
+        # pred_pose is un-scaled too, exactly as in the reference where pred_smpltrans is a view of pred_pose)
+        o = self.smplx.forward_twoview(pose, betas, batch["intr0"], batch["intr1"], trans_scale=TRANS_SCALE,
+                                       in_smpltrans=in_trans, focal_length=self.focal_length, want_rotmat=want_rotmat)
         out = {}
         for v in (0, 1):
-            sl = slice(v * B, (v + 1) * B)
             out["pred_pose%d" % v] = pose[v]
             out["pred_betas%d" % v] = betas[v]
             out["pred_smpltrans%d" % v] = pose[v, :, :3]
-            out["pred_vertices_cam%d" % v] = o["vertices_cam"][sl]
-            out["pred_j3d_cam%d" % v] = o["j3d_cam"][sl]
-            out["pred_j2d_cam%d" % v] = o["j2d_cam"][sl]
+            out["pred_vertices_cam%d" % v] = o["vertices_cam"][v]
+            out["pred_j3d_cam%d" % v] = o["j3d_cam"][v]
+            out["pred_j2d_cam%d" % v] = o["j2d_cam"][v]
             if want_rotmat:
-                out["pred_rotmat%d" % v] = o["rotmat"][sl]
+                out["pred_rotmat%d" % v] = o["rotmat"][v]
+            if want_input_mesh:                            # :258-279, 330-331, 342-343
+                out["pred_vertices_cam_in%d" % v] = o["vertices_cam_in"][v]
+                out["in_smpltrans%d" % v] = in_trans[v]
         if want_angles:                                    # test-mode output of the caller, :323-324
             if not want_rotmat:
                 raise ValueError("want_angles needs want_rotmat")

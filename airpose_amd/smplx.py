@@ -172,6 +172,52 @@ class SMPLX(nn.Module):
                                                N.stream_ptr(dev)), "ap_smplx_fwd_fused")
         return {"vertices_cam": verts, "j3d_cam": joints, "j2d_cam": j2d, "rotmat": rot}
 
+    def forward_twoview(self, pred_pose, pred_betas, intr0, intr1, trans_scale=0.0, in_smpltrans=None,
+                        focal_length=(1475.0, 1475.0), want_rotmat=True):
+        """The caller slice for both views in ONE native call (ap_smplx_fwd_twoview; copenet_twoview.py:214-223,
+        237-279, 307-317).  pred_pose (2,B,135) / pred_betas (2,B,10): view 0 first, contiguous; with trans_scale > 0
+        the translation columns of pred_pose are un-scaled IN PLACE (the reference's ``pred_smpltrans /= trans_scale``
+        on a view of pred_pose).  in_smpltrans (2,B,3): also emit the test-mode input meshes (betas = 0, identity
+        root).  Returns dict of (2,B,...) tensors."""
+        if not pred_pose.is_cuda:
+            raise RuntimeError("airpose_amd.SMPLX: inputs must be CUDA (ROCm) tensors; there is no CPU path")
+        dev = pred_pose.device
+        if pred_pose.dim() != 3 or pred_pose.shape[0] != 2 or pred_pose.shape[2] != 135 or not pred_pose.is_contiguous() \
+                or pred_pose.dtype != torch.float32:
+            raise RuntimeError("forward_twoview: pred_pose must be a contiguous fp32 (2, B, 135) tensor")
+        B = pred_pose.shape[1]
+        pred_betas = N.f32c(pred_betas, dev)
+        if tuple(pred_betas.shape) != (2, B, 10):
+            raise RuntimeError("forward_twoview: pred_betas must be (2, B, 10)")
+        intr0, intr1 = N.f32c(intr0, dev), N.f32c(intr1, dev)
+        for t in (intr0, intr1):
+            if t is not None and tuple(t.shape) != (B, 3, 3):
+                raise RuntimeError("forward_twoview: intr must be (B, 3, 3)")
+        in_smpltrans = N.f32c(in_smpltrans, dev)
+        if in_smpltrans is not None and tuple(in_smpltrans.shape) != (2, B, 3):
+            raise RuntimeError("forward_twoview: in_smpltrans must be (2, B, 3)")
+        nv = 4 if in_smpltrans is not None else 2
+        verts = torch.empty(nv, B, self.num_verts, 3, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            nj = self.num_joints_out
+            joints = torch.empty(2, B, nj, 3, device=dev, dtype=torch.float32)
+            j2d = torch.empty(2, B, nj, 2, device=dev, dtype=torch.float32) if intr0 is not None else None
+            rot = torch.empty(2, B, 22, 3, 3, device=dev, dtype=torch.float32) if want_rotmat else None
+            N.check(N.lib().ap_smplx_fwd_twoview(h, B, N.dptr(pred_pose), 135, float(trans_scale), N.dptr(pred_betas),
+                                                 N.dptr(intr0), N.dptr(intr1), float(focal_length[0]),
+                                                 float(focal_length[1]), N.dptr(in_smpltrans), N.dptr(verts),
+                                                 N.dptr(joints), N.dptr(j2d), N.dptr(rot), N.stream_ptr(dev)),
+                    "ap_smplx_fwd_twoview")
+        return {"vertices_cam": verts[:2], "vertices_cam_in": verts[2:] if nv == 4 else None, "j3d_cam": joints,
+                "j2d_cam": j2d, "rotmat": rot}
+
+    def set_blend_precision(self, precision):
+        """'bf16x2' (default): blend-shape contraction as split-bf16 products on the bf16 matrix pipe; 'fp32': exact
+        fp32 MFMA chain (4x slower; the two differ by ~1e-7 of the vertex scale)."""
+        N.check(N.lib().ap_smplx_set_blend_precision(self._native(torch.device("cuda", torch.cuda.current_device())),
+                                                     N.PRECISIONS[precision]), "ap_smplx_set_blend_precision")
+
     def enable_timing(self, on=True):
         N.check(N.lib().ap_smplx_enable_timing(self._native(torch.device("cuda", torch.cuda.current_device())),
                                                int(on)), "ap_smplx_enable_timing")

@@ -389,10 +389,15 @@ def main():
             # algorithmic contraction length: 10 shape + 21 body joints x 9 pose-feature entries, not the
             # zero-padded operand width the kernel runs
             gemm_flops = 2.0 * BLEND_K_ALGORITHMIC * 31425 * n_img
-            res["smplx_blend_roofline"] = {"bound": "mfma-fp32", "achieved": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12,
-                                           "peak": PEAK_FP32_TFLOPS, "unit": "TFLOP/s",
-                                           "frac": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12 / PEAK_FP32_TFLOPS,
-                                           "flops": gemm_flops, "formula": "2 * 199 * 31425 * n_bodies"}
+            # the contraction runs in split-bf16 form on the bf16 matrix pipe: four MFMA products per algorithmic product,
+            # so the pipe's ceiling for ALGORITHMIC flops is a quarter of the dense bf16 peak
+            blend_peak = PEAK_BF16_DENSE_TFLOPS / 4
+            res["smplx_blend_roofline"] = {"bound": "mfma-bf16 (split-bf16 operands, 4 MFMA products per product)",
+                                           "achieved": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12,
+                                           "peak": blend_peak, "unit": "TFLOP/s",
+                                           "frac": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12 / blend_peak,
+                                           "flops": gemm_flops, "formula": "2 * 199 * 31425 * n_bodies",
+                                           "note": "output-bound: the launch writes n_bodies * 125.7 KB of fp32 v_posed"}
         if parity is not None:
             res["parity_mode"] = parity
         if vs is not None:

@@ -213,6 +213,24 @@ int ap_smplx_fwd(ap_smplx* h, int n, const float* betas, const float* expression
 int ap_smplx_fwd_fused(ap_smplx* h, int n, const float* pred_pose, int pose_ld, const float* betas,
                        const float* cam_center, float fx, float fy, float* vertices_cam, float* joints_cam,
                        float* joints2d, float* rotmat, void* stream);
+/* The caller slice of copenet_twoview.fwd_pass_and_loss for BOTH views in one pass, nothing left to the host between
+ * the network and the tail (copenet_twoview.py:214-223, 237-279, 307-317):
+ *   pred_smpltrans /= trans_scale          in place on pred_pose[:, :3] (:214-218; skipped when trans_scale == 0)
+ *   rot6d_to_rotmat -> SMPLX.forward(betas, body rotations, global_orient = I, transl = 0) ->
+ *   transform_smpl([R_root | pred_smpltrans]) -> perspective_projection(camera_center = intr[:, :2, 2])
+ * and, in test mode (in_smpltrans != NULL), the "input" meshes of :258-279: betas = 0, the same body rotations,
+ * transform_smpl([I | in_smpltrans]).
+ * pred_pose [2B][pose_ld] (view 0 rows first), betas [2B][10], intr0 / intr1 [B][3][3] (or both NULL: no projection),
+ * in_smpltrans [2B][3] or NULL.  Outputs: vertices [2B (4B with in_smpltrans)][V][3] (rows 2B.. = the input meshes),
+ * joints_cam [2B][127][3], joints2d [2B][127][2] or NULL, rotmat [2B][22][3][3] or NULL. */
+int ap_smplx_fwd_twoview(ap_smplx* h, int B, float* pred_pose, int pose_ld, float trans_scale, const float* betas,
+                         const float* intr0, const float* intr1, float fx, float fy, const float* in_smpltrans,
+                         float* vertices, float* joints_cam, float* joints2d, float* rotmat, void* stream);
+
+/* Arithmetic of the blend-shape contraction v_posed = v_template + [beta | expr | pose_feature] . dirs^T:
+ * AP_PREC_BF16X2 (default) = operands as split-bf16 pairs, four-term products on the bf16 matrix pipe, fp32 accumulate
+ * and fp32 result (~1e-7 of the vertex scale from the fp32 path); AP_PREC_FP32 = exact fp32 MFMA chain (4x slower). */
+int ap_smplx_set_blend_precision(ap_smplx* h, int precision);
 int ap_smplx_enable_timing(ap_smplx* h, int on);
 /* ms[0]=prep/chain, ms[1]=blend-shape GEMM, ms[2]=skin, ms[3]=joints+projection */
 int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);

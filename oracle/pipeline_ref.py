@@ -35,7 +35,19 @@ def body_outputs(model, pred_pose, pred_betas, intr, focal=FOCAL_LENGTH, dtype=t
     return dict(rotmat=rotmat, vertices_cam=v_cam, j3d_cam=j_cam, j2d_cam=j2d, smpltrans=trans)
 
 
-def infer(sd, model, im0, im1, bb0, bb1, intr0, intr1, iters=3):
+def input_mesh(model, rotmat, in_smpltrans, dtype=torch.float32):
+    """copenet_twoview.py:258-279 (test mode): betas = 0, the predicted body rotations, identity global orientation,
+    then transform_smpl([I | in_smpltrans]) -> pred_vertices_cam_in."""
+    B = rotmat.shape[0]
+    verts, joints = smplx_ref.smplx_forward(model, torch.zeros(B, 10, dtype=dtype), rotmat[:, 1:],
+                                            global_orient=torch.eye(3).expand(B, 1, 3, 3),
+                                            transl=torch.zeros(B, 3), dtype=dtype)
+    tm = torch.cat([torch.eye(3, dtype=dtype).expand(B, 3, 3), in_smpltrans.to(dtype).unsqueeze(2)], dim=2)
+    v_cam, _ = geometry_ref.transform_smpl(tm, verts, joints)
+    return v_cam
+
+
+def infer(sd, model, im0, im1, bb0, bb1, intr0, intr1, iters=3, want_input_mesh=False):
     """Whole hot path on CPU; returns the reference's test-mode output dict (tensor subset)."""
     B = im0.shape[0]
     p0, b0, p1, b1 = copenet_ref.copenet_forward(sd, im0.float(), im1.float(), bb0, bb1,
@@ -55,4 +67,9 @@ def infer(sd, model, im0, im1, bb0, bb1, intr0, intr1, iters=3):
         rm = o["rotmat"].reshape(-1, 3, 3)
         out["pred_angles%d" % v] = geometry_ref.rotation_matrix_to_angle_axis(
             torch.cat([rm, torch.zeros(rm.shape[0], 3, 1, dtype=rm.dtype)], 2)).view(B, 22, 3)
+        if want_input_mesh:
+            # in_smpltrans = [0,0,10] * trans_scale (:184-203) ... /= trans_scale (:216-218) before it is used at :264
+            in_t = init_position(B) / TRANS_SCALE
+            out["in_smpltrans%d" % v] = in_t
+            out["pred_vertices_cam_in%d" % v] = input_mesh(model, o["rotmat"], in_t)
     return out

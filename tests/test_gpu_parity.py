@@ -686,6 +686,30 @@ def test_smplx_forward_matches_oracle(body, smplx_model, dev):
     assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
 
 
+def test_smplx_split_bf16_blend_matches_fp32_blend(body, smplx_model, dev):
+    """The blend-shape contraction on the bf16 matrix pipe (split-bf16 operands, four-term products; the default)
+    against the exact fp32 MFMA chain: <= 1e-5 of the vertex scale (measured ~1e-7), both <= 1e-4 of the oracle."""
+    from oracle import smplx_ref
+    gen = torch.Generator().manual_seed(13)
+    B = 6
+    betas, expr = torch.randn(B, 10, generator=gen) * 2, torch.randn(B, 10, generator=gen)
+    bp = _rand_rot(B * 21, gen).view(B, 21, 3, 3)
+    lh = _rand_rot(B * 15, gen).view(B, 15, 3, 3)
+    kw = dict(betas=betas.to(dev), body_pose=bp.to(dev), expression=expr.to(dev), left_hand_pose=lh.to(dev), pose2rot=False)
+    want_v, _ = smplx_ref.smplx_forward(smplx_model, betas, bp, expression=expr, left_hand_pose=lh)
+    try:
+        body.set_blend_precision("fp32")
+        v32 = body.forward(**kw).vertices.cpu()
+    finally:
+        body.set_blend_precision("bf16x2")
+    vx2 = body.forward(**kw).vertices.cpu()
+    e = rel_err(vx2.numpy(), v32.numpy())
+    print("split-bf16 blend vs fp32 blend: %.3e; vs oracle %.3e / %.3e" % (e, rel_err(vx2.numpy(), want_v.numpy()),
+                                                                       rel_err(v32.numpy(), want_v.numpy())))
+    assert e < 1e-5
+    assert rel_err(vx2.numpy(), want_v.numpy()) < TOL32 and rel_err(v32.numpy(), want_v.numpy()) < TOL32
+
+
 def test_smplx_hands_face_expression(body, smplx_model, dev):
     from oracle import smplx_ref
     gen = torch.Generator().manual_seed(12)
@@ -843,6 +867,33 @@ def test_whole_pipeline_fp32_matches_oracle(net32, body, copenet_sd, copenet_inp
         for nm, e in key_errs(k, got[k].cpu().numpy(), want[k].numpy()).items():
             print("%-28s rel err %.3e" % (nm, e))
             assert e < TOL32, nm
+
+
+def test_test_mode_input_meshes_match_oracle(net32, body, copenet_sd, copenet_inputs, smplx_model, dev):
+    """The rest of the reference's test-mode dict (copenet_twoview.py:258-279, 330-331, 342-343): the beta = 0 meshes
+    placed at in_smpltrans, produced by the same native call as 2B more bodies; and nothing but the two C-ABI calls
+    runs on the stream (the translation un-scale and the camera centres are inside ap_smplx_fwd_twoview)."""
+    from airpose_amd import pipeline
+    from oracle import pipeline_ref
+    inp = copenet_inputs
+    with torch.no_grad():
+        want = pipeline_ref.infer(copenet_sd, smplx_model, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"],
+                                  inp["intr0"], inp["intr1"], want_input_mesh=True)
+    pipe = pipeline.TwoViewInference(net32, body)
+    gin = {k: v.to(dev) for k, v in inp.items()}
+    got = pipe(gin, want_angles=True, want_input_mesh=True)
+    assert set(want) <= set(got)
+    for k in sorted(want):
+        for nm, e in key_errs(k, got[k].cpu().numpy(), want[k].numpy()).items():
+            assert e < TOL32, (nm, e)
+    assert torch.equal(got["in_smpltrans0"].cpu(), want["in_smpltrans0"])
+    # the un-scale happened in place on the network's own output buffer, as in the reference (:214-218)
+    assert got["pred_smpltrans0"].data_ptr() == got["pred_pose0"].data_ptr()
+    assert abs(float(got["pred_pose0"][0, 2]) - float(want["pred_pose0"][0, 2])) < 1e-3 and float(got["pred_pose0"][0, 2]) > 1.0
+    # without the input meshes the other outputs are bit-identical (same bodies, same kernels)
+    plain = pipe(gin, want_angles=True)
+    for k in plain:
+        assert torch.equal(plain[k], got[k]), k
 
 
 def test_full_size_properties_bf16(netbf, body, dev):
