@@ -18,6 +18,12 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+// Timing-only builds for tuning (results WRONG, times valid): -DRP_ABLATE=<bits>
+//   1 no DMA in the K loop | 2 no fragment reads in the K loop | 4 no MFMAs | 8 no barrier in the K loop
+#ifndef RP_ABLATE
+#define RP_ABLATE 0
+#endif
+
 namespace {
 
 template <typename T> using Elem2 = ElemKind<T>;
@@ -34,8 +40,22 @@ template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
 // with lgkmcnt(0), which serialises the fragment double-buffering; the waits are placed by hand instead.
 template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
     u32x4 r;
+#if RP_ABLATE & 2
+    r = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+    asm volatile("" : "+v"(r) : "v"(addr));
+#else
     asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+#endif
     return r;
+}
+__device__ __forceinline__ f32x4 rp_mfma_bf16(const u32x4& w, const u32x4& x, const f32x4& c) {
+#if RP_ABLATE & 4
+    f32x4 r = c;
+    asm volatile("" : "+v"(r) : "v"(w), "v"(x));
+    return r;
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+#endif
 }
 
 template <typename T, int FM, int FN>
@@ -91,11 +111,9 @@ __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&w
     for (int j = 0; j < NM; ++j) {
         const int jj = j % (FM * FN), fm = jj / FN, fn = jj % FN;
         if constexpr (KIND == K_BF16) {
-            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+            acc[fm][fn] = rp_mfma_bf16(wf[fn], xf[fm], acc[fm][fn]);
         } else if constexpr (KIND == K_SPLIT) {
-            acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, j < FM * FN ? xf[fm] : xr[fm]), acc[fm][fn], 0, 0, 0);
+            acc[fm][fn] = rp_mfma_bf16(wf[fn], j < FM * FN ? xf[fm] : xr[fm], acc[fm][fn]);
         } else {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -346,13 +364,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             else if (S > 3 && younger == 1) wait_vmcnt<LPW>();
             else wait_vmcnt<0>();
             AP_STAMP(5);
-            __builtin_amdgcn_s_barrier();
+            if (!(RP_ABLATE & 8)) __builtin_amdgcn_s_barrier();
             AP_STAMP(6);
             const int ns = cs + 1 == S ? 0 : cs + 1;
             load_frags(xa0 + ns * STAGE, wa0 + ns * STAGE, xf0, wf0);   // first half of tile kt+1
         }
         AP_STAMP(7);
-        mma_issue<T, FM, FN, LPW>(xf1, wf1, acc, [&](int i) { if (refill) issue_piece(i, cs); });
+        mma_issue<T, FM, FN, LPW>(xf1, wf1, acc, [&](int i) { if (refill && !(RP_ABLATE & 1)) issue_piece(i, cs); });
         if (++cs == S) cs = 0;
         __builtin_amdgcn_sched_barrier(0);
         AP_STAMP(8);
