@@ -43,6 +43,8 @@ SIGNATURES = {
     "ap_regressor_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ap_copenet_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_singleview_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ap_singleview_reg": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ap_hmr_reg": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ap_muhmr_fwd": (_i, [_vp, _vp, _vp] + [_vp, _i] * 6 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_hmr_fwd": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ap_conv2d_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 9 + [_vp]),

@@ -40,10 +40,29 @@ class copenet(_copenet_base):
                     "ap_singleview_fwd")
         return pose, betas
 
-    def forward_reg(self, *a, **k):
-        raise NotImplementedError("the single-view head runs fused inside forward() (ap_singleview_fwd)")
+    def forward_reg(self, xf, bb, pred_pose, pred_shape, iters=1):
+        """One regressor evaluation from trunk features (model_copenet_singleview.py:159-170):
+        (xf (B,2048), bb (B,3), pose (B,135) = trans3 | 6-D, shape (B,10)) -> the updated (pose, shape)."""
+        self._check_eval()
+        dev = self._dev(xf)
+        B = xf.shape[0]
+        xf, bb, p, s = (N.f32c(t, dev) for t in (xf, bb, pred_pose, pred_shape))
+        if xf.shape != (B, 2048) or bb.shape != (B, 3) or p.shape != (B, 135) or s.shape != (B, 10):
+            raise RuntimeError("forward_reg: xf (B,2048), bb (B,3), pred_pose (B,135), pred_shape (B,10)")
+        pose = torch.empty(B, 135, device=dev, dtype=torch.float32)
+        betas = torch.empty(B, 10, device=dev, dtype=torch.float32)
+        pos, th = p[:, :3].contiguous(), p[:, 3:].contiguous()
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(N.lib().ap_singleview_reg(h, N.dptr(xf), N.dptr(bb), N.dptr(pos), N.dptr(th), 132, N.dptr(s), 10, B,
+                                              int(iters), N.dptr(pose), N.dptr(betas), N.stream_ptr(dev)),
+                    "ap_singleview_reg")
+        return pose, betas
 
-    forward_ief = regressor_step = forward_reg
+    def forward_ief(self, *a, **k):
+        raise NotImplementedError("model_copenet_singleview has no two-view IEF entry; use forward() or forward_reg()")
+
+    regressor_step = forward_ief
 
 
 def getcopenet(smpl_mean_params, pretrained=True, precision="bf16", **kwargs):

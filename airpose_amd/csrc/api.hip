@@ -928,6 +928,17 @@ int ap_singleview_fwd(ap_net* h, const float* x, const float* bb, const float* p
     return regressor_run(h, in, B, iters, 0, nullptr, 0, 3, pose, betas, nullptr, nullptr, st);
 }
 
+// feature-level evaluation of the single-view head: `iters` regressor evaluations from pre-computed trunk features
+// (model_copenet_singleview.py:159-170 for iters = 1)
+int ap_singleview_reg(ap_net* h, const float* xf, const float* bb, const float* pos, const float* init_theta, int theta_bs,
+                      const float* init_shape, int shape_bs, int B, int iters, float* pose, float* betas, void* stream) {
+    if (!h || !xf || !bb || !pos || !pose || !betas) return fail(AP_EINVAL, "ap_singleview_reg: null argument");
+    if (h->variant != 2) return fail(AP_ESTATE, "ap_singleview_reg needs a copenet_singleview (variant 2) handle");
+    if (B <= 0) return fail(AP_EINVAL, "ap_singleview_reg: bad batch");
+    RegInputs in{xf, nullptr, bb, nullptr, pos, nullptr, init_theta, nullptr, init_shape, nullptr, theta_bs, 0, shape_bs, 0};
+    return regressor_run(h, in, B, iters, 0, nullptr, 0, 3, pose, betas, nullptr, nullptr, (hipStream_t)stream);
+}
+
 int ap_muhmr_fwd(ap_net* h, const float* x0, const float* x1, const float* init_cam0, int cam0_bs, const float* init_cam1,
                  int cam1_bs, const float* init_theta0, int theta0_bs, const float* init_theta1, int theta1_bs,
                  const float* init_shape0, int shape0_bs, const float* init_shape1, int shape1_bs, int B, int iters,
@@ -1022,19 +1033,17 @@ int ap_set_conv_config(int cfg) {
     return AP_OK;
 }
 
-int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_theta, int theta_bs,
-               const float* init_shape, int shape_bs, const float* init_cam, int cam_bs, float* rotmat, float* betas,
-               float* cam, void* stream) {
-    if (!h || !x || B <= 0 || iters < 1 || !rotmat || !betas || !cam) return fail(AP_EINVAL, "ap_hmr_fwd: bad argument");
-    if (h->variant != 1) return fail(AP_ESTATE, "ap_hmr_fwd needs an hmr (variant 1) handle");
-    hipStream_t st = (hipStream_t)stream;
-    HIP_TRY(h->ws_feat.reserve((size_t)B * 2048 * 4));
+}  // extern "C"
+
+namespace {
+// IEF of the HMR head from trunk features: state rows of 160 floats = pose132 | shape10 | cam3 | pad, left in ws_state
+int hmr_ief(ap_net* h, const float* feat, int B, int iters, const float* init_theta, int theta_bs, const float* init_shape,
+            int shape_bs, const float* init_cam, int cam_bs, hipStream_t st) {
     HIP_TRY(h->ws_H.reserve((size_t)B * DLD * 4));
     HIP_TRY(h->ws_D.reserve((size_t)B * DLD * 4));
     HIP_TRY(h->ws_state.reserve((size_t)B * 160 * 4));
-    float *feat = h->ws_feat.as<float>(), *Hb = h->ws_H.as<float>(), *D = h->ws_D.as<float>(), *state = h->ws_state.as<float>();
-    int rc = trunk_fwd(h, x, B, nullptr, 0, feat, st);
-    if (rc) return rc;
+    float *Hb = h->ws_H.as<float>(), *D = h->ws_D.as<float>(), *state = h->ws_state.as<float>();
+    int rc;
     if ((rc = run_gemm(h->fold_feat, feat, 2048, 2048, B, Hb, DLD, nullptr, 0, st))) return rc;
     HIP_TRY(ap_launch_hmr_init(init_theta, theta_bs, init_shape, shape_bs, init_cam, cam_bs, h->mean_pose.as<float>(),
                                h->mean_shape.as<float>(), h->mean_cam.as<float>(), state, B, st));
@@ -1042,10 +1051,45 @@ int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_th
         if ((rc = run_gemm(h->fold_state, state, 160, 160, B, D, DLD, Hb, DLD, st))) return rc;
         HIP_TRY(ap_launch_hmr_update(state, D, DLD, B, st));
     }
-    HIP_TRY(ap_launch_hmr_output(state, rotmat, betas, cam, B, st));
+    return AP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+// model_hmr.copenet.forward_reg (:160-172) from pre-computed features: `iters` evaluations, the raw 6-D pose / shape /
+// camera state out (no rot6d conversion)
+int ap_hmr_reg(ap_net* h, const float* xf, int B, int iters, const float* pose_in, int pose_bs, const float* shape_in,
+               int shape_bs, const float* cam_in, int cam_bs, float* pose_out, float* shape_out, float* cam_out,
+               void* stream) {
+    if (!h || !xf || B <= 0 || iters < 1 || !pose_out || !shape_out || !cam_out)
+        return fail(AP_EINVAL, "ap_hmr_reg: bad argument");
+    if (h->variant != 1) return fail(AP_ESTATE, "ap_hmr_reg needs an hmr (variant 1) handle");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = hmr_ief(h, xf, B, iters, pose_in, pose_bs, shape_in, shape_bs, cam_in, cam_bs, st);
+    if (rc) return rc;
+    const float* state = h->ws_state.as<float>();
+    HIP_TRY(hipMemcpy2DAsync(pose_out, 132 * 4, state, 160 * 4, 132 * 4, B, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(shape_out, 10 * 4, state + 132, 160 * 4, 10 * 4, B, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(cam_out, 3 * 4, state + 142, 160 * 4, 3 * 4, B, hipMemcpyDeviceToDevice, st));
     return AP_OK;
 }
 
+int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_theta, int theta_bs,
+               const float* init_shape, int shape_bs, const float* init_cam, int cam_bs, float* rotmat, float* betas,
+               float* cam, void* stream) {
+    if (!h || !x || B <= 0 || iters < 1 || !rotmat || !betas || !cam) return fail(AP_EINVAL, "ap_hmr_fwd: bad argument");
+    if (h->variant != 1) return fail(AP_ESTATE, "ap_hmr_fwd needs an hmr (variant 1) handle");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(h->ws_feat.reserve((size_t)B * 2048 * 4));
+    float* feat = h->ws_feat.as<float>();
+    int rc = trunk_fwd(h, x, B, nullptr, 0, feat, st);
+    if (rc) return rc;
+    if ((rc = hmr_ief(h, feat, B, iters, init_theta, theta_bs, init_shape, shape_bs, init_cam, cam_bs, st))) return rc;
+    float* state = h->ws_state.as<float>();
+    HIP_TRY(ap_launch_hmr_output(state, rotmat, betas, cam, B, st));
+    return AP_OK;
+}
 int ap_net_enable_timing(ap_net* h, int on) {
     if (!h || on < 0 || on > 2) return fail(AP_EINVAL, "ap_net_enable_timing: handle, on in {0, 1, 2}");
     h->tm.on = on;

@@ -39,10 +39,26 @@ class copenet(_copenet_base):
                                        N.dptr(rot), N.dptr(betas), N.dptr(cam), N.stream_ptr(dev)), "ap_hmr_fwd")
         return rot, betas, cam
 
-    def forward_reg(self, *a, **k):
-        raise NotImplementedError("the HMR head runs fused inside forward() (ap_hmr_fwd)")
+    def forward_reg(self, xf, pred_pose, pred_shape, pred_cam, iters=1):
+        """One regressor evaluation from trunk features (model_hmr.py:160-172): (xf (B,2048), pose (B,132) 6-D,
+        shape (B,10), cam (B,3)) -> the updated (pose, shape, cam)."""
+        self._check_eval()
+        dev = self._dev(xf)
+        B = xf.shape[0]
+        xf, p, s, c = (N.f32c(t, dev) for t in (xf, pred_pose, pred_shape, pred_cam))
+        if xf.shape != (B, 2048) or p.shape != (B, 132) or s.shape != (B, 10) or c.shape != (B, 3):
+            raise RuntimeError("forward_reg: xf (B,2048), pred_pose (B,132), pred_shape (B,10), pred_cam (B,3)")
+        po, so, co = (torch.empty(B, n, device=dev, dtype=torch.float32) for n in (132, 10, 3))
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(N.lib().ap_hmr_reg(h, N.dptr(xf), B, int(iters), N.dptr(p), 132, N.dptr(s), 10, N.dptr(c), 3, N.dptr(po),
+                                       N.dptr(so), N.dptr(co), N.stream_ptr(dev)), "ap_hmr_reg")
+        return po, so, co
 
-    forward_ief = regressor_step = forward_reg
+    def forward_ief(self, *a, **k):
+        raise NotImplementedError("model_hmr has no two-view IEF entry; use forward() or forward_reg()")
+
+    regressor_step = forward_ief
 
 
 def getcopenet(smpl_mean_params, pretrained=True, precision="bf16", **kwargs):

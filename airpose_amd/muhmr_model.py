@@ -49,10 +49,35 @@ class copenet(_copenet_base):
                     "ap_muhmr_fwd")
         return out[0, :, 3:], betas[0], out[0, :, :3], out[1, :, 3:], betas[1], out[1, :, :3]
 
-    def forward_reg(self, *a, **k):
-        raise NotImplementedError("the muhmr head runs fused inside forward() (ap_muhmr_fwd)")
+    def forward_reg(self, xf0, xf1, pred_orient0, pred_orient1, pred_art_pose0, pred_art_pose1, pred_shape0, pred_shape1,
+                    pred_cam0, pred_cam1):
+        """One regressor evaluation for both views from trunk features (model_muhmr.py:177-203) ->
+        (pred_pose0 (B,132), pred_shape0, pred_cam0, pred_pose1, pred_shape1, pred_cam1).  Runs the two-view kernels
+        with the cameras in the translation slots (the re-mapped fc1 of this variant gives bb zero weight)."""
+        self._check_eval()
+        dev = self._dev(xf0)
+        B = xf0.shape[0]
+        xf0, xf1 = N.f32c(xf0), N.f32c(xf1, dev)
+        th0 = torch.cat([N.f32c(pred_orient0, dev), N.f32c(pred_art_pose0, dev)], 1).contiguous()
+        th1 = torch.cat([N.f32c(pred_orient1, dev), N.f32c(pred_art_pose1, dev)], 1).contiguous()
+        s0, s1, c0, c1 = (N.f32c(t, dev) for t in (pred_shape0, pred_shape1, pred_cam0, pred_cam1))
+        if xf0.shape != (B, 2048) or xf1.shape != (B, 2048) or th0.shape != (B, 132) or th1.shape != (B, 132) \
+                or s0.shape != (B, 10) or s1.shape != (B, 10) or c0.shape != (B, 3) or c1.shape != (B, 3):
+            raise RuntimeError("forward_reg: xf (B,2048), orient (B,6), art_pose (B,126), shape (B,10), cam (B,3) per view")
+        out = torch.empty(2, B, 135, device=dev, dtype=torch.float32)
+        betas = torch.empty(2, B, 10, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(N.lib().ap_regressor_fwd(h, N.dptr(xf0), N.dptr(xf1), N.dptr(xf0), N.dptr(xf1), N.dptr(c0), N.dptr(c1),
+                                             N.dptr(th0), 132, N.dptr(th1), 132, N.dptr(s0), 10, N.dptr(s1), 10, B, 1,
+                                             N.dptr(out[0]), N.dptr(betas[0]), N.dptr(out[1]), N.dptr(betas[1]),
+                                             N.stream_ptr(dev)), "ap_regressor_fwd")
+        return out[0, :, 3:], betas[0], out[0, :, :3], out[1, :, 3:], betas[1], out[1, :, :3]
 
-    forward_ief = regressor_step = forward_reg
+    def forward_ief(self, *a, **k):
+        raise NotImplementedError("model_muhmr has no translation-based IEF entry; use forward() or forward_reg()")
+
+    regressor_step = forward_ief
 
 
 def getcopenet(smpl_mean_params, pretrained=True, precision="bf16", **kwargs):

@@ -111,6 +111,19 @@ int ap_hmr_fwd(ap_net* h, const float* x, int B, int iters, const float* init_th
                const float* init_shape, int shape_bs, const float* init_cam, int cam_bs, float* rotmat, float* betas,
                float* cam, void* stream);
 
+/* Feature-level evaluations of the baseline heads (the reference modules expose them as forward_reg):
+ *   ap_hmr_reg         model_hmr.copenet.forward_reg (copenet/src/copenet/models/model_hmr.py:160-172), `iters` evaluations
+ *                      from features xf [B][2048]; state in / out = 6-D pose [B][132] | shape [B][10] | cam [B][3]
+ *                      (NULL inputs = the model's mean parameters; *_bs = batch stride in floats, 0 = broadcast)
+ *   ap_singleview_reg  model_copenet_singleview.copenet.forward_reg (models/model_copenet_singleview.py:159-170)
+ * The muhmr head (models/model_muhmr.py:177-203) runs through ap_regressor_fwd on its variant-3 handle with the cameras
+ * in the position slots. */
+int ap_hmr_reg(ap_net* h, const float* xf, int B, int iters, const float* pose_in, int pose_bs, const float* shape_in,
+               int shape_bs, const float* cam_in, int cam_bs, float* pose_out, float* shape_out, float* cam_out,
+               void* stream);
+int ap_singleview_reg(ap_net* h, const float* xf, const float* bb, const float* pos, const float* init_theta, int theta_bs,
+                      const float* init_shape, int shape_bs, int B, int iters, float* pose, float* betas, void* stream);
+
 /* One fused convolution of the trunk: y = act(conv(x, w) * scale + shift (+ res)), the building block of
  * Bottleneck.forward (model_copenet.py:27-47: conv -> BN -> [+ residual] -> ReLU).  Exposed so the kernel can be
  * unit-tested and reused.  NHWC activations x [N][H][W][Cin], y/res [N][Ho][Wo][Cout]; w [Cout_pad][k][k][Cin]

@@ -1177,3 +1177,54 @@ def test_view_split_two_processes_on_one_gpu_match_golden(golden, net32, copenet
         assert ep < TOL32 and eb < TOL32
         # and against the fused single-process IEF on the same GPU (different kernels: step chain vs fused loop)
         assert pose_err(d["pose"], one[2 * r]) < 1e-5 and rel_err(d["betas"], one[2 * r + 1].cpu().numpy()) < 1e-5
+
+
+# ------------------------------------------------------------------------------------------------ forward_reg of the baseline heads
+def test_baseline_heads_expose_forward_reg(golden, dev):
+    """model_hmr.forward_reg (:160-172), model_copenet_singleview.forward_reg (:159-170) and model_muhmr.forward_reg
+    (:177-203): ONE regressor evaluation from trunk features, as the reference modules expose it, against the oracle's
+    linear layers on the same weights; and consistency with forward(): iterating forward_reg reproduces it."""
+    from airpose_amd import copenet_singleview_model, hmr_model, muhmr_model, weights as W
+    from oracle import copenet_ref
+    gen = torch.Generator().manual_seed(77)
+    B = 3
+    xf0, xf1 = torch.randn(B, 2048, generator=gen), torch.randn(B, 2048, generator=gen)
+    pose = torch.randn(B, 132, generator=gen) * 0.5
+    pose1 = torch.randn(B, 132, generator=gen) * 0.5
+    shape, shape1 = torch.randn(B, 10, generator=gen) * 0.5, torch.randn(B, 10, generator=gen) * 0.5
+    cam, cam1 = torch.randn(B, 3, generator=gen) * 0.3, torch.randn(B, 3, generator=gen) * 0.3
+    bb, pos = torch.rand(B, 3, generator=gen), torch.randn(B, 3, generator=gen) * 0.3
+    d = lambda t: t.to(dev)
+    # ---- hmr
+    sd = W.to_torch(W.copenet_state_dict(int(golden["hmr_b1"]["weights_seed"]), MEAN_PARAMS, variant="hmr"))
+    net = hmr_model.getcopenet(MEAN_PARAMS, precision="fp32").eval()
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        want = copenet_ref.hmr_forward_reg(sd, xf0, pose, shape, cam)
+    got = net.forward_reg(d(xf0), d(pose), d(shape), d(cam))
+    for g_, w_, nm in zip(got, want, ("pose", "shape", "cam")):
+        assert rel_err(g_.cpu().numpy(), w_.numpy()) < TOL32, "hmr " + nm
+    # ---- copenet_singleview
+    sd = W.to_torch(W.copenet_state_dict(int(golden["singleview_b1"]["weights_seed"]), MEAN_PARAMS, variant="singleview"))
+    net = copenet_singleview_model.getcopenet(MEAN_PARAMS, precision="fp32").eval()
+    net.load_state_dict(sd)
+    p135 = torch.cat([pos, pose], 1)
+    with torch.no_grad():
+        xc = copenet_ref._lin(copenet_ref._lin(torch.cat([xf0, bb, p135, shape], 1), sd, "fc1"), sd, "fc2")
+        want = (copenet_ref._lin(xc, sd, "decpose") + p135, copenet_ref._lin(xc, sd, "decshape") + shape)
+    got = net.forward_reg(d(xf0), d(bb), d(p135), d(shape))
+    assert pose_err(got[0], want[0]) < TOL32 and rel_err(got[1].cpu().numpy(), want[1].numpy()) < TOL32
+    # ---- muhmr
+    sd = W.to_torch(W.copenet_state_dict(int(golden["muhmr_b1"]["weights_seed"]), MEAN_PARAMS, variant="muhmr"))
+    net = muhmr_model.getcopenet(MEAN_PARAMS, precision="fp32").eval()
+    net.load_state_dict(sd)
+    with torch.no_grad():
+        xc0 = copenet_ref._lin(copenet_ref._lin(torch.cat([xf0, cam, pose, shape, pose1[:, 6:], shape1], 1), sd, "fc1"), sd, "fc2")
+        xc1 = copenet_ref._lin(copenet_ref._lin(torch.cat([xf1, cam1, pose1, shape1, pose[:, 6:], shape], 1), sd, "fc1"), sd, "fc2")
+        want = (pose + copenet_ref._lin(xc0, sd, "decpose"), shape + copenet_ref._lin(xc0, sd, "decshape"),
+                cam + copenet_ref._lin(xc0, sd, "deccam"), pose1 + copenet_ref._lin(xc1, sd, "decpose"),
+                shape1 + copenet_ref._lin(xc1, sd, "decshape"), cam1 + copenet_ref._lin(xc1, sd, "deccam"))
+    got = net.forward_reg(d(xf0), d(xf1), d(pose[:, :6]), d(pose1[:, :6]), d(pose[:, 6:]), d(pose1[:, 6:]), d(shape), d(shape1),
+                          d(cam), d(cam1))
+    for g_, w_, nm in zip(got, want, ("pose0", "shape0", "cam0", "pose1", "shape1", "cam1")):
+        assert rel_err(g_.cpu().numpy(), w_.numpy()) < TOL32, "muhmr " + nm
