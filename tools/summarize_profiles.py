@@ -17,7 +17,7 @@ CONV = ("conv_pipe_kernel", "conv_igemm_kernel", "bneck256_kernel", "bneck64ds_k
 
 
 def is_trunk_conv(name):     # the bf16 conv-stack kernels (the fp32 instances are the blend-shape GEMM)
-    return any(k in name for k in CONV) and "<float" not in name
+    return any(k in name for k in CONV) and "<float" not in name and "bsplit_t" not in name
 
 
 db = glob.glob(os.path.join(O, tag + "_trace", "**", "*_results.db"), recursive=True)
@@ -89,7 +89,7 @@ if macc:
         if tg:
             f.write('"conv stack (all bf16 conv kernels)",,%.0f,,%.0f,%.2f\n' % (tb, tg, 100 * tb / (tg * 1024)))
             print("conv stack MFMA busy %.2f %%" % (100 * tb / (tg * 1024)))
-for f in ("bench", "bench_b64", "bench_fp32"):
+for f in ("bench", "bench_b64", "bench_x2", "bench_fp32"):
     p = os.path.join(O, "%s_%s.json" % (tag, f))
     if os.path.exists(p) and os.path.getsize(p):
         d = json.loads(open(p).read().strip().splitlines()[-1])
