@@ -24,28 +24,37 @@ __device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) 
     hi = __builtin_bit_cast(float, u & 0xffff0000u);
 }
 
-// Split-bf16 storage ("bf16x2" precision): one value as two bf16, hi = rne(x) in the low half of a 32-bit word and
-// lo = rne(x - hi) in the high half, value = hi + lo (16 mantissa bits, same bytes as fp32).  Products of two such
-// values run on the bf16 matrix pipe: the 8 bf16 positions of a 16-byte fragment chunk are 4 (hi, lo) pairs, so
-//   mfma(w, x)          contracts  hi*hi + lo*lo   per pair
-//   mfma(w, rot16(x))   contracts  hi*lo + lo*hi
-// i.e. the full product (hi + lo)(hi' + lo') in two v_mfma_f32_16x16x32_bf16 per 4 K elements, fp32 accumulate:
-// 4x the rate of the exact-fp32 v_mfma_f32_16x16x4_f32 path at ~2^-17 relative operand error.
+// Split-bf16 storage ("bf16x2" precision): one value as two bf16, hi = rne(x) and lo = rne(x - hi), value = hi + lo
+// (16 mantissa bits, the bytes of an fp32).  Layout: PLANAR in groups of 8 consecutive elements of the innermost
+// (channel / K) dimension -- 32 bytes = [8 x bf16 hi | 8 x bf16 lo] -- so that the 16-byte chunk a lane feeds to
+// v_mfma_f32_16x16x32_bf16 is 8 hi parts or 8 lo parts of the same 8 K elements, and a product of two such values is
+//   mfma(w_hi, x_hi) + mfma(w_hi, x_lo) + mfma(w_lo, x_hi)          (lo*lo, 2^-18 relative, is dropped)
+// three MFMAs per 8 K elements, fp32 accumulate: 5.3x the rate of the exact-fp32 v_mfma_f32_16x16x4_f32 path at ~2^-17
+// relative operand error.  An element is addressed as a 4-byte unit (bsplit_t) and only ever touched in aligned groups of 8.
 struct bsplit_t { uint32_t u; };
-__device__ __forceinline__ uint32_t split_pack(float f) {
-    const bf16_t hi = f32_to_bf16(f);
-    const bf16_t lo = f32_to_bf16(f - bf16_to_f32(hi));
-    return (uint32_t)hi | ((uint32_t)lo << 16);
+__device__ __forceinline__ void split8_pack(const float (&v)[8], u32x4& hi, u32x4& lo) {
+    bf16_t h[8], l[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        h[i] = f32_to_bf16(v[i]);
+        l[i] = f32_to_bf16(v[i] - bf16_to_f32(h[i]));
+    }
+    hi.x = (uint32_t)h[0] | ((uint32_t)h[1] << 16); hi.y = (uint32_t)h[2] | ((uint32_t)h[3] << 16);
+    hi.z = (uint32_t)h[4] | ((uint32_t)h[5] << 16); hi.w = (uint32_t)h[6] | ((uint32_t)h[7] << 16);
+    lo.x = (uint32_t)l[0] | ((uint32_t)l[1] << 16); lo.y = (uint32_t)l[2] | ((uint32_t)l[3] << 16);
+    lo.z = (uint32_t)l[4] | ((uint32_t)l[5] << 16); lo.w = (uint32_t)l[6] | ((uint32_t)l[7] << 16);
 }
-__device__ __forceinline__ float split_unpack(uint32_t u) {
-    return __builtin_bit_cast(float, u << 16) + __builtin_bit_cast(float, u & 0xffff0000u);
+__device__ __forceinline__ void split8_unpack(const u32x4& hi, const u32x4& lo, float (&v)[8]) {
+    const uint32_t hh[4] = {hi.x, hi.y, hi.z, hi.w}, ll[4] = {lo.x, lo.y, lo.z, lo.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        v[2 * i] = __builtin_bit_cast(float, hh[i] << 16) + __builtin_bit_cast(float, ll[i] << 16);
+        v[2 * i + 1] = __builtin_bit_cast(float, hh[i] & 0xffff0000u) + __builtin_bit_cast(float, ll[i] & 0xffff0000u);
+    }
 }
-__device__ __forceinline__ u32x4 split_rot16(const u32x4& v) {
-    u32x4 r;
-    r.x = (v.x >> 16) | (v.x << 16); r.y = (v.y >> 16) | (v.y << 16);
-    r.z = (v.z >> 16) | (v.z << 16); r.w = (v.w >> 16) | (v.w << 16);
-    return r;
-}
+// bf16 positions (in units of 2 bytes from the start of a row of 4-byte elements) of element i
+__device__ __forceinline__ int split_hi_pos(int i) { return (i >> 3) * 16 + (i & 7); }
+__device__ __forceinline__ int split_lo_pos(int i) { return (i >> 3) * 16 + 8 + (i & 7); }
 // storage kinds (= the AP_PREC_* values of include/airpose_hip.h)
 constexpr int K_F32 = 0, K_BF16 = 1, K_SPLIT = 2;
 template <typename T> struct ElemKind;
@@ -56,11 +65,9 @@ template <> struct ElemKind<bsplit_t> { static constexpr int KIND = K_SPLIT, EPC
 template <typename T> __device__ __forceinline__ float elem_load(const T* p);
 template <> __device__ __forceinline__ float elem_load<float>(const float* p) { return *p; }
 template <> __device__ __forceinline__ float elem_load<bf16_t>(const bf16_t* p) { return bf16_to_f32(*p); }
-template <> __device__ __forceinline__ float elem_load<bsplit_t>(const bsplit_t* p) { return split_unpack(p->u); }
 template <typename T> __device__ __forceinline__ void elem_store(T* p, float v);
 template <> __device__ __forceinline__ void elem_store<float>(float* p, float v) { *p = v; }
 template <> __device__ __forceinline__ void elem_store<bf16_t>(bf16_t* p, float v) { *p = f32_to_bf16(v); }
-template <> __device__ __forceinline__ void elem_store<bsplit_t>(bsplit_t* p, float v) { p->u = split_pack(v); }
 
 // Bijective XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): give every XCD a
 // contiguous run of logical tile ids so neighbouring tiles (which share an operand panel) hit one L2.
@@ -86,9 +93,12 @@ static inline uint16_t host_f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-static inline uint32_t host_split_pack(float f) {
-    const uint16_t hi = host_f32_to_bf16(f);
-    const float hf = __builtin_bit_cast(float, (uint32_t)hi << 16);
-    const uint16_t lo = host_f32_to_bf16(f - hf);
-    return (uint32_t)hi | ((uint32_t)lo << 16);
+static inline void host_split_parts(float f, uint16_t* hi, uint16_t* lo) {
+    *hi = host_f32_to_bf16(f);
+    *lo = host_f32_to_bf16(f - __builtin_bit_cast(float, (uint32_t)*hi << 16));
+}
+// n floats (n % 8 == 0, rows are multiples of 8) -> planar split-bf16: dst holds 2n uint16, group g at [16g, 16g + 16)
+static inline void host_split_pack_planar(const float* src, size_t n, uint16_t* dst) {
+    for (size_t i = 0; i < n; ++i)
+        host_split_parts(src[i], &dst[(i >> 3) * 16 + (i & 7)], &dst[(i >> 3) * 16 + 8 + (i & 7)]);
 }

@@ -297,9 +297,9 @@ int pack_conv(ap_net* h, const std::string& wname, const std::string& bnname, in
                 for (int r = 0; r < k; ++r)
                     for (int s = 0; s < k; ++s)
                         pk[(size_t)o * L.wld + (r * k + s) * cin + c] = w->data[(((size_t)o * cin + c) * k + r) * k + s];
-        if (h->prec == AP_PREC_BF16X2) {
-            std::vector<uint32_t> ps(n);
-            for (size_t i = 0; i < n; ++i) ps[i] = host_split_pack(pk[i]);
+        if (h->prec == AP_PREC_BF16X2) {                    // rows of k*k*cin elements, cin a multiple of 8: planar groups of 8
+            std::vector<uint16_t> ps(2 * n);
+            host_split_pack_planar(pk.data(), n, ps.data());
             HIP_TRY(upload(L.w, ps.data(), n * 4));
         } else {
             HIP_TRY(upload(L.w, pk.data(), n * 4));
@@ -338,8 +338,8 @@ int pack_c3_ds(ap_net* h, const std::string& P, int planes, int inplanes, int st
         for (size_t i = 0; i < n; ++i) pb[i] = host_f32_to_bf16(pk[i]);
         HIP_TRY(upload(L.w, pb.data(), n * 2));
     } else if (h->prec == AP_PREC_BF16X2) {
-        std::vector<uint32_t> ps(n);
-        for (size_t i = 0; i < n; ++i) ps[i] = host_split_pack(pk[i]);
+        std::vector<uint16_t> ps(2 * n);
+        host_split_pack_planar(pk.data(), n, ps.data());
         HIP_TRY(upload(L.w, ps.data(), n * 4));
     } else {
         HIP_TRY(upload(L.w, pk.data(), n * 4));
@@ -455,7 +455,9 @@ int finalize_trunk(ap_net* h) {
                     for (int r = 0; r < 7; ++r)
                         for (int s2 = 0; s2 < 7; ++s2) {
                             const float wv = w->data[((o * 3 + c) * 7 + r) * 7 + s2];
-                            pl[o * 232 + r * 32 + s2 * 4 + c] = (uint16_t)(host_split_pack(wv) >> 16);
+                            uint16_t hi, lo;
+                            host_split_parts(wv, &hi, &lo);
+                            pl[o * 232 + r * 32 + s2 * 4 + c] = lo;
                         }
             HIP_TRY(upload(h->stem_wpk_lo, pl.data(), pl.size() * 2));
         }
@@ -988,7 +990,7 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
         !shift || !y || N <= 0 ||
         H <= 0 || W <= 0 || ksize <= 0 || stride <= 0 || pad < 0)
         return fail(AP_EINVAL, "ap_conv2d_nhwc: bad argument");
-    if (Cin % (bf ? 64 : 32) || Cout % (bf ? 8 : 4) || Cin <= 0 || Cout <= 0)
+    if (Cin % (bf ? 64 : 32) || Cout % (precision == AP_PREC_FP32 ? 4 : 8) || Cin <= 0 || Cout <= 0)
         return fail(AP_ESHAPE, "ap_conv2d_nhwc: Cin must be a multiple of 64 (bf16) / 32 (fp32), Cout of 8 / 4");
     ConvArgs a{};
     a.x = x; a.w = w; a.scale = scale; a.shift = shift; a.res = res; a.y = y;
@@ -1226,9 +1228,9 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
         }
         hipError_t e = upload(L.w, pk.data(), pk.size() * 4);
         if (e == hipSuccess) {
-            std::vector<uint32_t> ps(pk.size());
-            for (size_t i = 0; i < pk.size(); ++i) ps[i] = host_split_pack(pk[i]);
-            e = upload(h->dirs_split, ps.data(), ps.size() * 4);
+            std::vector<uint16_t> ps(2 * pk.size());          // rows of 512 coefficients: planar groups of 8
+            host_split_pack_planar(pk.data(), pk.size(), ps.data());
+            e = upload(h->dirs_split, ps.data(), pk.size() * 4);
         }
         if (e == hipSuccess) e = upload(L.scale, scale.data(), scale.size() * 4);
         if (e == hipSuccess) e = upload(L.shift, shift.data(), shift.size() * 4);

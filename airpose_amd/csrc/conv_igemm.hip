@@ -36,19 +36,6 @@ __device__ __forceinline__ void mma_chunk(const u32x4 (&xf)[FM], const u32x4 (&w
             for (int fn = 0; fn < FN; ++fn)
                 acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
-    } else if constexpr (Elem<T>::KIND == K_SPLIT) {
-        // (hi, lo) pairs: straight = hi*hi + lo*lo, against the 16-bit rotated activations = the two cross terms
-        u32x4 xr[FM];
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass)          // (the two MFMAs of one accumulator FM*FN instructions apart)
-#pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < FN; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, pass ? xr[fm] : xf[fm]), acc[fm][fn], 0, 0, 0);
     } else {
         // lane group g holds k = 4g..4g+3 of a 16-deep slab; MFMA t contracts {4g'+t : g'=0..3}
 #pragma unroll
@@ -63,6 +50,22 @@ __device__ __forceinline__ void mma_chunk(const u32x4 (&xf)[FM], const u32x4 (&w
                         __builtin_bit_cast(float, wv), __builtin_bit_cast(float, xv), acc[fm][fn], 0, 0, 0);
                 }
     }
+}
+
+// split-bf16 (planar): hi and lo fragments of the same 8 K elements per lane; w_hi*x_hi, w_hi*x_lo, w_lo*x_hi, each pass over
+// all accumulators before the next so that the MFMAs of one accumulator are FM*FN instructions apart
+template <int FM, int FN>
+__device__ __forceinline__ void mma_split3(const u32x4 (&xh)[FM], const u32x4 (&xl)[FM], const u32x4 (&wh)[FN],
+                                           const u32x4 (&wl)[FN], f32x4 (&acc)[FM][FN]) {
+#pragma unroll
+    for (int pass = 0; pass < 3; ++pass)
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn)
+                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    __builtin_bit_cast(bf16x8, pass == 2 ? wl[fn] : wh[fn]),
+                    __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn], 0, 0, 0);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -160,7 +163,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
 
     // ---------------------------------------------------------------- MFMA state
     const int lr = lane & 15, g = lane >> 4;
-    const int sw0 = ((g ^ (lr & 7)) << 4), sw1 = (((4 + g) ^ (lr & 7)) << 4);
+    // chunk of a 128-byte row read by lane group g: bf16 / fp32: g then 4 + g (two 32- / 16-deep halves);
+    // split-bf16: 2g (hi parts of elements 8g .. 8g+7) and 2g + 1 (their lo parts)
+    constexpr bool SPLIT = Elem<T>::KIND == K_SPLIT;
+    const int c0 = SPLIT ? 2 * g : g, c1 = SPLIT ? 2 * g + 1 : 4 + g;
+    const int sw0 = ((c0 ^ (lr & 7)) << 4), sw1 = ((c1 ^ (lr & 7)) << 4);
     const int xfrag = (wm * (BM / WAVES_M) + lr) * 128;
     const int wfrag = BM * 128 + (wn * (BN / WAVES_N) + lr) * 128;
     f32x4 acc[FM][FN];
@@ -181,12 +188,21 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         for (int fm = 0; fm < FM; ++fm) xf[fm] = *(const u32x4*)(sb + xfrag + fm * 16 * 128 + sw0);
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) wf[fn] = *(const u32x4*)(sb + wfrag + fn * 16 * 128 + sw0);
-        mma_chunk<T, FM, FN>(xf, wf, acc);
+        if constexpr (SPLIT) {
+            u32x4 xl[FM], wl[FN];
 #pragma unroll
-        for (int fm = 0; fm < FM; ++fm) xf[fm] = *(const u32x4*)(sb + xfrag + fm * 16 * 128 + sw1);
+            for (int fm = 0; fm < FM; ++fm) xl[fm] = *(const u32x4*)(sb + xfrag + fm * 16 * 128 + sw1);
 #pragma unroll
-        for (int fn = 0; fn < FN; ++fn) wf[fn] = *(const u32x4*)(sb + wfrag + fn * 16 * 128 + sw1);
-        mma_chunk<T, FM, FN>(xf, wf, acc);
+            for (int fn = 0; fn < FN; ++fn) wl[fn] = *(const u32x4*)(sb + wfrag + fn * 16 * 128 + sw1);
+            mma_split3<FM, FN>(xf, xl, wf, wl, acc);
+        } else {
+            mma_chunk<T, FM, FN>(xf, wf, acc);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) xf[fm] = *(const u32x4*)(sb + xfrag + fm * 16 * 128 + sw1);
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) wf[fn] = *(const u32x4*)(sb + wfrag + fn * 16 * 128 + sw1);
+            mma_chunk<T, FM, FN>(xf, wf, acc);
+        }
         if (more) store_tile((kt + 1) & 1);
         __syncthreads();
     }
@@ -211,15 +227,18 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
         }
     }
     __syncthreads();
-    constexpr int CPR = BN / EPC;               // 16-byte output chunks per tile row
+    // epilogue items: 8 channels for bf16 (16 B) and split-bf16 (32 B = 8 hi | 8 lo), 4 channels for fp32 (16 B)
+    constexpr int KIND = Elem<T>::KIND;
+    constexpr int EPO = KIND == K_F32 ? 4 : 8;
+    constexpr int CPR = BN / EPO;
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
     for (int q = tid; q < BM * CPR; q += 256) {
         const int px = q / CPR, cc = q - px * CPR;
-        const int m = bm * BM + px, ch = bn * BN + cc * EPC;
+        const int m = bm * BM + px, ch = bn * BN + cc * EPO;
         if (m >= p.M || ch >= p.Cout) continue;
-        const float* src = ct + px * CLD + cc * EPC;
-        if constexpr (sizeof(T) == 2) {
+        const float* src = ct + px * CLD + cc * EPO;
+        if constexpr (KIND == K_BF16) {
             float4 a = *(const float4*)src, b = *(const float4*)(src + 4);
             if (rg) {
                 const u32x4 rv = *(const u32x4*)(rg + (size_t)m * p.ldr + ch);
@@ -237,35 +256,46 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w);
             o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
             *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
+        } else if constexpr (KIND == K_SPLIT) {
+            float v[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = src[e];
+            const bool second = ch + 4 < p.Cout;             // (fp32 output: Cout may end on a multiple of 4)
+            if (rg) {
+                if (p.out_f32) {
+                    const float* rp = (const float*)rg + (size_t)m * p.ldr + ch;
+                    const float4 r0 = *(const float4*)rp, r1 = second ? *(const float4*)(rp + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                    v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w; v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+                } else {
+                    const u32x4* rp = (const u32x4*)(rg + (size_t)m * p.ldr + ch);
+                    float r[8];
+                    split8_unpack(rp[0], rp[1], r);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += r[e];
+                }
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.out_f32) {
+                float* yp = (float*)yg + (size_t)m * p.ldy + ch;
+                *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                if (second) *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                u32x4 hi, lo;
+                split8_pack(v, hi, lo);
+                u32x4* yp = (u32x4*)(yg + (size_t)m * p.ldy + ch);
+                yp[0] = hi; yp[1] = lo;
+            }
         } else {
             float4 a = *(const float4*)src;
             if (rg) {
-                if constexpr (Elem<T>::KIND == K_SPLIT) {
-                    const u32x4 rv = *(const u32x4*)(rg + (size_t)m * p.ldr + ch);
-                    if (p.out_f32) {
-                        a.x += __builtin_bit_cast(float, rv.x); a.y += __builtin_bit_cast(float, rv.y);
-                        a.z += __builtin_bit_cast(float, rv.z); a.w += __builtin_bit_cast(float, rv.w);
-                    } else {
-                        a.x += split_unpack(rv.x); a.y += split_unpack(rv.y); a.z += split_unpack(rv.z); a.w += split_unpack(rv.w);
-                    }
-                } else {
-                    const float4 rv = *(const float4*)(rg + (size_t)m * p.ldr + ch);
-                    a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
-                }
+                const float4 rv = *(const float4*)(rg + (size_t)m * p.ldr + ch);
+                a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
             }
             if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-            if constexpr (Elem<T>::KIND == K_SPLIT) {
-                u32x4 o;
-                if (p.out_f32) {
-                    o.x = __builtin_bit_cast(uint32_t, a.x); o.y = __builtin_bit_cast(uint32_t, a.y);
-                    o.z = __builtin_bit_cast(uint32_t, a.z); o.w = __builtin_bit_cast(uint32_t, a.w);
-                } else {
-                    o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
-                }
-                *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
-            } else {
-                *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
-            }
+            *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
         }
     }
 }

@@ -67,18 +67,6 @@ __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&
             for (int fn = 0; fn < FN; ++fn)
                 acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                     __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
-    } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
-        u32x4 xr[FM];
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
-#pragma unroll
-        for (int pass = 0; pass < 2; ++pass)
-#pragma unroll
-            for (int fm = 0; fm < FM; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < FN; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, pass ? xr[fm] : xf[fm]), acc[fm][fn], 0, 0, 0);
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -94,27 +82,16 @@ __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&
     }
 }
 
-// MFMA cluster with NP callbacks (one LDS-DMA piece each) spread evenly between the MFMAs.  Split-bf16: the FM*FN
-// straight products first, then the FM*FN products against the rotated activations, so that the two MFMAs of one
-// accumulator are FM*FN instructions apart (back to back they would wait for each other).
+// MFMA cluster with NP callbacks (one LDS-DMA piece each) spread evenly between the MFMAs
 template <typename T, int FM, int FN, int NP, typename F>
 __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN], F&& piece) {
     constexpr int KIND = Elem2<T>::KIND;
-    constexpr int NM = FM * FN * (KIND == K_SPLIT ? 2 : 1);
+    constexpr int NM = FM * FN;
     static_assert(NM >= NP + 1, "need more MFMAs than DMA pieces per cluster");
-    u32x4 xr[KIND == K_SPLIT ? FM : 1];
-    if constexpr (KIND == K_SPLIT) {
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) xr[fm] = split_rot16(xf[fm]);
-    }
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
-        const int jj = j % (FM * FN), fm = jj / FN, fn = jj % FN;
-        if constexpr (KIND == K_BF16) {
-            acc[fm][fn] = rp_mfma_bf16(wf[fn], xf[fm], acc[fm][fn]);
-        } else if constexpr (KIND == K_SPLIT) {
-            acc[fm][fn] = rp_mfma_bf16(wf[fn], j < FM * FN ? xf[fm] : xr[fm], acc[fm][fn]);
-        } else {
+        const int fm = j / FN, fn = j % FN;
+        if constexpr (KIND == K_F32) {
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
                 const uint32_t wv = t == 0 ? wf[fn].x : t == 1 ? wf[fn].y : t == 2 ? wf[fn].z : wf[fn].w;
@@ -122,8 +99,31 @@ __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&w
                 acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x4f32(
                     __builtin_bit_cast(float, wv), __builtin_bit_cast(float, xv), acc[fm][fn], 0, 0, 0);
             }
+        } else {
+            acc[fm][fn] = rp_mfma_bf16(wf[fn], xf[fm], acc[fm][fn]);
         }
         // piece k goes after MFMA number (k+1)*NM/(NP+1)  (all indices fold at compile time)
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if ((k + 1) * NM / (NP + 1) == j + 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                piece(k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
+// split-bf16 (planar) second cluster of a K step: w_hi * x_lo over all accumulators, then w_lo * x_hi (the first cluster
+// is the plain mma_issue on the hi fragments), the two MFMAs of one accumulator FM*FN instructions apart
+template <int FM, int FN, int NP, typename F>
+__device__ __forceinline__ void mma_issue_cross(const u32x4 (&xh)[FM], const u32x4 (&xl)[FM], const u32x4 (&wh)[FN],
+                                                const u32x4 (&wl)[FN], f32x4 (&acc)[FM][FN], F&& piece) {
+    constexpr int NM = 2 * FM * FN;
+    static_assert(NM >= NP + 1, "need more MFMAs than DMA pieces per cluster");
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int jj = j % (FM * FN), fm = jj / FN, fn = jj % FN;
+        acc[fm][fn] = rp_mfma_bf16(j < FM * FN ? wh[fn] : wl[fn], j < FM * FN ? xl[fm] : xh[fm], acc[fm][fn]);
 #pragma unroll
         for (int k = 0; k < NP; ++k)
             if ((k + 1) * NM / (NP + 1) == j + 1) {
@@ -256,7 +256,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
 
     // ---------------------------------------------------------------- MFMA state
     const int lr = lane & 15, g4 = lane >> 4;
-    const int sw0 = ((g4 ^ (lr & 7)) << 4), sw1 = (((4 + g4) ^ (lr & 7)) << 4);
+    // chunks of a 128-byte row read by lane group g4: g4 and 4 + g4 (the two 32-deep halves of a bf16 K step / 16-deep of an
+    // fp32 one); split-bf16: 2*g4 = hi parts of elements 8*g4 .. 8*g4+7, 2*g4 + 1 = their lo parts
+    constexpr bool SPLIT = Elem2<T>::KIND == K_SPLIT;
+    static_assert(!(SPLIT && DIRECT), "the split-bf16 kind uses the LDS-staged epilogue (8-channel groups)");
+    const int ck0 = SPLIT ? 2 * g4 : g4, ck1 = SPLIT ? 2 * g4 + 1 : 4 + g4;
+    const int sw0 = ((ck0 ^ (lr & 7)) << 4), sw1 = ((ck1 ^ (lr & 7)) << 4);
     const int xfrag = (wm * (BM / WAVES_M) + lr) * 128;
     const int wfrag = BM * 128 + (wn * (BN / WAVES_N) + lr) * 128;
     f32x4 acc[FM][FN];
@@ -331,7 +336,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
     else wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     AP_BSTAMP(3);
-    load_frags(xa0, wa0, xf0, wf0);
+    if constexpr (!SPLIT) load_frags(xa0, wa0, xf0, wf0);
 
 #ifdef AP_TRACE
     const bool trace = p.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 4) && lane == 0;
@@ -347,7 +352,10 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
         AP_STAMP(0);
         const uint32_t so = cs * STAGE;
         const bool refill = kt + S < KT;                     // tile kt+S goes into the slot of tile kt
-        load_frags(xa1 + so, wa1 + so, xf1, wf1);            // second half of tile kt
+        // split-bf16: the second cluster needs the hi fragments too, so they are read here, at the top of their own K step,
+        // instead of under the previous step's second cluster
+        if constexpr (SPLIT) load_frags(xa0 + so, wa0 + so, xf0, wf0);
+        load_frags(xa1 + so, wa1 + so, xf1, wf1);            // second half of tile kt (split-bf16: its lo parts)
         AP_STAMP(1);
         wait_lgkmcnt<NFR>();                                 // first half (read one phase earlier) has landed
         AP_STAMP(2);
@@ -366,11 +374,16 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             AP_STAMP(5);
             if (!(RP_ABLATE & 8)) __builtin_amdgcn_s_barrier();
             AP_STAMP(6);
-            const int ns = cs + 1 == S ? 0 : cs + 1;
-            load_frags(xa0 + ns * STAGE, wa0 + ns * STAGE, xf0, wf0);   // first half of tile kt+1
+            if constexpr (!SPLIT) {
+                const int ns = cs + 1 == S ? 0 : cs + 1;
+                load_frags(xa0 + ns * STAGE, wa0 + ns * STAGE, xf0, wf0);   // first half of tile kt+1
+            }
         }
         AP_STAMP(7);
-        mma_issue<T, FM, FN, LPW>(xf1, wf1, acc, [&](int i) { if (refill && !(RP_ABLATE & 1)) issue_piece(i, cs); });
+        if constexpr (SPLIT)
+            mma_issue_cross<FM, FN, LPW>(xf0, xf1, wf0, wf1, acc, [&](int i) { if (refill && !(RP_ABLATE & 1)) issue_piece(i, cs); });
+        else
+            mma_issue<T, FM, FN, LPW>(xf1, wf1, acc, [&](int i) { if (refill && !(RP_ABLATE & 1)) issue_piece(i, cs); });
         if (++cs == S) cs = 0;
         __builtin_amdgcn_sched_barrier(0);
         AP_STAMP(8);
@@ -397,11 +410,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                         float lo, hi;
                         unpack_bf16x2(rpre[(fm * FN + fn) * 2], lo, hi); v0 += lo; v1 += hi;
                         unpack_bf16x2(rpre[(fm * FN + fn) * 2 + 1], lo, hi); v2 += lo; v3 += hi;
-                    } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
-                        v0 += split_unpack(rpre[(fm * FN + fn) * 4]);
-                        v1 += split_unpack(rpre[(fm * FN + fn) * 4 + 1]);
-                        v2 += split_unpack(rpre[(fm * FN + fn) * 4 + 2]);
-                        v3 += split_unpack(rpre[(fm * FN + fn) * 4 + 3]);
                     } else {
                         v0 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4]);
                         v1 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4 + 1]);
@@ -415,10 +423,6 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                         uint2 o;
                         o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
                         *(uint2*)(yg + (size_t)m * p.ldy + ch) = o;
-                    } else if constexpr (Elem2<T>::KIND == K_SPLIT) {
-                        u32x4 o;
-                        o.x = split_pack(v0); o.y = split_pack(v1); o.z = split_pack(v2); o.w = split_pack(v3);
-                        *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
                     } else {
                         *(float4*)(yg + (size_t)m * p.ldy + ch) = make_float4(v0, v1, v2, v3);
                     }
@@ -453,6 +457,59 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
     __syncthreads();
     AP_BSTAMP(6);
     T* __restrict__ yg = (T*)p.y;
+    if constexpr (SPLIT) {
+        // split-bf16: items of 8 channels = 32 bytes [8 hi | 8 lo] (fp32 output for the blend-shape contraction: 2 x 16 B)
+        constexpr int CP8 = BN / 8, NI8 = BM * CP8 / NT;
+        static_assert(BM * CP8 % NT == 0, "epilogue items must divide evenly");
+        u32x4 rh[NI8], rl[NI8];
+        if (rg) {
+#pragma unroll
+            for (int it = 0; it < NI8; ++it) {
+                const int q = tid + it * NT, px = q / CP8, cc = q - px * CP8;
+                const int m = bm * BM + px, ch = bn * BN + cc * 8;
+                const bool ok = m < p.M && ch < p.Cout;
+                const u32x4* rp = (const u32x4*)(ok ? rg + (size_t)m * p.ldr + ch : (const T*)p.zero);
+                rh[it] = rp[0];
+                rl[it] = (ok && ch + 4 < p.Cout) ? rp[1] : rp[0];
+            }
+        }
+#pragma unroll
+        for (int it = 0; it < NI8; ++it) {
+            const int q = tid + it * NT, px = q / CP8, cc = q - px * CP8;
+            const int m = bm * BM + px, ch = bn * BN + cc * 8;
+            if (m >= p.M || ch >= p.Cout) continue;
+            const float* sp = ct + px * CLD + cc * 8;
+            const float4 a = *(const float4*)sp, b = *(const float4*)(sp + 4);
+            float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            const bool second = ch + 4 < p.Cout;             // (fp32 output: Cout may end on a multiple of 4)
+            if (rg) {
+                float r[8];
+                if (p.out_f32) {
+                    const uint32_t w[8] = {rh[it].x, rh[it].y, rh[it].z, rh[it].w, rl[it].x, rl[it].y, rl[it].z, rl[it].w};
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) r[e] = (e < 4 || second) ? __builtin_bit_cast(float, w[e]) : 0.f;
+                } else {
+                    split8_unpack(rh[it], rl[it], r);
+                }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += r[e];
+            }
+            if (p.relu) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            if (p.out_f32) {
+                float* yp = (float*)yg + (size_t)m * p.ldy + ch;
+                *(float4*)yp = make_float4(v[0], v[1], v[2], v[3]);
+                if (second) *(float4*)(yp + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                u32x4 hi, lo;
+                split8_pack(v, hi, lo);
+                u32x4* yp = (u32x4*)(yg + (size_t)m * p.ldy + ch);
+                yp[0] = hi; yp[1] = lo;
+            }
+        }
+    } else {
     if constexpr (!DIRECT) {
         if (rg) {
 #pragma unroll
@@ -494,32 +551,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             if (rg) {
                 // (copy the lanes out first: bit_cast applied directly to a vector element mis-compiles)
                 const uint32_t r0 = rv[it].x, r1 = rv[it].y, r2 = rv[it].z, r3 = rv[it].w;
-                if constexpr (Elem2<T>::KIND == K_SPLIT) {
-                    if (p.out_f32) {
-                        a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
-                        a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
-                    } else {
-                        a.x += split_unpack(r0); a.y += split_unpack(r1); a.z += split_unpack(r2); a.w += split_unpack(r3);
-                    }
-                } else {
-                    a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
-                    a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
-                }
+                a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
+                a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
             }
             if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
-            if constexpr (Elem2<T>::KIND == K_SPLIT) {
-                u32x4 o;
-                if (p.out_f32) {
-                    o.x = __builtin_bit_cast(uint32_t, a.x); o.y = __builtin_bit_cast(uint32_t, a.y);
-                    o.z = __builtin_bit_cast(uint32_t, a.z); o.w = __builtin_bit_cast(uint32_t, a.w);
-                } else {
-                    o.x = split_pack(a.x); o.y = split_pack(a.y); o.z = split_pack(a.z); o.w = split_pack(a.w);
-                }
-                *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
-            } else {
-                *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
-            }
+            *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
         }
+    }
     }
     AP_BSTAMP(7);
 }

@@ -41,7 +41,16 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
     const int sb = inmesh ? b - a.n_main : b;
     // the blend-shape contraction runs on the bf16 matrix pipe in split-bf16 form (m.coef_split): the coefficient row is
     // written as (hi, lo) pairs, 4 bytes per coefficient like the fp32 it replaces
-    auto put = [&](int i, float v) { coef[i] = m.coef_split ? __builtin_bit_cast(float, split_pack(v)) : v; };
+    auto put = [&](int i, float v) {
+        if (m.coef_split) {                                 // planar: group of 8 coefficients = 8 hi | 8 lo (bf16)
+            bf16_t* c16 = (bf16_t*)coef;
+            const bf16_t hi = f32_to_bf16(v);
+            c16[split_hi_pos(i)] = hi;
+            c16[split_lo_pos(i)] = f32_to_bf16(v - bf16_to_f32(hi));
+        } else {
+            coef[i] = v;
+        }
+    };
     if (j < 20) {
         float c = j < 10 ? a.betas[(size_t)sb * 10 + j] : (a.expression ? a.expression[(size_t)sb * 10 + j - 10] : 0.f);
         if (inmesh) c = 0.f;

@@ -66,9 +66,18 @@ __global__ void __launch_bounds__(256) stem_direct_kernel(const float* __restric
             o.y = pack_bf16x2(v[2], v[3]);
             *(uint2*)(dst + 4 * q) = o;
         } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
-            u32x4 o;
-            o.x = split_pack(v[0]); o.y = split_pack(v[1]); o.z = split_pack(v[2]); o.w = split_pack(v[3]);
-            *(u32x4*)(dst + 4 * q) = o;
+            if (q & 1) {                                    // groups of 8 channels: [8 hi | 8 lo]
+                float v8[8];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    v8[e] = fmaxf(acc[4 * (q - 1) + e] * scale[4 * (q - 1) + e] + shift[4 * (q - 1) + e], 0.f);
+                    v8[4 + e] = v[e];
+                }
+                u32x4 hi, lo;
+                split8_pack(v8, hi, lo);
+                *(u32x4*)(dst + 4 * (q - 1)) = hi;
+                *(u32x4*)(dst + 4 * q) = lo;
+            }
         } else {
             *(float4*)(dst + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
         }
@@ -233,12 +242,21 @@ __global__ void __launch_bounds__(256) stem_mfma_split_kernel(const float* __res
 #pragma unroll
         for (int fm = 0; fm < 4; ++fm) {
             const int oy = ty0 + wave * 4 + fm, ox = tx0 + lr;
-            u32x4 o;
-            o.x = split_pack(fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f));
-            o.y = split_pack(fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f));
-            o.z = split_pack(fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f));
-            o.w = split_pack(fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f));
-            *(u32x4*)(y + (((size_t)n * SO + oy) * SO + ox) * SC + ch) = o;
+            // a group of 8 channels = this lane's 4 and those of lane ^ 16 (g ^ 1): the even-g lane stores the 8 hi parts,
+            // the odd-g lane the 8 lo parts
+            float own[4] = {fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f), fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f),
+                            fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f), fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f)};
+            float v8[8];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float other = __shfl_xor(own[e], 16);
+                v8[e] = (g & 1) ? other : own[e];
+                v8[4 + e] = (g & 1) ? own[e] : other;
+            }
+            u32x4 hi, lo;
+            split8_pack(v8, hi, lo);
+            const int ch8 = fn * 16 + (g >> 1) * 8;
+            *(u32x4*)(y + (((size_t)n * SO + oy) * SO + ox) * SC + ch8 + (g & 1) * 4) = (g & 1) ? lo : hi;
         }
     }
   }
@@ -427,9 +445,6 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T
                 unpack_bf16x2(v.y, lo, hi); m[2] = fmaxf(m[2], lo); m[3] = fmaxf(m[3], hi);
                 unpack_bf16x2(v.z, lo, hi); m[4] = fmaxf(m[4], lo); m[5] = fmaxf(m[5], hi);
                 unpack_bf16x2(v.w, lo, hi); m[6] = fmaxf(m[6], lo); m[7] = fmaxf(m[7], hi);
-            } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
-                m[0] = fmaxf(m[0], split_unpack(v.x)); m[1] = fmaxf(m[1], split_unpack(v.y));
-                m[2] = fmaxf(m[2], split_unpack(v.z)); m[3] = fmaxf(m[3], split_unpack(v.w));
             } else {
                 m[0] = fmaxf(m[0], __builtin_bit_cast(float, v.x));
                 m[1] = fmaxf(m[1], __builtin_bit_cast(float, v.y));
@@ -442,14 +457,70 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T
     if constexpr (sizeof(T) == 2) {
         o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
         o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
-    } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
-        // (hi + lo is exact in fp32 and split_pack of it returns the same word: the maximum is one of the inputs, bit for bit)
-        o.x = split_pack(m[0]); o.y = split_pack(m[1]); o.z = split_pack(m[2]); o.w = split_pack(m[3]);
     } else {
         o.x = __builtin_bit_cast(uint32_t, m[0]); o.y = __builtin_bit_cast(uint32_t, m[1]);
         o.z = __builtin_bit_cast(uint32_t, m[2]); o.w = __builtin_bit_cast(uint32_t, m[3]);
     }
     *(uint4*)(y + (size_t)pix * SC + cc * EPC) = o;
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-bf16 pools: one thread = one group of 8 channels (32 bytes: 8 hi | 8 lo)
+__global__ void __launch_bounds__(256) maxpool_split_kernel(const bsplit_t* __restrict__ x, bsplit_t* __restrict__ y, int total) {
+    constexpr int GPP = SC / 8;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int gc = idx % GPP, pix = idx / GPP;
+    const int ow = pix % PO, t = pix / PO, oh = t % PO, n = t / PO;
+    float m[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) m[e] = -INFINITY;
+    for (int r = 0; r < 3; ++r) {
+        const int ih = 2 * oh - 1 + r;
+        if ((unsigned)ih >= (unsigned)SO) continue;
+        for (int s = 0; s < 3; ++s) {
+            const int iw = 2 * ow - 1 + s;
+            if ((unsigned)iw >= (unsigned)SO) continue;
+            const u32x4* src = (const u32x4*)(x + (((size_t)n * SO + ih) * SO + iw) * SC + gc * 8);
+            float v[8];
+            split8_unpack(src[0], src[1], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) m[e] = fmaxf(m[e], v[e]);
+        }
+    }
+    // hi + lo is exact in fp32 and packing it again returns the same parts: the maximum is one of the inputs, bit for bit
+    u32x4 hi, lo;
+    split8_pack(m, hi, lo);
+    u32x4* dst = (u32x4*)(y + (size_t)pix * SC + gc * 8);
+    dst[0] = hi; dst[1] = lo;
+}
+
+__global__ void __launch_bounds__(256) avgpool_split_kernel(const bsplit_t* __restrict__ x, float* __restrict__ y, int C, int total) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int gpr = C / 8, gc = idx % gpr, n = idx / gpr;
+    float s[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) s[e] = 0.f;
+    const bsplit_t* src = x + (size_t)n * 49 * C + gc * 8;
+    for (int p0 = 0; p0 < 49; p0 += 7) {                    // 7 x 2 loads in flight per thread, summed in pixel order
+        u32x4 vh[7], vl[7];
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            const u32x4* q = (const u32x4*)(src + (size_t)(p0 + u) * C);
+            vh[u] = q[0]; vl[u] = q[1];
+        }
+#pragma unroll
+        for (int u = 0; u < 7; ++u) {
+            float v[8];
+            split8_unpack(vh[u], vl[u], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) s[e] += v[e];
+        }
+    }
+    float* dst = y + (size_t)n * C + gc * 8;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dst[e] = s[e] / 49.0f;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -476,8 +547,6 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, f
             unpack_bf16x2(v.y, lo, hi); s[2] += lo; s[3] += hi;
             unpack_bf16x2(v.z, lo, hi); s[4] += lo; s[5] += hi;
             unpack_bf16x2(v.w, lo, hi); s[6] += lo; s[7] += hi;
-        } else if constexpr (ElemKind<T>::KIND == K_SPLIT) {
-            s[0] += split_unpack(v.x); s[1] += split_unpack(v.y); s[2] += split_unpack(v.z); s[3] += split_unpack(v.w);
         } else {
             s[0] += __builtin_bit_cast(float, v.x); s[1] += __builtin_bit_cast(float, v.y);
             s[2] += __builtin_bit_cast(float, v.z); s[3] += __builtin_bit_cast(float, v.w);
@@ -595,8 +664,8 @@ hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, co
 
 hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStream_t st) {
     if (kind == K_SPLIT) {
-        const int total = n_img * PO * PO * (SC / 4);
-        hipLaunchKernelGGL(maxpool_kernel<bsplit_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x,
+        const int total = n_img * PO * PO * (SC / 8);
+        hipLaunchKernelGGL(maxpool_split_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x,
                            (bsplit_t*)y, total);
     } else if (kind == K_BF16) {
         const int total = n_img * PO * PO * (SC / 8);
@@ -612,9 +681,9 @@ hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStr
 
 hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int kind, hipStream_t st) {
     if (kind == K_SPLIT) {
-        const int total = n_img * (C / 4);
-        hipLaunchKernelGGL(avgpool_kernel<bsplit_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x, y,
-                           C, total);
+        const int total = n_img * (C / 8);
+        hipLaunchKernelGGL(avgpool_split_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x, y, C,
+                           total);
     } else if (kind == K_BF16) {
         const int total = n_img * (C / 8);
         hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, y, C,

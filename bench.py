@@ -155,8 +155,8 @@ def parity_block(args, sd, body, batch, net_bf, sample, want, dev):
         torch.cuda.empty_cache()
     res = dict(modes["bf16x2"])
     res.update({"dtype": "bf16x2", "bar": 1e-4,
-                "arithmetic": "split-bf16 storage (hi + lo bf16 pair per value, fp32 bytes); each product as hi*hi + hi*lo + "
-                              "lo*hi + lo*lo in two v_mfma_f32_16x16x32_bf16 per 4 K elements, fp32 accumulate",
+                "arithmetic": "split-bf16 storage (hi + lo bf16 per value, planar groups of 8 channels, fp32 bytes); each product as "
+                              "hi*hi + hi*lo + lo*hi in three v_mfma_f32_16x16x32_bf16 per 8 K elements, fp32 accumulate",
                 "fp32_mode": dict(modes["fp32"], arithmetic="fp32 storage, v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain)")})
     if gin is not None:
         ebf = slice_errs({k: v.float().cpu() for k, v in
@@ -335,7 +335,7 @@ def main():
         chunk = args.chunk or 512
         # 52 convs: 4 downsample convs folded into conv3, layer1's 3 bottlenecks are one fused kernel each (bf16)
         launches = (42 if args.precision == "bf16" else 48) * ((2 * B + chunk - 1) // chunk)
-        # bf16x2 runs on the bf16 matrix pipe (4 MFMA products per algorithmic product): priced against the same peak
+        # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
         res = {
@@ -389,10 +389,10 @@ def main():
             # algorithmic contraction length: 10 shape + 21 body joints x 9 pose-feature entries, not the
             # zero-padded operand width the kernel runs
             gemm_flops = 2.0 * BLEND_K_ALGORITHMIC * 31425 * n_img
-            # the contraction runs in split-bf16 form on the bf16 matrix pipe: four MFMA products per algorithmic product,
-            # so the pipe's ceiling for ALGORITHMIC flops is a quarter of the dense bf16 peak
-            blend_peak = PEAK_BF16_DENSE_TFLOPS / 4
-            res["smplx_blend_roofline"] = {"bound": "mfma-bf16 (split-bf16 operands, 4 MFMA products per product)",
+            # the contraction runs in split-bf16 form on the bf16 matrix pipe: three MFMA products per algorithmic product,
+            # so the pipe's ceiling for ALGORITHMIC flops is a third of the dense bf16 peak
+            blend_peak = PEAK_BF16_DENSE_TFLOPS / 3
+            res["smplx_blend_roofline"] = {"bound": "mfma-bf16 (split-bf16 operands, 3 MFMA products per product)",
                                            "achieved": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12,
                                            "peak": blend_peak, "unit": "TFLOP/s",
                                            "frac": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12 / blend_peak,

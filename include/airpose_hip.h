@@ -31,9 +31,10 @@ extern "C" {
 
 #define AP_PREC_FP32 0 /* fp32 storage, v_mfma_f32_16x16x4_f32: parity mode (1e-4 vs the CPU reference) */
 #define AP_PREC_BF16 1 /* bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate: throughput mode */
-#define AP_PREC_BF16X2 2 /* split-bf16 storage (hi + lo bf16 pair per value, 16 mantissa bits, fp32 bytes): every product as
-                          * hi*hi + hi*lo + lo*hi + lo*lo on the bf16 matrix pipe (two MFMAs per 4 K elements), fp32
-                          * accumulate: the fast parity mode (meets the 1e-4 bar at ~4x the fp32-MFMA rate) */
+#define AP_PREC_BF16X2 2 /* split-bf16 storage: every value as hi = rne(x), lo = rne(x - hi) in bf16 (16 mantissa bits, fp32
+                          * bytes), planar in groups of 8 channels (32 bytes = 8 hi | 8 lo); every product as
+                          * hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (three MFMAs per 8 K elements), fp32 accumulate:
+                          * the fast parity mode (meets the 1e-4 bar at ~5x the fp32-MFMA rate) */
 
 typedef struct ap_net ap_net;     /* ResNet-50 trunk + IEF regressor */
 typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
@@ -128,8 +129,8 @@ int ap_singleview_reg(ap_net* h, const float* xf, const float* bb, const float* 
  * Bottleneck.forward (model_copenet.py:27-47: conv -> BN -> [+ residual] -> ReLU).  Exposed so the kernel can be
  * unit-tested and reused.  NHWC activations x [N][H][W][Cin], y/res [N][Ho][Wo][Cout]; w [Cout_pad][k][k][Cin]
  * with Cout_pad = Cout rounded up to 128 (zero rows), scale/shift [Cout_pad]; element type of x/w/res/y is
- * bf16 (AP_PREC_BF16), float (AP_PREC_FP32) or split-bf16 pairs (AP_PREC_BF16X2, 4 bytes per element like float);
- * Cin a multiple of 64 (bf16) / 32 (fp32, bf16x2), Cout of 8 / 4. */
+ * bf16 (AP_PREC_BF16), float (AP_PREC_FP32) or split-bf16 (AP_PREC_BF16X2: 4 bytes per element, planar groups of 8
+ * channels = 8 bf16 hi parts then 8 bf16 lo parts); Cin a multiple of 64 (bf16) / 32 (fp32, bf16x2), Cout of 8 (4: fp32). */
 int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* scale, const float* shift,
                    const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
                    int relu, void* stream);

@@ -73,18 +73,28 @@ def test_native_library_is_loaded():
 
 
 # ------------------------------------------------------------------------------------------------ conv primitive
-def _split_pack(t):
-    """fp32 tensor -> (int32 words hi | lo << 16, the fp32 values hi + lo they stand for): the bf16x2 storage format"""
+def _split_parts(t):
+    """fp32 tensor -> (bf16 hi, bf16 lo, the fp32 values hi + lo they stand for): the bf16x2 representation"""
     hi = t.to(torch.bfloat16)
     lo = (t - hi.float()).to(torch.bfloat16)
-    word = (hi.view(torch.int16).to(torch.int32) & 0xffff) | (lo.view(torch.int16).to(torch.int32) << 16)
-    return word, hi.float() + lo.float()
+    return hi, lo, hi.float() + lo.float()
+
+
+def _split_pack(t):
+    """fp32 tensor (channels last, C % 8 == 0) -> (int32 tensor of the same shape in the bf16x2 storage layout: every
+    group of 8 channels = 32 bytes = 8 bf16 hi parts | 8 bf16 lo parts;  the fp32 values it stands for)"""
+    hi, lo, val = _split_parts(t)
+    C = t.shape[-1]
+    assert C % 8 == 0
+    g = torch.stack([hi.reshape(*t.shape[:-1], C // 8, 8), lo.reshape(*t.shape[:-1], C // 8, 8)], dim=-2)  # (.., C/8, 2, 8) bf16
+    return g.contiguous().view(torch.int32).reshape(*t.shape[:-1], C), val
 
 
 def _split_unpack(word):
-    hi = (word << 16).view(torch.float32)
-    lo = (word & -65536).view(torch.float32)
-    return hi + lo
+    """inverse of _split_pack: int32 (.., C) in the bf16x2 layout -> fp32 (.., C)"""
+    C = word.shape[-1]
+    g = word.contiguous().view(torch.bfloat16).reshape(*word.shape[:-1], C // 8, 2, 8).float()
+    return (g[..., 0, :] + g[..., 1, :]).reshape(*word.shape[:-1], C)
 
 
 def _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed):
@@ -127,8 +137,9 @@ def _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed):
 
 
 def _conv_case_split(dev, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed):
-    """ap_conv2d_nhwc in split-bf16 storage: operands and residual are (hi, lo) bf16 pairs; the fp64 oracle runs on the
-    values those pairs stand for, so what is tested is the four-term product on the bf16 matrix pipe + fp32 accumulate."""
+    """ap_conv2d_nhwc in split-bf16 storage: operands and residual are (hi, lo) bf16 parts in planar groups of 8 channels;
+    the fp64 oracle runs on the values they stand for, so what is tested is the three-term product on the bf16 matrix
+    pipe + fp32 accumulate (the dropped lo*lo term is 2^-18 relative) and the 2^-17 rounding of the stored result."""
     from airpose_amd import _native as Nn
     g = torch.Generator().manual_seed(seed)
     x = torch.randn(N, Cin, H, H, generator=g)
@@ -136,23 +147,23 @@ def _conv_case_split(dev, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed):
     scale = torch.rand(Cout, generator=g) + 0.5
     shift = torch.randn(Cout, generator=g) * 0.1
     Ho = (H + 2 * pad - k) // stride + 1
-    xw, xq = _split_pack(x)
-    ww, wq = _split_pack(w)
-    ref = F.conv2d(xq.double(), wq.double(), stride=stride, padding=pad)
+    xw, xq = _split_pack(x.permute(0, 2, 3, 1).contiguous())            # NHWC
+    ww, wq = _split_pack(w.permute(0, 2, 3, 1).contiguous())            # [Cout][kh][kw][Cin]
+    ref = F.conv2d(xq.permute(0, 3, 1, 2).double(), wq.permute(0, 3, 1, 2).double(), stride=stride, padding=pad)
     ref = ref * scale.double().view(1, -1, 1, 1) + shift.double().view(1, -1, 1, 1)
     rd = None
     if use_res:
-        rw, rq = _split_pack(torch.randn(N, Cout, Ho, Ho, generator=g))
-        ref = ref + rq.double()
-        rd = rw.permute(0, 2, 3, 1).contiguous().to(dev)
+        rw, rq = _split_pack(torch.randn(N, Ho, Ho, Cout, generator=g))
+        ref = ref + rq.permute(0, 3, 1, 2).double()
+        rd = rw.to(dev)
     if relu:
         ref = ref.clamp_min(0)
     cpad = (Cout + 127) // 128 * 128
     wp = torch.zeros(cpad, k, k, Cin, dtype=torch.int32)
-    wp[:Cout] = ww.permute(0, 2, 3, 1)
+    wp[:Cout] = ww
     sp, hp = torch.ones(cpad), torch.zeros(cpad)
     sp[:Cout], hp[:Cout] = scale, shift
-    xd = xw.permute(0, 2, 3, 1).contiguous().to(dev)
+    xd = xw.to(dev)
     wd, sd_, hd = wp.to(dev), sp.to(dev), hp.to(dev)
     y = torch.full((N, Ho, Ho, Cout), 0x7fc07fc0, dtype=torch.int32, device=dev)      # NaN | NaN
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
@@ -290,7 +301,7 @@ def test_trunk_with_and_without_phase_kernel_bitwise(netbf, dev):
 @pytest.mark.parametrize("cfg", [-1, 11, 12, 100])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_primitive_split_bf16(dev, case, cfg):
-    """bf16x2 storage (the fast parity mode): every product = hi*hi + hi*lo + lo*hi + lo*lo on the bf16 matrix pipe.
+    """bf16x2 storage (the fast parity mode): every product = hi*hi + hi*lo + lo*hi on the bf16 matrix pipe.
     Against the fp64 oracle on the values the pairs stand for; the bar is that of the fp32 kernel plus the 2^-17
     rounding of the stored result."""
     from airpose_amd import _native as Nn
