@@ -53,6 +53,7 @@ SIGNATURES = {
     "ap_net_enable_timing": (_i, [_vp, _i]),
     "ap_net_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
     "ap_net_set_chunk": (_i, [_vp, _i]),
+    "ap_net_set_dual_stream": (_i, [_vp, _i]),
     "ap_net_set_fold": (_i, [_vp, _i]),
     "ap_net_set_fuse_ief": (_i, [_vp, _i]),
     "ap_net_set_fuse_stem": (_i, [_vp, _i]),

@@ -294,6 +294,11 @@ class copenet(nn.Module):
         N.check(N.lib().ap_net_set_fuse_stem(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_fuse_stem")
 
+    def set_dual_stream(self, on):
+        """Two-view forwards of >= 128 pairs: the two views as two concurrent trunk passes (default) or one pass."""
+        N.check(N.lib().ap_net_set_dual_stream(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+                "ap_net_set_dual_stream")
+
     def set_chunk(self, images):
         N.check(N.lib().ap_net_set_chunk(self._native(torch.device("cuda", torch.cuda.current_device())), int(images)),
                 "ap_net_set_chunk")

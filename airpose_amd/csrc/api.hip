@@ -76,6 +76,7 @@ struct Timing {
     std::vector<hipEvent_t> pool;
     size_t used = 0;
     std::vector<size_t> marks[4];   // pairs of event indices per stage
+    std::vector<size_t> quads[4];   // two-stream passes: (start A, end A, start B, end B): the stage's span over both streams
     int64_t passes = 0;
     hipError_t rec(hipStream_t st, size_t* idx) {
         if (used == pool.size()) {
@@ -98,10 +99,24 @@ struct Timing {
                 if (r != hipSuccess) return r;
                 ms[s] += t;
             }
+            for (size_t i = 0; i + 3 < quads[s].size(); i += 4) {
+                float span = 0.f;
+                for (int a = 0; a < 2; ++a)
+                    for (int b = 0; b < 2; ++b) {            // latest end minus earliest start (negative pairs lose)
+                        hipError_t r = hipEventSynchronize(pool[quads[s][i + 1 + 2 * b]]);
+                        if (r != hipSuccess) return r;
+                        float t = 0.f;
+                        r = hipEventElapsedTime(&t, pool[quads[s][i + 2 * a]], pool[quads[s][i + 1 + 2 * b]]);
+                        if (r != hipSuccess) return r;
+                        span = std::max(span, t);
+                    }
+                ms[s] += span;
+            }
         }
         *n = passes;
         if (reset) {
             for (auto& m : marks) m.clear();
+            for (auto& q : quads) q.clear();
             used = 0;
             passes = 0;
         }
@@ -217,7 +232,16 @@ struct ap_net {
     DevBuf mean_pose, mean_shape, mean_cam;
     // workspace
     int chunk = 0;
-    DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds, ws_feat;
+    struct TrunkWs { DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds; };
+    TrunkWs tw[2];                 // [1]: the second view's pass when the two views run on two streams
+    DevBuf ws_feat;
+    // two-view forward: view 0 and view 1 as two concurrent trunk passes on two internal streams (an HBM-bound layer of
+    // one pass overlaps an MFMA-bound layer of the other: -4 % trunk time at 2 x 256 images); 0 = one pass over both views
+    bool dual_stream = true;
+    int dual_skew = 0;             // experiment: the second pass starts after the first has finished its stem (1) / its block k-2 (k >= 2)
+    hipEvent_t ev_skew = nullptr;
+    hipStream_t aux[2] = {nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     DevBuf ws_H, ws_S, ws_T1, ws_T2, ws_D, ws_state;
     Timing tm;
     size_t esize() const { return prec == AP_PREC_BF16 ? 2 : 4; }   // fp32 and split-bf16 pairs: 4 bytes
@@ -656,42 +680,46 @@ int finalize_regressor(ap_net* h) {
 }
 
 // one depth-first pass over n = n0 + n1 images: the first n0 from x0, the rest from x1 (two views, one pass)
-int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
+int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st,
+                size_t* ev_out = nullptr, int signal_at = 0) {
     const int bf = h->prec == AP_PREC_BF16;                  // gates the bf16-only fused kernels
     const int kind = h->prec;                                // storage kind of every generic kernel
     const size_t es = h->esize();
     const int n = n0 + n1;
-    if (!(bf && h->fuse_stem)) HIP_TRY(h->ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
-    HIP_TRY(h->ws_a.reserve((size_t)n * 802816 * es));
-    HIP_TRY(h->ws_b.reserve((size_t)n * 802816 * es));
-    HIP_TRY(h->ws_ds.reserve((size_t)n * 802816 * es));
-    HIP_TRY(h->ws_t1.reserve((size_t)n * 401408 * es));
-    HIP_TRY(h->ws_t2.reserve((size_t)n * 200704 * es));
+    if (!(bf && h->fuse_stem)) HIP_TRY(w.ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
+    HIP_TRY(w.ws_a.reserve((size_t)n * 802816 * es));
+    HIP_TRY(w.ws_b.reserve((size_t)n * 802816 * es));
+    HIP_TRY(w.ws_ds.reserve((size_t)n * 802816 * es));
+    HIP_TRY(w.ws_t1.reserve((size_t)n * 401408 * es));
+    HIP_TRY(w.ws_t2.reserve((size_t)n * 200704 * es));
     size_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
         HIP_TRY(ap_launch_stem_pool(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                    h->ws_a.p, n, st));
+                                    w.ws_a.p, n, st));
     } else if (bf) {
         HIP_TRY(ap_launch_stem_conv_mfma(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
-                                         h->stem_shift.as<float>(), h->ws_stem.p, n, st));
+                                         h->stem_shift.as<float>(), w.ws_stem.p, n, st));
     } else if (kind == AP_PREC_BF16X2) {
         HIP_TRY(ap_launch_stem_conv_mfma_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
-                                               h->stem_shift.as<float>(), h->ws_stem.p, n, st));
+                                               h->stem_shift.as<float>(), w.ws_stem.p, n, st));
     } else {
         if (n0)
             HIP_TRY(ap_launch_stem_conv(x0, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                        h->ws_stem.p, n0, kind, st));
+                                        w.ws_stem.p, n0, kind, st));
         if (n1)
             HIP_TRY(ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                        (char*)h->ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, kind, st));
+                                        (char*)w.ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, kind, st));
     }
-    if (!(bf && h->fuse_stem)) HIP_TRY(ap_launch_maxpool(h->ws_stem.p, h->ws_a.p, n, kind, st));
+    if (!(bf && h->fuse_stem)) HIP_TRY(ap_launch_maxpool(w.ws_stem.p, w.ws_a.p, n, kind, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
-    void *cur = h->ws_a.p, *nxt = h->ws_b.p;
+    if (signal_at == 1) HIP_TRY(hipEventRecord(h->ev_skew, st));
+    void *cur = w.ws_a.p, *nxt = w.ws_b.p;
     int H = 56;
     int rc;
+    int blk = 0;
     for (auto& B : h->blocks) {
+        if (signal_at >= 2 && blk++ == signal_at - 2) HIP_TRY(hipEventRecord(h->ev_skew, st));
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
         if (bf && h->fuse_block && B.c2.cout == 64 && B.c2.stride == 1 && H % 14 == 0 && (!B.has_down || B.c1.cin == 64)) {
             // layer1: conv1 -> conv2 -> conv3 (+identity | folded downsample) in one kernel, intermediates in LDS
@@ -700,26 +728,30 @@ int trunk_chunk(ap_net* h, const float* x0, int n0, const float* x1, int n1, flo
             std::swap(cur, nxt);
             continue;
         }
-        if ((rc = run_conv(B.c1, cur, n, H, H, h->ws_t1.p, nullptr, 1, kind, st))) return rc;
-        if ((rc = run_conv(B.c2, h->ws_t1.p, n, H, H, h->ws_t2.p, nullptr, 1, kind, st))) return rc;
+        if ((rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, kind, st))) return rc;
+        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, kind, st))) return rc;
         if (B.has_down && h->fuse_ds) {
-            if ((rc = run_c3_ds(B.c3ds, h->ws_t2.p, cur, n, Ho, H, nxt, kind, st))) return rc;
+            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, kind, st))) return rc;
         } else {
             const void* res = cur;
             if (B.has_down) {
-                if ((rc = run_conv(B.down, cur, n, H, H, h->ws_ds.p, nullptr, 0, kind, st))) return rc;
-                res = h->ws_ds.p;
+                if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, kind, st))) return rc;
+                res = w.ws_ds.p;
             }
-            if ((rc = run_conv(B.c3, h->ws_t2.p, n, Ho, Ho, nxt, res, 1, kind, st))) return rc;
+            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, kind, st))) return rc;
         }
         std::swap(cur, nxt);
         H = Ho;
     }
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e2));
     HIP_TRY(ap_launch_avgpool(cur, feat, n, 2048, kind, st));
+    if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e3));
+    if (ev_out) {                                            // the caller combines the events of two concurrent passes
+        ev_out[0] = e0; ev_out[1] = e1; ev_out[2] = e2; ev_out[3] = e3;
+        return AP_OK;
+    }
     if (h->tm.on) { h->tm.marks[1].push_back(e1); h->tm.marks[1].push_back(e2); }
     if (h->tm.on == 1) {
-        HIP_TRY(h->tm.rec(st, &e3));
         h->tm.marks[0].push_back(e0); h->tm.marks[0].push_back(e1);
         h->tm.marks[2].push_back(e2); h->tm.marks[2].push_back(e3);
     }
@@ -733,11 +765,42 @@ int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float
     if (n0 <= 0 || n1 < 0 || !x0 || (n1 && !x1) || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
     const int chunk = h->chunk > 0 ? h->chunk : 512;
     const size_t IMG_ELEMS = (size_t)3 * 224 * 224;
+    if (h->dual_stream && n0 >= 128 && n1 >= 128 && n_img <= chunk) {
+        // two views = two concurrent passes: fork from the caller's stream, one pass per internal stream, join
+        if (!h->aux[0]) {
+            for (int i = 0; i < 2; ++i) {
+                HIP_TRY(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
+                HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
+            }
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&h->ev_skew, hipEventDisableTiming));
+        }
+        HIP_TRY(hipEventRecord(h->ev_fork, st));
+        size_t ev[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+        for (int v = 0; v < 2; ++v) {
+            HIP_TRY(hipStreamWaitEvent(h->aux[v], h->ev_fork, 0));
+            if (v == 1 && h->dual_skew) HIP_TRY(hipStreamWaitEvent(h->aux[1], h->ev_skew, 0));
+            int rc = trunk_chunk(h, h->tw[v], v ? x1 : x0, v ? n1 : n0, nullptr, 0, feat + (v ? (size_t)n0 * 2048 : 0),
+                                 h->aux[v], ev[v], v == 0 ? h->dual_skew : 0);
+            if (rc) return rc;
+            HIP_TRY(hipEventRecord(h->ev_join[v], h->aux[v]));
+        }
+        for (int v = 0; v < 2; ++v) HIP_TRY(hipStreamWaitEvent(st, h->ev_join[v], 0));
+        if (h->tm.on) {
+            auto quad = [&](int stage, int a, int b) {
+                for (int v = 0; v < 2; ++v) { h->tm.quads[stage].push_back(ev[v][a]); h->tm.quads[stage].push_back(ev[v][b]); }
+            };
+            quad(1, 1, 2);
+            if (h->tm.on == 1) { quad(0, 0, 1); quad(2, 2, 3); }
+            h->tm.passes++;
+        }
+        return AP_OK;
+    }
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
         const int i1 = std::min(n_img, i0 + chunk);
         const int a0 = std::min(i0, n0), a1 = std::min(i1, n0);          // part taken from x0
         const int b0 = std::max(i0, n0) - n0, b1 = std::max(i1, n0) - n0; // part taken from x1
-        int rc = trunk_chunk(h, x0 + a0 * IMG_ELEMS, a1 - a0, x1 ? x1 + b0 * IMG_ELEMS : nullptr, b1 - b0,
+        int rc = trunk_chunk(h, h->tw[0], x0 + a0 * IMG_ELEMS, a1 - a0, x1 ? x1 + b0 * IMG_ELEMS : nullptr, b1 - b0,
                              feat + (size_t)i0 * 2048, st);
         if (rc) return rc;
     }
@@ -850,8 +913,9 @@ void ap_net_destroy(ap_net* h) {
     if (!h) return;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_wpk_lo, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->mean_cam, &h->ws_stem, &h->ws_a,
-                      &h->ws_b, &h->ws_t1, &h->ws_t2, &h->ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
+    for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_wpk_lo, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->mean_cam, &h->tw[0].ws_stem, &h->tw[0].ws_a,
+                      &h->tw[0].ws_b, &h->tw[0].ws_t1, &h->tw[0].ws_t2, &h->tw[0].ws_ds, &h->tw[1].ws_stem, &h->tw[1].ws_a, &h->tw[1].ws_b,
+                      &h->tw[1].ws_t1, &h->tw[1].ws_t2, &h->tw[1].ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
                       &h->ws_D, &h->ws_state})
         b->release();
     auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
@@ -859,6 +923,11 @@ void ap_net_destroy(ap_net* h) {
     rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec); rel(h->fold_feat); rel(h->fold_state);
     h->foldT_feat.release(); h->foldT_state.release(); h->fold_bias.release();
     h->tm.destroy();
+    for (int i = 0; i < 2; ++i) {
+        if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
+        if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
+    }
+    if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     delete h;
 }
 
@@ -1131,6 +1200,13 @@ int ap_net_set_fuse_stem(ap_net* h, int on) {
 int ap_net_set_fold(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fold = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_dual_stream(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->dual_stream = on != 0;
+    h->dual_skew = on > 1 ? on - 1 : 0;                      // (tuning: on = 1 + skew point)
     return AP_OK;
 }
 

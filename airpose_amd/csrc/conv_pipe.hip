@@ -23,6 +23,11 @@
 #ifndef RP_ABLATE
 #define RP_ABLATE 0
 #endif
+// placement of a cluster's NP callbacks (DMA pieces) among its NM MFMAs: 0 = spread evenly (piece k after MFMA
+// (k+1)*NM/(NP+1)), 1 = front-loaded (piece k after MFMA k+1), 2 = all before the first MFMA
+#ifndef RP_PIECES
+#define RP_PIECES 0
+#endif
 
 namespace {
 
@@ -105,7 +110,7 @@ __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&w
         // piece k goes after MFMA number (k+1)*NM/(NP+1)  (all indices fold at compile time)
 #pragma unroll
         for (int k = 0; k < NP; ++k)
-            if ((k + 1) * NM / (NP + 1) == j + 1) {
+            if ((RP_PIECES == 0 ? (k + 1) * NM / (NP + 1) : RP_PIECES == 1 ? k + 1 : 1) == j + 1) {
                 __builtin_amdgcn_sched_barrier(0);
                 piece(k);
                 __builtin_amdgcn_sched_barrier(0);
