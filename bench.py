@@ -230,6 +230,7 @@ def main():
     ap.add_argument("--no-tail", action="store_true", help="time the network only (BASELINE config 2 shape)")
     ap.add_argument("--stage-steps", type=int, default=5, help="extra untimed steps with per-stage HIP events")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test aid)")
+    ap.add_argument("--dual-stream", type=int, default=1, help="two-view trunk as two concurrent passes (default) or one pass (0)")
     ap.add_argument("--repeat-blocks", type=int, default=4, help="extra K-step blocks after the contract's one (spread)")
     ap.add_argument("--parity-steps", type=int, default=3, help="steps of the parity-grade mode after the main loop (0 = skip)")
     args = ap.parse_args()
@@ -264,6 +265,9 @@ def main():
     if args.chunk:
         torch.zeros(1, device=dev)
         net.set_chunk(args.chunk)
+    if not args.dual_stream:
+        torch.zeros(1, device=dev)
+        net.set_dual_stream(0)
 
     def step():
         if args.no_tail:
@@ -336,7 +340,7 @@ def main():
         # 52 convs: 4 downsample convs folded into conv3, layer1's 3 bottlenecks are one fused kernel each (bf16)
         # two-view forwards of >= 128 pairs run the two views as two concurrent trunk passes (two internal streams):
         # twice the launches at half the images each; conv_ms is then the span over both passes
-        dual = B >= 128 and 2 * B <= chunk
+        dual = bool(args.dual_stream) and B >= 128 and 2 * B <= chunk
         launches = (42 if args.precision == "bf16" else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
         # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS

@@ -9,7 +9,11 @@ python $R/bench.py --steps 20 --warmup 5 --batch 64 --no-tail --cpu-sample 0 --p
 python $R/bench.py --steps 10 --warmup 2 --precision bf16x2 --cpu-sample 0 --parity-steps 0 --repeat-blocks 1 > $O/${TAG}_bench_x2.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --steps 5 --warmup 2 --precision fp32 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 > $O/${TAG}_bench_fp32.json 2>> $O/${TAG}_bench.err
 rm -rf $O/${TAG}_trace $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE
-rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $R/bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 > $O/${TAG}_trace.log 2>&1
+# kernel trace of the single-pass trunk (--dual-stream 0): one kernel at a time, so the per-layer table is attributable;
+# the product's default (two concurrent passes) is what the bench lines and the counter passes below run
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace -- python $R/bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 --dual-stream 0 > $O/${TAG}_trace.log 2>&1
+rm -rf $O/${TAG}_trace2
+rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace2 -- python $R/bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 > $O/${TAG}_trace2.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -- python $R/bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 > $O/${TAG}_pmc_$C.log 2>&1
 done

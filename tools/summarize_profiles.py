@@ -25,12 +25,22 @@ if db:
     c = sqlite3.connect(db[0])
     rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     with open(os.path.join(O, tag + "_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0  (%s)\n" % tag)
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 --dual-stream 0  (%s)\n" % tag)
         f.write("name,calls,total_us,avg_us,pct\n")
         for n, calls, tot, avg, pct in rows:
             f.write('"%s",%d,%.3f,%.3f,%.2f\n' % (n[:110], calls, tot, avg, pct))
     with open(os.path.join(O, tag + "_layer_table.txt"), "w") as f:
         subprocess.run([sys.executable, os.path.join(R, "tools", "layer_profile.py"), db[0], "512"], stdout=f, stderr=subprocess.STDOUT)
+
+db2 = glob.glob(os.path.join(O, tag + "_trace2", "**", "*_results.db"), recursive=True)
+if db2:
+    c = sqlite3.connect(db2[0])
+    rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
+    with open(os.path.join(O, tag + "_kernel_stats_two_streams.csv"), "w") as f:
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0  (%s; default = two concurrent trunk passes: kernel durations overlap)\n" % tag)
+        f.write("name,calls,total_us,avg_us,pct\n")
+        for n, calls, tot, avg, pct in rows:
+            f.write('"%s",%d,%.3f,%.3f,%.2f\n' % (n[:110], calls, tot, avg, pct))
 
 acc = collections.defaultdict(lambda: [0, 0.0, 0.0])
 steps = 3                                                   # --steps 2 --warmup 1
