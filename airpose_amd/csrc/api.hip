@@ -233,15 +233,16 @@ struct ap_net {
     // workspace
     int chunk = 0;
     struct TrunkWs { DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds; };
-    TrunkWs tw[2];                 // [1]: the second view's pass when the two views run on two streams
+    TrunkWs tw[4];                 // [1..]: the other concurrent passes when the views run on several streams
     DevBuf ws_feat;
     // two-view forward: view 0 and view 1 as two concurrent trunk passes on two internal streams (an HBM-bound layer of
     // one pass overlaps an MFMA-bound layer of the other: -4 % trunk time at 2 x 256 images); 0 = one pass over both views
     bool dual_stream = true;
     int dual_skew = 0;             // experiment: the second pass starts after the first has finished its stem (1) / its block k-2 (k >= 2)
     hipEvent_t ev_skew = nullptr;
-    hipStream_t aux[2] = {nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    int passes_per_view = 1;       // experiment: 2 = each view as two concurrent half passes (four streams)
     DevBuf ws_H, ws_S, ws_T1, ws_T2, ws_D, ws_state;
     Timing tm;
     size_t esize() const { return prec == AP_PREC_BF16 ? 2 : 4; }   // fp32 and split-bf16 pairs: 4 bytes
@@ -768,7 +769,7 @@ int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float
     if (h->dual_stream && n0 >= 128 && n1 >= 128 && n_img <= chunk) {
         // two views = two concurrent passes: fork from the caller's stream, one pass per internal stream, join
         if (!h->aux[0]) {
-            for (int i = 0; i < 2; ++i) {
+            for (int i = 0; i < 4; ++i) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
                 HIP_TRY(hipEventCreateWithFlags(&h->ev_join[i], hipEventDisableTiming));
             }
@@ -776,19 +777,23 @@ int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float
             HIP_TRY(hipEventCreateWithFlags(&h->ev_skew, hipEventDisableTiming));
         }
         HIP_TRY(hipEventRecord(h->ev_fork, st));
-        size_t ev[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-        for (int v = 0; v < 2; ++v) {
-            HIP_TRY(hipStreamWaitEvent(h->aux[v], h->ev_fork, 0));
-            if (v == 1 && h->dual_skew) HIP_TRY(hipStreamWaitEvent(h->aux[1], h->ev_skew, 0));
-            int rc = trunk_chunk(h, h->tw[v], v ? x1 : x0, v ? n1 : n0, nullptr, 0, feat + (v ? (size_t)n0 * 2048 : 0),
-                                 h->aux[v], ev[v], v == 0 ? h->dual_skew : 0);
+        const int ppv = h->passes_per_view == 2 ? 2 : 1, np = 2 * ppv;
+        size_t ev[4][4] = {};
+        for (int q = 0; q < np; ++q) {
+            const int v = q / ppv, part = q % ppv;
+            const int nv = v ? n1 : n0, lo = part * (nv / ppv), cnt = part == ppv - 1 ? nv - lo : nv / ppv;
+            const float* xv = (v ? x1 : x0) + (size_t)lo * IMG_ELEMS;
+            HIP_TRY(hipStreamWaitEvent(h->aux[q], h->ev_fork, 0));
+            if (q == 1 && np == 2 && h->dual_skew) HIP_TRY(hipStreamWaitEvent(h->aux[1], h->ev_skew, 0));
+            int rc = trunk_chunk(h, h->tw[q], xv, cnt, nullptr, 0, feat + ((v ? (size_t)n0 : 0) + lo) * 2048, h->aux[q], ev[q],
+                                 (q == 0 && np == 2) ? h->dual_skew : 0);
             if (rc) return rc;
-            HIP_TRY(hipEventRecord(h->ev_join[v], h->aux[v]));
+            HIP_TRY(hipEventRecord(h->ev_join[q], h->aux[q]));
         }
-        for (int v = 0; v < 2; ++v) HIP_TRY(hipStreamWaitEvent(st, h->ev_join[v], 0));
+        for (int q = 0; q < np; ++q) HIP_TRY(hipStreamWaitEvent(st, h->ev_join[q], 0));
         if (h->tm.on) {
-            auto quad = [&](int stage, int a, int b) {
-                for (int v = 0; v < 2; ++v) { h->tm.quads[stage].push_back(ev[v][a]); h->tm.quads[stage].push_back(ev[v][b]); }
+            auto quad = [&](int stage, int a, int b) {       // span over the first and the last pass issued (two streams: exact)
+                for (int q : {0, np - 1}) { h->tm.quads[stage].push_back(ev[q][a]); h->tm.quads[stage].push_back(ev[q][b]); }
             };
             quad(1, 1, 2);
             if (h->tm.on == 1) { quad(0, 0, 1); quad(2, 2, 3); }
@@ -915,7 +920,9 @@ void ap_net_destroy(ap_net* h) {
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&h->stem_w, &h->stem_wpk, &h->stem_wpk_lo, &h->stem_scale, &h->stem_shift, &h->mean_pose, &h->mean_shape, &h->mean_cam, &h->tw[0].ws_stem, &h->tw[0].ws_a,
                       &h->tw[0].ws_b, &h->tw[0].ws_t1, &h->tw[0].ws_t2, &h->tw[0].ws_ds, &h->tw[1].ws_stem, &h->tw[1].ws_a, &h->tw[1].ws_b,
-                      &h->tw[1].ws_t1, &h->tw[1].ws_t2, &h->tw[1].ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
+                      &h->tw[1].ws_t1, &h->tw[1].ws_t2, &h->tw[1].ws_ds, &h->tw[2].ws_stem, &h->tw[2].ws_a, &h->tw[2].ws_b, &h->tw[2].ws_t1,
+                      &h->tw[2].ws_t2, &h->tw[2].ws_ds, &h->tw[3].ws_stem, &h->tw[3].ws_a, &h->tw[3].ws_b, &h->tw[3].ws_t1, &h->tw[3].ws_t2,
+                      &h->tw[3].ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
                       &h->ws_D, &h->ws_state})
         b->release();
     auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
@@ -923,7 +930,7 @@ void ap_net_destroy(ap_net* h) {
     rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec); rel(h->fold_feat); rel(h->fold_state);
     h->foldT_feat.release(); h->foldT_state.release(); h->fold_bias.release();
     h->tm.destroy();
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         if (h->aux[i]) (void)hipStreamDestroy(h->aux[i]);
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
@@ -1206,7 +1213,8 @@ int ap_net_set_fold(ap_net* h, int on) {
 int ap_net_set_dual_stream(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->dual_stream = on != 0;
-    h->dual_skew = on > 1 ? on - 1 : 0;                      // (tuning: on = 1 + skew point)
+    h->passes_per_view = on == 100 ? 2 : 1;                  // (tuning: 100 = four half passes)
+    h->dual_skew = (on > 1 && on < 100) ? on - 1 : 0;        // (tuning: on = 1 + skew point)
     return AP_OK;
 }
 
