@@ -215,7 +215,8 @@ def view_split_block(args, net, batch, dev, rank, world):
     return {"pairs_per_s": (world // 2) * B * args.steps / float(t.item()), "ms_per_step": 1e3 * float(t.item()) / args.steps,
             "exchange_us": 1e6 * float(tx.item()), "n_exchanges": n_ex, "bytes_per_exchange": B * 136 * 4,
             "topology": "%d pair groups of 2 ranks, one view per rank, %d pairs per group" % (world // 2, B),
-            "collective": "2-rank all_gather on RCCL (torch.distributed backend nccl)"}
+            "collective": "2-rank all_gather on the pair group, torch.distributed backend %s%s" % (
+                dist.get_backend(), " (= RCCL over xGMI)" if dist.get_backend() == "nccl" else " (host-staged: test aid)")}
 
 
 def main():
@@ -246,13 +247,21 @@ def main():
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
+    # test aid (a 1-GPU box cannot host two RCCL ranks): AIRPOSE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo
+    # backend, so the N > 1 code paths (max-over-ranks timing, view_split block) can be exercised on one GPU
+    share = os.environ.get("AIRPOSE_BENCH_SHARE_GPU") == "1"
+    if share:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     use_dist = world > 1 or args.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if share:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     B = args.batch
     sd = W.to_torch(W.copenet_state_dict(20240901, MEAN))
