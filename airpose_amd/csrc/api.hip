@@ -131,11 +131,12 @@ struct Timing {
 constexpr double BN_EPS = 1e-5;
 
 unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_trace)
-int g_conv_cfg = -1;            // -1 auto, 0..13 conv_pipe config, 20/24..28 conv_phase, 100 = register-staged kernel
+int g_conv_cfg = -1;            // -1 auto, 0..13 conv_pipe config, 14 = slab kernel for stride-1 3x3 (conv_slab.hip), 20/24..28 conv_phase, 100 = register-staged kernel
 // auto mode may pick the phase-interleaved 256-channel tiles (ap_set_conv_config(-3)).  OFF by default: measured inside the
 // trunk at 512 images (profiles/r02_phase_*) the one-workgroup-per-CU kernel is slower than the two-workgroups-per-CU ring
 // kernel on 7 of the 10 layer shapes it can run and equal on the rest, although it wins 15-20 % on layer4 in isolation
 bool g_conv_phase = false;
+bool g_conv_slab = true;        // auto mode uses the slab kernel for stride-1 3x3 layers (ap_set_conv_config(-4) turns it off)
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -189,7 +190,8 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
         //   the 128x64 tiles (twice the workgroups; 46-48 us against 72-83 us for the register-staged kernel there)
         const long mt128 = (a.M + 127) / 128, nt128 = (a.Cout + 127) / 128, nt64 = (a.Cout + 63) / 64;
         //   (a folded downsample = second K segment needs the 128-wide tiles or the register-staged kernel)
-        if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : 11;
+        //   14  the same 128x128 tile with the nine taps of a stride-1 3x3 read from one LDS slab per channel chunk
+        if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : (g_conv_slab && ap_conv_slab_supported(a, is_bf16)) ? 14 : 11;
         else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
     }
@@ -197,6 +199,11 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
     hipError_t e = zero_line(&a.zero);
     if (e != hipSuccess) return e;
     a.dbg = g_conv_dbg;
+    if (cfg == 14) {
+        // explicit 14 on a shape the slab kernel cannot run: the ring kernel's tile of the same shape
+        if (!ap_conv_slab_supported(a, is_bf16)) return ap_launch_conv_pipe(a, is_bf16, 11, st);
+        return ap_launch_conv_slab(a, st);
+    }
     if (cfg >= 20) {                                         // 20: planner; 24..28: one height (4..8 fragments) for all rows
         if (!ap_conv_phase_supported(a, is_bf16 == AP_PREC_BF16)) return hipErrorInvalidValue;
         int n_cu = 0;
@@ -1104,10 +1111,11 @@ int ap_debug_set_trace(void* device_buf_160_u64) {
 }
 
 int ap_set_conv_config(int cfg) {
-    if (cfg != -1 && cfg != -3 && cfg != 100 && cfg != 20 && !(cfg >= 24 && cfg <= 28) && (cfg < 0 || cfg > 13))
-        return fail(AP_EINVAL, "ap_set_conv_config: -1, -3, 0..13, 20, 24..28 or 100");
+    if (cfg != -1 && cfg != -3 && cfg != -4 && cfg != 100 && cfg != 20 && !(cfg >= 24 && cfg <= 28) && (cfg < 0 || cfg > 14))
+        return fail(AP_EINVAL, "ap_set_conv_config: -1, -3, -4, 0..14, 20, 24..28 or 100");
     g_conv_phase = cfg == -3;
-    g_conv_cfg = cfg == -3 ? -1 : cfg;
+    g_conv_slab = cfg != -4 && cfg != -3;    // (-3 compares the phase kernel against the ring kernel: no slab either)
+    g_conv_cfg = (cfg == -3 || cfg == -4) ? -1 : cfg;
     return AP_OK;
 }
 

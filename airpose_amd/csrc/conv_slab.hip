@@ -1,0 +1,361 @@
+// Stride-1 3x3 convolution with the nine taps served from ONE LDS slab per 64-channel chunk (bf16, gfx950).
+//
+// Same tile program as conv_pipe.hip's <bf16,128,128,2,4,2> (8 waves, 64x32 per wave, one barrier per K step, two
+// workgroups per CU, counted waits, LDS-staged epilogue; see there for the reference lines it replaces), but the
+// activation operand is not re-fetched per tap.  The K loop runs channel chunk OUTER, tap INNER:
+//
+//   per 64-channel chunk:  a slab of the 130 + 2W input pixels [p0 - W - 1, p0 + 128 + W + 1) of the tile's 128 output
+//                          pixels (linear NHW index: the 3x3 neighbours of pixel m are m + (r-1)W + (s-1)), 128 B per
+//                          pixel, fetched ONCE by LDS-DMA (24 pieces of 8 rows, padded with zero rows) into one of two
+//                          slab buffers -- the next chunk's slab arrives under the nine K steps of the current one;
+//   per tap (K step):      the wave's four pixel fragments read slab rows base + (r-1)W + (s-1) (taps that fall outside
+//                          the image read the slab's zero row instead: one v_cndmask per fragment), the 128 x 64 weight
+//                          tile of that tap streams through a 2-slot ring as in the ring kernel.
+//
+// Operand DMA per chunk: 24 KiB of slab + 9 x 16 KiB of weights = 168 KiB instead of 9 x 32 KiB = 288 KiB (-42 %); the
+// ring kernel's timing-only builds price the activation stream of these layers at 20-27 % of their time.
+// The accumulation order differs from the ring kernel's (taps outer there), so results agree with it to fp32
+// re-association, not bitwise; both are tested against an fp64 convolution of the same bf16 operands.
+//
+// LDS (80 KiB, two workgroups per CU): slab0 [0, 24K) | slab1 [24K, 48K) | weights0 [48K, 64K) | weights1 [64K, 80K);
+// rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7) on the DMA source side.
+#include "ap_common.h"
+#include "kernels.h"
+
+// Timing-only builds (results WRONG, times valid): -DSL_ABLATE=<bits>
+//   1 no slab DMA in the K loop | 2 fragment addresses computed once | 4 weight rows walked sequentially (the ring kernel's
+//   order) | 8 no weight DMA in the K loop | 16 slab pieces of the K loop issued, but from the zero line
+#ifndef SL_ABLATE
+#define SL_ABLATE 0
+#endif
+// slab pieces the slab wave issues per K step (multiple of 3), starting at tap 0 of the previous chunk
+// cache policy bits of the slab loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+#ifndef SL_NT
+#define SL_NT 0
+#endif
+#ifndef SL_PER_STEP
+#define SL_PER_STEP 3
+#endif
+
+namespace {
+
+constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 4, NT = 512, FM = 4, FN = 2;
+constexpr int SLAB_ROWS = 192, SLAB_BYTES = SLAB_ROWS * 128, WT_BYTES = BN * 128;
+constexpr int W_BASE = 2 * SLAB_BYTES;                      // weight ring after the two slabs
+constexpr int LDS_BYTES = 2 * SLAB_BYTES + 2 * WT_BYTES;    // 81920
+constexpr int ZROW = SLAB_ROWS - 1;                         // always sourced from the zero line
+constexpr int WLP = 3;                                      // weight DMA pieces per wave and K step (the third: waves 0, 1)
+constexpr int CLD = BN + 4;
+static_assert(BM * CLD * 4 <= LDS_BYTES, "the fp32 epilogue stage reuses the operand buffers");
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+// MFMA with the accumulator tied in place.  With the nine taps unrolled the register allocator otherwise lets the eight
+// accumulators migrate (v_mfma d, a, b, c with d != c), which costs ~25 registers and spills; spill reloads sit behind
+// s_waitcnt vmcnt(0) and would drain the DMA queue every K step.  (Hazards the compiler no longer sees: consecutive MFMAs
+// here never share an accumulator back to back with different operands, and the epilogue's first VALU read of an
+// accumulator is fenced by s_nop below.)
+__device__ __forceinline__ void mfma_acc(f32x4& c, const u32x4& w, const u32x4& x) {
+    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
+}
+
+// 8 MFMAs with NP callbacks spread evenly between them
+template <int NP, typename F>
+__device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&wf)[FN], f32x4 (&acc)[FM][FN], F&& piece) {
+    constexpr int NM = FM * FN;
+#pragma unroll
+    for (int j = 0; j < NM; ++j) {
+        const int fm = j / FN, fn = j % FN;
+        mfma_acc(acc[fm][fn], wf[fn], xf[fm]);
+#pragma unroll
+        for (int k = 0; k < NP; ++k)
+            if ((k + 1) * NM / (NP + 1) == j + 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                piece(k);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+    }
+}
+
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4))) conv_slab_kernel(const ConvArgs p) {
+    typedef bf16_t T;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int bm = tile / p.ntiles, bn = tile % p.ntiles;
+    const int W = p.W, HW = p.H * p.W;
+    const int cpb = p.Cin / 64;
+
+    // ---------------------------------------------------------------- DMA roles, split by wave.  vmcnt retires in order
+    // per wave, so a slab piece (first touch of the activations: HBM / Infinity-Cache latency) queued in front of a weight
+    // piece (L2 hit) makes the K step wait for the long-latency stream.  Wave 7 therefore issues ALL slab pieces (four
+    // per K step on taps 0..5, for the NEXT chunk) and waits for them once per chunk, at tap 8; waves 0..6 share the 16
+    // weight pieces of a K step (two each, waves 0 and 1 a third) and drain their queue every step.
+    const bool srole = wave == 7;                            // wave-uniform
+    const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
+    const unsigned char* zg = (const unsigned char*)p.zero;
+    const unsigned char* xg = (const unsigned char*)p.x;
+    const unsigned char* wg = (const unsigned char*)p.w;
+    // the kernel-argument loads complete HERE on every path: a scalar load the compiler still believes pending inside the
+    // K loop costs an s_waitcnt lgkmcnt(0) in front of every DMA instruction, which also drains the fragment reads in flight
+    asm volatile("" ::"s"(zg), "s"(xg), "s"(wg));
+    const int nrows = BM + 2 * W + 2;                        // slab rows that hold pixels (the rest stay zero)
+    const int need = (nrows + 7) >> 3;                       // ... in 8-row pieces
+    uint32_t doff[WLP];                                      // weight waves: running byte offsets of their rows into p.w
+#pragma unroll
+    for (int i = 0; i < WLP; ++i) {                          // weight rows are padded to multiples of 128: always valid
+        const int piece = i < 2 ? 2 * wave + i : 14 + wave;  // (slab wave, and i == 2 on waves >= 2: unused)
+        const int row = (piece & 15) * 8 + prow;
+        doff[i] = (uint32_t)(((size_t)(bn * BN + row) * p.wld + pchunk * 8) * sizeof(T));
+    }
+    const uint32_t wstep = (uint32_t)p.Cin * sizeof(T);      // next tap, same chunk
+    const uint32_t wwrap = 128u - 8u * wstep;                // tap 8 -> tap 0 of the next chunk (mod 2^32)
+    // weight piece i of this wave for the tile of tap TT into ring slot `slot`, then on to the next tile's row segment
+    auto issue_weights = [&](int slot, int i, bool last_tap) {
+        const int piece = i < 2 ? 2 * wave + i : 14 + wave;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + doff[i]),
+                                         (__attribute__((address_space(3))) void*)(smem + W_BASE + slot * WT_BYTES + piece * 1024),
+                                         16, 0, 0);
+        doff[i] += (SL_ABLATE & 4) ? 128u : last_tap ? wwrap : wstep;
+        asm volatile("" : "+v"(doff[i]));                    // keep the offset 32-bit (uniform base + VGPR offset addressing)
+    };
+    // Slab wave: piece j = slab rows 8j .. 8j+7 = input pixels p0 + 8j + prow.  Pixels outside [0, M) are clamped, not
+    // predicated: only taps that fall outside their image would read such a row, and those read the zero row instead.
+    // Rows >= nrows are never read either, except the zero row (the slab's last): it is written once, in the prologue,
+    // and the K loop's DMA leaves it alone (the lanes of rows >= nrows are switched off: an LDS-DMA lane that is not
+    // executed writes nothing).
+    const int p0 = bm * BM - (W + 1);                        // input pixel of slab row 0
+    const uint32_t rowbytes = (uint32_t)p.ldx * sizeof(T);
+    const uint32_t lane_off = (uint32_t)pchunk * 16u;
+    auto issue_slab = [&](int buf, int cb, int piece) {      // 8 rows of chunk cb
+        int row = piece * 8 + prow;
+        asm volatile("" : "+v"(row));                        // computed where it is used: hoisted out of the chunk loop the 24
+                                                             // source offsets of a slab would take 24 registers
+        const int q = min(max(p0 + row, 0), p.M - 1);
+        const uint32_t off = (uint32_t)q * rowbytes + lane_off + (uint32_t)cb * 128u;
+        if (row < nrows && !((SL_ABLATE & 16) && cb > 0))
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xg + off),
+                                             (__attribute__((address_space(3))) void*)(smem + buf * SLAB_BYTES + piece * 1024),
+                                             16, 0, SL_NT);
+    };
+    auto issue_zero_row = [&](int buf) {                     // prologue only: the last piece of a slab from the zero line
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)zg,
+                                         (__attribute__((address_space(3))) void*)(smem + buf * SLAB_BYTES + (SLAB_ROWS / 8 - 1) * 1024),
+                                         16, 0, 0);
+    };
+
+    // ---------------------------------------------------------------- MFMA state
+    const int lr = lane & 15, g4 = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    // The slab row a fragment reads depends on (lane, fragment, tap) only, not on the chunk: all 36 are computed once per
+    // tile (valid ? centre + (r-1)W + (s-1) : the zero row) and kept as bytes, the four fragments of a tap in one register.
+    uint32_t pk[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) pk[t] = 0u;
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm) {
+        const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
+        const int m = bm * BM + px;
+        const int rem = m % HW, ho = rem / W, wo = rem - ho * W;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int r = t / 3, sx = t % 3;
+            const bool ok = m < p.M && (unsigned)(ho + r - 1) < (unsigned)p.H && (unsigned)(wo + sx - 1) < (unsigned)W;
+            const int row = ok ? px + W + 1 + (r - 1) * W + (sx - 1) : ZROW;
+            pk[t] |= (uint32_t)row << (fm * 8);
+        }
+    }
+    const uint32_t g4s = (uint32_t)g4 << 4;
+    const uint32_t wa = lds0 + W_BASE + (wn * (BN / WAVES_N) + lr) * 128 + ((g4 ^ (lr & 7)) << 4);
+    f32x4 acc[FM][FN];
+#pragma unroll
+    for (int fm = 0; fm < FM; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    auto load_x = [&](const uint32_t (&xa)[FM], uint32_t flip, u32x4 (&xf)[FM]) {
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) xf[fm] = lds_read_b128<0>(xa[fm] ^ flip);
+    };
+    auto load_w = [&](uint32_t a, u32x4 (&wf)[FN]) {
+        wf[0] = lds_read_b128<0>(a);
+        wf[1] = lds_read_b128<2048>(a);
+    };
+    // chunk g4 of the 128-byte row (first K half) sits at position g4 ^ (row & 7); chunk 4 + g4 (second half) at that address ^ 64
+    auto tap_addr = [&](uint32_t f, uint32_t sbase, uint32_t (&xa)[FM]) {
+        asm volatile("" : "+v"(f));                          // unpack HERE: hoisted out of the chunk loop the 36 addresses
+                                                             // would be 36 registers instead of 9
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const uint32_t row = (f >> (fm * 8)) & 0xffu;
+            xa[fm] = (sbase + (row << 7)) | (((row & 7u) << 4) ^ g4s);
+        }
+        asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]));   // ... and finished here, between the MFMAs
+                                                             // (left alone the compiler sinks the arithmetic to the reads
+                                                             // behind the barrier, onto the critical path)
+    };
+
+    // ---------------------------------------------------------------- prologue: slab 0 (+ the zero piece of slab 1, which
+    // the K loop skips when the slab is short), weight tiles 0 and 1
+    if (srole) {
+        issue_zero_row(0);
+        issue_zero_row(1);
+        wait_vmcnt<0>();                                     // (the same wave overwrites rows of that piece below)
+        for (int j = 0; j < need; ++j) issue_slab(0, 0, j);
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            issue_weights(t, 0, false);
+            issue_weights(t, 1, false);
+            if (wave < 2) issue_weights(t, 2, false);
+        }
+    }
+    uint32_t xa[FM];                                         // fragment addresses of the tile whose first half is read next
+    tap_addr(pk[0], lds0, xa);
+    wait_vmcnt<0>();
+    __builtin_amdgcn_s_barrier();
+    u32x4 xf0[FM], wf0[FN], xf1[FM], wf1[FN];
+    load_x(xa, 0u, xf0);
+    load_w(wa, wf0);
+
+    // K loop: as the ring kernel's, one barrier per K step between the two MFMA clusters; the nine taps of a chunk are
+    // unrolled so that everything tap-dependent is an immediate.  Weight tile kt+2 goes into the slot of tile kt after the
+    // barrier of step kt.
+    int ws = 0;                                              // ring slot of the weight tile of this step
+    for (int cb = 0; cb < cpb; ++cb) {
+        const uint32_t sb_cur = lds0 + (cb & 1) * SLAB_BYTES, sb_nxt = lds0 + ((cb & 1) ^ 1) * SLAB_BYTES;
+        const bool more = cb + 1 < cpb;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            const bool last = !more && tap == 8;             // last K step of the tile
+            const bool refill = more || tap < 7;             // tile kt+2 exists
+            load_x(xa, 64u, xf1);                            // second K half of tile kt (the addresses are consumed at issue:
+                                                             // the first cluster overwrites them with the next tile's)
+            load_w((wa + ws * WT_BYTES) ^ 64u, wf1);
+            wait_lgkmcnt<FM + FN>();                         // first half (read one phase earlier) has landed
+            mma_issue<1>(xf0, wf0, acc, [&](int) {
+                if (!(SL_ABLATE & 2)) tap_addr(pk[tap == 8 ? 0 : tap + 1], tap == 8 ? sb_nxt : sb_cur, xa);
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkmcnt<0>();                               // all of this wave's reads of tile kt are done
+            if (!last) {
+                if (!srole || tap == 8) wait_vmcnt<0>();
+                __builtin_amdgcn_s_barrier();
+                load_x(xa, 0u, xf0);                         // first half of tile kt+1
+                load_w(wa + (ws ^ 1) * WT_BYTES, wf0);
+            }
+            // one MFMA cluster for both roles (two copies cost the compiler 20 registers in accumulator copies); only the
+            // DMA issue between the MFMAs branches on the role
+            mma_issue<WLP>(xf1, wf1, acc, [&](int i) {
+                if (!srole) {
+                    if (refill && (i < 2 || wave < 2) && !(SL_ABLATE & 8)) issue_weights(ws, i, (tap + 2) % 9 == 8);
+                } else if (more && tap * SL_PER_STEP < 24 && !(SL_ABLATE & 1)) {   // SL_PER_STEP pieces per step from tap 0
+                    constexpr int PC = SL_PER_STEP / 3;      // per callback
+#pragma unroll
+                    for (int k = 0; k < PC; ++k) {
+                        const int piece = SL_PER_STEP * tap + PC * i + k;
+                        if (piece < need) issue_slab((cb & 1) ^ 1, cb + 1, piece);
+                    }
+                }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+            ws ^= 1;
+        }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results settle before the epilogue's VALU reads them
+    __syncthreads();                                         // all MFMA reads done before the buffers are reused
+
+    // ---------------------------------------------------------------- epilogue (as conv_pipe.hip: fp32 stage in LDS,
+    // BatchNorm + residual + ReLU, 16-byte coalesced stores)
+    float* ct = (float*)smem;
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int chl = wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
+        const int ch = bn * BN + chl;
+        const float4 sc = *(const float4*)(p.scale + ch);
+        const float4 sh = *(const float4*)(p.shift + ch);
+#pragma unroll
+        for (int fm = 0; fm < FM; ++fm) {
+            const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
+            float4 v;
+            v.x = acc[fm][fn][0] * sc.x + sh.x;
+            v.y = acc[fm][fn][1] * sc.y + sh.y;
+            v.z = acc[fm][fn][2] * sc.z + sh.z;
+            v.w = acc[fm][fn][3] * sc.w + sh.w;
+            *(float4*)(ct + px * CLD + chl) = v;
+        }
+    }
+    __syncthreads();
+    constexpr int CPR = BN / 8, NIT = BM * CPR / NT;
+    T* __restrict__ yg = (T*)p.y;
+    const T* __restrict__ rg = (const T*)p.res;
+    u32x4 rv[NIT];
+    if (rg) {
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
+            const int m = bm * BM + px, ch = bn * BN + cc * 8;
+            const bool ok = m < p.M && ch < p.Cout;
+            rv[it] = *(const u32x4*)(ok ? rg + (size_t)m * p.ldr + ch : (const T*)p.zero);
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
+        const int m = bm * BM + px, ch = bn * BN + cc * 8;
+        if (m >= p.M || ch >= p.Cout) continue;
+        const float* sp = ct + px * CLD + cc * 8;
+        float4 a = *(const float4*)sp, b = *(const float4*)(sp + 4);
+        if (rg) {
+            float lo, hi;
+            unpack_bf16x2(rv[it][0], lo, hi); a.x += lo; a.y += hi;
+            unpack_bf16x2(rv[it][1], lo, hi); a.z += lo; a.w += hi;
+            unpack_bf16x2(rv[it][2], lo, hi); b.x += lo; b.y += hi;
+            unpack_bf16x2(rv[it][3], lo, hi); b.z += lo; b.w += hi;
+        }
+        if (p.relu) {
+            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
+            b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+        }
+        u32x4 o;
+        o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
+        o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
+        *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
+    }
+}
+
+}  // namespace
+
+// stride-1 3x3, pad 1, bf16, 64-channel chunks, rows short enough that the 130 + 2W pixel slab (+ its zero row) fits
+bool ap_conv_slab_supported(const ConvArgs& a, int kind) {
+    return kind == K_BF16 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.x2 && a.Cin % 64 == 0 &&
+           a.Cin >= 64 && a.Ho == a.H && a.Wo == a.W && BM + 2 * a.W + 2 <= ZROW && a.ldx == a.Cin &&
+           (long long)a.M * a.ldx * 2 < 0xffffffffll && (long long)a.wld * 2 * ((a.Cout + 127) / 128 * 128) < 0xffffffffll;
+}
+
+hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st) {
+    static bool attr_set[AP_MAX_DEVICES] = {};
+    if (!a.zero || !ap_conv_slab_supported(a, K_BF16)) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)conv_slab_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    a.mtiles = (a.M + BM - 1) / BM;
+    a.ntiles = (a.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL(conv_slab_kernel, dim3(a.mtiles * a.ntiles), dim3(NT), LDS_BYTES, st, a);
+    return hipGetLastError();
+}

@@ -38,6 +38,10 @@ bool ap_conv_phase_supported(const ConvArgs& a, int is_bf16);
 hipError_t ap_launch_conv_phase(ConvArgs a, int fmw, int row0, int mtiles, hipStream_t st);
 hipError_t ap_conv_phase_auto(const ConvArgs& a, int n_cu, hipStream_t st);
 
+// stride-1 3x3 with the nine taps read from one LDS slab per 64-channel chunk (conv_slab.hip); bf16, 128x128 tiles
+bool ap_conv_slab_supported(const ConvArgs& a, int kind);
+hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st);
+
 // ---- fused layer1 bottleneck (bottleneck.hip); bf16 only
 struct BneckArgs {
     const void* x;                // [N][H][W][cin] bf16 (cin = 256, or 64 for the downsample block)

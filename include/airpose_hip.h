@@ -150,8 +150,12 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
  * -3 = automatic with the phase-interleaved kernel where it applies (experimental, see conv_phase.hip), 0..13 = software-pipelined LDS-DMA ring kernel (tile / wave /
  * ring-depth variants, conv_pipe.hip), 20 = phase-interleaved 256-channel tiles with the planner that fits tile heights
  * to the CU count, 24..28 = the same with one fixed height of 4..8 pixel fragments per wave (conv_phase.hip; bf16,
- * C_out % 256 == 0, no residual: anything else is refused), 100 = register-staged 2-stage kernel.
- * Results are identical (bitwise) for every setting. */
+ * C_out % 256 == 0, no residual: anything else is refused), 100 = register-staged 2-stage kernel,
+ * 14 = stride-1 3x3 convolutions with the nine taps read from one LDS slab per 64-channel chunk (conv_slab.hip; bf16,
+ * image rows of at most 30 pixels; other shapes run configuration 11), which the automatic choice uses for the conv2
+ * layers of layer2-4; -4 = automatic without it (ring kernel everywhere).
+ * Results are identical (bitwise) for every setting except 14 / the automatic choice on those layers: the slab kernel sums
+ * the K range channel-chunk-outer, tap-inner instead of tap-outer, i.e. it agrees to fp32 re-association. */
 int ap_set_conv_config(int cfg);
 /* Profiling aid: device buffer of 160 uint64 receiving per-phase cycle stamps of workgroup 0 of the pipelined
  * convolution kernel (2 waves x 8 K steps x 10 stamps); NULL (default) disables it. */

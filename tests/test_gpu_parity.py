@@ -192,7 +192,7 @@ CONV_CASES = [
 
 # -1 = automatic choice; 0..3 = LDS-DMA pipelined kernel (256x128, 128x128, 128x64, 256x64 tiles), 4..7 = the same
 # with the register epilogue; 8..13 = 2-stage rings with 4 or 8 waves; 100 = register-staged kernel
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 100])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 100])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_primitive(dev, prec, case, cfg):
@@ -243,6 +243,87 @@ def test_conv_phase_primitive(dev, case, cfg):
     assert torch.equal(outs[0], outs[1])
 
 
+SLAB_CASES = [
+    # N, H, Cin, Cout, relu, res   (conv_slab.hip: stride-1 3x3, pad 1, bf16)
+    (3, 14, 256, 256, True, False),        # ragged M (588 rows), tiles that straddle images
+    (5, 7, 512, 512, True, False),         # 7-pixel rows: a tile spans 2.6 images, K = 4608
+    (3, 28, 128, 192, True, True),         # 28-pixel rows (186-row slab), ragged N, residual
+    (2, 28, 128, 128, False, False),       # no relu
+    (1, 14, 64, 128, True, False),         # a single channel chunk: no second slab
+    (9, 14, 192, 128, True, False),        # three chunks: both slab buffers refilled
+    (1, 30, 64, 128, True, False),         # longest supported row
+]
+
+
+@pytest.mark.parametrize("case", SLAB_CASES)
+def test_conv_slab_primitive(dev, case):
+    """The slab kernel (nine taps of a stride-1 3x3 from one LDS slab per channel chunk, border taps from the zero row)
+    against the fp64 oracle on identical bf16 operands, and against the ring kernel: same products, different fp32
+    summation order, so the bf16 results may differ by one rounding step in a few places and nowhere by more."""
+    from airpose_amd import _native as Nn
+    N, H, Cin, Cout, relu, use_res = case
+    outs = []
+    for c in (14, 11):
+        Nn.check(Nn.lib().ap_set_conv_config(c), "ap_set_conv_config")
+        try:
+            got, ref = _conv_case(dev, "bf16", N, H, Cin, Cout, 3, 1, 1, relu, use_res, seed=hash(case) % 10000)
+        finally:
+            Nn.lib().ap_set_conv_config(-1)
+        outs.append(got)
+    assert torch.isfinite(outs[0]).all()
+    assert rel_err(outs[0].numpy(), ref.numpy()) < 6e-3
+    d = (outs[0] - outs[1]).abs()
+    assert (d <= 2.0 ** -7 * outs[1].abs().clamp_min(2.0 ** -6)).all()          # at most one bf16 step
+    assert (d > 0).double().mean() < 0.05
+
+
+def test_conv_slab_full_size_is_deterministic(dev):
+    """BASELINE-size layer2 / layer3 / layer4 conv2 (512 images; two workgroups of 80 KiB per CU, counted waits under
+    full memory load): repeated runs identical, one bf16 step from the ring kernel at most."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    for n, H, C in ((512, 28, 128), (512, 14, 256), (512, 7, 512)):
+        g = torch.Generator(device="cpu").manual_seed(3)
+        x = torch.randn(n, H, H, C, generator=g).to(torch.bfloat16).to(dev)
+        w = (torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).to(torch.bfloat16).to(dev)
+        sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
+        outs = []
+        for cfg in (14, 14, 14, 11):
+            L.ap_set_conv_config(cfg)
+            try:
+                y = torch.full((n, H, H, C), float("nan"), dtype=torch.bfloat16, device=dev)
+                Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(x), p(w), p(sc), p(sh), None, p(y), n, H, H, C, C, 3, 1, 1,
+                                          1, Nn.stream_ptr(dev)), "conv")
+                torch.cuda.synchronize()
+            finally:
+                L.ap_set_conv_config(-1)
+            outs.append(y.float())
+        assert torch.isfinite(outs[0]).all()
+        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
+        d = (outs[0] - outs[3]).abs()
+        assert (d <= 2.0 ** -7 * outs[3].abs().clamp_min(2.0 ** -6)).all()
+        assert (d > 0).double().mean() < 0.05
+
+
+def test_trunk_slab_kernel_against_ring_kernel(netbf, dev):
+    """Trunk features with the automatic choice (slab kernel on the stride-1 3x3 layers of layer2-4) against the ring
+    kernel everywhere: the difference is fp32 re-association under bf16 rounding, far below the bf16 mode's own error."""
+    from airpose_amd import _native as Nn
+    gen = torch.Generator(device="cpu").manual_seed(22)
+    x = torch.randn(128, 3, 224, 224, generator=gen).to(dev)
+    a = netbf.forward_feat_ext(x)
+    Nn.check(Nn.lib().ap_set_conv_config(-4), "ap_set_conv_config")
+    try:
+        b = netbf.forward_feat_ext(x)
+    finally:
+        Nn.lib().ap_set_conv_config(-1)
+    assert torch.isfinite(a).all()
+    e = rel_err(a.cpu().numpy(), b.cpu().numpy())
+    print("slab vs ring trunk features rel %.2e" % e)
+    assert 0 < e < 2e-3
+
+
 def test_conv_phase_refuses_what_it_cannot_do(dev):
     from airpose_amd import _native as Nn
     for case in ((2, 56, 64, 256, 1, 1, 0, True, True),      # residual
@@ -289,13 +370,14 @@ def test_trunk_with_and_without_phase_kernel_bitwise(netbf, dev):
     from airpose_amd import _native as Nn
     gen = torch.Generator(device="cpu").manual_seed(21)
     x = torch.randn(128, 3, 224, 224, generator=gen).to(dev)
-    a = netbf.forward_feat_ext(x)
-    Nn.check(Nn.lib().ap_set_conv_config(-3), "ap_set_conv_config")
-    try:
-        b = netbf.forward_feat_ext(x)
-    finally:
-        Nn.lib().ap_set_conv_config(-1)
-    assert torch.equal(a, b)
+    feats = []
+    for cfg in (-4, -3):                                     # ring kernel everywhere | phase kernel where it applies
+        Nn.check(Nn.lib().ap_set_conv_config(cfg), "ap_set_conv_config")
+        try:
+            feats.append(netbf.forward_feat_ext(x))
+        finally:
+            Nn.lib().ap_set_conv_config(-1)
+    assert torch.equal(feats[0], feats[1])
 
 
 @pytest.mark.parametrize("cfg", [-1, 11, 12, 100])
