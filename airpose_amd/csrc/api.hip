@@ -190,8 +190,12 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
         //   the 128x64 tiles (twice the workgroups; 46-48 us against 72-83 us for the register-staged kernel there)
         const long mt128 = (a.M + 127) / 128, nt128 = (a.Cout + 127) / 128, nt64 = (a.Cout + 63) / 64;
         //   (a folded downsample = second K segment needs the 128-wide tiles or the register-staged kernel)
-        //   14  the same 128x128 tile with the nine taps of a stride-1 3x3 read from one LDS slab per channel chunk
-        if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : (g_conv_slab && ap_conv_slab_supported(a, is_bf16)) ? 14 : 11;
+        //   14  the same 128x128 tile with the nine taps of a stride-1 3x3 read from one LDS slab per channel chunk: every
+        //       shape it can run, at EVERY size (it is the one kernel whose fp32 summation order differs from the others',
+        //       so a size-dependent choice would make a pair's result depend on the batch it arrives in; measured equal or
+        //       faster than the small-problem configurations from 2 to 512 images)
+        if (g_conv_slab && ap_conv_slab_supported(a, is_bf16)) cfg = 14;
+        else if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : 11;
         else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
     }

@@ -55,7 +55,7 @@ for (nm, M, N, K, inel, res) in shapes:
     r = rows[k]
     k += 1
     assert "conv_" in r[0], r[0]
-    cfg = r[0].split("<")[1].split(">")[0].replace("unsigned short", "bf16")
+    cfg = r[0].split("<")[1].split(">")[0].replace("unsigned short", "bf16") if "<" in r[0] else r[0].split("::")[-1].split("(")[0]
     fl, dur = 2.0 * M * N * K, r[3] / 1e3
     tot += dur
     by = (inel + M * N * (1 + res)) * 2
