@@ -43,7 +43,9 @@ constexpr int BM = 128, BN = 128, WAVES_M = 2, WAVES_N = 4, NT = 512, FM = 4, FN
 constexpr int SLAB_ROWS = 192, SLAB_BYTES = SLAB_ROWS * 128, WT_BYTES = BN * 128;
 constexpr int W_BASE = 2 * SLAB_BYTES;                      // weight ring after the two slabs
 constexpr int LDS_BYTES = 2 * SLAB_BYTES + 2 * WT_BYTES;    // 81920
-constexpr int ZROW = SLAB_ROWS - 1;                         // always sourced from the zero line
+constexpr int ZROW = SLAB_ROWS - 1;                         // rows ZROW - 1 and ZROW stay zero (one per row parity: a b128 read is
+                                                            // conflict-free when the 16 lanes of a group hit 16 different
+                                                            // (row parity, chunk position) pairs)
 constexpr int WLP = 3;                                      // weight DMA pieces per wave and K step (the third: waves 0, 1)
 constexpr int CLD = BN + 4;
 static_assert(BM * CLD * 4 <= LDS_BYTES, "the fp32 epilogue stage reuses the operand buffers");
@@ -171,11 +173,13 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         for (int t = 0; t < 9; ++t) {
             const int r = t / 3, sx = t % 3;
             const bool ok = m < p.M && (unsigned)(ho + r - 1) < (unsigned)p.H && (unsigned)(wo + sx - 1) < (unsigned)W;
-            const int row = ok ? px + W + 1 + (r - 1) * W + (sx - 1) : ZROW;
+            const int nat = px + W + 1 + (r - 1) * W + (sx - 1);          // the row the tap would read
+            const int row = ok ? nat : ZROW - 1 + (nat & 1);             // outside the image: the zero row of the same parity
             pk[t] |= (uint32_t)row << (fm * 8);
         }
     }
     const uint32_t g4s = (uint32_t)g4 << 4;
+    const int c7 = lr + W + 1;                               // centre-tap row of every fragment of this lane, mod 8 (fragments are 16 rows apart)
     const uint32_t wa = lds0 + W_BASE + (wn * (BN / WAVES_N) + lr) * 128 + ((g4 ^ (lr & 7)) << 4);
     f32x4 acc[FM][FN];
 #pragma unroll
@@ -191,14 +195,20 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         wf[0] = lds_read_b128<0>(a);
         wf[1] = lds_read_b128<2048>(a);
     };
-    // chunk g4 of the 128-byte row (first K half) sits at position g4 ^ (row & 7); chunk 4 + g4 (second half) at that address ^ 64
-    auto tap_addr = [&](uint32_t f, uint32_t sbase, uint32_t (&xa)[FM]) {
+    // chunk g4 of the 128-byte row (first K half) sits at position g4 ^ (row & 7); chunk 4 + g4 (second half) at that address ^ 64.
+    // A lane whose tap falls outside the image reads a zero row of ITS OWN ROW'S PARITY at the position its own row would
+    // have, (centre + d) & 7: bank = 32 * (row & 1) + 4 * position, and the 16 lanes of a ds_read_b128 group cover the 16
+    // (parity, position) pairs exactly once for any tap shift -- only as long as a substituted row keeps both (with one zero
+    // row at its own position 7 ^ g4, SQ_LDS_BANK_CONFLICT was 27 % of the LDS cycles)
+    auto tap_addr = [&](uint32_t f, int tap, uint32_t sbase, uint32_t (&xa)[FM]) {
         asm volatile("" : "+v"(f));                          // unpack HERE: hoisted out of the chunk loop the 36 addresses
                                                              // would be 36 registers instead of 9
+        const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
+        const uint32_t swz = (((uint32_t)(c7 + d) & 7u) << 4) ^ g4s;
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
             const uint32_t row = (f >> (fm * 8)) & 0xffu;
-            xa[fm] = (sbase + (row << 7)) | (((row & 7u) << 4) ^ g4s);
+            xa[fm] = (sbase + (row << 7)) | swz;
         }
         asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]));   // ... and finished here, between the MFMAs
                                                              // (left alone the compiler sinks the arithmetic to the reads
@@ -221,7 +231,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         }
     }
     uint32_t xa[FM];                                         // fragment addresses of the tile whose first half is read next
-    tap_addr(pk[0], lds0, xa);
+    tap_addr(pk[0], 0, lds0, xa);
     wait_vmcnt<0>();
     __builtin_amdgcn_s_barrier();
     u32x4 xf0[FM], wf0[FN], xf1[FM], wf1[FN];
@@ -244,7 +254,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
             load_w((wa + ws * WT_BYTES) ^ 64u, wf1);
             wait_lgkmcnt<FM + FN>();                         // first half (read one phase earlier) has landed
             mma_issue<1>(xf0, wf0, acc, [&](int) {
-                if (!(SL_ABLATE & 2)) tap_addr(pk[tap == 8 ? 0 : tap + 1], tap == 8 ? sb_nxt : sb_cur, xa);
+                if (!(SL_ABLATE & 2)) tap_addr(pk[tap == 8 ? 0 : tap + 1], tap == 8 ? 0 : tap + 1, tap == 8 ? sb_nxt : sb_cur, xa);
             });
             __builtin_amdgcn_sched_barrier(0);
             wait_lgkmcnt<0>();                               // all of this wave's reads of tile kt are done
@@ -339,7 +349,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 // stride-1 3x3, pad 1, bf16, 64-channel chunks, rows short enough that the 130 + 2W pixel slab (+ its zero row) fits
 bool ap_conv_slab_supported(const ConvArgs& a, int kind) {
     return kind == K_BF16 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.x2 && a.Cin % 64 == 0 &&
-           a.Cin >= 64 && a.Ho == a.H && a.Wo == a.W && BM + 2 * a.W + 2 <= ZROW && a.ldx == a.Cin &&
+           a.Cin >= 64 && a.Ho == a.H && a.Wo == a.W && BM + 2 * a.W + 2 <= ZROW - 1 && a.ldx == a.Cin &&
            (long long)a.M * a.ldx * 2 < 0xffffffffll && (long long)a.wld * 2 * ((a.Cout + 127) / 128 * 128) < 0xffffffffll;
 }
 

@@ -152,7 +152,7 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
  * to the CU count, 24..28 = the same with one fixed height of 4..8 pixel fragments per wave (conv_phase.hip; bf16,
  * C_out % 256 == 0, no residual: anything else is refused), 100 = register-staged 2-stage kernel,
  * 14 = stride-1 3x3 convolutions with the nine taps read from one LDS slab per 64-channel chunk (conv_slab.hip; bf16,
- * image rows of at most 30 pixels; other shapes run configuration 11), which the automatic choice uses for the conv2
+ * image rows of at most 29 pixels; other shapes run configuration 11), which the automatic choice uses for the conv2
  * layers of layer2-4; -4 = automatic without it (ring kernel everywhere).
  * Results are identical (bitwise) for every setting except 14 / the automatic choice on those layers: the slab kernel sums
  * the K range channel-chunk-outer, tap-inner instead of tap-outer, i.e. it agrees to fp32 re-association. */

@@ -251,7 +251,7 @@ SLAB_CASES = [
     (2, 28, 128, 128, False, False),       # no relu
     (1, 14, 64, 128, True, False),         # a single channel chunk: no second slab
     (9, 14, 192, 128, True, False),        # three chunks: both slab buffers refilled
-    (1, 30, 64, 128, True, False),         # longest supported row
+    (1, 29, 64, 128, True, False),         # longest supported row
 ]
 
 

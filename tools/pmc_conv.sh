@@ -11,7 +11,7 @@ P3="TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum GRBM_GUI_ACTIVE"
 i=0
 for P in "$P1" "$P2" "$P3"; do
   i=$((i+1))
-  rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python $R/tools/conv_bench.py --images $IMG --only $ONLY --cfgs $CFG --iters 5 > $OUT/pass$i.log 2>&1 || true
+  timeout -k 5 150 rocprofv3 --pmc $P --output-format csv -d $OUT/pass$i -- python $R/tools/conv_bench.py --images $IMG --only $ONLY --cfgs=$CFG --iters 5 > $OUT/pass$i.log 2>&1 || true
 done
 python - <<PY
 import csv, glob, collections
