@@ -200,19 +200,25 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // have, (centre + d) & 7: bank = 32 * (row & 1) + 4 * position, and the 16 lanes of a ds_read_b128 group cover the 16
     // (parity, position) pairs exactly once for any tap shift -- only as long as a substituted row keeps both (with one zero
     // row at its own position 7 ^ g4, SQ_LDS_BANK_CONFLICT was 27 % of the LDS cycles)
-    auto tap_addr = [&](uint32_t f, int tap, uint32_t sbase, uint32_t (&xa)[FM]) {
-        asm volatile("" : "+v"(f));                          // unpack HERE: hoisted out of the chunk loop the 36 addresses
+    // (in FM pieces, one between each pair of MFMAs of the first cluster: the matrix pipe works on the wave's previous MFMA
+    // while these issue; done in one block they left the pipe idle for ~100 cycles per K step on both waves of a SIMD at once)
+    uint32_t a_f = 0, a_swz = 0;
+    auto tap_addr_part = [&](int part, uint32_t f, int tap, uint32_t sbase, uint32_t (&xa)[FM]) {
+        if (part == 0) {
+            a_f = f;
+            asm volatile("" : "+v"(a_f));                    // unpack HERE: hoisted out of the chunk loop the 36 addresses
                                                              // would be 36 registers instead of 9
-        const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
-        const uint32_t swz = (((uint32_t)(c7 + d) & 7u) << 4) ^ g4s;
-#pragma unroll
-        for (int fm = 0; fm < FM; ++fm) {
-            const uint32_t row = (f >> (fm * 8)) & 0xffu;
-            xa[fm] = (sbase + (row << 7)) | swz;
+            const int d = (tap / 3 - 1) * W + (tap % 3 - 1);
+            a_swz = (((uint32_t)(c7 + d) & 7u) << 4) ^ g4s;
         }
-        asm volatile("" : "+v"(xa[0]), "+v"(xa[1]), "+v"(xa[2]), "+v"(xa[3]));   // ... and finished here, between the MFMAs
-                                                             // (left alone the compiler sinks the arithmetic to the reads
-                                                             // behind the barrier, onto the critical path)
+        const uint32_t row = (a_f >> (part * 8)) & 0xffu;
+        xa[part] = (sbase + (row << 7)) | a_swz;
+        asm volatile("" : "+v"(xa[part]));                   // ... and finished here, between the MFMAs (left alone the compiler
+                                                             // sinks the arithmetic to the reads behind the barrier)
+    };
+    auto tap_addr = [&](uint32_t f, int tap, uint32_t sbase, uint32_t (&xa)[FM]) {
+#pragma unroll
+        for (int part = 0; part < FM; ++part) tap_addr_part(part, f, tap, sbase, xa);
     };
 
     // ---------------------------------------------------------------- prologue: slab 0 (+ the zero piece of slab 1, which
@@ -253,8 +259,13 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                                              // the first cluster overwrites them with the next tile's)
             load_w((wa + ws * WT_BYTES) ^ 64u, wf1);
             wait_lgkmcnt<FM + FN>();                         // first half (read one phase earlier) has landed
-            mma_issue<1>(xf0, wf0, acc, [&](int) {
-                if (!(SL_ABLATE & 2)) tap_addr(pk[tap == 8 ? 0 : tap + 1], tap == 8 ? 0 : tap + 1, tap == 8 ? sb_nxt : sb_cur, xa);
+            mma_issue<FM>(xf0, wf0, acc, [&](int part) {
+                if (!(SL_ABLATE & 2)) {
+                    if (part == 0) tap_addr_part(0, pk[tap == 8 ? 0 : tap + 1], tap == 8 ? 0 : tap + 1, tap == 8 ? sb_nxt : sb_cur, xa);
+                    else if (part == 1) tap_addr_part(1, 0, 0, tap == 8 ? sb_nxt : sb_cur, xa);
+                    else if (part == 2) tap_addr_part(2, 0, 0, tap == 8 ? sb_nxt : sb_cur, xa);
+                    else tap_addr_part(3, 0, 0, tap == 8 ? sb_nxt : sb_cur, xa);
+                }
             });
             __builtin_amdgcn_sched_barrier(0);
             wait_lgkmcnt<0>();                               // all of this wave's reads of tile kt are done
