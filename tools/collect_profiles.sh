@@ -17,7 +17,9 @@ rocprofv3 --kernel-trace --stats -d $O/${TAG}_trace2 -- python $R/bench.py --ste
 for C in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --pmc $C --output-format csv -d $O/${TAG}_pmc_$C -- python $R/bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 > $O/${TAG}_pmc_$C.log 2>&1
 done
-# MFMA-busy pass (SQ + GRBM counters in one pass: independent blocks)
+# MFMA-busy pass (SQ + GRBM counters in one pass: independent blocks).  Single trunk pass (--dual-stream 0): with the two
+# concurrent passes of the default a kernel's GRBM_GUI_ACTIVE also counts the cycles it shares the chip with the other pass's
+# kernel, and busy / active comes out 4 points low (19 % instead of 23 % for the ring kernel)
 rm -rf $O/${TAG}_pmc_MFMA
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_MFMA -- python $R/bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 > $O/${TAG}_pmc_MFMA.log 2>&1
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d $O/${TAG}_pmc_MFMA -- python $R/bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 --dual-stream 0 > $O/${TAG}_pmc_MFMA.log 2>&1
 python $R/tools/summarize_profiles.py $TAG

@@ -85,7 +85,7 @@ for p in glob.glob(os.path.join(O, tag + "_pmc_MFMA", "**", "*counter_collection
 if macc:
     tb = tg = 0.0
     with open(os.path.join(O, tag + "_pmc_mfma_busy.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0  (%s)\n" % tag)
+        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --dual-stream 0  (%s)\n" % tag)
         f.write("# mfma_busy_pct = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); 100 %% = every SIMD's matrix pipe busy for the whole dispatch\n")
         f.write("kernel,launches,mfma_busy_cycles,insts_mfma,gui_active_cycles_per_xcd,mfma_busy_pct\n")
         for k, d in sorted(macc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
