@@ -136,6 +136,7 @@ int g_conv_cfg = -1;            // -1 auto, 0..13 conv_pipe config, 14 = slab ke
 // trunk at 512 images (profiles/r02_phase_*) the one-workgroup-per-CU kernel is slower than the two-workgroups-per-CU ring
 // kernel on 7 of the 10 layer shapes it can run and equal on the rest, although it wins 15-20 % on layer4 in isolation
 bool g_conv_phase = false;
+bool g_conv_lean = true;        // auto mode uses the lean pointwise kernel on conv3-shaped layers (-4 turns it off too)
 bool g_conv_slab = true;        // auto mode uses the slab kernel for stride-1 3x3 layers (ap_set_conv_config(-4) turns it off)
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
@@ -194,7 +195,10 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
         //       shape it can run, at EVERY size (it is the one kernel whose fp32 summation order differs from the others',
         //       so a size-dependent choice would make a pair's result depend on the batch it arrives in; measured equal or
         //       faster than the small-problem configurations from 2 to 512 images)
+        //   17  pointwise layers with a short contraction and many channel tiles (conv3 of layer2-4: K <= 512, C_out >= 512)
+        //       on three lean workgroups per CU (conv_lean.hip, bit-identical to 11): -4..6 % there, +20 % on K >= 1024
         if (g_conv_slab && ap_conv_slab_supported(a, is_bf16)) cfg = 14;
+        else if (g_conv_lean && a.Cin <= 512 && a.Cout >= 512 && mt128 * nt128 >= 768 && ap_conv_lean_supported(a, is_bf16)) cfg = 17;
         else if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : 11;
         else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
@@ -203,6 +207,10 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
     hipError_t e = zero_line(&a.zero);
     if (e != hipSuccess) return e;
     a.dbg = g_conv_dbg;
+    if (cfg == 17) {                                         // lean pointwise kernel; other shapes: the ring kernel's tile
+        if (!ap_conv_lean_supported(a, is_bf16)) return ap_launch_conv_pipe(a, is_bf16, 11, st);
+        return ap_launch_conv_lean(a, st);
+    }
     if (cfg == 14) {
         // explicit 14 on a shape the slab kernel cannot run: the ring kernel's tile of the same shape
         if (!ap_conv_slab_supported(a, is_bf16)) return ap_launch_conv_pipe(a, is_bf16, 11, st);
@@ -1115,11 +1123,12 @@ int ap_debug_set_trace(void* device_buf_160_u64) {
 }
 
 int ap_set_conv_config(int cfg) {
-    if (cfg != -1 && cfg != -3 && cfg != -4 && cfg != 100 && cfg != 20 && !(cfg >= 24 && cfg <= 28) && (cfg < 0 || cfg > 14))
+    if (cfg != -1 && cfg != -3 && cfg != -4 && cfg != -5 && cfg != 100 && cfg != 20 && !(cfg >= 24 && cfg <= 28) && (cfg < 0 || cfg > 14) && cfg != 17)
         return fail(AP_EINVAL, "ap_set_conv_config: -1, -3, -4, 0..14, 20, 24..28 or 100");
     g_conv_phase = cfg == -3;
+    g_conv_lean = cfg != -4 && cfg != -3 && cfg != -5;
     g_conv_slab = cfg != -4 && cfg != -3;    // (-3 compares the phase kernel against the ring kernel: no slab either)
-    g_conv_cfg = (cfg == -3 || cfg == -4) ? -1 : cfg;
+    g_conv_cfg = (cfg == -3 || cfg == -4 || cfg == -5) ? -1 : cfg;
     return AP_OK;
 }
 

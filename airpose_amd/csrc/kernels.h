@@ -42,6 +42,10 @@ hipError_t ap_conv_phase_auto(const ConvArgs& a, int n_cu, hipStream_t st);
 bool ap_conv_slab_supported(const ConvArgs& a, int kind);
 hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st);
 
+// pointwise convolutions on three workgroups per CU (conv_lean.hip); bf16, 128x128 tiles, bit-identical to conv_pipe
+bool ap_conv_lean_supported(const ConvArgs& a, int kind);
+hipError_t ap_launch_conv_lean(ConvArgs a, hipStream_t st);
+
 // ---- fused layer1 bottleneck (bottleneck.hip); bf16 only
 struct BneckArgs {
     const void* x;                // [N][H][W][cin] bf16 (cin = 256, or 64 for the downsample block)

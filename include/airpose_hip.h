@@ -153,7 +153,9 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
  * C_out % 256 == 0, no residual: anything else is refused), 100 = register-staged 2-stage kernel,
  * 14 = stride-1 3x3 convolutions with the nine taps read from one LDS slab per 64-channel chunk (conv_slab.hip; bf16,
  * image rows of at most 29 pixels; other shapes run configuration 11), which the automatic choice uses for the conv2
- * layers of layer2-4; -4 = automatic without it (ring kernel everywhere).
+ * layers of layer2-4; 17 = pointwise convolutions on three lean workgroups per CU (conv_lean.hip; bf16; bit-identical to 11;
+ * other shapes run configuration 11), which the automatic choice uses for short contractions with many channel tiles
+ * (conv3 of layer2-4); -4 = automatic without either (ring kernel everywhere), -5 = automatic without configuration 17.
  * Results are identical (bitwise) for every setting except 14 / the automatic choice on those layers: the slab kernel sums
  * the K range channel-chunk-outer, tap-inner instead of tap-outer, i.e. it agrees to fp32 re-association. */
 int ap_set_conv_config(int cfg);

@@ -192,7 +192,7 @@ CONV_CASES = [
 
 # -1 = automatic choice; 0..3 = LDS-DMA pipelined kernel (256x128, 128x128, 128x64, 256x64 tiles), 4..7 = the same
 # with the register epilogue; 8..13 = 2-stage rings with 4 or 8 waves; 100 = register-staged kernel
-@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 100])
+@pytest.mark.parametrize("cfg", [-1, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 17, 100])
 @pytest.mark.parametrize("prec", ["fp32", "bf16"])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_primitive(dev, prec, case, cfg):
@@ -322,6 +322,37 @@ def test_trunk_slab_kernel_against_ring_kernel(netbf, dev):
     e = rel_err(a.cpu().numpy(), b.cpu().numpy())
     print("slab vs ring trunk features rel %.2e" % e)
     assert 0 < e < 2e-3
+
+
+LEAN_CASES = [
+    # N, H, Cin, Cout, relu, res   (conv_lean.hip: pointwise, bf16)
+    (2, 56, 64, 256, True, True),          # two K steps, residual
+    (1, 56, 256, 128, True, False),        # one channel tile
+    (3, 14, 1024, 256, True, False),       # 32 K steps, ragged M (588 rows)
+    (1, 7, 512, 2048, True, True),         # tiny M = 49, wide N
+    (64, 28, 128, 512, True, True),        # large M
+    (2, 14, 64, 200, False, False),        # two K steps, ragged N, no relu
+    (2, 14, 192, 128, True, False),        # six K steps: every ring slot twice
+]
+
+
+@pytest.mark.parametrize("case", LEAN_CASES)
+def test_conv_lean_primitive(dev, case):
+    """The three-workgroups-per-CU pointwise kernel against the fp64 oracle and bit for bit against the ring kernel (same MFMA
+    sequence per output element, same epilogue expression)."""
+    from airpose_amd import _native as Nn
+    N, H, Cin, Cout, relu, use_res = case
+    outs = []
+    for c in (17, 11):
+        Nn.check(Nn.lib().ap_set_conv_config(c), "ap_set_conv_config")
+        try:
+            got, ref = _conv_case(dev, "bf16", N, H, Cin, Cout, 1, 1, 0, relu, use_res, seed=hash(case) % 10000)
+        finally:
+            Nn.lib().ap_set_conv_config(-1)
+        outs.append(got)
+    assert torch.isfinite(outs[0]).all()
+    assert rel_err(outs[0].numpy(), ref.numpy()) < 6e-3
+    assert torch.equal(outs[0], outs[1])
 
 
 def test_conv_phase_refuses_what_it_cannot_do(dev):
