@@ -295,7 +295,7 @@ class copenet(nn.Module):
                 "ap_net_set_fuse_stem")
 
     def set_dual_stream(self, on):
-        """Two-view forwards of >= 128 pairs: the two views as two concurrent trunk passes (default) or one pass."""
+        """Two-view forwards of >= 64 pairs: the two views as two concurrent trunk passes (default) or one pass."""
         N.check(N.lib().ap_net_set_dual_stream(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_set_dual_stream")
 

@@ -350,9 +350,9 @@ def main():
         conv_ms_step = tm["conv_ms"] / max(tm["passes"], 1)
         chunk = args.chunk or 512
         # 52 convs: 4 downsample convs folded into conv3, layer1's 3 bottlenecks are one fused kernel each (bf16)
-        # two-view forwards of >= 128 pairs run the two views as two concurrent trunk passes (two internal streams):
+        # two-view forwards of >= 64 pairs run the two views as two concurrent trunk passes (two internal streams):
         # twice the launches at half the images each; conv_ms is then the span over both passes
-        dual = bool(args.dual_stream) and B >= 128 and 2 * B <= chunk
+        dual = bool(args.dual_stream) and B >= 64 and 2 * B <= chunk
         launches = (42 if args.precision == "bf16" else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
         # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS

@@ -193,7 +193,7 @@ int ap_net_set_fuse_stem(ap_net* h, int on);
 int ap_net_set_fuse_block(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);
-/* Two-view forwards (>= 128 images per view, both views within one chunk) run the two views as two concurrent trunk
+/* Two-view forwards (>= 64 images per view, both views within one chunk) run the two views as two concurrent trunk
  * passes on two internal streams forked from / joined to the caller's stream (default on; results are bit-identical to
  * the single pass).  0 = one pass over the concatenated views. */
 int ap_net_set_dual_stream(ap_net* h, int on);

@@ -447,7 +447,7 @@ def test_split_bf16_configs_agree_bitwise(dev):
 
 
 def test_two_stream_trunk_is_bit_identical_to_single_pass(netbf, net32, dev):
-    """Two-view forwards of >= 128 pairs run the two views as two concurrent trunk passes on two internal streams
+    """Two-view forwards of >= 64 pairs run the two views as two concurrent trunk passes on two internal streams
     (fork / join on the caller's stream).  Same kernels on the same rows: bit-identical to the single pass over the
     concatenated views, in both storage types, and repeatable (no race on the per-pass workspaces)."""
     gen = torch.Generator(device="cpu").manual_seed(31)
