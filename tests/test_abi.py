@@ -95,3 +95,18 @@ def test_synthetic_inputs_contract():
     assert d["im0"].shape == (3, 3, 224, 224) and d["im0"].dtype == np.float32
     assert d["bb0"].shape == (3, 3) and (d["bb0"][:, 2] >= 0.2).all()
     assert d["intr0"][0, 0, 0] == 1475 and d["intr0"][0, 0, 2] == 960 and d["intr0"][0, 1, 2] == 540
+
+
+def test_conv_config_knob_validates_on_the_host():
+    """ap_set_conv_config is host-only state: every documented value is accepted, anything else is refused with AP_EINVAL
+    and leaves the automatic choice in place (no GPU needed)."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    ok = [-1, -3, -4, -5, 100, 20, 24, 25, 26, 27, 28, 17] + list(range(0, 15))
+    try:
+        for c in ok:
+            assert L.ap_set_conv_config(c) == 0, c
+        for c in (-2, -6, 15, 16, 18, 19, 21, 23, 29, 99, 101):
+            assert L.ap_set_conv_config(c) != 0, c
+    finally:
+        assert L.ap_set_conv_config(-1) == 0
