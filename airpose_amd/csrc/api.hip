@@ -195,10 +195,11 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
         //       shape it can run, at EVERY size (it is the one kernel whose fp32 summation order differs from the others',
         //       so a size-dependent choice would make a pair's result depend on the batch it arrives in; measured equal or
         //       faster than the small-problem configurations from 2 to 512 images)
-        //   17  pointwise layers with a short contraction and many channel tiles (conv3 of layer2-4: K <= 512, C_out >= 512)
+        //   17  pointwise layers with a short contraction and several channel tiles (conv3 of layer2-4, layer3.0 conv1: K <= 512,
+        //       C_out >= 256)
         //       on three lean workgroups per CU (conv_lean.hip, bit-identical to 11): -4..6 % there, +20 % on K >= 1024
         if (g_conv_slab && ap_conv_slab_supported(a, is_bf16)) cfg = 14;
-        else if (g_conv_lean && a.Cin <= 512 && a.Cout >= 512 && mt128 * nt128 >= 768 && ap_conv_lean_supported(a, is_bf16)) cfg = 17;
+        else if (g_conv_lean && a.Cin <= 512 && a.Cout >= 256 && mt128 * nt128 >= 768 && ap_conv_lean_supported(a, is_bf16)) cfg = 17;
         else if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : 11;
         else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
