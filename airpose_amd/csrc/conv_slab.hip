@@ -28,13 +28,9 @@
 #ifndef SL_ABLATE
 #define SL_ABLATE 0
 #endif
-// slab pieces the slab wave issues per K step (multiple of 3), starting at tap 0 of the previous chunk
-// cache policy bits of the slab loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+// cache policy bits of the slab loads (gfx950: 1 = sc0, 2 = nt, 16 = sc1); measured: no effect
 #ifndef SL_NT
 #define SL_NT 0
-#endif
-#ifndef SL_PER_STEP
-#define SL_PER_STEP 3
 #endif
 
 namespace {
@@ -100,10 +96,12 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
     // ---------------------------------------------------------------- DMA roles, split by wave.  vmcnt retires in order
     // per wave, so a slab piece (first touch of the activations: HBM / Infinity-Cache latency) queued in front of a weight
-    // piece (L2 hit) makes the K step wait for the long-latency stream.  Wave 7 therefore issues ALL slab pieces (four
-    // per K step on taps 0..5, for the NEXT chunk) and waits for them once per chunk, at tap 8; waves 0..6 share the 16
-    // weight pieces of a K step (two each, waves 0 and 1 a third) and drain their queue every step.
-    const bool srole = wave == 7;                            // wave-uniform
+    // piece (L2 hit) makes the K step wait for the long-latency stream.  Waves 6 and 7 therefore issue the slab pieces (three
+    // per K step on taps 0..7, for the NEXT chunk: 1 or 2 each) and wait for them once per chunk, at tap 8; waves 0..5 share
+    // the 16 weight pieces of a K step (piece j on wave j % 6: three on waves 0..3, two on 4 and 5) and drain their queue
+    // every step.  (A DMA piece costs its wave 75-140 cycles of issue; with all three slab pieces on one wave that wave's
+    // second cluster took 700 cycles against 480 and every step waited for it at the barrier: tools/probes/slab_trace.py.)
+    const bool srole = wave >= 6;                            // wave-uniform
     const int prow = lane >> 3, pchunk = (lane & 7) ^ prow;
     const unsigned char* zg = (const unsigned char*)p.zero;
     const unsigned char* xg = (const unsigned char*)p.x;
@@ -116,7 +114,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     uint32_t doff[WLP];                                      // weight waves: running byte offsets of their rows into p.w
 #pragma unroll
     for (int i = 0; i < WLP; ++i) {                          // weight rows are padded to multiples of 128: always valid
-        const int piece = i < 2 ? 2 * wave + i : 14 + wave;  // (slab wave, and i == 2 on waves >= 2: unused)
+        const int piece = (wave + 6 * i) & 15;               // (slab waves, and i == 2 on waves 4, 5: unused)
         const int row = (piece & 15) * 8 + prow;
         doff[i] = (uint32_t)(((size_t)(bn * BN + row) * p.wld + pchunk * 8) * sizeof(T));
     }
@@ -124,7 +122,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const uint32_t wwrap = 128u - 8u * wstep;                // tap 8 -> tap 0 of the next chunk (mod 2^32)
     // weight piece i of this wave for the tile of tap TT into ring slot `slot`, then on to the next tile's row segment
     auto issue_weights = [&](int slot, int i, bool last_tap) {
-        const int piece = i < 2 ? 2 * wave + i : 14 + wave;
+        const int piece = wave + 6 * i;
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wg + doff[i]),
                                          (__attribute__((address_space(3))) void*)(smem + W_BASE + slot * WT_BYTES + piece * 1024),
                                          16, 0, 0);
@@ -139,13 +137,21 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     const int p0 = bm * BM - (W + 1);                        // input pixel of slab row 0
     const uint32_t rowbytes = (uint32_t)p.ldx * sizeof(T);
     const uint32_t lane_off = (uint32_t)pchunk * 16u;
+    // Two VALU instructions per piece (the cycle stamps of tools/probes/slab_trace.py showed the slab wave's second cluster
+    // at 850 cycles against 480 on the weight waves with the row index clamped and multiplied per piece: every K step
+    // waited for it at the barrier): the byte offset is linear in the piece, and the clamp is on the offset.
+    const int prow_rb = prow * (int)rowbytes;                // this lane's row within a piece, in bytes
+    const int p0_rb = p0 * (int)rowbytes, hi_rb = (p.M - 1) * (int)rowbytes;         // (scalars)
     auto issue_slab = [&](int buf, int cb, int piece) {      // 8 rows of chunk cb
-        int row = piece * 8 + prow;
-        asm volatile("" : "+v"(row));                        // computed where it is used: hoisted out of the chunk loop the 24
-                                                             // source offsets of a slab would take 24 registers
-        const int q = min(max(p0 + row, 0), p.M - 1);
-        const uint32_t off = (uint32_t)q * rowbytes + lane_off + (uint32_t)cb * 128u;
-        if (row < nrows && !((SL_ABLATE & 16) && cb > 0))
+        int base = prow_rb, rb = (int)rowbytes;
+        asm volatile("" : "+v"(base), "+s"(rb));             // computed where it is used (hoisted out of the unrolled loop the
+                                                             // 24 offsets and products spill VGPRs and SGPRs)
+        const int x = min(max(base + (p0_rb + piece * 8 * rb), 0), hi_rb);           // row offset, clamped into the tensor
+        const uint32_t off = (uint32_t)x + lane_off + (uint32_t)cb * 128u;
+        if ((SL_ABLATE & 16) && cb > 0) return;
+        // the slab's last piece holds the two zero rows: its lanes of rows 6 and 7 never execute the DMA (an LDS-DMA lane that
+        // is switched off writes nothing); rows past the last pixel row receive clamped garbage nobody reads
+        if (piece != SLAB_ROWS / 8 - 1 || prow < 6)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(xg + off),
                                              (__attribute__((address_space(3))) void*)(smem + buf * SLAB_BYTES + piece * 1024),
                                              16, 0, SL_NT);
@@ -224,16 +230,18 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     // ---------------------------------------------------------------- prologue: slab 0 (+ the zero piece of slab 1, which
     // the K loop skips when the slab is short), weight tiles 0 and 1
     if (srole) {
-        issue_zero_row(0);
-        issue_zero_row(1);
-        wait_vmcnt<0>();                                     // (the same wave overwrites rows of that piece below)
-        for (int j = 0; j < need; ++j) issue_slab(0, 0, j);
+        if (wave == 7) {
+            issue_zero_row(0);
+            issue_zero_row(1);
+            wait_vmcnt<0>();                                 // (the same wave overwrites rows of that piece below)
+        }
+        for (int j = wave - 6; j < need; j += 2) issue_slab(0, 0, j);   // wave 7: the odd pieces, among them the last one
     } else {
 #pragma unroll
         for (int t = 0; t < 2; ++t) {
             issue_weights(t, 0, false);
             issue_weights(t, 1, false);
-            if (wave < 2) issue_weights(t, 2, false);
+            if (wave < 4) issue_weights(t, 2, false);
         }
     }
     uint32_t xa[FM];                                         // fragment addresses of the tile whose first half is read next
@@ -244,6 +252,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     load_x(xa, 0u, xf0);
     load_w(wa, wf0);
 
+#ifdef AP_TRACE
+    // cycle stamps of workgroup 0, waves 0 and 7 (the slab wave), taps 0..7 of chunk 1: p.dbg[(w7 * 8 + tap) * 10 + k]
+    const bool trace = p.dbg != nullptr && blockIdx.x == 0 && (wave == 0 || wave == 7) && lane == 0;
+#define SL_STAMP(k)                                                                                              \
+    do {                                                                                                         \
+        if (trace && cb == 1 && tap < 8) p.dbg[((wave == 7 ? 8 : 0) + tap) * 10 + (k)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+#define SL_STAMP(k) do {} while (0)
+#endif
     // K loop: as the ring kernel's, one barrier per K step between the two MFMA clusters; the nine taps of a chunk are
     // unrolled so that everything tap-dependent is an immediate.  Weight tile kt+2 goes into the slot of tile kt after the
     // barrier of step kt.
@@ -255,10 +273,13 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         for (int tap = 0; tap < 9; ++tap) {
             const bool last = !more && tap == 8;             // last K step of the tile
             const bool refill = more || tap < 7;             // tile kt+2 exists
+            SL_STAMP(0);
             load_x(xa, 64u, xf1);                            // second K half of tile kt (the addresses are consumed at issue:
                                                              // the first cluster overwrites them with the next tile's)
             load_w((wa + ws * WT_BYTES) ^ 64u, wf1);
+            SL_STAMP(1);
             wait_lgkmcnt<FM + FN>();                         // first half (read one phase earlier) has landed
+            SL_STAMP(2);
             mma_issue<FM>(xf0, wf0, acc, [&](int part) {
                 if (!(SL_ABLATE & 2)) {
                     if (part == 0) tap_addr_part(0, pk[tap == 8 ? 0 : tap + 1], tap == 8 ? 0 : tap + 1, tap == 8 ? sb_nxt : sb_cur, xa);
@@ -268,28 +289,31 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
+            SL_STAMP(3);
             wait_lgkmcnt<0>();                               // all of this wave's reads of tile kt are done
+            SL_STAMP(4);
             if (!last) {
                 if (!srole || tap == 8) wait_vmcnt<0>();
+                SL_STAMP(5);
                 __builtin_amdgcn_s_barrier();
+                SL_STAMP(6);
                 load_x(xa, 0u, xf0);                         // first half of tile kt+1
                 load_w(wa + (ws ^ 1) * WT_BYTES, wf0);
+                SL_STAMP(7);
             }
             // one MFMA cluster for both roles (two copies cost the compiler 20 registers in accumulator copies); only the
             // DMA issue between the MFMAs branches on the role
             mma_issue<WLP>(xf1, wf1, acc, [&](int i) {
                 if (!srole) {
-                    if (refill && (i < 2 || wave < 2) && !(SL_ABLATE & 8)) issue_weights(ws, i, (tap + 2) % 9 == 8);
-                } else if (more && tap * SL_PER_STEP < 24 && !(SL_ABLATE & 1)) {   // SL_PER_STEP pieces per step from tap 0
-                    constexpr int PC = SL_PER_STEP / 3;      // per callback
-#pragma unroll
-                    for (int k = 0; k < PC; ++k) {
-                        const int piece = SL_PER_STEP * tap + PC * i + k;
-                        if (piece < need) issue_slab((cb & 1) ^ 1, cb + 1, piece);
-                    }
+                    if (refill && (i < 2 || wave < 4) && !(SL_ABLATE & 8)) issue_weights(ws, i, (tap + 2) % 9 == 8);
+                } else if (more && tap < 8 && !(SL_ABLATE & 1)) {
+                    // pieces 3 tap .. 3 tap + 2 of the next chunk's slab: wave 6 takes the even ones, wave 7 the odd ones
+                    const int piece = 3 * tap + i;
+                    if (((piece ^ wave) & 1) == 0 && piece < need) issue_slab((cb & 1) ^ 1, cb + 1, piece);
                 }
             });
             __builtin_amdgcn_sched_barrier(0);
+            SL_STAMP(8);
             ws ^= 1;
         }
     }
@@ -361,7 +385,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 bool ap_conv_slab_supported(const ConvArgs& a, int kind) {
     return kind == K_BF16 && a.KH == 3 && a.KW == 3 && a.stride == 1 && a.pad == 1 && !a.x2 && a.Cin % 64 == 0 &&
            a.Cin >= 64 && a.Ho == a.H && a.Wo == a.W && BM + 2 * a.W + 2 <= ZROW - 1 && a.ldx == a.Cin &&
-           (long long)a.M * a.ldx * 2 < 0xffffffffll && (long long)a.wld * 2 * ((a.Cout + 127) / 128 * 128) < 0xffffffffll;
+           (long long)(a.M + 256) * a.ldx * 2 < 0x7fffffffll && (long long)a.wld * 2 * ((a.Cout + 127) / 128 * 128) < 0xffffffffll;
 }
 
 hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st) {
