@@ -75,6 +75,7 @@ SIGNATURES = {
     "ap_preprocess_crops": (_i, [_vp, _c.c_int64, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp]),
     "ap_rot6d_to_rotmat": (_i, [_vp, _i, _vp, _vp]),
     "ap_rotmat_to_angle_axis": (_i, [_vp, _i, _i, _vp, _vp]),
+    "ap_batch_rodrigues": (_i, [_vp, _i, _i, _vp, _vp]),
     "ap_transform_points": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }

@@ -1514,6 +1514,13 @@ int ap_rotmat_to_angle_axis(const float* rotmat, int n, int cols, float* angle_a
     return AP_OK;
 }
 
+int ap_batch_rodrigues(const float* angle_axis, int n, int variant, float* rotmat, void* stream) {
+    if (!angle_axis || !rotmat || n <= 0 || (variant != 0 && variant != 1))
+        return fail(AP_EINVAL, "ap_batch_rodrigues: bad argument (variant 0 = smplx lbs, 1 = copenet geometry)");
+    HIP_TRY(ap_launch_batch_rodrigues(angle_axis, n, variant, rotmat, (hipStream_t)stream));
+    return AP_OK;
+}
+
 int ap_rot6d_to_rotmat(const float* x6, int n, float* rotmat, void* stream) {
     if (!x6 || !rotmat || n <= 0) return fail(AP_EINVAL, "ap_rot6d_to_rotmat: bad argument");
     HIP_TRY(ap_launch_rot6d(x6, n, rotmat, (hipStream_t)stream));

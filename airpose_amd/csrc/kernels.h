@@ -180,6 +180,7 @@ hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a,
 // ---- stand-alone geometry helpers (smplx.hip)
 hipError_t ap_launch_rot6d(const float* x6, int n, float* R, hipStream_t st);
 hipError_t ap_launch_rotmat_to_angle_axis(const float* R, int n, int ld, float* out, hipStream_t st);
+hipError_t ap_launch_batch_rodrigues(const float* aa, int n, int variant, float* R, hipStream_t st);
 hipError_t ap_launch_transform_points(const float* rt, const float* pts, int B, int P, float* out, hipStream_t st);
 hipError_t ap_launch_projection(const float* pts, int B, int P, const float* R, const float* t, float fx, float fy,
                                 const float* center, float* out, hipStream_t st);

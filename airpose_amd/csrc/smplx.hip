@@ -333,6 +333,36 @@ __global__ void rot6d_kernel(const float* __restrict__ x6, int n, float* __restr
     for (int e = 0; e < 9; ++e) R[(size_t)i * 9 + e] = r[e];
 }
 
+// axis-angle -> rotation matrix, [n][3] -> [n][3][3], in the two forms the reference uses:
+//   variant 0: smplx lbs.batch_rodrigues (the fork's `lbs` export, copenet/dsets/aerialpeople.py:177): angle = |r + 1e-8|,
+//              K = skew(r / angle), R = I + sin(angle) K + (1 - cos(angle)) K K
+//   variant 1: copenet/utils/geometry.py:9-45 batch_rodrigues: the same angle and axis through a re-normalised unit quaternion
+__global__ void batch_rodrigues_kernel(const float* __restrict__ aa, int n, int variant, float* __restrict__ R) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float rx = aa[(size_t)i * 3], ry = aa[(size_t)i * 3 + 1], rz = aa[(size_t)i * 3 + 2];
+    const float ex = rx + 1e-8f, ey = ry + 1e-8f, ez = rz + 1e-8f;
+    const float angle = sqrtf(ex * ex + ey * ey + ez * ez);
+    const float dx = rx / angle, dy = ry / angle, dz = rz / angle;
+    float* o = R + (size_t)i * 9;
+    if (variant == 0) {
+        const float s = sinf(angle), c1 = 1.f - cosf(angle);
+        // K = [[0,-dz,dy],[dz,0,-dx],[-dy,dx,0]];  K K = d d^T - |d|^2 I
+        const float dd = dx * dx + dy * dy + dz * dz;
+        o[0] = 1.f + c1 * (dx * dx - dd);      o[1] = -s * dz + c1 * dx * dy;        o[2] = s * dy + c1 * dx * dz;
+        o[3] = s * dz + c1 * dx * dy;          o[4] = 1.f + c1 * (dy * dy - dd);     o[5] = -s * dx + c1 * dy * dz;
+        o[6] = -s * dy + c1 * dx * dz;         o[7] = s * dx + c1 * dy * dz;         o[8] = 1.f + c1 * (dz * dz - dd);
+    } else {
+        const float h = angle * 0.5f, sh = sinf(h);
+        float w = cosf(h), x = sh * dx, y = sh * dy, z = sh * dz;
+        const float qn = sqrtf(w * w + x * x + y * y + z * z);
+        w /= qn; x /= qn; y /= qn; z /= qn;
+        o[0] = w * w + x * x - y * y - z * z;  o[1] = 2 * x * y - 2 * w * z;         o[2] = 2 * w * y + 2 * x * z;
+        o[3] = 2 * w * z + 2 * x * y;          o[4] = w * w - x * x + y * y - z * z; o[5] = 2 * y * z - 2 * w * x;
+        o[6] = 2 * x * z - 2 * w * y;          o[7] = 2 * w * x + 2 * y * z;         o[8] = w * w - x * x - y * y + z * z;
+    }
+}
+
 // rotation_matrix_to_angle_axis of torchgeometry 0.1.2 (rotation_matrix_to_quaternion on the TRANSPOSED matrix with its
 // four trace branches, eps = 1e-6, then quaternion_to_angle_axis), as called at copenet_twoview.py:323-324
 __global__ void rotmat_to_angle_axis_kernel(const float* __restrict__ R, int n, int ld, float* __restrict__ out) {
@@ -405,6 +435,11 @@ hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, h
 
 hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(smplx_joints_kernel, dim3(a.n_main > 0 ? a.n_main : a.n), dim3(128), 0, st, m, a);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_batch_rodrigues(const float* aa, int n, int variant, float* R, hipStream_t st) {
+    hipLaunchKernelGGL(batch_rodrigues_kernel, dim3((n + 255) / 256), dim3(256), 0, st, aa, n, variant, R);
     return hipGetLastError();
 }
 

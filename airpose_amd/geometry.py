@@ -22,6 +22,22 @@ def rot6d_to_rotmat(x):
     return out
 
 
+def _rodrigues(theta, variant, name):
+    dev = _cuda(theta, name)
+    t = N.f32c(theta).reshape(-1, 3)
+    out = torch.empty(t.shape[0], 3, 3, device=dev, dtype=torch.float32)
+    if t.shape[0]:
+        with torch.cuda.device(dev):
+            N.check(N.lib().ap_batch_rodrigues(N.dptr(t), t.shape[0], variant, N.dptr(out), N.stream_ptr(dev)),
+                    "ap_batch_rodrigues")
+    return out
+
+
+def batch_rodrigues(theta):
+    """(N,3) axis-angle -> (N,3,3) through a unit quaternion   [geometry.py:9-45]"""
+    return _rodrigues(theta, 1, "batch_rodrigues")
+
+
 def rotation_matrix_to_angle_axis(rotation_matrix):
     """tgm.rotation_matrix_to_angle_axis (torchgeometry 0.1.2): (N,3,4) -- or (N,3,3) -- -> (N,3), the conversion the
     caller applies to pred_rotmat for pred_angles [copenet_twoview.py:323-324]."""

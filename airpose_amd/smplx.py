@@ -109,9 +109,20 @@ class SMPLX(nn.Module):
                 transl=None, expression=None, jaw_pose=None, leye_pose=None, reye_pose=None, return_verts=True,
                 return_full_pose=False, pose2rot=True, **kwargs):
         if pose2rot:
-            raise NotImplementedError("airpose_amd.SMPLX implements the inference call of the reference "
-                                      "(pose2rot=False, rotation-matrix inputs); axis-angle input is only used "
-                                      "by the reference's dataset code (copenet/dsets/aerialpeople.py:177-197)")
+            # axis-angle inputs (the upstream default): converted with lbs.batch_rodrigues, then the rotation-matrix path.
+            # Hands as flat axis-angle only: the PCA hand space of upstream (use_pca=True) needs `hands_components` of the
+            # licensed model file, which the inference path of the reference never touches.
+            from . import lbs
+
+            def aa(t, n, name):
+                if t is None:
+                    return None
+                if t.numel() % (n * 3) or not t.is_cuda:
+                    raise RuntimeError("%s must be CUDA axis-angle vectors of %d joints per body (pose2rot=True)" % (name, n))
+                return lbs.batch_rodrigues(t.reshape(-1, 3)).reshape(-1, n, 3, 3)
+            global_orient, body_pose = aa(global_orient, 1, "global_orient"), aa(body_pose, 21, "body_pose")
+            jaw_pose, leye_pose, reye_pose = aa(jaw_pose, 1, "jaw_pose"), aa(leye_pose, 1, "leye_pose"), aa(reye_pose, 1, "reye_pose")
+            left_hand_pose, right_hand_pose = aa(left_hand_pose, 15, "left_hand_pose"), aa(right_hand_pose, 15, "right_hand_pose")
         if betas is None or body_pose is None:
             raise RuntimeError("betas and body_pose are required (the reference creates no learnable defaults "
                                "on this path: create_transl=False, copenet_twoview.py:36-45)")

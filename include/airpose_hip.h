@@ -300,6 +300,11 @@ int ap_rot6d_to_rotmat(const float* x6, int n, float* rotmat, void* stream);    
 /* tgm.rotation_matrix_to_angle_axis (torchgeometry 0.1.2) as called for pred_angles at copenet_twoview.py:323-324:
  * [n][3][cols] row-major (cols = 3, or 4 for the caller's zero-padded 3x4 input) -> [n][3] */
 int ap_rotmat_to_angle_axis(const float* rotmat, int n, int cols, float* angle_axis, void* stream);
+/* Axis-angle -> rotation matrix, [n][3] -> [n][3][3].  variant 0: smplx lbs.batch_rodrigues (Rodrigues formula with
+ * angle = |r + 1e-8|), the function the reference's dataset code takes from the body-model package
+ * (copenet/dsets/aerialpeople.py:177) and SMPLX.forward(pose2rot=True) applies to its pose inputs; variant 1:
+ * copenet/utils/geometry.py:9-45 batch_rodrigues (through a unit quaternion). */
+int ap_batch_rodrigues(const float* angle_axis, int n, int variant, float* rotmat, void* stream);
 int ap_transform_points(const float* rt, const float* pts, int B, int P, float* out, void* stream); /* rt [B][3][4] */
 int ap_perspective_projection(const float* pts, int B, int P, const float* rotation, const float* translation,
                               float fx, float fy, const float* center, float* out, void* stream);
