@@ -19,11 +19,16 @@ def shard_pairs(n_global, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
-def make_pair_groups(world):
-    """One 2-rank group per (2k, 2k+1); every rank must call this (new_group is collective)."""
+def make_pair_groups(world, timeout_s=None):
+    """One 2-rank group per (2k, 2k+1); every rank must call this (new_group is collective).  timeout_s bounds every
+    collective on these groups (a lost partner then raises instead of hanging the caller)."""
     if world % 2:
         raise ValueError("view-split mode needs an even number of ranks")
-    return [dist.new_group([2 * k, 2 * k + 1]) for k in range(world // 2)]
+    kw = {}
+    if timeout_s:
+        import datetime
+        kw["timeout"] = datetime.timedelta(seconds=timeout_s)
+    return [dist.new_group([2 * k, 2 * k + 1], **kw) for k in range(world // 2)]
 
 
 def pack_wire(pose, betas):

@@ -177,7 +177,7 @@ def view_split_block(args, net, batch, dev, rank, world):
     from airpose_amd import dist as D
     if world % 2:
         return None
-    groups = D.make_pair_groups(world)
+    groups = D.make_pair_groups(world, timeout_s=120)
     ief = D.ViewSplitIEF(net.regressor_step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
     v = rank % 2
     im, bb = batch["im%d" % v], batch["bb%d" % v]
@@ -342,7 +342,14 @@ def main():
     if rank == 0 and world == 1 and args.cpu_sample > 0:
         cpu, sample, want = cpu_baseline(sd, md, args.cpu_sample)
     parity = parity_block(args, sd, body, batch, net, sample, want, dev) if (rank == 0 and world == 1 and not args.no_tail) else None
-    vs = view_split_block(args, net, batch, dev, rank, world) if world >= 2 else None
+    # the secondary measurement must never cost the primary one: an exception in the view-split block (it needs the pair
+    # communicators of a multi-GPU node, which no box of this round offered) is reported in the line instead of ending the run
+    vs = None
+    if world >= 2:
+        try:
+            vs = view_split_block(args, net, batch, dev, rank, world)
+        except Exception as e:                               # noqa: BLE001 (reported, not swallowed)
+            vs = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         n_img = 2 * B
