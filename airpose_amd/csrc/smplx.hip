@@ -57,7 +57,9 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
         cf[j] = c;
         put(j, c);
     }
-    for (int i = 20 + (m.J - 1) * 9 + j; i < m.ncoef; i += 64) coef[i] = 0.f;
+    // pad coefficients: through put(), so that in split mode both bf16 halves of every pad slot are written (the
+    // workspace comes from a raw hipMalloc and 0 x NaN would poison every vertex of the body) and no live slot is touched
+    for (int i = 20 + (m.J - 1) * 9 + j; i < m.ncoef; i += 64) put(i, 0.f);
 
     float R[9] = {1.f, 0.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 1.f};
     if (a.pose6d) {

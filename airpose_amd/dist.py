@@ -56,22 +56,42 @@ class ViewSplitIEF(object):
         # RCCL ("nccl") moves device buffers directly over xGMI; gloo (CPU tests, and the 2-process test that shares
         # one GPU) takes host tensors, so the 544 B/sample message is staged through the host there
         self._host_staged = dist.get_backend(pair_group) == "gloo"
+        self._buf_key, self._mine, self._both, self._dev = None, None, None, None
+
+    def _buffers(self, B, device):
+        """Preallocated send row and (2, B, 136) gather buffer, cached per (B, device): no allocation per exchange."""
+        key = (int(B), str(device))
+        if self._buf_key != key:
+            self._mine = torch.empty(B, 136, dtype=torch.float32, device=device)
+            self._both = torch.empty(2, B, 136, dtype=torch.float32, device=device)
+            self._buf_key = key
+        return self._mine, self._both
+
+    def exchange_start(self, pose, betas):
+        """Issue the 2-rank all-gather of [art_pose | shape] into the preallocated (2, B, 136) buffer
+        (all_gather_into_tensor: one flat receive buffer, no per-rank list copies) and return its work handle;
+        the caller may run this view's partner-independent kernels before exchange_wait()."""
+        host = self._host_staged and pose.is_cuda
+        mine, both = self._buffers(pose.shape[0], torch.device("cpu") if host else pose.device)
+        mine[:, :126].copy_(pose[:, 9:135], non_blocking=not host)        # art_pose | shape
+        mine[:, 126:].copy_(betas, non_blocking=not host)
+        self._dev = pose.device
+        self.n_exchanges += 1
+        return dist.all_gather_into_tensor(both.view(2 * both.shape[1], 136), mine, group=self.group, async_op=True)
+
+    def exchange_wait(self, work):
+        work.wait()                                                       # RCCL: orders the current stream behind the collective
+        return self._both[1 - self.me].to(self._dev, non_blocking=True)
 
     def exchange(self, pose, betas):
-        mine = torch.cat([pose[:, 9:], betas], dim=1).contiguous()        # art_pose | shape
-        dev = mine.device
-        if self._host_staged and mine.is_cuda:
-            mine = mine.cpu()
-        both = [torch.empty_like(mine), torch.empty_like(mine)]
-        dist.all_gather(both, mine, group=self.group)
-        self.n_exchanges += 1
-        return both[1 - self.me].to(dev)
+        return self.exchange_wait(self.exchange_start(pose, betas))
 
-    def run(self, xf, bb, init_position, init_theta, init_shape, iters=3, shared_init=True):
-        """shared_init: both ranks were handed the SAME init_theta / init_shape (the model's mean parameters
-        unless the caller supplies state, model_copenet.py:121-136).  The partner's initial [art_pose | shape]
-        is then this rank's own, so iteration 1 needs no exchange: iters - 1 collectives per forward.
-        With per-view caller state (init_theta0 != init_theta1) pass shared_init=False: one more exchange."""
+    def run(self, xf, bb, init_position, init_theta, init_shape, iters=3, shared_init=False):
+        """shared_init=True is an opt-in promise that both ranks were handed the SAME init_theta / init_shape (the
+        model's mean parameters, model_copenet.py:121-136): the partner's initial [art_pose | shape] is then this
+        rank's own and iteration 1 needs no exchange: iters - 1 collectives per forward.  The default
+        (False) exchanges before every iteration, which is always correct, also with per-view caller state
+        (init_theta0 != init_theta1)."""
         B = xf.shape[0]
         theta = init_theta[:, :132].expand(B, -1)
         pose = torch.cat([init_position, theta], dim=1).contiguous()

@@ -186,7 +186,7 @@ def view_split_block(args, net, batch, dev, rank, world):
     th, sh = net.init_pose.to(dev), net.init_shape.to(dev)
 
     def vstep():
-        return ief.run(net.forward_feat_ext(im), bb, pos, th, sh, iters=3)
+        return ief.run(net.forward_feat_ext(im), bb, pos, th, sh, iters=3, shared_init=True)
 
     def fence():
         torch.cuda.synchronize()

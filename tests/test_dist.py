@@ -65,7 +65,7 @@ def _worker(rank, world, port, out_dir):
     groups = D.make_pair_groups(world)
     ief = D.ViewSplitIEF(step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
     with torch.no_grad():
-        pose, betas = ief.run(xf[rank], bb[rank], pos[rank], sd["init_pose"], sd["init_shape"], iters=3)
+        pose, betas = ief.run(xf[rank], bb[rank], pos[rank], sd["init_pose"], sd["init_shape"], iters=3, shared_init=True)
         assert ief.n_exchanges == 2            # both views start from the model's mean state: none before iteration 1
         want = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], iters=3)
         # caller-supplied per-view initial state (model_copenet.py:121-136): the first exchange is needed
