@@ -135,6 +135,8 @@ class copenet(nn.Module):
             N.check(L.ap_net_create(ctypes.byref(h), device.index or 0, N.PRECISIONS[self.precision], self.variant),
                     "ap_net_create")
             self._handle, self._hdev = h, device.index
+            for entry, value in getattr(self, "_knobs", {}).items():     # knobs set on the previous handle
+                N.check(getattr(L, entry)(self._handle, value), entry)
         for name, t in self.state_dict().items():
             if not t.dtype.is_floating_point:
                 continue                                   # num_batches_tracked
@@ -271,37 +273,43 @@ class copenet(nn.Module):
         N.check(N.lib().ap_net_timing(self._handle, ms, ctypes.byref(n), int(reset)), "ap_net_timing")
         return {"stem_ms": ms[0], "conv_ms": ms[1], "avgpool_ms": ms[2], "regressor_ms": ms[3], "passes": n.value}
 
+    def _set_knob(self, entry, value):
+        """Per-handle knob: remembered on the module and re-applied whenever the native handle is re-created (a call
+        with inputs on another GPU destroys the handle of the first device; its knobs must not fall back to defaults)."""
+        self._knobs = dict(getattr(self, "_knobs", {}))
+        self._knobs[entry] = int(value)
+        with self._lock:
+            h = self._native(torch.device("cuda", torch.cuda.current_device()))
+            N.check(getattr(N.lib(), entry)(h, int(value)), entry)
+
     def set_fold(self, on):
         """Evaluate fc1 -> fc2 -> dec as one folded affine map (default) or as the literal chain."""
-        N.check(N.lib().ap_net_set_fold(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
-                "ap_net_set_fold")
+        self._set_knob("ap_net_set_fold", on)
 
     def set_fuse_ief(self, on):
         """Folded map: all IEF iterations in one kernel (default) or one GEMM per iteration."""
-        N.check(N.lib().ap_net_set_fuse_ief(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
-                "ap_net_set_fuse_ief")
+        self._set_knob("ap_net_set_fuse_ief", on)
 
     def set_fuse_ds(self, on):
-        N.check(N.lib().ap_net_set_fuse_ds(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
-                "ap_net_set_fuse_ds")
+        self._set_knob("ap_net_set_fuse_ds", on)
 
     def set_fuse_block(self, on):
         """bf16: run each layer1 bottleneck as one fused kernel (default) or as separate convolutions."""
-        N.check(N.lib().ap_net_set_fuse_block(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
-                "ap_net_set_fuse_block")
+        self._set_knob("ap_net_set_fuse_block", on)
+
+    def set_fuse_pair(self, on):
+        """bf16: conv3 of an identity block and conv1 of the next block as one pixel-local kernel (default) or two."""
+        self._set_knob("ap_net_set_fuse_pair", on)
 
     def set_fuse_stem(self, on):
-        N.check(N.lib().ap_net_set_fuse_stem(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
-                "ap_net_set_fuse_stem")
+        self._set_knob("ap_net_set_fuse_stem", on)
 
     def set_dual_stream(self, on):
         """Two-view forwards of >= 64 pairs: the two views as two concurrent trunk passes (default) or one pass."""
-        N.check(N.lib().ap_net_set_dual_stream(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
-                "ap_net_set_dual_stream")
+        self._set_knob("ap_net_set_dual_stream", on)
 
     def set_chunk(self, images):
-        N.check(N.lib().ap_net_set_chunk(self._native(torch.device("cuda", torch.cuda.current_device())), int(images)),
-                "ap_net_set_chunk")
+        self._set_knob("ap_net_set_chunk", images)
 
 
 def getcopenet(smpl_mean_params, pretrained=True, precision="bf16", **kwargs):

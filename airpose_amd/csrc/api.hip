@@ -6,6 +6,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <atomic>
 #include <map>
 #include <string>
 #include <vector>
@@ -131,13 +132,10 @@ struct Timing {
 constexpr double BN_EPS = 1e-5;
 
 unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_trace)
-int g_conv_cfg = -1;            // -1 auto, 0..13 conv_pipe config, 14 = slab kernel for stride-1 3x3 (conv_slab.hip), 20/24..28 conv_phase, 100 = register-staged kernel
-// auto mode may pick the phase-interleaved 256-channel tiles (ap_set_conv_config(-3)).  OFF by default: measured inside the
-// trunk at 512 images (profiles/r02_phase_*) the one-workgroup-per-CU kernel is slower than the two-workgroups-per-CU ring
-// kernel on 7 of the 10 layer shapes it can run and equal on the rest, although it wins 15-20 % on layer4 in isolation
-bool g_conv_phase = false;
-bool g_conv_lean = true;        // auto mode uses the lean pointwise kernel on conv3-shaped layers (-4 turns it off too)
-bool g_conv_slab = true;        // auto mode uses the slab kernel for stride-1 3x3 layers (ap_set_conv_config(-4) turns it off)
+// Tuning knob of ap_set_conv_config, process-wide: ONE atomic word holding the raw value (-1 automatic, -4 automatic
+// without the slab / lean kernels, -5 automatic without the lean kernel, 0..14 / 17 / 100 one explicit configuration);
+// dispatch_conv reads it once per launch and decodes it, so handles on different threads never see a torn setting.
+std::atomic<int> g_conv_mode{-1};
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -170,16 +168,9 @@ hipError_t device_cus(int* n) {
 
 // choose the tile configuration: large tiles need enough tiles to fill 256 CUs (1 workgroup per CU)
 hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipStream_t st) {
-    int cfg = g_conv_cfg;
-    if (cfg < 0 && g_conv_phase && ap_conv_phase_supported(a, is_bf16 == AP_PREC_BF16) && a.KH * a.KW * a.Cin + (a.x2 ? a.Cin2 : 0) >= 256) {
-        // deep contractions with >= 256 output channels and no residual: one 8-wave workgroup per CU on 256-channel
-        // tiles whose heights the planner fits to the CU count -- once there are enough rows for at least four
-        // pixel fragments per wave and CU (below that the small tiles of the ring kernel fill the chip better)
-        int n_cu = 0;
-        hipError_t e = device_cus(&n_cu);
-        if (e != hipSuccess) return e;
-        if ((long)a.M * (a.Cout / 256) >= (long)n_cu * 100) cfg = 20;
-    }
+    const int mode = g_conv_mode.load(std::memory_order_relaxed);
+    const bool use_slab = mode == -1 || mode == -5, use_lean = mode == -1;
+    int cfg = mode < 0 ? -1 : mode;
     if (cfg < 0) {
         // Measured on MI355X at 512 images (tools/conv_bench.py, profiles/r01_d_conv_configs.txt): the 2-stage
         // LDS-DMA ring with 8 waves per 128-row tile wins on every trunk layer -- two workgroups (16 waves) per CU
@@ -198,8 +189,8 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
         //   17  pointwise layers with a short contraction and several channel tiles (conv3 of layer2-4, layer3.0 conv1: K <= 512,
         //       C_out >= 256)
         //       on three lean workgroups per CU (conv_lean.hip, bit-identical to 11): -4..6 % there, +20 % on K >= 1024
-        if (g_conv_slab && ap_conv_slab_supported(a, is_bf16)) cfg = 14;
-        else if (g_conv_lean && a.Cin <= 512 && a.Cout >= 256 && mt128 * nt128 >= 768 && ap_conv_lean_supported(a, is_bf16)) cfg = 17;
+        if (use_slab && ap_conv_slab_supported(a, is_bf16)) cfg = 14;
+        else if (use_lean && a.Cin <= 512 && a.Cout >= 256 && mt128 * nt128 >= 768 && ap_conv_lean_supported(a, is_bf16)) cfg = 17;
         else if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : 11;
         else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
@@ -216,15 +207,6 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
         // explicit 14 on a shape the slab kernel cannot run: the ring kernel's tile of the same shape
         if (!ap_conv_slab_supported(a, is_bf16)) return ap_launch_conv_pipe(a, is_bf16, 11, st);
         return ap_launch_conv_slab(a, st);
-    }
-    if (cfg >= 20) {                                         // 20: planner; 24..28: one height (4..8 fragments) for all rows
-        if (!ap_conv_phase_supported(a, is_bf16 == AP_PREC_BF16)) return hipErrorInvalidValue;
-        int n_cu = 0;
-        e = device_cus(&n_cu);
-        if (e != hipSuccess) return e;
-        if (cfg == 20) return ap_conv_phase_auto(a, n_cu, st);
-        const int fmw = cfg - 20;
-        return ap_launch_conv_phase(a, fmw, 0, (a.M + 32 * fmw - 1) / (32 * fmw), st);
     }
     return ap_launch_conv_pipe(a, is_bf16, cfg, st);
 }
@@ -700,6 +682,19 @@ int finalize_regressor(ap_net* h) {
     return AP_OK;
 }
 
+// workspace of one pass over n images (a grow may synchronise the device and free: never while a sibling pass is in flight)
+int reserve_trunk_ws(ap_net* h, ap_net::TrunkWs& w, int n) {
+    const bool bf = h->prec == AP_PREC_BF16;
+    const size_t es = h->esize();
+    if (!(bf && h->fuse_stem)) HIP_TRY(w.ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
+    HIP_TRY(w.ws_a.reserve((size_t)n * 802816 * es));
+    HIP_TRY(w.ws_b.reserve((size_t)n * 802816 * es));
+    HIP_TRY(w.ws_ds.reserve((size_t)n * 802816 * es));
+    HIP_TRY(w.ws_t1.reserve((size_t)n * 401408 * es));
+    HIP_TRY(w.ws_t2.reserve((size_t)n * 200704 * es));
+    return AP_OK;
+}
+
 // one depth-first pass over n = n0 + n1 images: the first n0 from x0, the rest from x1 (two views, one pass)
 int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st,
                 size_t* ev_out = nullptr, int signal_at = 0) {
@@ -707,12 +702,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     const int kind = h->prec;                                // storage kind of every generic kernel
     const size_t es = h->esize();
     const int n = n0 + n1;
-    if (!(bf && h->fuse_stem)) HIP_TRY(w.ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
-    HIP_TRY(w.ws_a.reserve((size_t)n * 802816 * es));
-    HIP_TRY(w.ws_b.reserve((size_t)n * 802816 * es));
-    HIP_TRY(w.ws_ds.reserve((size_t)n * 802816 * es));
-    HIP_TRY(w.ws_t1.reserve((size_t)n * 401408 * es));
-    HIP_TRY(w.ws_t2.reserve((size_t)n * 200704 * es));
+    { int rc0 = reserve_trunk_ws(h, w, n); if (rc0) return rc0; }
     size_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
@@ -797,21 +787,33 @@ int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float
             HIP_TRY(hipEventCreateWithFlags(&h->ev_fork, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&h->ev_skew, hipEventDisableTiming));
         }
-        HIP_TRY(hipEventRecord(h->ev_fork, st));
         const int ppv = h->passes_per_view == 2 ? 2 : 1, np = 2 * ppv;
-        size_t ev[4][4] = {};
+        // every pass's workspace is sized BEFORE the fork: a grow inside a pass would synchronise the device and free
+        // buffers while the sibling pass is in flight
         for (int q = 0; q < np; ++q) {
+            const int v = q / ppv, part = q % ppv, nv = v ? n1 : n0, lo = part * (nv / ppv);
+            int rc = reserve_trunk_ws(h, h->tw[q], part == ppv - 1 ? nv - lo : nv / ppv);
+            if (rc) return rc;
+        }
+        HIP_TRY(hipEventRecord(h->ev_fork, st));
+        size_t ev[4][4] = {};
+        int rc = AP_OK, forked = 0;
+        for (int q = 0; q < np && !rc; ++q) {
             const int v = q / ppv, part = q % ppv;
             const int nv = v ? n1 : n0, lo = part * (nv / ppv), cnt = part == ppv - 1 ? nv - lo : nv / ppv;
             const float* xv = (v ? x1 : x0) + (size_t)lo * IMG_ELEMS;
             HIP_TRY(hipStreamWaitEvent(h->aux[q], h->ev_fork, 0));
+            forked = q + 1;
             if (q == 1 && np == 2 && h->dual_skew) HIP_TRY(hipStreamWaitEvent(h->aux[1], h->ev_skew, 0));
-            int rc = trunk_chunk(h, h->tw[q], xv, cnt, nullptr, 0, feat + ((v ? (size_t)n0 : 0) + lo) * 2048, h->aux[q], ev[q],
-                                 (q == 0 && np == 2) ? h->dual_skew : 0);
-            if (rc) return rc;
-            HIP_TRY(hipEventRecord(h->ev_join[q], h->aux[q]));
+            rc = trunk_chunk(h, h->tw[q], xv, cnt, nullptr, 0, feat + ((v ? (size_t)n0 : 0) + lo) * 2048, h->aux[q], ev[q],
+                             (q == 0 && np == 2) ? h->dual_skew : 0);
         }
-        for (int q = 0; q < np; ++q) HIP_TRY(hipStreamWaitEvent(st, h->ev_join[q], 0));
+        // join every stream that forked, also after a failed launch: later calls reuse tw[q] on the caller's stream order
+        for (int q = 0; q < forked; ++q) {
+            HIP_TRY(hipEventRecord(h->ev_join[q], h->aux[q]));
+            HIP_TRY(hipStreamWaitEvent(st, h->ev_join[q], 0));
+        }
+        if (rc) return rc;
         if (h->tm.on) {
             auto quad = [&](int stage, int a, int b) {       // span over the first and the last pass issued (two streams: exact)
                 for (int q : {0, np - 1}) { h->tm.quads[stage].push_back(ev[q][a]); h->tm.quads[stage].push_back(ev[q][b]); }
@@ -956,6 +958,7 @@ void ap_net_destroy(ap_net* h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_skew) (void)hipEventDestroy(h->ev_skew);
     delete h;
 }
 
@@ -1125,12 +1128,9 @@ int ap_debug_set_trace(void* device_buf_160_u64) {
 }
 
 int ap_set_conv_config(int cfg) {
-    if (cfg != -1 && cfg != -3 && cfg != -4 && cfg != -5 && cfg != 100 && cfg != 20 && !(cfg >= 24 && cfg <= 28) && (cfg < 0 || cfg > 14) && cfg != 17)
-        return fail(AP_EINVAL, "ap_set_conv_config: -1, -3, -4, 0..14, 20, 24..28 or 100");
-    g_conv_phase = cfg == -3;
-    g_conv_lean = cfg != -4 && cfg != -3 && cfg != -5;
-    g_conv_slab = cfg != -4 && cfg != -3;    // (-3 compares the phase kernel against the ring kernel: no slab either)
-    g_conv_cfg = (cfg == -3 || cfg == -4 || cfg == -5) ? -1 : cfg;
+    if (cfg != -1 && cfg != -4 && cfg != -5 && cfg != 100 && (cfg < 0 || cfg > 14) && cfg != 17)
+        return fail(AP_EINVAL, "ap_set_conv_config: -1, -4, -5, 0..14, 17 or 100");
+    g_conv_mode.store(cfg, std::memory_order_relaxed);
     return AP_OK;
 }
 

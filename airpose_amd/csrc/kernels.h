@@ -24,7 +24,6 @@ struct ConvArgs {
     int ldx, ldy, ldr, wld;
     int relu;
     int mtiles, ntiles;   // filled by the launcher
-    int row0;             // first pixel row of this launch (conv_phase only; 0 elsewhere)
     int out_f32;          // split-bf16 kind only: y (and res) are plain fp32 [M][ldy] instead of split pairs
 };
 
@@ -32,11 +31,6 @@ int ap_conv_cout_pad(void);
 hipError_t ap_launch_conv(const ConvArgs& a, int kind, hipStream_t st);   // kind = AP_PREC_*: 0 fp32, 1 bf16, 2 split-bf16
 // software-pipelined (LDS-DMA ring) variant; cfg: 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 256x64
 hipError_t ap_launch_conv_pipe(const ConvArgs& a, int kind, int cfg, hipStream_t st);
-
-// phase-interleaved 256-channel tiles, one 8-wave workgroup per CU (conv_phase.hip); bf16, no residual, Cout % 256 == 0
-bool ap_conv_phase_supported(const ConvArgs& a, int is_bf16);
-hipError_t ap_launch_conv_phase(ConvArgs a, int fmw, int row0, int mtiles, hipStream_t st);
-hipError_t ap_conv_phase_auto(const ConvArgs& a, int n_cu, hipStream_t st);
 
 // stride-1 3x3 with the nine taps read from one LDS slab per 64-channel chunk (conv_slab.hip); bf16, 128x128 tiles
 bool ap_conv_slab_supported(const ConvArgs& a, int kind);

@@ -31,7 +31,7 @@ class SMPLX(nn.Module):
     NUM_JOINTS = 55
 
     def __init__(self, model_path=None, batch_size=1, create_transl=False, gender="neutral", model_data=None,
-                 num_betas=10, num_expression_coeffs=10, **kwargs):
+                 num_betas=10, num_expression_coeffs=10, use_pca=True, num_pca_comps=6, flat_hand_mean=False, **kwargs):
         """model_path: directory holding SMPLX_{GENDER}.npz or the file itself (reference call sites);
         model_data: dict from smplx_model.make_synthetic_model / load_model_npz (tests, bench)."""
         super().__init__()
@@ -45,6 +45,10 @@ class SMPLX(nn.Module):
         self.batch_size = batch_size
         self.gender = gender
         self.num_betas, self.num_expression_coeffs = int(num_betas), int(num_expression_coeffs)
+        # hand pose space of pose2rot=True calls (upstream SMPLH/SMPLX ctor defaults: 6 PCA components, non-flat mean)
+        self.use_pca, self.num_pca_comps, self.flat_hand_mean = bool(use_pca), int(num_pca_comps), bool(flat_hand_mean)
+        if not 1 <= self.num_pca_comps <= 45:
+            raise ValueError("num_pca_comps must be in 1..45")
         self._md = {k: (np.ascontiguousarray(v) if isinstance(v, np.ndarray) else v) for k, v in model_data.items()}
         self.faces = self._md["faces"]                                   # ndarray, as upstream
         self.register_buffer("faces_tensor", torch.from_numpy(self._md["faces"].astype(np.int64)))
@@ -109,20 +113,48 @@ class SMPLX(nn.Module):
                 transl=None, expression=None, jaw_pose=None, leye_pose=None, reye_pose=None, return_verts=True,
                 return_full_pose=False, pose2rot=True, **kwargs):
         if pose2rot:
-            # axis-angle inputs (the upstream default): converted with lbs.batch_rodrigues, then the rotation-matrix path.
-            # Hands as flat axis-angle only: the PCA hand space of upstream (use_pca=True) needs `hands_components` of the
-            # licensed model file, which the inference path of the reference never touches.
+            # Axis-angle inputs (the upstream default; the reference's dataset code, aerialpeople.py:56-64).  smplx 0.1.28
+            # SMPLX.forward: hands = pca_coeffs @ hands_components[:num_pca_comps] when use_pca, full_pose += pose_mean (the
+            # model file's mean hand pose unless flat_hand_mean; zero for every other joint), un-supplied poses are the
+            # module's zero parameters, then lbs.batch_rodrigues.  The hand arrays come with the model file
+            # (hands_mean{l,r}, hands_components{l,r}); a model dict without them can only serve flat hands.
             from . import lbs
+            ref = next((t for t in (body_pose, global_orient, betas) if t is not None), None)
+            if ref is None or not ref.is_cuda:
+                raise RuntimeError("airpose_amd.SMPLX: inputs must be CUDA (ROCm) tensors; there is no CPU path")
+            dev0, Bp = ref.device, (body_pose.shape[0] if body_pose is not None else ref.shape[0])
 
             def aa(t, n, name):
                 if t is None:
                     return None
-                if t.numel() % (n * 3) or not t.is_cuda:
-                    raise RuntimeError("%s must be CUDA axis-angle vectors of %d joints per body (pose2rot=True)" % (name, n))
+                if t.dim() < 2 or t.shape[0] != Bp or t.numel() != Bp * n * 3 or not t.is_cuda:
+                    raise RuntimeError("%s must be CUDA axis-angle vectors (B, %d), pose2rot=True" % (name, n * 3))
                 return lbs.batch_rodrigues(t.reshape(-1, 3)).reshape(-1, n, 3, 3)
+
+            def hand(t, side):
+                mean, comp = self._md.get("hands_mean" + side), self._md.get("hands_components" + side)
+                have = mean is not None and comp is not None
+                if t is None and (self.flat_hand_mean or not have):
+                    return None                               # identity hand rotations (flat_hand_mean=True semantics)
+                if not have:
+                    raise RuntimeError("hand poses with pose2rot=True need hands_mean%s / hands_components%s of the "
+                                       "SMPL-X model file; this model dict carries none" % (side, side))
+                width = self.num_pca_comps if self.use_pca else 45
+                if t is None:
+                    t = torch.zeros(Bp, width, device=dev0)
+                if tuple(t.shape) != (Bp, width) or not t.is_cuda:
+                    raise RuntimeError("%s_hand_pose must be CUDA (B, %d) (%s), got %s" % (
+                        "left" if side == "l" else "right", width,
+                        "PCA coefficients, use_pca=True" if self.use_pca else "axis-angle, use_pca=False", tuple(t.shape)))
+                t = t.to(torch.float32)
+                if self.use_pca:
+                    t = t @ torch.from_numpy(np.ascontiguousarray(comp[:width])).to(dev0)
+                if not self.flat_hand_mean:
+                    t = t + torch.from_numpy(np.ascontiguousarray(mean)).to(dev0)
+                return lbs.batch_rodrigues(t.reshape(-1, 3)).reshape(-1, 15, 3, 3)
             global_orient, body_pose = aa(global_orient, 1, "global_orient"), aa(body_pose, 21, "body_pose")
             jaw_pose, leye_pose, reye_pose = aa(jaw_pose, 1, "jaw_pose"), aa(leye_pose, 1, "leye_pose"), aa(reye_pose, 1, "reye_pose")
-            left_hand_pose, right_hand_pose = aa(left_hand_pose, 15, "left_hand_pose"), aa(right_hand_pose, 15, "right_hand_pose")
+            left_hand_pose, right_hand_pose = hand(left_hand_pose, "l"), hand(right_hand_pose, "r")
         if betas is None or body_pose is None:
             raise RuntimeError("betas and body_pose are required (the reference creates no learnable defaults "
                                "on this path: create_transl=False, copenet_twoview.py:36-45)")

@@ -94,7 +94,12 @@ def make_synthetic_model(seed=4321, num_verts=NUM_VERTS, num_faces=NUM_FACES, ma
     bary = rs.uniform(0.05, 1.0, size=(NUM_LANDMARKS, 3))
     lmk_bary_coords = (bary / bary.sum(1, keepdims=True)).astype(np.float32)
     extra = EXTRA_JOINT_VERTS if V > EXTRA_JOINT_VERTS.max() else rs.randint(0, V, size=21).astype(np.int64)
-    return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs,
+    # hand pose space of the model file (hands_mean{l,r} (45,), hands_components{l,r} (45,45): rows = PCA directions), from
+    # its own stream so that every array above keeps the values it always had
+    rh = np.random.RandomState(seed + 7)
+    hands = {k: (rh.standard_normal(45) * 0.2).astype(np.float32) for k in ("hands_meanl", "hands_meanr")}
+    hands.update({k: (rh.standard_normal((45, 45)) * 0.3).astype(np.float32) for k in ("hands_componentsl", "hands_componentsr")})
+    return dict(hands, v_template=v_template, shapedirs=shapedirs, posedirs=posedirs,
                 J_regressor=J_regressor, parents=PARENTS.copy(), lbs_weights=weights,
                 faces=faces, lmk_faces_idx=lmk_faces_idx, lmk_bary_coords=lmk_bary_coords,
                 extra_joint_verts=extra.copy(), synthetic=True)
@@ -122,7 +127,9 @@ def load_model_npz(path, num_betas=NUM_BETAS, num_expr=NUM_EXPR):
     posedirs = np.reshape(pd, [-1, pd.shape[-1]]).T.copy()     # (486, V*3)
     parents = np.asarray(d["kintree_table"])[0].astype(np.int64).copy()
     parents[0] = -1
-    return dict(v_template=np.asarray(d["v_template"], np.float32),
+    hands = {k: np.asarray(d[k], np.float32) for k in ("hands_meanl", "hands_meanr", "hands_componentsl", "hands_componentsr")
+             if k in d.files}
+    return dict(hands, v_template=np.asarray(d["v_template"], np.float32),
                 shapedirs=np.concatenate([shape, expr], -1),
                 posedirs=posedirs,
                 J_regressor=np.asarray(d["J_regressor"], np.float32),

@@ -433,6 +433,10 @@ def main():
             res["view_split"] = vs
         if cpu is not None:
             res["cpu_baseline"] = cpu
+            # BASELINE.md publishes no throughput for this metric and names the CPU path measured on the target box as the
+            # baseline (section 1 / 3): vs_baseline = value / that measurement, same unit (null when the CPU leg is skipped)
+            res["vs_baseline"] = res["value"] / cpu["value"]
+            res["vs_baseline_of"] = "cpu_baseline.value (BASELINE.md: no published number; baseline = the CPU path on this box)"
         print(json.dumps(res))
     if use_dist:
         dist.barrier()

@@ -146,11 +146,9 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
                          const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
                          int N, int H, int W, int Cin, int downsample, void* stream);
 
-/* Tuning/testing knob (process-wide): tile configuration of the convolution kernels.  -1 = automatic,
- * -3 = automatic with the phase-interleaved kernel where it applies (experimental, see conv_phase.hip), 0..13 = software-pipelined LDS-DMA ring kernel (tile / wave /
- * ring-depth variants, conv_pipe.hip), 20 = phase-interleaved 256-channel tiles with the planner that fits tile heights
- * to the CU count, 24..28 = the same with one fixed height of 4..8 pixel fragments per wave (conv_phase.hip; bf16,
- * C_out % 256 == 0, no residual: anything else is refused), 100 = register-staged 2-stage kernel,
+/* Tuning/testing knob (process-wide, one atomic word: safe to set while handles run on other threads; a launch sees the
+ * old or the new value): tile configuration of the convolution kernels.  -1 = automatic, 0..13 = software-pipelined
+ * LDS-DMA ring kernel (tile / wave / ring-depth variants, conv_pipe.hip), 100 = register-staged 2-stage kernel,
  * 14 = stride-1 3x3 convolutions with the nine taps read from one LDS slab per 64-channel chunk (conv_slab.hip; bf16,
  * image rows of at most 29 pixels; other shapes run configuration 11), which the automatic choice uses for the conv2
  * layers of layer2-4; 17 = pointwise convolutions on three lean workgroups per CU (conv_lean.hip; bf16; bit-identical to 11;

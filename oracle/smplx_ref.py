@@ -106,3 +106,41 @@ def smplx_forward(model, betas, body_pose, global_orient=None, transl=None, expr
         joints = joints + transl.to(dtype).unsqueeze(1)
         verts = verts + transl.to(dtype).unsqueeze(1)
     return verts, joints
+
+
+def batch_rodrigues(rot_vecs, epsilon=1e-8):
+    """upstream lbs.batch_rodrigues: angle = |r + eps|, K = skew(r / angle), R = I + sin K + (1 - cos) K K."""
+    N = rot_vecs.shape[0]
+    angle = torch.norm(rot_vecs + epsilon, dim=1, keepdim=True)
+    rot_dir = rot_vecs / angle
+    cos, sin = torch.cos(angle).unsqueeze(1), torch.sin(angle).unsqueeze(1)
+    rx, ry, rz = torch.split(rot_dir, 1, dim=1)
+    zeros = torch.zeros(N, 1, dtype=rot_vecs.dtype)
+    K = torch.cat([zeros, -rz, ry, rz, zeros, -rx, -ry, rx, zeros], dim=1).view(N, 3, 3)
+    ident = torch.eye(3, dtype=rot_vecs.dtype).unsqueeze(0)
+    return ident + sin * K + (1 - cos) * torch.bmm(K, K)
+
+
+def smplx_forward_axis_angle(model, betas, body_pose, global_orient=None, transl=None, expression=None, jaw_pose=None,
+                             leye_pose=None, reye_pose=None, left_hand_pose=None, right_hand_pose=None, use_pca=True,
+                             num_pca_comps=6, flat_hand_mean=False, dtype=torch.float32):
+    """upstream body_models.SMPLX.forward(..., pose2rot=True) of smplx 0.1.28 (the call of the reference's dataset code,
+    copenet/src/copenet/dsets/aerialpeople.py:56-64,181-197): un-supplied poses are the module's zero parameters, hands
+    are `coeffs @ hands_components[:num_pca_comps]` when use_pca, `full_pose += pose_mean` (mean hand pose of the model file
+    unless flat_hand_mean, zero elsewhere), then lbs with batch_rodrigues on every joint."""
+    B = betas.shape[0]
+    z = lambda n: torch.zeros(B, n, dtype=dtype)
+    t = lambda a: torch.as_tensor(a).to(dtype)
+    hands = []
+    for side, h in (("l", left_hand_pose), ("r", right_hand_pose)):
+        h = z(num_pca_comps if use_pca else 45) if h is None else h.to(dtype)
+        if use_pca:
+            h = torch.einsum("bi,ij->bj", h, t(model["hands_components" + side])[:num_pca_comps])
+        hands.append(h + (0 if flat_hand_mean else t(model["hands_mean" + side])))
+    full = torch.cat([z(3) if global_orient is None else global_orient.reshape(B, 3).to(dtype), body_pose.reshape(B, 63).to(dtype),
+                      z(3) if jaw_pose is None else jaw_pose.reshape(B, 3).to(dtype),
+                      z(3) if leye_pose is None else leye_pose.reshape(B, 3).to(dtype),
+                      z(3) if reye_pose is None else reye_pose.reshape(B, 3).to(dtype), hands[0], hands[1]], dim=1)
+    R = batch_rodrigues(full.reshape(-1, 3)).reshape(B, 55, 3, 3)
+    return smplx_forward(model, betas, R[:, 1:22], R[:, :1], transl, expression, R[:, 22:23], R[:, 23:24], R[:, 24:25],
+                         R[:, 25:40], R[:, 40:55], dtype=dtype)

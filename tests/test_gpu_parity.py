@@ -209,208 +209,6 @@ def test_conv_primitive(dev, prec, case, cfg):
     assert rel_err(got.numpy(), ref.numpy()) < tol
 
 
-PHASE_CASES = [
-    # N, H, Cin, Cout, k, stride, pad, relu   (conv_phase.hip: bf16, Cout % 256 == 0, no residual)
-    (3, 14, 256, 256, 3, 1, 1, True),       # ragged M (588 rows), 3x3 halo, 36 K-tiles
-    (5, 7, 512, 512, 3, 1, 1, True),        # K = 4608, two channel tiles
-    (2, 28, 256, 256, 3, 2, 1, True),       # stride-2 3x3 (layer3.0 conv2)
-    (2, 56, 256, 512, 1, 2, 0, False),      # stride-2 1x1 through the tap path, no relu
-    (4, 14, 1024, 256, 1, 1, 0, True),      # pointwise, K = 1024 (layer3 conv1)
-    (9, 14, 256, 1024, 1, 1, 0, True),      # pointwise, K = 256: four K-tiles, wide N
-    (1, 14, 64, 256, 1, 1, 0, True),        # a single K-tile (prologue-only pipeline)
-    (1, 14, 128, 256, 1, 1, 0, False),      # two K-tiles
-    (7, 14, 192, 256, 1, 1, 0, True),       # three K-tiles, 1372 rows
-]
-
-
-@pytest.mark.parametrize("cfg", [20, 24, 25, 26, 27, 28])
-@pytest.mark.parametrize("case", PHASE_CASES)
-def test_conv_phase_primitive(dev, case, cfg):
-    """The phase-interleaved 256-channel kernel at every tile height against the fp64 oracle on identical operands,
-    and bit-for-bit against the ring kernel (same K order, same MFMA, same epilogue expression)."""
-    from airpose_amd import _native as Nn
-    N, H, Cin, Cout, k, stride, pad, relu = case
-    outs = []
-    for c in (cfg, 11):
-        Nn.check(Nn.lib().ap_set_conv_config(c), "ap_set_conv_config")
-        try:
-            got, ref = _conv_case(dev, "bf16", N, H, Cin, Cout, k, stride, pad, relu, False, seed=hash(case) % 10000)
-        finally:
-            Nn.lib().ap_set_conv_config(-1)
-        outs.append(got)
-    assert torch.isfinite(outs[0]).all()
-    assert rel_err(outs[0].numpy(), ref.numpy()) < 6e-3
-    assert torch.equal(outs[0], outs[1])
-
-
-SLAB_CASES = [
-    # N, H, Cin, Cout, relu, res   (conv_slab.hip: stride-1 3x3, pad 1, bf16)
-    (3, 14, 256, 256, True, False),        # ragged M (588 rows), tiles that straddle images
-    (5, 7, 512, 512, True, False),         # 7-pixel rows: a tile spans 2.6 images, K = 4608
-    (3, 28, 128, 192, True, True),         # 28-pixel rows (186-row slab), ragged N, residual
-    (2, 28, 128, 128, False, False),       # no relu
-    (1, 14, 64, 128, True, False),         # a single channel chunk: no second slab
-    (9, 14, 192, 128, True, False),        # three chunks: both slab buffers refilled
-    (1, 29, 64, 128, True, False),         # longest supported row
-]
-
-
-@pytest.mark.parametrize("case", SLAB_CASES)
-def test_conv_slab_primitive(dev, case):
-    """The slab kernel (nine taps of a stride-1 3x3 from one LDS slab per channel chunk, border taps from the zero row)
-    against the fp64 oracle on identical bf16 operands, and against the ring kernel: same products, different fp32
-    summation order, so the bf16 results may differ by one rounding step in a few places and nowhere by more."""
-    from airpose_amd import _native as Nn
-    N, H, Cin, Cout, relu, use_res = case
-    outs = []
-    for c in (14, 11):
-        Nn.check(Nn.lib().ap_set_conv_config(c), "ap_set_conv_config")
-        try:
-            got, ref = _conv_case(dev, "bf16", N, H, Cin, Cout, 3, 1, 1, relu, use_res, seed=hash(case) % 10000)
-        finally:
-            Nn.lib().ap_set_conv_config(-1)
-        outs.append(got)
-    assert torch.isfinite(outs[0]).all()
-    assert rel_err(outs[0].numpy(), ref.numpy()) < 6e-3
-    d = (outs[0] - outs[1]).abs()
-    assert (d <= 2.0 ** -7 * outs[1].abs().clamp_min(2.0 ** -6)).all()          # at most one bf16 step
-    assert (d > 0).double().mean() < 0.05
-
-
-def test_conv_slab_full_size_is_deterministic(dev):
-    """BASELINE-size layer2 / layer3 / layer4 conv2 (512 images; two workgroups of 80 KiB per CU, counted waits under
-    full memory load): repeated runs identical, one bf16 step from the ring kernel at most."""
-    from airpose_amd import _native as Nn
-    L = Nn.lib()
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    for n, H, C in ((512, 28, 128), (512, 14, 256), (512, 7, 512)):
-        g = torch.Generator(device="cpu").manual_seed(3)
-        x = torch.randn(n, H, H, C, generator=g).to(torch.bfloat16).to(dev)
-        w = (torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).to(torch.bfloat16).to(dev)
-        sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
-        outs = []
-        for cfg in (14, 14, 14, 11):
-            L.ap_set_conv_config(cfg)
-            try:
-                y = torch.full((n, H, H, C), float("nan"), dtype=torch.bfloat16, device=dev)
-                Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(x), p(w), p(sc), p(sh), None, p(y), n, H, H, C, C, 3, 1, 1,
-                                          1, Nn.stream_ptr(dev)), "conv")
-                torch.cuda.synchronize()
-            finally:
-                L.ap_set_conv_config(-1)
-            outs.append(y.float())
-        assert torch.isfinite(outs[0]).all()
-        assert torch.equal(outs[1], outs[0]) and torch.equal(outs[2], outs[0])
-        d = (outs[0] - outs[3]).abs()
-        assert (d <= 2.0 ** -7 * outs[3].abs().clamp_min(2.0 ** -6)).all()
-        assert (d > 0).double().mean() < 0.05
-
-
-def test_trunk_slab_kernel_against_ring_kernel(netbf, dev):
-    """Trunk features with the automatic choice (slab kernel on the stride-1 3x3 layers of layer2-4) against the ring
-    kernel everywhere: the difference is fp32 re-association under bf16 rounding, far below the bf16 mode's own error."""
-    from airpose_amd import _native as Nn
-    gen = torch.Generator(device="cpu").manual_seed(22)
-    x = torch.randn(128, 3, 224, 224, generator=gen).to(dev)
-    a = netbf.forward_feat_ext(x)
-    Nn.check(Nn.lib().ap_set_conv_config(-4), "ap_set_conv_config")
-    try:
-        b = netbf.forward_feat_ext(x)
-    finally:
-        Nn.lib().ap_set_conv_config(-1)
-    assert torch.isfinite(a).all()
-    e = rel_err(a.cpu().numpy(), b.cpu().numpy())
-    print("slab vs ring trunk features rel %.2e" % e)
-    assert 0 < e < 2e-3
-
-
-LEAN_CASES = [
-    # N, H, Cin, Cout, relu, res   (conv_lean.hip: pointwise, bf16)
-    (2, 56, 64, 256, True, True),          # two K steps, residual
-    (1, 56, 256, 128, True, False),        # one channel tile
-    (3, 14, 1024, 256, True, False),       # 32 K steps, ragged M (588 rows)
-    (1, 7, 512, 2048, True, True),         # tiny M = 49, wide N
-    (64, 28, 128, 512, True, True),        # large M
-    (2, 14, 64, 200, False, False),        # two K steps, ragged N, no relu
-    (2, 14, 192, 128, True, False),        # six K steps: every ring slot twice
-]
-
-
-@pytest.mark.parametrize("case", LEAN_CASES)
-def test_conv_lean_primitive(dev, case):
-    """The three-workgroups-per-CU pointwise kernel against the fp64 oracle and bit for bit against the ring kernel (same MFMA
-    sequence per output element, same epilogue expression)."""
-    from airpose_amd import _native as Nn
-    N, H, Cin, Cout, relu, use_res = case
-    outs = []
-    for c in (17, 11):
-        Nn.check(Nn.lib().ap_set_conv_config(c), "ap_set_conv_config")
-        try:
-            got, ref = _conv_case(dev, "bf16", N, H, Cin, Cout, 1, 1, 0, relu, use_res, seed=hash(case) % 10000)
-        finally:
-            Nn.lib().ap_set_conv_config(-1)
-        outs.append(got)
-    assert torch.isfinite(outs[0]).all()
-    assert rel_err(outs[0].numpy(), ref.numpy()) < 6e-3
-    assert torch.equal(outs[0], outs[1])
-
-
-def test_conv_phase_refuses_what_it_cannot_do(dev):
-    from airpose_amd import _native as Nn
-    for case in ((2, 56, 64, 256, 1, 1, 0, True, True),      # residual
-                 (1, 56, 256, 128, 1, 1, 0, True, False)):   # 128 output channels
-        Nn.lib().ap_set_conv_config(20)
-        try:
-            with pytest.raises(RuntimeError):
-                _conv_case(dev, "bf16", *case, seed=1)
-        finally:
-            Nn.lib().ap_set_conv_config(-1)
-
-
-def test_conv_phase_full_size_is_deterministic_and_matches_ring(dev):
-    """BASELINE-size layer3 conv2 (512 images: 100 352 rows = one round of 224-row tiles + one of 192-row tiles on 256
-    CUs, hand-counted waits under full memory load): repeated runs identical, and identical to the ring kernel."""
-    from airpose_amd import _native as Nn
-    L = Nn.lib()
-    g = torch.Generator(device="cpu").manual_seed(3)
-    n, H, C = 512, 14, 256
-    x = torch.randn(n, H, H, C, generator=g).to(torch.bfloat16).to(dev)
-    w = (torch.randn(C, 3, 3, C, generator=g) * (2.0 / (9 * C)) ** 0.5).to(torch.bfloat16).to(dev)
-    sc, sh = (torch.rand(C, generator=g) + 0.5).to(dev), (torch.randn(C, generator=g) * 0.1).to(dev)
-    p = lambda t: ctypes.c_void_p(t.data_ptr())
-    outs = []
-    for cfg in (20, 20, 20, 11):
-        L.ap_set_conv_config(cfg)
-        try:
-            y = torch.full((n, H, H, C), float("nan"), dtype=torch.bfloat16, device=dev)
-            Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(x), p(w), p(sc), p(sh), None, p(y), n, H, H, C, C, 3, 1, 1, 1,
-                                      Nn.stream_ptr(dev)), "conv")
-            torch.cuda.synchronize()
-        finally:
-            L.ap_set_conv_config(-1)
-        outs.append(y)
-    assert torch.isfinite(outs[0].float()).all()
-    for o in outs[1:]:
-        assert torch.equal(o, outs[0])
-
-
-def test_trunk_with_and_without_phase_kernel_bitwise(netbf, dev):
-    """The automatic choice with the phase kernel enabled (layer2.0 conv3+downsample, layer3/4 conv1, conv2,
-    conv3+downsample at this size: pointwise, 3x3, strided and two-segment contractions) against the ring kernel
-    everywhere: identical trunk features, bit for bit.  128 images put layer3 over the planner's threshold."""
-    from airpose_amd import _native as Nn
-    gen = torch.Generator(device="cpu").manual_seed(21)
-    x = torch.randn(128, 3, 224, 224, generator=gen).to(dev)
-    feats = []
-    for cfg in (-4, -3):                                     # ring kernel everywhere | phase kernel where it applies
-        Nn.check(Nn.lib().ap_set_conv_config(cfg), "ap_set_conv_config")
-        try:
-            feats.append(netbf.forward_feat_ext(x))
-        finally:
-            Nn.lib().ap_set_conv_config(-1)
-    assert torch.equal(feats[0], feats[1])
-
-
 @pytest.mark.parametrize("cfg", [-1, 11, 12, 100])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_primitive_split_bf16(dev, case, cfg):
@@ -1037,7 +835,7 @@ def test_batch_rodrigues_both_forms(golden, dev):
 
 
 def test_smplx_forward_axis_angle_inputs(body, smplx_model, dev):
-    """SMPLX.forward(pose2rot=True): axis-angle pose inputs (upstream's default calling convention) give what the
+    """SMPLX.forward(pose2rot=True) with use_pca=False, flat_hand_mean=True: axis-angle pose inputs give what the
     rotation-matrix call gives on lbs.batch_rodrigues of them, and match the CPU oracle."""
     from airpose_amd import lbs
     from oracle import fitting_ref as Fr
@@ -1048,8 +846,13 @@ def test_smplx_forward_axis_angle_inputs(body, smplx_model, dev):
     bp, go, jaw = torch.randn(B, 63, generator=gen) * 0.6, torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen) * 0.3
     lh = torch.randn(B, 45, generator=gen) * 0.4
     tr = torch.randn(B, 3, generator=gen)
-    out = body.forward(betas=betas.to(dev), body_pose=bp.to(dev), global_orient=go.to(dev), jaw_pose=jaw.to(dev),
-                       left_hand_pose=lh.to(dev), transl=tr.to(dev), pose2rot=True)
+    old = (body.use_pca, body.flat_hand_mean)
+    body.use_pca, body.flat_hand_mean = False, True
+    try:
+        out = body.forward(betas=betas.to(dev), body_pose=bp.to(dev), global_orient=go.to(dev), jaw_pose=jaw.to(dev),
+                           left_hand_pose=lh.to(dev), transl=tr.to(dev), pose2rot=True)
+    finally:
+        body.use_pca, body.flat_hand_mean = old
     rm = lambda t, n: lbs.batch_rodrigues(t.to(dev).reshape(-1, 3)).reshape(B, n, 3, 3)
     ref = body.forward(betas=betas.to(dev), body_pose=rm(bp, 21), global_orient=rm(go, 1), jaw_pose=rm(jaw, 1),
                        left_hand_pose=rm(lh, 15), transl=tr.to(dev), pose2rot=False)
@@ -1057,6 +860,33 @@ def test_smplx_forward_axis_angle_inputs(body, smplx_model, dev):
     cr = lambda t, n: Fr.lbs_batch_rodrigues(t.reshape(-1, 3)).reshape(B, n, 3, 3)
     want_v, want_j = smplx_ref.smplx_forward(smplx_model, betas, cr(bp, 21), global_orient=cr(go, 1), jaw_pose=cr(jaw, 1),
                                              left_hand_pose=cr(lh, 15), transl=tr)
+    assert rel_err(out.vertices.cpu().numpy(), want_v.numpy()) < TOL32
+    assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
+
+
+@pytest.mark.parametrize("use_pca,flat", [(True, False), (True, True), (False, False)])
+def test_smplx_forward_hand_pca_and_mean_pose(body, smplx_model, dev, use_pca, flat):
+    """The upstream default calling convention of SMPLX.forward (pose2rot=True; the reference's dataset code,
+    aerialpeople.py:56-64): hands as num_pca_comps PCA coefficients through hands_components, the model file's mean hand
+    pose added unless flat_hand_mean, un-supplied hands = the mean pose -- against the oracle's restatement of smplx 0.1.28."""
+    from oracle import smplx_ref
+    gen = torch.Generator().manual_seed(29)
+    B = 4
+    betas, bp = torch.randn(B, 10, generator=gen), torch.randn(B, 63, generator=gen) * 0.5
+    go, reye = torch.randn(B, 3, generator=gen), torch.randn(B, 3, generator=gen) * 0.2
+    lh = torch.randn(B, 6 if use_pca else 45, generator=gen) * 0.5
+    old = (body.use_pca, body.flat_hand_mean, body.num_pca_comps)
+    body.use_pca, body.flat_hand_mean, body.num_pca_comps = use_pca, flat, 6
+    try:
+        out = body.forward(betas=betas.to(dev), body_pose=bp.to(dev), global_orient=go.to(dev), reye_pose=reye.to(dev),
+                           left_hand_pose=lh.to(dev), pose2rot=True)                       # right hand: not supplied
+        with pytest.raises(RuntimeError):                                               # the other convention's width
+            body.forward(betas=betas.to(dev), body_pose=bp.to(dev), left_hand_pose=torch.zeros(B, 45 if use_pca else 6, device=dev),
+                         pose2rot=True)
+    finally:
+        body.use_pca, body.flat_hand_mean, body.num_pca_comps = old
+    want_v, want_j = smplx_ref.smplx_forward_axis_angle(smplx_model, betas, bp, global_orient=go, reye_pose=reye, left_hand_pose=lh,
+                                                        use_pca=use_pca, num_pca_comps=6, flat_hand_mean=flat)
     assert rel_err(out.vertices.cpu().numpy(), want_v.numpy()) < TOL32
     assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
 

@@ -162,3 +162,30 @@ def test_sparse_skin_weights_keep_every_bone():
         assert np.array_equal(dense, W)
         live = np.where(w != 0, idx, 10 ** 6)
         assert (np.diff(live, axis=1) >= 0).all()              # ascending bone order, padding last
+
+
+def test_axis_angle_call_hand_pca_and_mean_pose_known_answers():
+    """pose2rot=True restatement (smplx 0.1.28 SMPLX.forward): with flat_hand_mean and no hand input the hands are identity,
+    i.e. the rotation-matrix call on batch_rodrigues of the body pose; without flat_hand_mean an un-supplied hand IS the
+    model file's mean hand pose; PCA coefficients act through the first num_pca_comps rows of hands_components."""
+    from airpose_amd import smplx_model as SM
+    md = SM.make_synthetic_model(4321, num_verts=600, num_faces=900)
+    gen = torch.Generator().manual_seed(1)
+    B = 2
+    betas, bp = torch.randn(B, 10, generator=gen), torch.randn(B, 63, generator=gen) * 0.4
+    rm = smplx_ref.batch_rodrigues(bp.reshape(-1, 3)).reshape(B, 21, 3, 3)
+    v_rot, j_rot = smplx_ref.smplx_forward(md, betas, rm)
+    v_flat, j_flat = smplx_ref.smplx_forward_axis_angle(md, betas, bp, flat_hand_mean=True)
+    assert torch.allclose(v_flat, v_rot, atol=1e-6) and torch.allclose(j_flat, j_rot, atol=1e-6)
+    # un-supplied hands, non-flat mean == explicit mean hand pose through the flat axis-angle convention
+    v_mean, _ = smplx_ref.smplx_forward_axis_angle(md, betas, bp)
+    ml, mr = torch.from_numpy(md["hands_meanl"]).expand(B, 45), torch.from_numpy(md["hands_meanr"]).expand(B, 45)
+    v_exp, _ = smplx_ref.smplx_forward_axis_angle(md, betas, bp, left_hand_pose=ml, right_hand_pose=mr, use_pca=False,
+                                                  flat_hand_mean=True)
+    assert torch.allclose(v_mean, v_exp, atol=1e-6) and (v_mean - v_flat).abs().max() > 1e-3
+    # 6 PCA coefficients == their expansion handed over as 45 axis-angle numbers
+    c = torch.randn(B, 6, generator=gen)
+    v_pca, _ = smplx_ref.smplx_forward_axis_angle(md, betas, bp, left_hand_pose=c, flat_hand_mean=True)
+    full = c @ torch.from_numpy(md["hands_componentsl"][:6])
+    v_full, _ = smplx_ref.smplx_forward_axis_angle(md, betas, bp, left_hand_pose=full, use_pca=False, flat_hand_mean=True)
+    assert torch.allclose(v_pca, v_full, atol=1e-6)
