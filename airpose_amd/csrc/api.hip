@@ -220,7 +220,8 @@ struct ap_net {
     std::map<std::string, HostTensor> tensors;
     // trunk
     DevBuf stem_w, stem_wpk, stem_wpk_lo, stem_scale, stem_shift;   // stem_wpk_lo: low plane of the split-bf16 stem weights
-    struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false; };
+    struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false;
+                   DevBuf pair; int pair_p = 0, pair_n1 = 0; };   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
     std::vector<Block> blocks;
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
@@ -230,6 +231,7 @@ struct ap_net {
     bool fold = true;
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
     bool fuse_block = true;        // bf16: layer1 bottlenecks as one kernel each (bottleneck.hip)
+    bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape, mean_cam;
     // workspace
@@ -518,6 +520,18 @@ int finalize_trunk(ap_net* h) {
             }
             inpl = pl * 4;
         }
+    // conv3 of an identity block + conv1 of the next block (conv_pair.hip): the two weight matrices as one stream of
+    // 16-KiB tiles in the order the fused kernel consumes them, built on the device from the rows packed above
+    if (h->prec == AP_PREC_BF16)
+        for (size_t b = 0; b + 1 < h->blocks.size(); ++b) {
+            ap_net::Block &A = h->blocks[b], &N = h->blocks[b + 1];
+            const int P = A.c3.cin, N1 = N.c1.cout;
+            if (A.has_down || A.c3.cout != 4 * P || N.c1.cin != 4 * P || !ap_conv_pair_supported(P, N1)) continue;
+            HIP_TRY(A.pair.reserve(ap_conv_pair_stream_bytes(P, N1)));
+            HIP_TRY(ap_launch_pair_pack(A.c3.w.p, N.c1.w.p, A.pair.p, P, N1, nullptr));
+            A.pair_p = P; A.pair_n1 = N1;
+        }
+    HIP_TRY(hipDeviceSynchronize());
     return AP_OK;
 }
 
@@ -729,6 +743,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     int H = 56;
     int rc;
     int blk = 0;
+    bool t1_ready = false;                                   // ws_t1 already holds this block's conv1 output (fused pair)
     for (auto& B : h->blocks) {
         if (signal_at >= 2 && blk++ == signal_at - 2) HIP_TRY(hipEventRecord(h->ev_skew, st));
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
@@ -739,9 +754,21 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             std::swap(cur, nxt);
             continue;
         }
-        if ((rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, kind, st))) return rc;
+        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, kind, st))) return rc;
+        t1_ready = false;
         if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, kind, st))) return rc;
-        if (B.has_down && h->fuse_ds) {
+        if (bf && h->fuse_pair && B.pair_p && &B != &h->blocks.back()) {
+            // identity block: conv3 (+ identity, ReLU) AND the next block's conv1 in one kernel -- the block output is
+            // written once and not read back for conv1 (model_copenet.py:38-45 of this block, :29-31 of the next)
+            const ap_net::Block& Nx = *(&B + 1);
+            PairArgs a{};
+            a.t2 = w.ws_t2.p; a.res = cur; a.wstream = B.pair.p;
+            a.s3 = B.c3.scale.as<float>(); a.h3 = B.c3.shift.as<float>();
+            a.s1 = Nx.c1.scale.as<float>(); a.h1 = Nx.c1.shift.as<float>();
+            a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho;
+            HIP_TRY(ap_launch_conv_pair(a, B.pair_p, B.pair_n1, st));
+            t1_ready = true;
+        } else if (B.has_down && h->fuse_ds) {
             if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, kind, st))) return rc;
         } else {
             const void* res = cur;
@@ -949,7 +976,7 @@ void ap_net_destroy(ap_net* h) {
                       &h->ws_D, &h->ws_state})
         b->release();
     auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
-    for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); rel(B.c3ds); }
+    for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); rel(B.c3ds); B.pair.release(); }
     rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec); rel(h->fold_feat); rel(h->fold_state);
     h->foldT_feat.release(); h->foldT_state.release(); h->fold_bias.release();
     h->tm.destroy();
@@ -1122,6 +1149,28 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
     return AP_OK;
 }
 
+int ap_conv_pair_nhwc(const void* t2, const void* w3, const float* s3, const float* h3, const void* res, const void* w1,
+                      const float* s1, const float* h1, void* out, void* t1n, int M, int P, int N1, void* stream) {
+    if (!t2 || !w3 || !s3 || !h3 || !res || !w1 || !s1 || !h1 || !out || !t1n || M <= 0)
+        return fail(AP_EINVAL, "ap_conv_pair_nhwc: bad argument");
+    if (!ap_conv_pair_supported(P, N1)) return fail(AP_ESHAPE, "ap_conv_pair_nhwc: (P, N1) must be (128,128), (128,256) or (256,256)");
+    // the weight stream of the last (w3, w1) pair is kept (tools/conv_bench.py times repeated calls)
+    static const void *k3 = nullptr, *k1 = nullptr;
+    static int kp = 0, kn = 0;
+    static DevBuf ws;
+    hipStream_t st = (hipStream_t)stream;
+    if (k3 != w3 || k1 != w1 || kp != P || kn != N1) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(ws.reserve(ap_conv_pair_stream_bytes(P, N1)));
+        HIP_TRY(ap_launch_pair_pack(w3, w1, ws.p, P, N1, st));
+        k3 = w3; k1 = w1; kp = P; kn = N1;
+    }
+    PairArgs a{};
+    a.t2 = t2; a.res = res; a.wstream = ws.p; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n; a.M = M;
+    HIP_TRY(ap_launch_conv_pair(a, P, N1, st));
+    return AP_OK;
+}
+
 int ap_debug_set_trace(void* device_buf_160_u64) {
     g_conv_dbg = (unsigned long long*)device_buf_160_u64;
     return AP_OK;
@@ -1212,6 +1261,12 @@ int ap_net_set_fuse_ds(ap_net* h, int on) {
 int ap_net_set_fuse_block(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_block = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_fuse_pair(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fuse_pair = on != 0;
     return AP_OK;
 }
 

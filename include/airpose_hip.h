@@ -146,6 +146,12 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
                          const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
                          int N, int H, int W, int Cin, int downsample, void* stream);
 
+/* Test / tuning entry of the fused pair kernel on NHWC bf16 tensors: t2 [M][P] (conv2 output), res [M][4P] (block input),
+ * w3 [4P][P] + s3/h3 (conv3 + bn3 of the block), w1 [N1][4P] + s1/h1 (conv1 + bn1 of the next block); writes
+ * out [M][4P] = relu(bn3(conv3 t2) + res) and t1n [M][N1] = relu(bn1(conv1 out)).  (P, N1) in {(128,128), (128,256), (256,256)}. */
+int ap_conv_pair_nhwc(const void* t2, const void* w3, const float* s3, const float* h3, const void* res, const void* w1,
+                      const float* s1, const float* h1, void* out, void* t1n, int M, int P, int N1, void* stream);
+
 /* Tuning/testing knob (process-wide, one atomic word: safe to set while handles run on other threads; a launch sees the
  * old or the new value): tile configuration of the convolution kernels.  -1 = automatic, 0..13 = software-pipelined
  * LDS-DMA ring kernel (tile / wave / ring-depth variants, conv_pipe.hip), 100 = register-staged 2-stage kernel,
@@ -189,6 +195,11 @@ int ap_net_set_fuse_stem(ap_net* h, int on);
 /* bf16 mode: on = 1 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
  * intermediates never leave LDS), on = 0 as its three (two + folded-downsample) convolutions.  Parity-tested. */
 int ap_net_set_fuse_block(ap_net* h, int on);
+/* bf16: conv3 (+ identity, ReLU) of an identity bottleneck and conv1 of the NEXT bottleneck as one pixel-local kernel
+ * (conv_pair.hip; layer2 and layer3 identity blocks, and layer2 -> layer3): the block output makes one HBM trip less per block
+ * boundary.  Bit-identical to the two stand-alone kernels.  Default on; replaces model_copenet.py:38-45 (+ :29-31 of the
+ * next block) per launch. */
+int ap_net_set_fuse_pair(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);
 /* Two-view forwards (>= 64 images per view, both views within one chunk) run the two views as two concurrent trunk

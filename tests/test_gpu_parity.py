@@ -209,6 +209,112 @@ def test_conv_primitive(dev, prec, case, cfg):
     assert rel_err(got.numpy(), ref.numpy()) < tol
 
 
+PAIR_CASES = [
+    # images, H, P (planes), N1 (next block's conv1 width)
+    (2, 28, 128, 128),      # layer2 identity block -> next layer2 block; M = 1568 (ragged: 24.5 tiles of 64 pixels)
+    (3, 28, 128, 256),      # layer2.3 -> layer3.0 (conv1 of the stage-first block runs before the stride)
+    (5, 14, 256, 256),      # layer3 identity pair; M = 980 (ragged)
+    (1, 7, 128, 128),       # M = 49: a single, partly empty tile
+]
+
+
+def _pair_case(dev, n, H, P, N1, seed):
+    """Operands of one fused pair: t2, identity x, conv3 / conv1 weights and BatchNorm constants (bf16 tensors on `dev`)."""
+    g = torch.Generator().manual_seed(seed)
+    M, C3 = n * H * H, 4 * P
+    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(torch.bfloat16)
+    x = torch.randn(M, C3, generator=g).clamp_min(0).to(torch.bfloat16)
+    w3 = (torch.randn(C3, P, generator=g) * (2.0 / P) ** 0.5).to(torch.bfloat16)
+    w1 = (torch.randn(N1, C3, generator=g) * (2.0 / C3) ** 0.5).to(torch.bfloat16)
+    s3, h3 = torch.rand(C3, generator=g) + 0.5, torch.randn(C3, generator=g) * 0.1
+    s1, h1 = torch.rand(N1, generator=g) + 0.5, torch.randn(N1, generator=g) * 0.1
+    return [t.to(dev) for t in (t2, x, w3, w1, s3, h3, s1, h1)]
+
+
+@pytest.mark.parametrize("case", PAIR_CASES)
+def test_conv_pair_equals_two_convs_and_fp64(dev, case):
+    """conv_pair.hip: conv3 (+ identity, ReLU) of a block and conv1 of the next block in one kernel.  Bit-identical to the two
+    stand-alone launches (same K order, same k-slot assignment, same epilogue expression), the block output against an fp64
+    evaluation on identical operands, and rows beyond M untouched (ragged last tile)."""
+    from airpose_amd import _native as Nn
+    n, H, P, N1 = case
+    L = Nn.lib()
+    M, C3 = n * H * H, 4 * P
+    t2, x, w3, w1, s3, h3, s1, h1 = _pair_case(dev, n, H, P, N1, seed=100 + P + N1 + H)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    guard = 8                                                # rows behind M must stay as they were
+    out = torch.full((M + guard, C3), float("nan"), dtype=torch.bfloat16, device=dev)
+    t1n = torch.full((M + guard, N1), float("nan"), dtype=torch.bfloat16, device=dev)
+    Nn.check(L.ap_conv_pair_nhwc(p(t2), p(w3), p(s3), p(h3), p(x), p(w1), p(s1), p(h1), p(out), p(t1n), M, P, N1,
+                                 Nn.stream_ptr(dev)), "ap_conv_pair_nhwc")
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:].float()).all() and torch.isnan(t1n[M:].float()).all()
+    # the two stand-alone launches (ring kernel, configuration 11)
+    ref_out = torch.empty(M, C3, dtype=torch.bfloat16, device=dev)
+    ref_t1 = torch.empty(M, N1, dtype=torch.bfloat16, device=dev)
+    L.ap_set_conv_config(11)
+    try:
+        Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(t2), p(w3), p(s3), p(h3), p(x), p(ref_out), n, H, H, P, C3, 1, 1, 0, 1,
+                                  Nn.stream_ptr(dev)), "conv3")
+        Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(ref_out), p(w1), p(s1), p(h1), None, p(ref_t1), n, H, H, C3, N1, 1, 1, 0, 1,
+                                  Nn.stream_ptr(dev)), "conv1")
+        torch.cuda.synchronize()
+    finally:
+        L.ap_set_conv_config(-1)
+    assert torch.equal(out[:M], ref_out)
+    assert torch.equal(t1n[:M], ref_t1)
+    # fp64 on identical operands
+    want = (t2.double() @ w3.double().T) * s3.double() + h3.double() + x.double()
+    want = want.clamp_min(0)
+    assert rel_err(out[:M].double().cpu().numpy(), want.cpu().numpy()) < 6e-3
+    want1 = ((out[:M].double() @ w1.double().T) * s1.double() + h1.double()).clamp_min(0)
+    assert rel_err(t1n[:M].double().cpu().numpy(), want1.cpu().numpy()) < 6e-3
+
+
+def test_conv_pair_full_size_is_deterministic(dev):
+    """BASELINE-size layer3 pair (256 images: 50 176 pixels, 784 workgroups on 512 slots, hand-counted waits under full
+    memory load): repeated runs identical, equal to the two stand-alone kernels."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    n, H, P, N1 = 256, 14, 256, 256
+    M, C3 = n * H * H, 4 * P
+    t2, x, w3, w1, s3, h3, s1, h1 = _pair_case(dev, n, H, P, N1, seed=5)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    outs = []
+    for _ in range(3):
+        out = torch.full((M, C3), float("nan"), dtype=torch.bfloat16, device=dev)
+        t1n = torch.full((M, N1), float("nan"), dtype=torch.bfloat16, device=dev)
+        Nn.check(L.ap_conv_pair_nhwc(p(t2), p(w3), p(s3), p(h3), p(x), p(w1), p(s1), p(h1), p(out), p(t1n), M, P, N1,
+                                     Nn.stream_ptr(dev)), "ap_conv_pair_nhwc")
+        torch.cuda.synchronize()
+        outs.append((out, t1n))
+    ref_out = torch.empty(M, C3, dtype=torch.bfloat16, device=dev)
+    ref_t1 = torch.empty(M, N1, dtype=torch.bfloat16, device=dev)
+    Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(t2), p(w3), p(s3), p(h3), p(x), p(ref_out), n, H, H, P, C3, 1, 1, 0, 1,
+                              Nn.stream_ptr(dev)), "conv3")
+    Nn.check(L.ap_conv2d_nhwc(Nn.PRECISIONS["bf16"], p(ref_out), p(w1), p(s1), p(h1), None, p(ref_t1), n, H, H, C3, N1, 1, 1, 0, 1,
+                              Nn.stream_ptr(dev)), "conv1")
+    torch.cuda.synchronize()
+    for o, t in outs:
+        assert torch.equal(o, ref_out) and torch.equal(t, ref_t1)
+
+
+def test_trunk_with_and_without_fused_pairs_bitwise(netbf, dev):
+    """The trunk with the fused conv3 -> conv1 pairs (layer2 / layer3 identity blocks, layer2 -> layer3) against the same
+    trunk with one convolution per launch: identical features, bit for bit; 6 images make every pair's pixel count ragged."""
+    gen = torch.Generator(device="cpu").manual_seed(23)
+    x = torch.randn(6, 3, 224, 224, generator=gen).to(dev)
+    feats = []
+    try:
+        for on in (0, 1, 1):
+            netbf.set_fuse_pair(on)
+            feats.append(netbf.forward_feat_ext(x).clone())
+    finally:
+        netbf.set_fuse_pair(1)
+    assert torch.isfinite(feats[0]).all()
+    assert torch.equal(feats[0], feats[1]) and torch.equal(feats[1], feats[2])
+
+
 @pytest.mark.parametrize("cfg", [-1, 11, 12, 100])
 @pytest.mark.parametrize("case", CONV_CASES)
 def test_conv_primitive_split_bf16(dev, case, cfg):
