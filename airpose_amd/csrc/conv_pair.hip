@@ -38,7 +38,7 @@
 
 namespace {
 
-constexpr int PR_BM = 64, PR_TILE = 16384, PR_S = 4, PR_NT = 256, PR_RING = PR_S * PR_TILE;
+constexpr int PR_TILE = 16384;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PR_SAFE ? 0 : N) : "memory");
@@ -77,6 +77,22 @@ __device__ __forceinline__ f32x4 mfma16(const u32x4& w, const u32x4& x, const f3
     return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
 }
 
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+// two fp32 -> one dword of two bf16 (round to nearest even: the instruction the compiler emits for a (__bf16) cast, but
+// once per PAIR -- the cast gives one v_cvt_pk per value plus shifts / ors to merge)
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// ReLU on two packed bf16: as signed 16-bit integers negative values (sign bit set, -0 included) are below zero, positive
+// ones keep their order -- max(x, 0) per half; rounding is monotonic and keeps the sign, so relu-then-round == round-then-relu
+__device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t u) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(u));
+    return r;
+}
+
 // channel (within its 128) of row rho of a weight tile: lane group g4 of fragment pair q = f >> 1 owns channels
 // q*32 + g4*8 .. + 7 (fragment f = 2q + e holds e*4 .. e*4 + 3 of them)
 __host__ __device__ __forceinline__ int pr_row_channel(int rho) {
@@ -104,31 +120,30 @@ __global__ void __launch_bounds__(256) pair_pack_kernel(const bf16_t* __restrict
     *(u32x4*)(dst + (size_t)idx * 16) = *(const u32x4*)src;
 }
 
-template <int P, int N1>
-__global__ void __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_pair_kernel(const PairArgs p) {
-    constexpr int C3 = 4 * P, KP = P / 64, HN = N1 / 128, KG = 2 * HN, NB = C3 / 128, SPC = KP + KG, S = PR_S;
-    constexpr int NXF = P / 32;
-    constexpr int TAB3 = PR_RING, TAB1 = TAB3 + 2 * C3 * 4;
-    static_assert(SPC >= S, "the tail waits assume at least S tiles per chunk");
+// Timing-only builds (results WRONG, times valid): -DPR_ABLATE=<bits>
+//   1 no identity loads | 2 no stores | 4 no weight DMA after the prologue | 8 no MFMAs | 16 no epilogue arithmetic |
+//   32 return behind the prologue | 64 identity loads as 8 rows x 128 B per instruction (shape experiment) | 128 stores likewise
+#ifndef PR_ABLATE
+#define PR_ABLATE 0
+#endif
+
+template <int P, int N1, int NW, int S, int D, bool IDB>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_pair_kernel(const PairArgs p) {
+    constexpr int C3 = 4 * P, KP = P / 64, HN = N1 / 128, KG = 2 * HN, NB = C3 / 128, SPC = KP + KG;
+    constexpr int NXF = P / 32, NT = 64 * NW, LPW = 16 / NW, RING = S * PR_TILE;
+    constexpr int TAB3 = RING, TAB1 = TAB3 + 2 * C3 * 4;
+    static_assert(S >= 3 && S - 1 <= SPC && NB % 2 == 0 && (LPW == 4 || LPW == 2), "tail waits / chunk pairs / piece placement");
+    static_assert((S & (S - 1)) == 0, "ring offsets wrap with a mask");
+    static_assert(D == 8 || D == 16, "fragment registers: half a tile or a whole tile ahead");
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g4 = lane >> 4;
-    const int m = blockIdx.x * PR_BM + wave * 16 + lr;
+    const int m = blockIdx.x * (16 * NW) + wave * 16 + lr;
     const bool mok = m < p.M;
     const size_t mc = mok ? (size_t)m : (size_t)(p.M - 1);      // ragged tail: loads clamped, stores masked
 
-    // BatchNorm tables into LDS (read in the epilogues by inline-asm ds_read: a load the compiler counts would be fenced
-    // against the LDS-DMA writes of the ring with vmcnt(0))
-    {
-        float* t3 = (float*)(smem + TAB3);
-        float* t1 = (float*)(smem + TAB1);
-        for (int i = tid; i < C3; i += PR_NT) { t3[i] = p.s3[i]; t3[C3 + i] = p.h3[i]; }
-        for (int i = tid; i < N1; i += PR_NT) { t1[i] = p.s1[i]; t1[N1 + i] = p.h1[i]; }
-    }
-    __syncthreads();
-
-    const unsigned char* wnext = (const unsigned char*)p.wstream + (size_t)(wave * 4) * 1024 + lane * 16;   // next tile to issue
+    const unsigned char* wnext = (const unsigned char*)p.wstream + (size_t)(wave * LPW) * 1024 + lane * 16;   // next tile to issue
     const unsigned char* t2p = (const unsigned char*)p.t2 + (mc * P + g4 * 8) * 2;
     const unsigned char* resp = (const unsigned char*)p.res + (mc * C3 + g4 * 8) * 2;
     unsigned char* outp = (unsigned char*)p.out + ((size_t)m * C3 + g4 * 8) * 2;
@@ -138,139 +153,196 @@ __global__ void __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2
     asm volatile("" ::"s"(p.wstream), "s"(p.t2), "s"(p.res), "s"(p.out), "s"(p.t1n), "s"(p.M));
 
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
-    // A fragment of tile row f*16 + lr, K half s: chunk s*4 + g4 at position (s*4 + g4) ^ (lr & 7)
-    const uint32_t fb0 = lds0 + lr * 128 + ((g4 ^ (lr & 7)) << 4), fb1 = fb0 ^ 64u;
+    // A fragment of tile row f*16 + lr, K half s: chunk s*4 + g4 at position (s*4 + g4) ^ (lr & 7): byte ^ 64 for s = 1
+    const uint32_t fb0 = lds0 + lr * 128 + ((g4 ^ (lr & 7)) << 4);
     const uint32_t tb3 = lds0 + TAB3 + g4 * 32, tb1 = lds0 + TAB1 + g4 * 32;
 
     int so = 0, si = (S - 1) * PR_TILE;                      // ring byte offsets: tile of this step / slot of the tile issued in it
     auto piece = [&](int i, bool issue) {                   // one 1-KiB piece of the tile S-1 steps ahead
         if (issue)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(wnext + i * 1024),
-                                             (__attribute__((address_space(3))) void*)(smem + si + (wave * 4 + i) * 1024), 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)(smem + si + (wave * LPW + i) * 1024), 16, 0, 0);
     };
-    // one weight tile: 16 MFMAs (8 row fragments x 2 K halves) on the 16 pixels of this wave
-    auto step = [&](f32x4* acc, const u32x4& b0, const u32x4& b1, bool issue) {
-        const uint32_t a0 = fb0 + so, a1 = fb1 + so;
-        u32x4 wa[4], wb[4];
-        wa[0] = lds_read_b128<0>(a0); wa[1] = lds_read_b128<2048>(a0); wa[2] = lds_read_b128<4096>(a0); wa[3] = lds_read_b128<6144>(a0);
-        wb[0] = lds_read_b128<8192>(a0); wb[1] = lds_read_b128<10240>(a0); wb[2] = lds_read_b128<12288>(a0); wb[3] = lds_read_b128<14336>(a0);
-        wait_lgkmcnt<4>();
+    auto mm = [&](f32x4& c, const u32x4& w, const u32x4& x) {
+        if (PR_ABLATE & 8) asm volatile("" : "+v"(c) : "v"(w), "v"(x)); else c = mfma16(w, x, c);
+    };
+    // Fragment k of a tile (k = 8 s + f: row fragment f, K half s) lives in wf[k % D].  The fragment reads run D fragments
+    // AHEAD of the MFMAs and straight across tile boundaries and barriers: the barrier of step t also covers tile t+1 (each
+    // wave waits for its pieces of tile t+1 before it), so fragments of tile t+1 are requested while tile t is multiplied --
+    // an LDS read has D - 4 .. D MFMAs of cover instead of a restart of the read pipeline behind every barrier (the first
+    // version, four fragments of cover, spent 1 900 cycles per tile on 256 cycles of MFMAs with no memory traffic at all).
+    u32x4 wf[D];
+    auto rd4 = [&](auto G, uint32_t a) {                     // fragments 4G .. 4G+3 of the tile at a (= fb0 + slot offset)
+        constexpr int g = G;
+        const uint32_t b = g >= 2 ? a ^ 64u : a;
+        constexpr int o = (g & 1) * 8192;
+        wf[(4 * g) % D] = lds_read_b128<o>(b); wf[(4 * g + 1) % D] = lds_read_b128<o + 2048>(b);
+        wf[(4 * g + 2) % D] = lds_read_b128<o + 4096>(b); wf[(4 * g + 3) % D] = lds_read_b128<o + 6144>(b);
+    };
+    // one weight tile: 16 MFMAs (8 row fragments x 2 K halves) on the 16 pixels of this wave; the wave's LPW DMA pieces go
+    // out between the MFMA groups (a piece costs its wave ~100 cycles of issue: under the matrix pipe, not in front of it).
+    // pre: the next tile exists (its fragments are requested as this tile's are consumed)
+    auto step = [&](f32x4* acc, const u32x4& b0, const u32x4& b1, bool issue, bool pre) {
+        const uint32_t a0 = fb0 + so, an = fb0 + ((so + PR_TILE) & (RING - 1));
+        sfor<0, 4>([&](auto G) {
+            constexpr int g = G;
+            if (pre) wait_lgkmcnt<D - 4>(); else wait_lgkmcnt<0>();     // (last tile: nothing younger follows its fragments)
 #pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = mfma16(wa[f], b0, acc[f]);
-        __builtin_amdgcn_sched_barrier(0);
-        piece(0, issue);
-        wa[0] = lds_read_b128<0>(a1); wa[1] = lds_read_b128<2048>(a1); wa[2] = lds_read_b128<4096>(a1); wa[3] = lds_read_b128<6144>(a1);
-        wait_lgkmcnt<4>();
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[4 + f] = mfma16(wb[f], b0, acc[4 + f]);
-        __builtin_amdgcn_sched_barrier(0);
-        piece(1, issue);
-        wb[0] = lds_read_b128<8192>(a1); wb[1] = lds_read_b128<10240>(a1); wb[2] = lds_read_b128<12288>(a1); wb[3] = lds_read_b128<14336>(a1);
-        wait_lgkmcnt<4>();
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[f] = mfma16(wa[f], b1, acc[f]);
-        __builtin_amdgcn_sched_barrier(0);
-        piece(2, issue);
-        wait_lgkmcnt<0>();
-#pragma unroll
-        for (int f = 0; f < 4; ++f) acc[4 + f] = mfma16(wb[f], b1, acc[4 + f]);
-        __builtin_amdgcn_sched_barrier(0);
-        piece(3, issue);
+            for (int f = 0; f < 4; ++f) mm(acc[(4 * g + f) & 7], wf[(4 * g + f) % D], g < 2 ? b0 : b1);
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (LPW == 4) piece(g, issue);
+            else if constexpr (g & 1) piece(g >> 1, issue);
+            // refill the four registers just consumed: D = 16 -> the same fragments of the next tile; D = 8 -> the other K
+            // half of this tile (groups 0, 1) or the first K half of the next tile (groups 2, 3)
+            if constexpr (D == 16) { if (pre) rd4(G, an); }
+            else if constexpr (g < 2) rd4(std::integral_constant<int, g + 2>{}, a0);
+            else { if (pre) rd4(std::integral_constant<int, g - 2>{}, an); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
         if (issue) wnext += PR_TILE;
-        so = (so + PR_TILE) & (PR_RING - 1);
-        si = (si + PR_TILE) & (PR_RING - 1);
+        so = (so + PR_TILE) & (RING - 1);
+        si = (si + PR_TILE) & (RING - 1);
     };
     // BN + (identity) + ReLU + bf16 of the 8 consecutive channels a lane holds in fragments (2q, 2q+1); sc / sh: their tables
     auto bn8 = [&](const f32x4& lo, const f32x4& hi, const f32x4& s0, const f32x4& s1, const f32x4& h0, const f32x4& h1,
                    const u32x4* res) -> u32x4 {
-        float v[8];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            v[e] = lo[e] * s0[e] + h0[e];
-            v[4 + e] = hi[e] * s1[e] + h1[e];
+        if (PR_ABLATE & 16) {
+            u32x4 o = res ? *res : u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            asm volatile("" : "+v"(o) : "v"(lo), "v"(hi), "v"(s0), "v"(s1), "v"(h0), "v"(h1));
+            return o;
         }
+        // two values per instruction (v_pk_fma_f32 / v_pk_add_f32: the same IEEE fma / add per component as the scalar
+        // epilogue of the stand-alone kernels), one v_cvt_pk + one packed integer max per pair
+        f32x2 v0 = __builtin_elementwise_fma(lo.xy, s0.xy, h0.xy), v1 = __builtin_elementwise_fma(lo.zw, s0.zw, h0.zw);
+        f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
         if (res) {
             const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
-            float a, b;
-            unpack_bf16x2(r0, a, b); v[0] += a; v[1] += b;
-            unpack_bf16x2(r1, a, b); v[2] += a; v[3] += b;
-            unpack_bf16x2(r2, a, b); v[4] += a; v[5] += b;
-            unpack_bf16x2(r3, a, b); v[6] += a; v[7] += b;
+            v0 += f32x2{__builtin_bit_cast(float, r0 << 16), __builtin_bit_cast(float, r0 & 0xffff0000u)};
+            v1 += f32x2{__builtin_bit_cast(float, r1 << 16), __builtin_bit_cast(float, r1 & 0xffff0000u)};
+            v2 += f32x2{__builtin_bit_cast(float, r2 << 16), __builtin_bit_cast(float, r2 & 0xffff0000u)};
+            v3 += f32x2{__builtin_bit_cast(float, r3 << 16), __builtin_bit_cast(float, r3 & 0xffff0000u)};
         }
         u32x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(fmaxf(v[2 * e], 0.f), fmaxf(v[2 * e + 1], 0.f));
+        o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));
+        o.z = relu_pk_bf16(cvt_pk_bf16(v2.x, v2.y)); o.w = relu_pk_bf16(cvt_pk_bf16(v3.x, v3.y));
         return o;
     };
+    auto load_identity = [&](int nb, u32x4 (&r)[4]) {        // 4 x 16 B per lane: channels nb*128 + q*32 + g4*8 .. + 7
+        if (PR_ABLATE & 1) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r[q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+            return;
+        }
+        if (PR_ABLATE & 64) {                                // same 4 KiB of the wave's 16 pixels, full 128-byte lines per row
+            const unsigned char* rq = (const unsigned char*)p.res + ((size_t)(mc - lr + (lane >> 3)) * C3 + nb * 128) * 2 + (lane & 7) * 16;
+            r[0] = gload_b128<0>(rq); r[1] = gload_b128<128>(rq);
+            rq += (size_t)8 * C3 * 2;
+            r[2] = gload_b128<0>(rq); r[3] = gload_b128<128>(rq);
+            return;
+        }
+        const unsigned char* rp = resp + nb * 256;
+        r[0] = gload_b128<0>(rp); r[1] = gload_b128<64>(rp); r[2] = gload_b128<128>(rp); r[3] = gload_b128<192>(rp);
+    };
 
-    // ---------------------------------------------------------------- prologue: t2 fragments, tiles 0 .. S-2
+    // ---------------------------------------------------------------- prologue: t2 fragments, (identity of chunk 0,)
+    // tiles 0 .. S-2, the first D fragments of tile 0
     u32x4 xf[NXF];
     sfor<0, NXF>([&](auto I) { xf[I] = gload_b128<I * 64>(t2p); });
+    // identity pieces of a chunk, then its packed result (= conv1 operand).  IDB: two sets, the next chunk's identity is
+    // requested a whole chunk ahead; otherwise one set, requested at the chunk's first step
+    u32x4 ra[4], rb[IDB ? 4 : 1];
+    if constexpr (IDB) load_identity(0, ra);
 #pragma unroll
     for (int t = 0; t < S - 1; ++t) {
         si = t * PR_TILE;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) piece(i, true);
+        for (int i = 0; i < LPW; ++i) piece(i, true);
         wnext += PR_TILE;
     }
     si = (S - 1) * PR_TILE;
     f32x4 acc1[HN * 8];
 #pragma unroll
     for (int i = 0; i < HN * 8; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    u32x4 ry[4];                                             // identity pieces of the chunk, then its packed result (= conv1 operand)
+    // BatchNorm tables into LDS while those requests fly (read in the epilogues by inline-asm ds_read: a load the compiler
+    // counts would be fenced against the LDS-DMA writes of the ring with vmcnt(0)).  The compiler waits for its table loads
+    // with vmcnt(0), which covers the t2 fragments, the identity and the first tiles as well
+    {
+        float* t3 = (float*)(smem + TAB3);
+        float* t1 = (float*)(smem + TAB1);
+        for (int i = tid; i < C3; i += NT) { t3[i] = p.s3[i]; t3[C3 + i] = p.h3[i]; }
+        for (int i = tid; i < N1; i += NT) { t1[i] = p.s1[i]; t1[N1 + i] = p.h1[i]; }
+    }
+    wait_vmcnt<0>();
+#pragma unroll
+    for (int i = 0; i < NXF; ++i) asm volatile("" : "+v"(xf[i]));
+    __syncthreads();
+    rd4(std::integral_constant<int, 0>{}, fb0);
+    rd4(std::integral_constant<int, 1>{}, fb0);
+    if constexpr (D == 16) { rd4(std::integral_constant<int, 2>{}, fb0); rd4(std::integral_constant<int, 3>{}, fb0); }
 
-    for (int nb = 0; nb < NB; ++nb) {
+    if (PR_ABLATE & 32) {                                    // timing build: the prologue alone
+        wait_lgkmcnt<0>();
+        asm volatile("" ::"v"(wf[0]), "v"(wf[D - 1]), "v"(xf[0]), "v"(xf[NXF - 1]), "v"(ra[0]), "v"(outp), "v"(t1p), "v"(resp));
+        return;
+    }
+    // one 128-channel chunk of conv3 + its share of conv1; cur: this chunk's identity / result, nxt: the next chunk's identity
+    auto chunk = [&](int nb, u32x4 (&cur)[4], u32x4 (&nxt)[IDB ? 4 : 1]) {
         const bool lastc = nb == NB - 1;
         f32x4 acc3[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         sfor<0, SPC>([&](auto J) {
             constexpr int j = J;
-            // own pieces of this step's tile have landed: S-2 younger tiles may stay in flight (fewer at the very end)
-            if (lastc && j == SPC - 1) wait_vmcnt<0>();
-            else if (lastc && j == SPC - 2) wait_vmcnt<4>();
-            else wait_vmcnt<4 * (S - 2)>();
-            if constexpr (j == 0) {                          // (first chunk: the t2 fragments are older than tile 0's pieces)
-#pragma unroll
-                for (int i = 0; i < NXF; ++i) asm volatile("" : "+v"(xf[i]));
-            }
-            __builtin_amdgcn_s_barrier();                    // everybody's pieces landed; the slot read last step is free
-            const bool issue = !(lastc && j + S - 1 >= SPC);
+            // own pieces of the NEXT step's tile have landed (its fragments are requested during this step): S-3 younger
+            // tiles may stay in flight, fewer at the very end; every other operation in the queue only makes the wait
+            // conservative.  After the barrier everybody's pieces of that tile have landed and the slot read last step is free.
+            constexpr int rem = SPC - 1 - j;                 // steps after this one in the chunk
+            constexpr int yl = rem - 1 < S - 3 ? (rem - 1 > 0 ? rem - 1 : 0) : S - 3;
+            if (lastc) { if constexpr (rem > 0) wait_vmcnt<LPW * yl>(); } else wait_vmcnt<LPW * (S - 3)>();
+            __builtin_amdgcn_s_barrier();
+            const bool issue = !(PR_ABLATE & 4) && !(lastc && rem < S - 1);
+            const bool pre = !(lastc && rem == 0);
             if constexpr (j < KP) {
-                step(acc3, xf[2 * j], xf[2 * j + 1], issue);
+                step(acc3, xf[2 * j], xf[2 * j + 1], issue, pre);
             } else {
                 constexpr int g = j - KP, kh = g / HN, hn = g % HN;
-                step(&acc1[hn * 8], ry[2 * kh], ry[2 * kh + 1], issue);
+                step(&acc1[hn * 8], cur[2 * kh], cur[2 * kh + 1], issue, pre);
             }
-            if constexpr (j == 0) {                          // identity of this chunk: 4 x 16 B per lane, behind the step's DMA pieces
-                const unsigned char* rp = resp + nb * 256;
-                ry[0] = gload_b128<0>(rp); ry[1] = gload_b128<64>(rp); ry[2] = gload_b128<128>(rp); ry[3] = gload_b128<192>(rp);
+            if constexpr (j == 0) {                          // behind this step's DMA pieces
+                if constexpr (IDB) { if (!lastc) load_identity(nb + 1, nxt); }
+                else load_identity(nb, cur);
             }
             if constexpr (j == KP - 1) {
-                // ---------------------------------------------------- conv3 epilogue of chunk nb, in registers
-                // younger than the identity loads: the DMA pieces of steps 1 .. KP-1 of this chunk (those that were issued)
-                constexpr int YS = 4 * (KP - 1);
-                constexpr int nl = (KP - 1 < SPC - S ? KP - 1 : (SPC - S > 0 ? SPC - S : 0));
-                if (lastc) wait_vmcnt<4 * nl>(); else wait_vmcnt<YS>();
-                asm volatile("" : "+v"(ry[0]), "+v"(ry[1]), "+v"(ry[2]), "+v"(ry[3]));
+                // ---------------------------------------------------- conv3 epilogue of chunk nb, in registers.
+                // Certainly younger than this chunk's identity loads -- IDB: the DMA pieces of steps 1 .. SPC-1 of the previous
+                // chunk (S-1 <= SPC: every step of a chunk that is not the last one issues), of the prologue for chunk 0;
+                // otherwise: the pieces of steps 1 .. KP-1 of this chunk (those that were issued)
+                if constexpr (IDB) {
+                    if (nb == 0) wait_vmcnt<LPW * (S - 1)>(); else wait_vmcnt<(LPW * (SPC - 1) < 60 ? LPW * (SPC - 1) : 60)>();
+                } else {
+                    constexpr int nl = KP - 1 < SPC - S ? KP - 1 : (SPC - S > 0 ? SPC - S : 0);
+                    if (lastc) wait_vmcnt<LPW * nl>(); else wait_vmcnt<LPW * (KP - 1)>();
+                }
+                asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
                 const uint32_t ta = tb3 + nb * 512;
-                f32x4 s0 = lds_read_f32x4<0>(ta), s1 = lds_read_f32x4<16>(ta), h0 = lds_read_f32x4<C3 * 4>(ta), h1 = lds_read_f32x4<C3 * 4 + 16>(ta);
                 sfor<0, 4>([&](auto Q) {
                     constexpr int q = Q;
-                    f32x4 ns0, ns1, nh0, nh1;
-                    if constexpr (q < 3) {
-                        ns0 = lds_read_f32x4<(q + 1) * 128>(ta); ns1 = lds_read_f32x4<(q + 1) * 128 + 16>(ta);
-                        nh0 = lds_read_f32x4<C3 * 4 + (q + 1) * 128>(ta); nh1 = lds_read_f32x4<C3 * 4 + (q + 1) * 128 + 16>(ta);
-                        wait_lgkmcnt<4>();
-                    } else {
-                        wait_lgkmcnt<0>();
-                    }
-                    ry[q] = bn8(acc3[2 * q], acc3[2 * q + 1], s0, s1, h0, h1, &ry[q]);
-                    if (mok) *(u32x4*)(outp + nb * 256 + q * 64) = ry[q];
-                    if constexpr (q < 3) { s0 = ns0; s1 = ns1; h0 = nh0; h1 = nh1; }
+                    const f32x4 s0 = lds_read_f32x4<q * 128>(ta), s1 = lds_read_f32x4<q * 128 + 16>(ta);
+                    const f32x4 h0 = lds_read_f32x4<C3 * 4 + q * 128>(ta), h1 = lds_read_f32x4<C3 * 4 + q * 128 + 16>(ta);
+                    wait_lgkmcnt<0>();
+                    cur[q] = bn8(acc3[2 * q], acc3[2 * q + 1], s0, s1, h0, h1, &cur[q]);
+                    if (PR_ABLATE & 2) asm volatile("" ::"v"(cur[q]), "v"(outp));   // (timing build: keep the value live)
+                    else if (PR_ABLATE & 128) {
+                        unsigned char* oq = (unsigned char*)p.out + ((size_t)(mc - lr + (lane >> 3) + (q >> 1) * 8) * C3 + nb * 128) * 2 + (lane & 7) * 16 + (q & 1) * 128;
+                        *(u32x4*)oq = cur[q];
+                    } else if (mok) *(u32x4*)(outp + nb * 256 + q * 64) = cur[q];
                 });
             }
         });
+    };
+    for (int nb = 0; nb < NB; nb += 2) {
+        if constexpr (IDB) { chunk(nb, ra, rb); chunk(nb + 1, rb, ra); }
+        else { chunk(nb, ra, rb); chunk(nb + 1, ra, rb); }
     }
     // ---------------------------------------------------------------- conv1 epilogue: BN + ReLU + bf16, 16-byte stores
     sfor<0, HN * 4>([&](auto I) {
@@ -279,16 +351,17 @@ __global__ void __launch_bounds__(PR_NT) __attribute__((amdgpu_waves_per_eu(2, 2
         const f32x4 s0 = lds_read_f32x4<0>(ta), s1 = lds_read_f32x4<16>(ta), h0 = lds_read_f32x4<N1 * 4>(ta), h1 = lds_read_f32x4<N1 * 4 + 16>(ta);
         wait_lgkmcnt<0>();
         const u32x4 o = bn8(acc1[hn * 8 + 2 * q], acc1[hn * 8 + 2 * q + 1], s0, s1, h0, h1, nullptr);
-        if (mok) *(u32x4*)(t1p + (hn * 128 + q * 32) * 2) = o;
+        if (PR_ABLATE & 2) asm volatile("" ::"v"(o), "v"(t1p));
+        else if (mok) *(u32x4*)(t1p + (hn * 128 + q * 32) * 2) = o;
     });
 }
 
-template <int P, int N1>
+template <int P, int N1, int NW, int S, int D, bool IDB>
 hipError_t launch_pair(const PairArgs& a, hipStream_t st) {
     static bool attr_set[AP_MAX_DEVICES] = {};
-    auto kern = conv_pair_kernel<P, N1>;
-    constexpr int lds = PR_RING + (2 * 4 * P + 2 * N1) * 4;
-    static_assert(lds <= 81920, "two workgroups per CU");
+    auto kern = conv_pair_kernel<P, N1, NW, S, D, IDB>;
+    constexpr int lds = S * PR_TILE + (2 * 4 * P + 2 * N1) * 4;
+    static_assert(NW == 8 || lds <= 81920, "two workgroups per CU");
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
@@ -297,7 +370,7 @@ hipError_t launch_pair(const PairArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + PR_BM - 1) / PR_BM), dim3(PR_NT), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, st, a);
     return hipGetLastError();
 }
 
@@ -319,8 +392,11 @@ hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P,
 
 hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int N1, hipStream_t st) {
     if (a.M <= 0 || !a.t2 || !a.res || !a.wstream || !a.out || !a.t1n) return hipErrorInvalidValue;
-    if (P == 128 && N1 == 128) return launch_pair<128, 128>(a, st);
-    if (P == 128 && N1 == 256) return launch_pair<128, 256>(a, st);
-    if (P == 256 && N1 == 256) return launch_pair<256, 256>(a, st);
+    // four waves per workgroup, two workgroups per CU, 4-slot ring, half a tile of fragment look-ahead.  Measured and not
+    // kept (tools/pair_bench.py, 256 images): eight waves x one workgroup per CU (half the weight DMA per MFMA) is 4-10 %
+    // slower; a whole tile of fragment look-ahead (64 registers) times the same
+    if (P == 128 && N1 == 128) return launch_pair<128, 128, 4, 4, 8, true>(a, st);
+    if (P == 128 && N1 == 256) return launch_pair<128, 256, 4, 4, 8, true>(a, st);
+    if (P == 256 && N1 == 256) return launch_pair<256, 256, 4, 4, 8, false>(a, st);
     return hipErrorInvalidValue;
 }

@@ -277,6 +277,8 @@ def main():
     if not args.dual_stream:
         torch.zeros(1, device=dev)
         net.set_dual_stream(0)
+    if os.environ.get("AIRPOSE_FUSE_PAIR"):                 # A/B aid: fused conv3 -> conv1 pairs on (default) / off
+        net.set_fuse_pair(int(os.environ["AIRPOSE_FUSE_PAIR"]))
     if os.environ.get("AIRPOSE_CONV_CONFIG"):                # A/B aid: tile configuration of the conv kernels (ap_set_conv_config)
         from airpose_amd import _native as Nn
         Nn.check(Nn.lib().ap_set_conv_config(int(os.environ["AIRPOSE_CONV_CONFIG"])), "ap_set_conv_config")
