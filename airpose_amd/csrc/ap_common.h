@@ -16,8 +16,16 @@ __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-even
     return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
+// two fp32 -> one dword of two bf16, round to nearest even.  One v_cvt_pk_bf16_f32 for the PAIR: written as two (__bf16) casts
+// and an or, hipcc emits the same instruction once per VALUE (second source a dummy) plus a shift / or to merge them -- three
+// VALU instructions per pair in every epilogue of the trunk instead of one (identical results: it is the same conversion).
 __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+#ifdef AP_PACK_CAST                                          // A/B build: the two-cast form
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+#endif
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
 }
 __device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) {
     lo = __builtin_bit_cast(float, u << 16);
