@@ -61,6 +61,7 @@ SIGNATURES = {
     "ap_net_set_fuse_block": (_i, [_vp, _i]),
     "ap_net_set_fuse_pair": (_i, [_vp, _i]),
     "ap_conv_pair_nhwc": (_i, [_vp] * 10 + [_i] * 3 + [_vp]),
+    "ap_conv_pair_ds_nhwc": (_i, [_vp] * 9 + [_i] * 6 + [_vp]),
     "ap_bottleneck64_nhwc": (_i, [_vp] * 11 + [_i] * 5 + [_vp]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),
     "ap_smplx_destroy": (None, [_vp]),

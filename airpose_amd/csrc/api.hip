@@ -221,7 +221,7 @@ struct ap_net {
     // trunk
     DevBuf stem_w, stem_wpk, stem_wpk_lo, stem_scale, stem_shift;   // stem_wpk_lo: low plane of the split-bf16 stem weights
     struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false;
-                   DevBuf pair; int pair_p = 0, pair_n1 = 0; };   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
+                   DevBuf pair; int pair_p = 0, pair_p2 = 0, pair_c3 = 0, pair_n1 = 0; };   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
     std::vector<Block> blocks;
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
@@ -520,16 +520,22 @@ int finalize_trunk(ap_net* h) {
             }
             inpl = pl * 4;
         }
-    // conv3 of an identity block + conv1 of the next block (conv_pair.hip): the two weight matrices as one stream of
-    // 16-KiB tiles in the order the fused kernel consumes them, built on the device from the rows packed above
+    // conv3 of a block + conv1 of the next block (conv_pair.hip): the two weight matrices as one stream of 16-KiB tiles in
+    // the order the fused kernel consumes them, built on the device from the rows packed above.  Identity blocks: conv3 +
+    // identity; stage-first blocks: conv3 with the downsample branch folded in as a second K segment (pack_c3_ds), with the
+    // next conv1 where the registers allow, alone otherwise
     if (h->prec == AP_PREC_BF16)
         for (size_t b = 0; b + 1 < h->blocks.size(); ++b) {
             ap_net::Block &A = h->blocks[b], &N = h->blocks[b + 1];
-            const int P = A.c3.cin, N1 = N.c1.cout;
-            if (A.has_down || A.c3.cout != 4 * P || N.c1.cin != 4 * P || !ap_conv_pair_supported(P, N1)) continue;
-            HIP_TRY(A.pair.reserve(ap_conv_pair_stream_bytes(P, N1)));
-            HIP_TRY(ap_launch_pair_pack(A.c3.w.p, N.c1.w.p, A.pair.p, P, N1, nullptr));
-            A.pair_p = P; A.pair_n1 = N1;
+            const Layer& L3 = A.has_down ? A.c3ds : A.c3;
+            const int P = L3.cin, P2 = A.has_down ? L3.cin2 : 0, C3 = L3.cout;
+            int N1 = N.c1.cout;
+            if (N.c1.cin != C3) continue;
+            if (!ap_conv_pair_supported(P, P2, C3, N1)) N1 = 0;
+            if (!ap_conv_pair_supported(P, P2, C3, N1)) continue;
+            HIP_TRY(A.pair.reserve(ap_conv_pair_stream_bytes(P, P2, C3, N1)));
+            HIP_TRY(ap_launch_pair_pack(L3.w.p, N1 ? N.c1.w.p : nullptr, A.pair.p, P, P2, C3, N1, nullptr));
+            A.pair_p = P; A.pair_p2 = P2; A.pair_c3 = C3; A.pair_n1 = N1;
         }
     HIP_TRY(hipDeviceSynchronize());
     return AP_OK;
@@ -757,17 +763,21 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, kind, st))) return rc;
         t1_ready = false;
         if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, kind, st))) return rc;
-        if (bf && h->fuse_pair && B.pair_p && &B != &h->blocks.back()) {
-            // identity block: conv3 (+ identity, ReLU) AND the next block's conv1 in one kernel -- the block output is
-            // written once and not read back for conv1 (model_copenet.py:38-45 of this block, :29-31 of the next)
+        if (bf && h->fuse_pair && B.pair_p && &B != &h->blocks.back() && (!B.has_down || h->fuse_ds)) {
+            // conv3 (+ identity | + folded downsample, ReLU) AND -- where the pair carries it -- the next block's conv1 in one
+            // kernel: the block output is written once and not read back for conv1 (model_copenet.py:38-45 of this block,
+            // :29-31 of the next)
             const ap_net::Block& Nx = *(&B + 1);
+            const Layer& L3 = B.has_down ? B.c3ds : B.c3;
             PairArgs a{};
-            a.t2 = w.ws_t2.p; a.res = cur; a.wstream = B.pair.p;
-            a.s3 = B.c3.scale.as<float>(); a.h3 = B.c3.shift.as<float>();
+            a.t2 = w.ws_t2.p; a.wstream = B.pair.p;
+            a.s3 = L3.scale.as<float>(); a.h3 = L3.shift.as<float>();
             a.s1 = Nx.c1.scale.as<float>(); a.h1 = Nx.c1.shift.as<float>();
             a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho;
-            HIP_TRY(ap_launch_conv_pair(a, B.pair_p, B.pair_n1, st));
-            t1_ready = true;
+            if (B.has_down) { a.x2 = cur; a.Ho = a.Wo = Ho; a.H2 = a.W2 = H; a.stride2 = L3.stride2; }
+            else a.res = cur;
+            HIP_TRY(ap_launch_conv_pair(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
+            t1_ready = B.pair_n1 > 0;
         } else if (B.has_down && h->fuse_ds) {
             if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, kind, st))) return rc;
         } else {
@@ -1153,21 +1163,47 @@ int ap_conv_pair_nhwc(const void* t2, const void* w3, const float* s3, const flo
                       const float* s1, const float* h1, void* out, void* t1n, int M, int P, int N1, void* stream) {
     if (!t2 || !w3 || !s3 || !h3 || !res || !w1 || !s1 || !h1 || !out || !t1n || M <= 0)
         return fail(AP_EINVAL, "ap_conv_pair_nhwc: bad argument");
-    if (!ap_conv_pair_supported(P, N1)) return fail(AP_ESHAPE, "ap_conv_pair_nhwc: (P, N1) must be (128,128), (128,256) or (256,256)");
-    // the weight stream of the last (w3, w1) pair is kept (tools/conv_bench.py times repeated calls)
+    if (!ap_conv_pair_supported(P, 0, 4 * P, N1)) return fail(AP_ESHAPE, "ap_conv_pair_nhwc: (P, N1) must be (128,128), (128,256) or (256,256)");
+    // the weight stream of the last (w3, w1) pair is kept (tools/pair_bench.py times repeated calls)
     static const void *k3 = nullptr, *k1 = nullptr;
     static int kp = 0, kn = 0;
     static DevBuf ws;
     hipStream_t st = (hipStream_t)stream;
     if (k3 != w3 || k1 != w1 || kp != P || kn != N1) {
         HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(ws.reserve(ap_conv_pair_stream_bytes(P, N1)));
-        HIP_TRY(ap_launch_pair_pack(w3, w1, ws.p, P, N1, st));
+        HIP_TRY(ws.reserve(ap_conv_pair_stream_bytes(P, 0, 4 * P, N1)));
+        HIP_TRY(ap_launch_pair_pack(w3, w1, ws.p, P, 0, 4 * P, N1, st));
         k3 = w3; k1 = w1; kp = P; kn = N1;
     }
     PairArgs a{};
     a.t2 = t2; a.res = res; a.wstream = ws.p; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n; a.M = M;
-    HIP_TRY(ap_launch_conv_pair(a, P, N1, st));
+    HIP_TRY(ap_launch_conv_pair(a, P, 0, 4 * P, N1, st));
+    return AP_OK;
+}
+
+int ap_conv_pair_ds_nhwc(const void* t2, const void* x, const void* w3d, const float* h3, const void* w1, const float* s1,
+                         const float* h1, void* out, void* t1n, int N, int Ho, int P, int P2, int stride, int N1, void* stream) {
+    if (!t2 || !x || !w3d || !h3 || !out || N <= 0 || Ho <= 0 || (N1 > 0 && (!w1 || !s1 || !h1 || !t1n)))
+        return fail(AP_EINVAL, "ap_conv_pair_ds_nhwc: bad argument");
+    const int C3 = 4 * P;
+    if (!ap_conv_pair_supported(P, P2, C3, N1) || stride < 1 || stride > 2)
+        return fail(AP_ESHAPE, "ap_conv_pair_ds_nhwc: (P, P2, N1) must be (128,256,128) or (256,512,0); stride 1 or 2");
+    static const void *k3 = nullptr, *k1 = nullptr;
+    static int kp = 0, kn = 0;
+    static DevBuf ws, ones;
+    hipStream_t st = (hipStream_t)stream;
+    if (k3 != w3d || k1 != w1 || kp != P || kn != N1) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(ws.reserve(ap_conv_pair_stream_bytes(P, P2, C3, N1)));
+        HIP_TRY(ap_launch_pair_pack(w3d, w1, ws.p, P, P2, C3, N1, st));
+        std::vector<float> one(C3, 1.f);                    // the BatchNorm scales are folded into w3d (pack_c3_ds)
+        HIP_TRY(upload(ones, one.data(), one.size() * 4));
+        k3 = w3d; k1 = w1; kp = P; kn = N1;
+    }
+    PairArgs a{};
+    a.t2 = t2; a.x2 = x; a.wstream = ws.p; a.s3 = ones.as<float>(); a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n;
+    a.M = N * Ho * Ho; a.Ho = a.Wo = Ho; a.H2 = a.W2 = Ho * stride; a.stride2 = stride;
+    HIP_TRY(ap_launch_conv_pair(a, P, P2, C3, N1, st));
     return AP_OK;
 }
 

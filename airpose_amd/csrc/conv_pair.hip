@@ -104,18 +104,18 @@ __host__ __device__ __forceinline__ int pr_row_channel(int rho) {
 // kh of the chunk and each 128-row half hn of conv1: one tile of conv1.  Tile = 128 rows x 128 B, 16-byte chunk c of row
 // rho at position c ^ (rho & 7); thread = one 16-byte chunk.
 __global__ void __launch_bounds__(256) pair_pack_kernel(const bf16_t* __restrict__ w3, const bf16_t* __restrict__ w1,
-                                                        unsigned char* __restrict__ dst, int P, int N1) {
-    const int KP = P / 64, HN = N1 / 128, SPC = KP + 2 * HN, T = (4 * P / 128) * SPC;
+                                                        unsigned char* __restrict__ dst, int KA, int C3, int N1) {
+    const int KP = KA / 64, HN = N1 / 128, SPC = KP + 2 * HN, T = (C3 / 128) * SPC;
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= T * 1024) return;
     const int t = idx >> 10, rho = (idx >> 3) & 127, c = (idx & 7) ^ (rho & 7);
     const int nb = t / SPC, j = t - nb * SPC, chl = pr_row_channel(rho);
     const bf16_t* src;
     if (j < KP) {
-        src = w3 + (size_t)(nb * 128 + chl) * P + j * 64 + c * 8;
+        src = w3 + (size_t)(nb * 128 + chl) * KA + j * 64 + c * 8;
     } else {
         const int g = j - KP, kh = g / HN, hn = g - kh * HN;
-        src = w1 + (size_t)(hn * 128 + chl) * (4 * P) + nb * 128 + kh * 64 + c * 8;
+        src = w1 + (size_t)(hn * 128 + chl) * C3 + nb * 128 + kh * 64 + c * 8;
     }
     *(u32x4*)(dst + (size_t)idx * 16) = *(const u32x4*)src;
 }
@@ -127,10 +127,14 @@ __global__ void __launch_bounds__(256) pair_pack_kernel(const bf16_t* __restrict
 #define PR_ABLATE 0
 #endif
 
-template <int P, int N1, int NW, int S, int D, bool IDB>
+// P: channels of t2 (first K segment); P2: channels of the second K segment (the folded downsample branch of a stage's first
+// block, model_copenet.py:41-42,97-102: x of the block sampled at the strided pixel, 1x1; 0 = identity block); C3: conv3
+// output channels; N1: conv1 width of the next block (0 = none: conv3 alone); RES: the block input is added before the ReLU
+template <int P, int P2, int C3, int N1, bool RES, int NW, int S, int D, bool IDB>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_pair_kernel(const PairArgs p) {
-    constexpr int C3 = 4 * P, KP = P / 64, HN = N1 / 128, KG = 2 * HN, NB = C3 / 128, SPC = KP + KG;
-    constexpr int NXF = P / 32, NT = 64 * NW, LPW = 16 / NW, RING = S * PR_TILE;
+    constexpr int KA = P + P2, KP = KA / 64, HN = N1 / 128, KG = 2 * HN, NB = C3 / 128, SPC = KP + KG;
+    constexpr int NXF = KA / 32, NXF1 = P / 32, NT = 64 * NW, LPW = 16 / NW, RING = S * PR_TILE;
+    static_assert(!(IDB && !RES) && (RES || P2 > 0) && P % 64 == 0 && P2 % 64 == 0, "identity look-ahead needs an identity");
     constexpr int TAB3 = RING, TAB1 = TAB3 + 2 * C3 * 4;
     static_assert(S >= 3 && S - 1 <= SPC && NB % 2 == 0 && (LPW == 4 || LPW == 2), "tail waits / chunk pairs / piece placement");
     static_assert((S & (S - 1)) == 0, "ring offsets wrap with a mask");
@@ -146,11 +150,16 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
     const unsigned char* wnext = (const unsigned char*)p.wstream + (size_t)(wave * LPW) * 1024 + lane * 16;   // next tile to issue
     const unsigned char* t2p = (const unsigned char*)p.t2 + (mc * P + g4 * 8) * 2;
     const unsigned char* resp = (const unsigned char*)p.res + (mc * C3 + g4 * 8) * 2;
+    const unsigned char* x2p = t2p;                          // second K segment: pixel (ho*stride2, wo*stride2) of image n in x2
+    if constexpr (P2 > 0) {
+        const int hw = p.Ho * p.Wo, n = (int)mc / hw, rem = (int)mc - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+        x2p = (const unsigned char*)p.x2 + ((((size_t)n * p.H2 + (size_t)ho * p.stride2) * p.W2 + (size_t)wo * p.stride2) * P2 + g4 * 8) * 2;
+    }
     unsigned char* outp = (unsigned char*)p.out + ((size_t)m * C3 + g4 * 8) * 2;
     unsigned char* t1p = (unsigned char*)p.t1n + ((size_t)m * N1 + g4 * 8) * 2;
     // every kernel-argument load completes here: a scalar load the compiler believes pending inside the loop costs an
     // s_waitcnt lgkmcnt(0) in front of each DMA instruction, which also drains the fragment reads in flight
-    asm volatile("" ::"s"(p.wstream), "s"(p.t2), "s"(p.res), "s"(p.out), "s"(p.t1n), "s"(p.M));
+    asm volatile("" ::"s"(p.wstream), "s"(p.t2), "s"(p.res), "s"(p.out), "s"(p.t1n), "s"(p.M), "s"(p.x2));
 
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // A fragment of tile row f*16 + lr, K half s: chunk s*4 + g4 at position (s*4 + g4) ^ (lr & 7): byte ^ 64 for s = 1
@@ -228,6 +237,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         return o;
     };
     auto load_identity = [&](int nb, u32x4 (&r)[4]) {        // 4 x 16 B per lane: channels nb*128 + q*32 + g4*8 .. + 7
+        if constexpr (!RES) return;
         if (PR_ABLATE & 1) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) r[q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
@@ -247,7 +257,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
     // ---------------------------------------------------------------- prologue: t2 fragments, (identity of chunk 0,)
     // tiles 0 .. S-2, the first D fragments of tile 0
     u32x4 xf[NXF];
-    sfor<0, NXF>([&](auto I) { xf[I] = gload_b128<I * 64>(t2p); });
+    sfor<0, NXF>([&](auto I) {
+        if constexpr (I < NXF1) xf[I] = gload_b128<I * 64>(t2p);
+        else xf[I] = gload_b128<(I - NXF1) * 64>(x2p);
+    });
     // identity pieces of a chunk, then its packed result (= conv1 operand).  IDB: two sets, the next chunk's identity is
     // requested a whole chunk ahead; otherwise one set, requested at the chunk's first step
     u32x4 ra[4], rb[IDB ? 4 : 1];
@@ -260,7 +273,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         wnext += PR_TILE;
     }
     si = (S - 1) * PR_TILE;
-    f32x4 acc1[HN * 8];
+    f32x4 acc1[HN > 0 ? HN * 8 : 1];
 #pragma unroll
     for (int i = 0; i < HN * 8; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // BatchNorm tables into LDS while those requests fly (read in the epilogues by inline-asm ds_read: a load the compiler
@@ -305,7 +318,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
             if constexpr (j < KP) {
                 step(acc3, xf[2 * j], xf[2 * j + 1], issue, pre);
             } else {
-                constexpr int g = j - KP, kh = g / HN, hn = g % HN;
+                constexpr int g = j - KP, kh = g / (HN > 0 ? HN : 1), hn = g % (HN > 0 ? HN : 1);
                 step(&acc1[hn * 8], cur[2 * kh], cur[2 * kh + 1], issue, pre);
             }
             if constexpr (j == 0) {                          // behind this step's DMA pieces
@@ -317,20 +330,23 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
                 // Certainly younger than this chunk's identity loads -- IDB: the DMA pieces of steps 1 .. SPC-1 of the previous
                 // chunk (S-1 <= SPC: every step of a chunk that is not the last one issues), of the prologue for chunk 0;
                 // otherwise: the pieces of steps 1 .. KP-1 of this chunk (those that were issued)
-                if constexpr (IDB) {
-                    if (nb == 0) wait_vmcnt<LPW * (S - 1)>(); else wait_vmcnt<(LPW * (SPC - 1) < 60 ? LPW * (SPC - 1) : 60)>();
-                } else {
-                    constexpr int nl = KP - 1 < SPC - S ? KP - 1 : (SPC - S > 0 ? SPC - S : 0);
-                    if (lastc) wait_vmcnt<LPW * nl>(); else wait_vmcnt<LPW * (KP - 1)>();
+                if constexpr (RES) {
+                    if constexpr (IDB) {
+                        if (nb == 0) wait_vmcnt<LPW * (S - 1)>(); else wait_vmcnt<(LPW * (SPC - 1) < 60 ? LPW * (SPC - 1) : 60)>();
+                    } else {
+                        constexpr int nl = KP - 1 < SPC - S ? KP - 1 : (SPC - S > 0 ? SPC - S : 0);
+                        constexpr int ys = LPW * (KP - 1) < 60 ? LPW * (KP - 1) : 60;
+                        if (lastc) wait_vmcnt<(LPW * nl < 60 ? LPW * nl : 60)>(); else wait_vmcnt<ys>();
+                    }
+                    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
                 }
-                asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
                 const uint32_t ta = tb3 + nb * 512;
                 sfor<0, 4>([&](auto Q) {
                     constexpr int q = Q;
                     const f32x4 s0 = lds_read_f32x4<q * 128>(ta), s1 = lds_read_f32x4<q * 128 + 16>(ta);
                     const f32x4 h0 = lds_read_f32x4<C3 * 4 + q * 128>(ta), h1 = lds_read_f32x4<C3 * 4 + q * 128 + 16>(ta);
                     wait_lgkmcnt<0>();
-                    cur[q] = bn8(acc3[2 * q], acc3[2 * q + 1], s0, s1, h0, h1, &cur[q]);
+                    cur[q] = bn8(acc3[2 * q], acc3[2 * q + 1], s0, s1, h0, h1, RES ? &cur[q] : nullptr);
                     if (PR_ABLATE & 2) asm volatile("" ::"v"(cur[q]), "v"(outp));   // (timing build: keep the value live)
                     else if (PR_ABLATE & 128) {
                         unsigned char* oq = (unsigned char*)p.out + ((size_t)(mc - lr + (lane >> 3) + (q >> 1) * 8) * C3 + nb * 128) * 2 + (lane & 7) * 16 + (q & 1) * 128;
@@ -356,11 +372,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
     });
 }
 
-template <int P, int N1, int NW, int S, int D, bool IDB>
+template <int P, int P2, int C3, int N1, bool RES, int NW, int S, int D, bool IDB>
 hipError_t launch_pair(const PairArgs& a, hipStream_t st) {
     static bool attr_set[AP_MAX_DEVICES] = {};
-    auto kern = conv_pair_kernel<P, N1, NW, S, D, IDB>;
-    constexpr int lds = S * PR_TILE + (2 * 4 * P + 2 * N1) * 4;
+    auto kern = conv_pair_kernel<P, P2, C3, N1, RES, NW, S, D, IDB>;
+    constexpr int lds = S * PR_TILE + (2 * C3 + 2 * N1) * 4;
     static_assert(NW == 8 || lds <= 81920, "two workgroups per CU");
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
@@ -376,27 +392,37 @@ hipError_t launch_pair(const PairArgs& a, hipStream_t st) {
 
 }  // namespace
 
-bool ap_conv_pair_supported(int P, int N1) { return (P == 128 && (N1 == 128 || N1 == 256)) || (P == 256 && N1 == 256); }
-
-size_t ap_conv_pair_stream_bytes(int P, int N1) {
-    return (size_t)(4 * P / 128) * (P / 64 + 2 * (N1 / 128)) * PR_TILE;
+// identity pairs: (P, 4P, N1) in (128,512,128) (128,512,256) (256,1024,256); stage-first blocks (conv3 + folded downsample,
+// P2 = channels of the block input): (128 | 256, 512, 128) with the next conv1, (256 | 512, 1024, 0) conv3 alone
+bool ap_conv_pair_supported(int P, int P2, int C3, int N1) {
+    if (P2 == 0) return C3 == 4 * P && ((P == 128 && (N1 == 128 || N1 == 256)) || (P == 256 && N1 == 256));
+    return (P == 128 && P2 == 256 && C3 == 512 && N1 == 128) || (P == 256 && P2 == 512 && C3 == 1024 && N1 == 0);
 }
 
-hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P, int N1, hipStream_t st) {
-    if (!ap_conv_pair_supported(P, N1)) return hipErrorInvalidValue;
-    const size_t chunks = ap_conv_pair_stream_bytes(P, N1) / 16;
+size_t ap_conv_pair_stream_bytes(int P, int P2, int C3, int N1) {
+    return (size_t)(C3 / 128) * ((P + P2) / 64 + 2 * (N1 / 128)) * PR_TILE;
+}
+
+hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P, int P2, int C3, int N1, hipStream_t st) {
+    if (!ap_conv_pair_supported(P, P2, C3, N1) || (N1 > 0 && !w1)) return hipErrorInvalidValue;
+    const size_t chunks = ap_conv_pair_stream_bytes(P, P2, C3, N1) / 16;
     hipLaunchKernelGGL(pair_pack_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w3,
-                       (const bf16_t*)w1, (unsigned char*)dst, P, N1);
+                       (const bf16_t*)w1, (unsigned char*)dst, P + P2, C3, N1);
     return hipGetLastError();
 }
 
-hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int N1, hipStream_t st) {
-    if (a.M <= 0 || !a.t2 || !a.res || !a.wstream || !a.out || !a.t1n) return hipErrorInvalidValue;
+hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int P2, int C3, int N1, hipStream_t st) {
+    if (a.M <= 0 || !a.t2 || !a.wstream || !a.out || (N1 > 0 && !a.t1n) || (P2 == 0 && !a.res) || (P2 > 0 && !a.x2))
+        return hipErrorInvalidValue;
     // four waves per workgroup, two workgroups per CU, 4-slot ring, half a tile of fragment look-ahead.  Measured and not
     // kept (tools/pair_bench.py, 256 images): eight waves x one workgroup per CU (half the weight DMA per MFMA) is 4-10 %
     // slower; a whole tile of fragment look-ahead (64 registers) times the same
-    if (P == 128 && N1 == 128) return launch_pair<128, 128, 4, 4, 8, true>(a, st);
-    if (P == 128 && N1 == 256) return launch_pair<128, 256, 4, 4, 8, true>(a, st);
-    if (P == 256 && N1 == 256) return launch_pair<256, 256, 4, 4, 8, false>(a, st);
+    if (P2 == 0 && C3 == 4 * P) {
+        if (P == 128 && N1 == 128) return launch_pair<128, 0, 512, 128, true, 4, 4, 8, true>(a, st);
+        if (P == 128 && N1 == 256) return launch_pair<128, 0, 512, 256, true, 4, 4, 8, true>(a, st);
+        if (P == 256 && N1 == 256) return launch_pair<256, 0, 1024, 256, true, 4, 4, 8, false>(a, st);
+    }
+    if (P == 128 && P2 == 256 && C3 == 512 && N1 == 128) return launch_pair<128, 256, 512, 128, false, 4, 4, 8, false>(a, st);
+    if (P == 256 && P2 == 512 && C3 == 1024 && N1 == 0) return launch_pair<256, 512, 1024, 0, false, 4, 4, 8, false>(a, st);
     return hipErrorInvalidValue;
 }

@@ -40,22 +40,25 @@ hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st);
 bool ap_conv_lean_supported(const ConvArgs& a, int kind);
 hipError_t ap_launch_conv_lean(ConvArgs a, hipStream_t st);
 
-// ---- conv3 of an identity block + conv1 of the next block in one pixel-local kernel (conv_pair.hip); bf16 only
+// ---- conv3 (+ identity | + folded downsample) of a block + conv1 of the next block in one pixel-local kernel (conv_pair.hip)
 struct PairArgs {
     const void* t2;               // [M][P] bf16: conv2 output of block k
-    const void* res;              // [M][4P] bf16: input of block k (its identity)
+    const void* res;              // identity block: [M][C3] bf16, the input of block k
     const void* wstream;          // weight tiles in consumption order (ap_launch_pair_pack)
-    const float *s3, *h3;         // BatchNorm scale / shift of conv3 [4P]
+    const float *s3, *h3;         // BatchNorm scale / shift of conv3 [C3]
     const float *s1, *h1;         // ... of the next block's conv1 [N1]
-    void* out;                    // [M][4P] bf16: output of block k
-    void* t1n;                    // [M][N1] bf16: conv1 output of block k+1
-    int M;                        // pixels (N*H*W)
+    void* out;                    // [M][C3] bf16: output of block k
+    void* t1n;                    // [M][N1] bf16: conv1 output of block k+1 (N1 > 0)
+    int M;                        // output pixels (N*Ho*Wo)
+    // stage-first block: second K segment = the block input x2 [N][H2][W2][P2] sampled at (ho*stride2, wo*stride2)
+    const void* x2;
+    int Ho, Wo, H2, W2, stride2;
 };
-bool ap_conv_pair_supported(int P, int N1);               // (128,128) (128,256) (256,256)
-size_t ap_conv_pair_stream_bytes(int P, int N1);
-// w3 [4P][P], w1 [N1][4P]: K-contiguous bf16 rows as packed for the stand-alone kernels
-hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P, int N1, hipStream_t st);
-hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int N1, hipStream_t st);
+bool ap_conv_pair_supported(int P, int P2, int C3, int N1);
+size_t ap_conv_pair_stream_bytes(int P, int P2, int C3, int N1);
+// w3 [C3][P + P2], w1 [N1][C3]: K-contiguous bf16 rows as packed for the stand-alone kernels
+hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P, int P2, int C3, int N1, hipStream_t st);
+hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int P2, int C3, int N1, hipStream_t st);
 
 // ---- fused layer1 bottleneck (bottleneck.hip); bf16 only
 struct BneckArgs {

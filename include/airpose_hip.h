@@ -151,6 +151,12 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
  * out [M][4P] = relu(bn3(conv3 t2) + res) and t1n [M][N1] = relu(bn1(conv1 out)).  (P, N1) in {(128,128), (128,256), (256,256)}. */
 int ap_conv_pair_nhwc(const void* t2, const void* w3, const float* s3, const float* h3, const void* res, const void* w1,
                       const float* s1, const float* h1, void* out, void* t1n, int M, int P, int N1, void* stream);
+/* The same kernel on a stage's first block: conv3 with the downsample branch folded in as a second K segment (w3d [4P][P + P2] =
+ * [conv3 | downsample conv], BatchNorm scales folded into the rows, h3 = shift3 + shift_ds; x [N][Ho*stride][Ho*stride][P2] is the
+ * block input, read at the strided pixel), no identity; with the next block's conv1 (N1 > 0) or alone (N1 = 0, w1 / s1 / h1 /
+ * t1n NULL).  (P, P2, N1) in {(128,256,128), (256,512,0)}.  Replaces model_copenet.py:38-45 with :41-42,97-102 per launch. */
+int ap_conv_pair_ds_nhwc(const void* t2, const void* x, const void* w3d, const float* h3, const void* w1, const float* s1,
+                         const float* h1, void* out, void* t1n, int N, int Ho, int P, int P2, int stride, int N1, void* stream);
 
 /* Tuning/testing knob (process-wide, one atomic word: safe to set while handles run on other threads; a launch sees the
  * old or the new value): tile configuration of the convolution kernels.  -1 = automatic, 0..13 = software-pipelined
@@ -196,8 +202,8 @@ int ap_net_set_fuse_stem(ap_net* h, int on);
  * intermediates never leave LDS), on = 0 as its three (two + folded-downsample) convolutions.  Parity-tested. */
 int ap_net_set_fuse_block(ap_net* h, int on);
 /* bf16: conv3 (+ identity, ReLU) of an identity bottleneck and conv1 of the NEXT bottleneck as one pixel-local kernel
- * (conv_pair.hip; layer2 and layer3 identity blocks, and layer2 -> layer3): the block output makes one HBM trip less per block
- * boundary.  Bit-identical to the two stand-alone kernels.  Default on; replaces model_copenet.py:38-45 (+ :29-31 of the
+ * (conv_pair.hip; layer2 and layer3 identity blocks, layer2 -> layer3, and the first blocks of layer2 / layer3 with their
+ * downsample branch as a second K segment): the block output makes one HBM trip less per block boundary.  Bit-identical to the two stand-alone kernels.  Default on; replaces model_copenet.py:38-45 (+ :29-31 of the
  * next block) per launch. */
 int ap_net_set_fuse_pair(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */

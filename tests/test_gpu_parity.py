@@ -271,6 +271,39 @@ def test_conv_pair_equals_two_convs_and_fp64(dev, case):
     assert rel_err(t1n[:M].double().cpu().numpy(), want1.cpu().numpy()) < 6e-3
 
 
+@pytest.mark.parametrize("case", [(3, 28, 128, 256, 128), (5, 14, 256, 512, 0), (1, 28, 128, 256, 128)])
+def test_conv_pair_stage_first_block_matches_fp64(dev, case):
+    """conv_pair.hip on a stage's first block: conv3 with the downsample branch as a second K segment (the block input read at
+    the stride-2 pixel), ReLU, and -- layer2.0 -- the next block's conv1 from the registers; against fp64 on identical operands."""
+    from airpose_amd import _native as Nn
+    n, Ho, P, P2, N1 = case
+    L = Nn.lib()
+    g = torch.Generator().manual_seed(7 + P + n)
+    H2, C3, M = 2 * Ho, 4 * P, n * Ho * Ho
+    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(torch.bfloat16)
+    x = torch.randn(n, H2, H2, P2, generator=g).clamp_min(0).to(torch.bfloat16)
+    w3d = (torch.randn(C3, P + P2, generator=g) * (1.0 / (P + P2)) ** 0.5).to(torch.bfloat16)
+    h3 = torch.randn(C3, generator=g) * 0.1
+    w1 = (torch.randn(max(N1, 128), C3, generator=g) * (2.0 / C3) ** 0.5).to(torch.bfloat16)
+    s1, h1 = torch.rand(max(N1, 128), generator=g) + 0.5, torch.randn(max(N1, 128), generator=g) * 0.1
+    d = lambda t: t.to(dev)
+    t2, x, w3d, h3, w1, s1, h1 = map(d, (t2, x, w3d, h3, w1, s1, h1))
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    out = torch.full((M + 8, C3), float("nan"), dtype=torch.bfloat16, device=dev)
+    t1n = torch.full((M + 8, max(N1, 1)), float("nan"), dtype=torch.bfloat16, device=dev)
+    Nn.check(L.ap_conv_pair_ds_nhwc(p(t2), p(x), p(w3d), p(h3), p(w1) if N1 else None, p(s1) if N1 else None, p(h1) if N1 else None,
+                                    p(out), p(t1n) if N1 else None, n, Ho, P, P2, 2, N1, Nn.stream_ptr(dev)), "ap_conv_pair_ds_nhwc")
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:].float()).all()
+    xs = x[:, ::2, ::2, :].reshape(M, P2)                       # the strided pixels of the block input
+    want = (torch.cat([t2, xs], 1).double() @ w3d.double().T + h3.double()).clamp_min(0)
+    assert rel_err(out[:M].double().cpu().numpy(), want.cpu().numpy()) < 6e-3
+    if N1:
+        assert torch.isnan(t1n[M:].float()).all()
+        want1 = ((out[:M].double() @ w1[:N1].double().T) * s1[:N1].double() + h1[:N1].double()).clamp_min(0)
+        assert rel_err(t1n[:M].double().cpu().numpy(), want1.cpu().numpy()) < 6e-3
+
+
 def test_conv_pair_full_size_is_deterministic(dev):
     """BASELINE-size layer3 pair (256 images: 50 176 pixels, 784 workgroups on 512 slots, hand-counted waits under full
     memory load): repeated runs identical, equal to the two stand-alone kernels."""
