@@ -257,7 +257,9 @@ struct ap_smplx {
     SmplxModelDev m{};
     Layer dirs;                 // blend-shape GEMM operand: rows = 3V, K = 512 (fp32: exact fp32 MFMA chain)
     DevBuf dirs_split;          // the same operand as split-bf16 pairs: four-term products on the bf16 matrix pipe (default)
+    DevBuf dirs_frag, jv_slot, skin_idx8, skin_w4, ws_side;   // fused contraction + skinning: directions in MFMA fragment order, joint-vertex slots / buffer
     bool blend_split = true;
+    bool fused = true;          // body-only pose feature, 4 bones per vertex, split-bf16 blend: one kernel for contraction + skinning
     DevBuf j_template, j_shapedirs, parents, depth, skin_idx, skin_w, extra_verts, lmk_tri, lmk_bary;
     DevBuf ws_coef, ws_A, ws_jposed, ws_post, ws_vposed, ws_cc;
     int n_out_joints = 0;
@@ -1430,6 +1432,25 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
             host_split_pack_planar(pk.data(), pk.size(), ps.data());
             e = upload(h->dirs_split, ps.data(), pk.size() * 4);
         }
+        if (e == hipSuccess) {
+            // the same directions for the fused kernel: split-bf16 MFMA A fragments in register order, K = 224 (20 shape /
+            // expression + the 21 body joints' 189 pose features; the 8th K step holds jaw / eye features, zero on that path):
+            // block ((g*8 + ks)*3 + c)*2 + plane = 64 lanes x 8 bf16, lane (lr, g4) = row 3*(16 g + lr) + c,
+            // coefficients 32 ks + 8 g4 .. + 7
+            const int ng = (V + 15) / 16;
+            std::vector<uint16_t> fr(ap_smplx_dirs_frag_bytes(V) / 2, 0);
+            for (int g = 0; g < ng; ++g)
+                for (int ks = 0; ks < 8; ++ks)
+                    for (int c = 0; c < 3; ++c)
+                        for (int lane = 0; lane < 64; ++lane) {
+                            const int v = g * 16 + (lane & 15), k0 = ks * 32 + (lane >> 4) * 8;
+                            if (v >= V) continue;
+                            uint16_t* hi = &fr[((((size_t)g * 8 + ks) * 3 + c) * 2) * 512 + lane * 8];
+                            uint16_t* lo = hi + 512;
+                            for (int i = 0; i < 8; ++i) host_split_parts(pk[(size_t)(3 * v + c) * L.wld + k0 + i], &hi[i], &lo[i]);
+                        }
+            e = upload(h->dirs_frag, fr.data(), fr.size() * 2);
+        }
         if (e == hipSuccess) e = upload(L.scale, scale.data(), scale.size() * 4);
         if (e == hipSuccess) e = upload(L.shift, shift.data(), shift.size() * 4);
         if (e != hipSuccess) { ap_smplx_destroy(h); return fail((int)e, std::string("upload: ") + hipGetErrorString(e)); }
@@ -1447,7 +1468,26 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
             if (tri[l * 3 + c] < 0 || tri[l * 3 + c] >= V) { ap_smplx_destroy(h); return fail(AP_ESHAPE, "face vertex id out of range"); }
         }
     }
+    // distinct vertices the joints kernel skins (vertex picks + landmark corners): their v_posed goes to a compact side buffer
+    std::vector<int> slot(V, -1);
+    int n_jv = 0;
+    for (int i = 0; i < md->num_extra; ++i) if (slot[ev[i]] < 0) slot[ev[i]] = n_jv++;
+    for (int i = 0; i < md->num_landmarks * 3; ++i) if (slot[tri[i]] < 0) slot[tri[i]] = n_jv++;
+    m.n_jv = std::max(n_jv, 1);
     hipError_t e = upload(h->j_template, jt.data(), jt.size() * 4);
+    if (e == hipSuccess) e = upload(h->jv_slot, slot.data(), slot.size() * 4);
+    if (e == hipSuccess && K == 4 && n_jv < 255) {           // fused kernel: bone indices as 6-bit fields + joint-vertex slot, weights padded to whole groups
+        const int vp = (V + 15) / 16 * 16;
+        std::vector<uint32_t> i8(vp, 0);
+        std::vector<float> w4((size_t)vp * 4, 0.f);
+        for (int v = 0; v < V; ++v) {
+            for (int k = 0; k < 4; ++k) i8[v] |= (uint32_t)(sidx[(size_t)v * 4 + k] & 0x3f) << (6 * k);
+            if (slot[v] >= 0 && slot[v] < 255) i8[v] |= (uint32_t)(slot[v] + 1) << 24;
+            memcpy(&w4[(size_t)v * 4], &sw[(size_t)v * 4], 16);
+        }
+        e = upload(h->skin_idx8, i8.data(), i8.size() * 4);
+        if (e == hipSuccess) e = upload(h->skin_w4, w4.data(), w4.size() * 4);
+    }
     if (e == hipSuccess) e = upload(h->j_shapedirs, jsd.data(), jsd.size() * 4);
     if (e == hipSuccess) e = upload(h->parents, par.data(), par.size() * 4);
     if (e == hipSuccess) e = upload(h->depth, dep.data(), dep.size() * 4);
@@ -1464,6 +1504,8 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
     m.skin_idx = h->skin_idx.as<int>(); m.skin_w = h->skin_w.as<float>();
     m.extra_verts = h->extra_verts.as<int>(); m.lmk_tri = h->lmk_tri.as<int>(); m.lmk_bary = h->lmk_bary.as<float>();
     m.n_extra = md->num_extra; m.n_lmk = md->num_landmarks;
+    m.dirs_frag = h->dirs_frag.p; m.v_template = h->dirs.shift.as<float>(); m.jv_slot = h->jv_slot.as<int>();
+    m.skin_idx8 = h->skin_idx8.as<uint32_t>(); m.skin_w4 = h->skin_w4.as<float>();
     h->n_out_joints = J + md->num_extra + md->num_landmarks;
     *out = h;
     return AP_OK;
@@ -1474,7 +1516,7 @@ void ap_smplx_destroy(ap_smplx* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&h->dirs.w, &h->dirs_split, &h->dirs.scale, &h->dirs.shift, &h->j_template, &h->j_shapedirs, &h->parents, &h->depth,
-                      &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A,
+                      &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A, &h->dirs_frag, &h->jv_slot, &h->skin_idx8, &h->skin_w4, &h->ws_side,
                       &h->ws_jposed, &h->ws_post, &h->ws_vposed, &h->ws_cc})
         b->release();
     h->tm.destroy();
@@ -1494,10 +1536,15 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     HIP_TRY(h->ws_A.reserve((size_t)n * m.J * 12 * 4));
     HIP_TRY(h->ws_jposed.reserve((size_t)n * m.J * 3 * 4));
     HIP_TRY(h->ws_post.reserve((size_t)n * 12 * 4));
-    HIP_TRY(h->ws_vposed.reserve((size_t)n * m.ldv * 4));
+    // body-only pose feature, 4 bones per vertex, split-bf16 coefficients: contraction + skinning in ONE kernel (v_posed stays
+    // on the chip); anything else (hand / face poses: K = 512, more bones per vertex, the fp32 contraction) takes the two kernels
+    const bool fused = h->fused && h->blend_split && body_only && ap_smplx_lbs_fused_supported(m);
+    if (fused) HIP_TRY(h->ws_side.reserve((size_t)n * m.n_jv * 3 * 4));
+    else HIP_TRY(h->ws_vposed.reserve((size_t)n * m.ldv * 4));
     a.coef = h->ws_coef.as<float>(); a.A = h->ws_A.as<float>(); a.jposed = h->ws_jposed.as<float>();
     a.post = (a.pose6d || a.post_rt) ? h->ws_post.as<float>() : nullptr;
     a.vposed = h->ws_vposed.as<float>();
+    a.vp_side = fused ? h->ws_side.as<float>() : nullptr;
     if (a.n_main > 0 && a.intr0) {                           // camera centres resolved by the prep kernel
         HIP_TRY(h->ws_cc.reserve((size_t)a.n_main * 2 * 4));
         a.cc_ws = h->ws_cc.as<float>();
@@ -1507,21 +1554,28 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[0]));
     HIP_TRY(ap_launch_smplx_prep(m, a, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[1]));
-    // v_posed = v_template + [betas | expr | pose_feature] . dirs^T; hand/face rows of the pose feature are
-    // identically zero when no extra pose is supplied, so the contraction stops after the 21 body joints
-    int K = body_only ? 20 + 21 * 9 : 20 + (m.J - 1) * 9;
-    K = ((K + 31) / 32) * 32;
-    ConvArgs g{};
-    g.x = a.coef; g.w = h->blend_split ? h->dirs_split.p : h->dirs.w.p;
-    g.scale = h->dirs.scale.as<float>(); g.shift = h->dirs.shift.as<float>();
-    g.out_f32 = 1;                                           // v_posed stays fp32 (only the split kind reads the flag)
-    g.res = nullptr; g.y = h->ws_vposed.p;
-    g.N = n; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = K; g.Cout = h->dirs.cout; g.KH = g.KW = 1; g.stride = 1; g.pad = 0;
-    g.M = n; g.ldx = m.ncoef; g.ldy = m.ldv; g.ldr = 0; g.wld = h->dirs.wld; g.relu = 0;
-    HIP_TRY(dispatch_conv(g, h->blend_split ? AP_PREC_BF16X2 : AP_PREC_FP32, st));
-    if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[2]));
-    HIP_TRY(ap_launch_smplx_skin(m, a, st));
-    if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[3]));
+    if (fused) {
+        int n_cu = 0;
+        HIP_TRY(device_cus(&n_cu));
+        HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, st));
+        if (h->tm.on) { HIP_TRY(h->tm.rec(st, &ev[2])); ev[3] = ev[2]; }     // stage 1 = the fused kernel, stage 2 empty
+    } else {
+        // v_posed = v_template + [betas | expr | pose_feature] . dirs^T; hand/face rows of the pose feature are
+        // identically zero when no extra pose is supplied, so the contraction stops after the 21 body joints
+        int K = body_only ? 20 + 21 * 9 : 20 + (m.J - 1) * 9;
+        K = ((K + 31) / 32) * 32;
+        ConvArgs g{};
+        g.x = a.coef; g.w = h->blend_split ? h->dirs_split.p : h->dirs.w.p;
+        g.scale = h->dirs.scale.as<float>(); g.shift = h->dirs.shift.as<float>();
+        g.out_f32 = 1;                                       // v_posed stays fp32 (only the split kind reads the flag)
+        g.res = nullptr; g.y = h->ws_vposed.p;
+        g.N = n; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = K; g.Cout = h->dirs.cout; g.KH = g.KW = 1; g.stride = 1; g.pad = 0;
+        g.M = n; g.ldx = m.ncoef; g.ldy = m.ldv; g.ldr = 0; g.wld = h->dirs.wld; g.relu = 0;
+        HIP_TRY(dispatch_conv(g, h->blend_split ? AP_PREC_BF16X2 : AP_PREC_FP32, st));
+        if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[2]));
+        HIP_TRY(ap_launch_smplx_skin(m, a, st));
+        if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[3]));
+    }
     HIP_TRY(ap_launch_smplx_joints(m, a, st));
     if (h->tm.on) {
         HIP_TRY(h->tm.rec(st, &ev[4]));
@@ -1583,6 +1637,12 @@ int ap_smplx_set_blend_precision(ap_smplx* h, int precision) {
     if (!h || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16X2))
         return fail(AP_EINVAL, "ap_smplx_set_blend_precision: AP_PREC_FP32 or AP_PREC_BF16X2");
     h->blend_split = precision == AP_PREC_BF16X2;
+    return AP_OK;
+}
+
+int ap_smplx_set_fused(ap_smplx* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fused = on != 0;
     return AP_OK;
 }
 

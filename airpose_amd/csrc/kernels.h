@@ -148,6 +148,14 @@ struct SmplxModelDev {
     const int* lmk_tri;           // [51][3]
     const float* lmk_bary;        // [51][3]
     int n_extra, n_lmk;
+    // fused contraction + skinning (smplx_lbs_fused_kernel)
+    const void* dirs_frag;        // blend-shape directions as split-bf16 MFMA A fragments in register order:
+                                  // [vertex group of 16][K step of 32 (8)][x, y, z][hi, lo][lane 64][8 bf16]
+    const float* v_template;      // [V padded to 16][3]
+    const uint32_t* skin_idx8;    // [V padded to 16]: the 4 bone indices of a vertex, 6 bits each (K == 4, J <= 64) | (joint-vertex slot + 1) << 24
+    const float* skin_w4;         // [V padded to 16][4]
+    const int* jv_slot;           // [V]: slot of the vertex in the joint-vertex side buffer, -1 = none
+    int n_jv;                     // slots (distinct vertices among the 21 picks and the 51 landmark triangles)
 };
 struct SmplxFwdArgs {
     int n;                        // bodies
@@ -186,10 +194,15 @@ struct SmplxFwdArgs {
     float* joints;                // [n][J+21+51][3]
     float* joints2d;              // [n][127][2] or NULL
     float* rotmat_out;            // [n][22][9] or NULL (pose6d mode)
+    float* vp_side;               // fused path: v_posed of the joint vertices [n][n_jv][3]; NULL: the joints kernel reads vposed
 };
 hipError_t ap_launch_smplx_prep(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);
 hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);
 hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);
+// blend-shape contraction + skinning in one kernel (K = 4 bones per vertex, body-only pose feature, split-bf16 coefficients)
+bool ap_smplx_lbs_fused_supported(const SmplxModelDev& m);
+size_t ap_smplx_dirs_frag_bytes(int V);
+hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, hipStream_t st);
 
 // ---- stand-alone geometry helpers (smplx.hip)
 hipError_t ap_launch_rot6d(const float* x6, int n, float* R, hipStream_t st);

@@ -261,6 +261,11 @@ class SMPLX(nn.Module):
         N.check(N.lib().ap_smplx_set_blend_precision(self._native(torch.device("cuda", torch.cuda.current_device())),
                                                      N.PRECISIONS[precision]), "ap_smplx_set_blend_precision")
 
+    def set_fused(self, on):
+        """Blend-shape contraction + skinning in one kernel where the call allows it (default) or always as two kernels."""
+        N.check(N.lib().ap_smplx_set_fused(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+                "ap_smplx_set_fused")
+
     def enable_timing(self, on=True):
         N.check(N.lib().ap_smplx_enable_timing(self._native(torch.device("cuda", torch.cuda.current_device())),
                                                int(on)), "ap_smplx_enable_timing")

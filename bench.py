@@ -277,6 +277,8 @@ def main():
     if not args.dual_stream:
         torch.zeros(1, device=dev)
         net.set_dual_stream(0)
+    if os.environ.get("AIRPOSE_SMPLX_FUSED"):               # A/B aid: fused contraction + skinning on (default) / off
+        body.set_fused(int(os.environ["AIRPOSE_SMPLX_FUSED"]))
     if os.environ.get("AIRPOSE_FUSE_PAIR"):                 # A/B aid: fused conv3 -> conv1 pairs on (default) / off
         net.set_fuse_pair(int(os.environ["AIRPOSE_FUSE_PAIR"]))
     if os.environ.get("AIRPOSE_CONV_CONFIG"):                # A/B aid: tile configuration of the conv kernels (ap_set_conv_config)
@@ -362,7 +364,10 @@ def main():
         # two-view forwards of >= 64 pairs run the two views as two concurrent trunk passes (two internal streams):
         # twice the launches at half the images each; conv_ms is then the span over both passes
         dual = bool(args.dual_stream) and B >= 64 and 2 * B <= chunk
-        launches = (42 if args.precision == "bf16" else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
+        # bf16: 3 fused layer1 bottlenecks + 13 blocks x 3 convs = 42 launches per pass, minus the 8 conv1 layers that ride in a
+        # fused conv3 -> conv1 pair (layer2.0-2.3, layer3.1-3.4 as producers): 34
+        pairs_on = args.precision == "bf16" and os.environ.get("AIRPOSE_FUSE_PAIR", "1") != "0"
+        launches = ((34 if pairs_on else 42) if args.precision == "bf16" else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
         # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
@@ -383,7 +388,8 @@ def main():
                        "sharding": "whole pairs per GPU, no data-path collective"},
             "roofline": {"bound": "mfma",
                          "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of the trunk in %d launches per step: conv_pipe_kernel "
-                                   "(dominant instance <T,128,128,2,4,2>; stride-1 3x3 layers in bf16: conv_slab_kernel, conv3 of the identity blocks: conv_lean_kernel, same tile) + the fused layer1 bottlenecks in bf16 "
+                                   "(dominant instance <T,128,128,2,4,2>; stride-1 3x3 layers in bf16: conv_slab_kernel; conv3 of layer2-3 blocks together with the next block's conv1: conv_pair_kernel; "
+                                   "conv3 of the layer4 identity blocks: conv_lean_kernel) + the fused layer1 bottlenecks in bf16 "
                                    "(bneck64ds_kernel, bneck256_kernel); time = HIP-event span of the conv stack "
                                    "(over both concurrent passes when the two views run on two streams)" % launches,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
@@ -403,7 +409,10 @@ def main():
                                 "max": srt[-1], "unit": "pairs/s", "note": "block 0 is `value`"}
         if tb is not None:
             p = max(tb["passes"], 1)
-            st = {"smplx_prep": tb["prep_ms"] / p, "smplx_blend_gemm": tb["blend_gemm_ms"] / p,
+            # default: blend-shape contraction + skinning are ONE kernel (smplx_lbs_fused_kernel), timed in the blend slot; the
+            # skin slot is then empty (two-kernel path: AIRPOSE_SMPLX_FUSED=0)
+            fused_tail = os.environ.get("AIRPOSE_SMPLX_FUSED", "1") != "0"
+            st = {"smplx_prep": tb["prep_ms"] / p, ("smplx_lbs_fused" if fused_tail else "smplx_blend_gemm"): tb["blend_gemm_ms"] / p,
                   "smplx_skin": tb["skin_ms"] / p, "smplx_joints": tb["joints_ms"] / p}
             res["stage_ms_per_step"].update(st)
             # the WHOLE tail (prep + blend-shape contraction + skinning + joints/projection: every kernel that
@@ -414,7 +423,8 @@ def main():
                                           "peak": PEAK_HBM_GBS, "unit": "GB/s",
                                           "frac": tail_bytes / (tail_ms * 1e-3) / 1e9 / PEAK_HBM_GBS,
                                           "bytes": tail_bytes, "ms": tail_ms,
-                                          "kernels": "smplx_prep + smplx_blend_gemm + smplx_skin + smplx_joints "
+                                          "kernels": ("smplx_prep + smplx_lbs_fused (blend-shape contraction + skinning in one kernel) + smplx_joints "
+                                                      if fused_tail else "smplx_prep + smplx_blend_gemm + smplx_skin + smplx_joints ") +
                                                      "(sum of their stage_ms_per_step)",
                                           "formula": "n_bodies * 129084 B + 25.5e6 B, n_bodies = 2 * pairs"}
             # algorithmic contraction length: 10 shape + 21 body joints x 9 pose-feature entries, not the
@@ -423,12 +433,15 @@ def main():
             # the contraction runs in split-bf16 form on the bf16 matrix pipe: three MFMA products per algorithmic product,
             # so the pipe's ceiling for ALGORITHMIC flops is a third of the dense bf16 peak
             blend_peak = PEAK_BF16_DENSE_TFLOPS / 3
+            blend_ms = st["smplx_lbs_fused"] if fused_tail else st["smplx_blend_gemm"]
             res["smplx_blend_roofline"] = {"bound": "mfma-bf16 (split-bf16 operands, 3 MFMA products per product)",
-                                           "achieved": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12,
+                                           "achieved": gemm_flops / (blend_ms * 1e-3) / 1e12,
                                            "peak": blend_peak, "unit": "TFLOP/s",
-                                           "frac": gemm_flops / (st["smplx_blend_gemm"] * 1e-3) / 1e12 / blend_peak,
+                                           "frac": gemm_flops / (blend_ms * 1e-3) / 1e12 / blend_peak,
                                            "flops": gemm_flops, "formula": "2 * 199 * 31425 * n_bodies",
-                                           "note": "output-bound: the launch writes n_bodies * 125.7 KB of fp32 v_posed"}
+                                           "note": ("the contraction is one phase of the fused contraction + skinning kernel: its time includes "
+                                                    "the skinning and the vertex stores" if fused_tail else
+                                                    "output-bound: the launch writes n_bodies * 125.7 KB of fp32 v_posed")}
         if parity is not None:
             res["parity_mode"] = parity
         if vs is not None:

@@ -270,6 +270,11 @@ int ap_smplx_fwd_twoview(ap_smplx* h, int B, float* pred_pose, int pose_ld, floa
  * AP_PREC_BF16X2 (default) = operands as split-bf16 pairs, four-term products on the bf16 matrix pipe, fp32 accumulate
  * and fp32 result (~1e-7 of the vertex scale from the fp32 path); AP_PREC_FP32 = exact fp32 MFMA chain (4x slower). */
 int ap_smplx_set_blend_precision(ap_smplx* h, int precision);
+/* Blend-shape contraction + skinning as ONE kernel (default on): taken when the call carries no hand / face poses (K = 224),
+ * the model has at most 4 bones per vertex and the contraction runs in split-bf16 form; v_posed then never leaves the chip.
+ * 0 = always the two-kernel path (contraction GEMM writing v_posed, then the skinning kernel).  Same arithmetic per product;
+ * results agree to fp32 re-association. */
+int ap_smplx_set_fused(ap_smplx* h, int on);
 int ap_smplx_enable_timing(ap_smplx* h, int on);
 /* ms[0]=prep/chain, ms[1]=blend-shape GEMM, ms[2]=skin, ms[3]=joints+projection */
 int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);

@@ -784,6 +784,37 @@ def test_smplx_forward_matches_oracle(body, smplx_model, dev):
     assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
 
 
+@pytest.mark.parametrize("B", [3, 32, 77])
+def test_smplx_fused_lbs_matches_two_kernel_path(body, smplx_model, dev, B):
+    """smplx_lbs_fused_kernel (blend-shape contraction + skinning in one kernel, v_posed on chip) against the two-kernel path
+    (contraction GEMM -> v_posed in HBM -> skinning kernel) and the CPU oracle: global orient, translation, expression; B = 3 /
+    32 / 77 bodies = a partly filled body group, exactly one, and a ragged third one."""
+    from oracle import geometry_ref, smplx_ref
+    gen = torch.Generator().manual_seed(40 + B)
+    betas, expr = torch.randn(B, 10, generator=gen), torch.randn(B, 10, generator=gen) * 0.5
+    R = geometry_ref.rot6d_to_rotmat(torch.randn(B * 22, 6, generator=gen)).reshape(B, 22, 3, 3)
+    tr = torch.randn(B, 3, generator=gen)
+    kw = dict(betas=betas.to(dev), expression=expr.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev),
+              transl=tr.to(dev), pose2rot=False)
+    try:
+        body.set_fused(0)
+        two = body.forward(**kw)
+        v2, j2 = two.vertices.clone(), two.joints.clone()
+        body.set_fused(1)
+        one = body.forward(**kw)
+    finally:
+        body.set_fused(1)
+    assert torch.isfinite(one.vertices).all() and torch.isfinite(one.joints).all()
+    assert rel_err(one.vertices.cpu().numpy(), v2.cpu().numpy()) < 2e-6
+    assert rel_err(one.joints.cpu().numpy(), j2.cpu().numpy()) < 2e-6
+    want_v, want_j = smplx_ref.smplx_forward(smplx_model, betas, R[:, 1:], global_orient=R[:, :1], transl=tr, expression=expr)
+    assert rel_err(one.vertices.cpu().numpy(), want_v.numpy()) < TOL32
+    assert rel_err(one.joints.cpu().numpy(), want_j.numpy()) < TOL32
+    # the extra joints are vertices of the mesh: the side buffer must hand the joints kernel the same v_posed
+    ev = torch.as_tensor(smplx_model["extra_joint_verts"]).long()
+    assert rel_err(one.joints[:, 55:76].cpu().numpy(), one.vertices[:, ev.to(dev)].cpu().numpy()) < 1e-6
+
+
 def test_smplx_split_bf16_blend_matches_fp32_blend(body, smplx_model, dev):
     """The blend-shape contraction on the bf16 matrix pipe (split-bf16 operands, four-term products; the default)
     against the exact fp32 MFMA chain: <= 1e-5 of the vertex scale (measured ~1e-7), both <= 1e-4 of the oracle."""

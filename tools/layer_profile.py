@@ -51,15 +51,34 @@ if "bneck" in rows[k][0]:        # layer1 as three fused bottleneck kernels: fol
             bi, M, "+ds" if bi == 0 else "+id", r[0].split("::")[-1].split("(")[0], r[4] // 512, dur, fl / dur / 1e6,
             by / 1e6, by / dur / 1e3))
     shapes = rest
-for (nm, M, N, K, inel, res) in shapes:
+import re
+skip = set()
+for si, (nm, M, N, K, inel, res) in enumerate(shapes):
+    if si in skip:
+        continue
     r = rows[k]
     k += 1
     assert "conv_" in r[0], r[0]
-    cfg = r[0].split("<")[1].split(">")[0].replace("unsigned short", "bf16") if "<" in r[0] else r[0].split("::")[-1].split("(")[0]
     fl, dur = 2.0 * M * N * K, r[3] / 1e3
-    tot += dur
     by = (inel + M * N * (1 + res)) * 2
+    if "conv_pair_kernel" in r[0]:
+        # conv3 (+ identity | + folded downsample) of this block and -- N1 > 0 -- conv1 of the next block in one launch:
+        # template arguments <P, P2, C3, N1, ...>; the merged row carries both layers' FLOPs and the fused kernel's bytes
+        targs = [int(v) for v in re.findall(r"-?\d+", r[0].split("<")[1])[:4]]
+        n1 = targs[3]
+        cfg = "pair<%d,%d,%d,%d>" % tuple(targs)
+        if n1 > 0:
+            nx = next(j for j in range(si + 1, len(shapes)) if shapes[j][0].endswith(".c1"))
+            _, M1, N1s, K1, _, _ = shapes[nx]
+            assert N1s == n1 and K1 == N and M1 == M, (shapes[nx], targs)
+            skip.add(nx)
+            fl += 2.0 * M1 * N1s * K1
+            by += M1 * N1s * 2                              # + the next block's conv1 output; its input never leaves the chip
+            nm = nm + "+" + shapes[nx][0].split(".", 2)[0][1:] + "." + shapes[nx][0].split(".")[1] + ".c1"
+    else:
+        cfg = r[0].split("<")[1].split(">")[0].replace("unsigned short", "bf16") if "<" in r[0] else r[0].split("::")[-1].split("(")[0]
+    tot += dur
     bylayer[nm[:2]] = bylayer.get(nm[:2], 0) + dur
-    print("%-9s M=%7d N=%4d K=%4d %-18s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
+    print("%-16s M=%7d N=%4d K=%4d %-22s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
         nm, M, N, K, cfg, r[4] // 256, dur, fl / dur / 1e6, by / 1e6, by / dur / 1e3))
 print("total conv us", tot, bylayer)
