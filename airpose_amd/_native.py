@@ -71,6 +71,7 @@ SIGNATURES = {
     "ap_smplx_fwd_twoview": (_i, [_vp, _i, _vp, _i, _f, _vp, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "ap_smplx_set_blend_precision": (_i, [_vp, _i]),
     "ap_smplx_set_fused": (_i, [_vp, _i]),
+    "ap_smplx_debug_poison_workspace": (_i, [_vp, _i]),
     "ap_smplx_enable_timing": (_i, [_vp, _i]),
     "ap_smplx_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
     "ap_fit_create": (_i, [_c.POINTER(_vp), _vp] + [_vp] * 6 + [_i]),

@@ -1640,6 +1640,15 @@ int ap_smplx_set_blend_precision(ap_smplx* h, int precision) {
     return AP_OK;
 }
 
+int ap_smplx_debug_poison_workspace(ap_smplx* h, int n) {
+    if (!h || n <= 0) return fail(AP_EINVAL, "ap_smplx_debug_poison_workspace: bad argument");
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(h->ws_coef.reserve((size_t)n * h->m.ncoef * 4));
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemset(h->ws_coef.p, 0xFF, h->ws_coef.bytes));           // NaN bit patterns in both storage forms
+    return AP_OK;
+}
+
 int ap_smplx_set_fused(ap_smplx* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fused = on != 0;

@@ -274,9 +274,9 @@ def main():
     if args.chunk:
         torch.zeros(1, device=dev)
         net.set_chunk(args.chunk)
-    if not args.dual_stream:
+    if args.dual_stream != 1:                               # 0 = one pass; 1 + k = the second pass starts k stages late (tuning)
         torch.zeros(1, device=dev)
-        net.set_dual_stream(0)
+        net.set_dual_stream(args.dual_stream)
     if os.environ.get("AIRPOSE_SMPLX_FUSED"):               # A/B aid: fused contraction + skinning on (default) / off
         body.set_fused(int(os.environ["AIRPOSE_SMPLX_FUSED"]))
     if os.environ.get("AIRPOSE_FUSE_PAIR"):                 # A/B aid: fused conv3 -> conv1 pairs on (default) / off

@@ -275,6 +275,9 @@ int ap_smplx_set_blend_precision(ap_smplx* h, int precision);
  * 0 = always the two-kernel path (contraction GEMM writing v_posed, then the skinning kernel).  Same arithmetic per product;
  * results agree to fp32 re-association. */
 int ap_smplx_set_fused(ap_smplx* h, int on);
+/* Test aid: fill the coefficient workspace for n bodies with 0xFF bytes (NaN patterns), as a raw allocation may hold: every slot
+ * the contraction reads must be rewritten by the next forward, the zero padding included. */
+int ap_smplx_debug_poison_workspace(ap_smplx* h, int n);
 int ap_smplx_enable_timing(ap_smplx* h, int on);
 /* ms[0]=prep/chain, ms[1]=blend-shape GEMM, ms[2]=skin, ms[3]=joints+projection */
 int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);

@@ -815,6 +815,31 @@ def test_smplx_fused_lbs_matches_two_kernel_path(body, smplx_model, dev, B):
     assert rel_err(one.joints[:, 55:76].cpu().numpy(), one.vertices[:, ev.to(dev)].cpu().numpy()) < 1e-6
 
 
+def test_smplx_coefficient_padding_is_rewritten_every_call(body, smplx_model, dev):
+    """The coefficient rows come from a raw allocation: with the workspace poisoned (0xFF = NaN patterns) a forward with hand /
+    face poses (K = 512: the contraction multiplies the 6 pad coefficients by zero directions) and a body-only forward (fused
+    kernel, K = 256) must both stay finite and equal the oracle -- i.e. every slot that is read was rewritten, both bf16 halves."""
+    from airpose_amd import _native as Nn
+    from oracle import geometry_ref, smplx_ref
+    gen = torch.Generator().manual_seed(61)
+    B = 5
+    betas = torch.randn(B, 10, generator=gen)
+    R = geometry_ref.rot6d_to_rotmat(torch.randn(B * 22, 6, generator=gen)).reshape(B, 22, 3, 3)
+    lh = geometry_ref.rot6d_to_rotmat(torch.randn(B * 15, 6, generator=gen)).reshape(B, 15, 3, 3)
+    h = body._native(dev)
+    for hands in (True, False):
+        Nn.check(Nn.lib().ap_smplx_debug_poison_workspace(h, 64), "poison")
+        kw = dict(betas=betas.to(dev), body_pose=R[:, 1:].to(dev), global_orient=R[:, :1].to(dev), pose2rot=False)
+        if hands:
+            kw["left_hand_pose"] = lh.to(dev)
+        out = body.forward(**kw)
+        assert torch.isfinite(out.vertices).all() and torch.isfinite(out.joints).all(), hands
+        want_v, want_j = smplx_ref.smplx_forward(smplx_model, betas, R[:, 1:], global_orient=R[:, :1],
+                                                 left_hand_pose=lh if hands else None)
+        assert rel_err(out.vertices.cpu().numpy(), want_v.numpy()) < TOL32
+        assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
+
+
 def test_smplx_split_bf16_blend_matches_fp32_blend(body, smplx_model, dev):
     """The blend-shape contraction on the bf16 matrix pipe (split-bf16 operands, four-term products; the default)
     against the exact fp32 MFMA chain: <= 1e-5 of the vertex scale (measured ~1e-7), both <= 1e-4 of the oracle."""
