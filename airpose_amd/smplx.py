@@ -3,7 +3,7 @@
 Mirrors ``smplx.SMPLX`` as the reference uses it (copenet/src/copenet/copenet_twoview.py:36-45 ctor,
 :237-241 ``forward(betas=, body_pose=, global_orient=, transl=, pose2rot=False)``, :64-65 ``.to()``,
 :69 ``.v_template``, :77 ``.faces``): the forward pass runs in libairpose_hip.so (pose prep + kinematic
-chain, fp32 MFMA blend-shape contraction, sparse skinning, joint/landmark gather).  Semantics follow
+chain, blend-shape contraction in split-bf16 form on the bf16 matrix pipe fused with the sparse skinning, joint/landmark gather).  Semantics follow
 upstream smplx 0.1.28 (the fork's source is absent from the reference checkout).
 """
 import ctypes
