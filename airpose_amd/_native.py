@@ -59,6 +59,7 @@ SIGNATURES = {
     "ap_net_set_fuse_stem": (_i, [_vp, _i]),
     "ap_net_set_fuse_ds": (_i, [_vp, _i]),
     "ap_net_set_fuse_block": (_i, [_vp, _i]),
+    "ap_set_bottleneck_cut": (_i, [_i]),
     "ap_net_set_fuse_pair": (_i, [_vp, _i]),
     "ap_conv_pair_nhwc": (_i, [_vp] * 10 + [_i] * 3 + [_vp]),
     "ap_conv_pair_ds_nhwc": (_i, [_vp] * 9 + [_i] * 6 + [_vp]),

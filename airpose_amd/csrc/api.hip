@@ -136,6 +136,7 @@ unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_
 // without the slab / lean kernels, -5 automatic without the lean kernel, 0..14 / 17 / 100 one explicit configuration);
 // dispatch_conv reads it once per launch and decodes it, so handles on different threads never see a torn setting.
 std::atomic<int> g_conv_mode{-1};
+std::atomic<int> g_bneck_cut{1};   // ap_bottleneck64_nhwc: 1 = bottleneck.hip, 2 = bottleneck2.hip for identity blocks
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -230,7 +231,7 @@ struct ap_net {
     bool fuse_ief = true;          // folded map: one split-K feature kernel + one kernel for all IEF iterations
     bool fold = true;
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
-    bool fuse_block = true;        // bf16: layer1 bottlenecks as one kernel each (bottleneck.hip)
+    int fuse_block = 1;            // bf16: layer1 bottlenecks as one kernel each: 1 bottleneck.hip, 2 identity blocks through bottleneck2.hip
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape, mean_cam;
@@ -431,7 +432,7 @@ int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int H
 
 // fused layer1 bottleneck (bf16): x [N][H][H][c1.cin] -> y [N][H][H][256]
 int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, const void* x, int N, int H, void* y,
-                hipStream_t st) {
+                int cut, hipStream_t st) {
     BneckArgs a{};
     a.x = x; a.y = y;
     a.w1 = c1.w.p; a.w2 = c2.w.p; a.w3 = c3.w.p;
@@ -441,7 +442,8 @@ int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, cons
     a.N = N; a.H = H; a.W = H;
     HIP_TRY(zero_line(&a.zero));
     a.dbg = g_conv_dbg;
-    HIP_TRY(ap_launch_bneck64(a, c1.cin, ds ? 1 : 0, st));
+    if (cut == 2 && !ds && c1.cin == 256) HIP_TRY(ap_launch_bneck2(a, st));
+    else HIP_TRY(ap_launch_bneck64(a, c1.cin, ds ? 1 : 0, st));
     return AP_OK;
 }
 
@@ -758,7 +760,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         if (bf && h->fuse_block && B.c2.cout == 64 && B.c2.stride == 1 && H % 14 == 0 && (!B.has_down || B.c1.cin == 64)) {
             // layer1: conv1 -> conv2 -> conv3 (+identity | folded downsample) in one kernel, intermediates in LDS
             const Layer& L3 = B.has_down ? B.c3ds : B.c3;
-            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, st))) return rc;
+            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, h->fuse_block, st))) return rc;
             std::swap(cur, nxt);
             continue;
         }
@@ -1157,7 +1159,8 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
     a.N = N; a.H = H; a.W = W;
     HIP_TRY(zero_line(&a.zero));
     a.dbg = g_conv_dbg;
-    HIP_TRY(ap_launch_bneck64(a, Cin, downsample ? 1 : 0, (hipStream_t)stream));
+    if (g_bneck_cut.load() == 2 && Cin == 256 && !downsample) HIP_TRY(ap_launch_bneck2(a, (hipStream_t)stream));
+    else HIP_TRY(ap_launch_bneck64(a, Cin, downsample ? 1 : 0, (hipStream_t)stream));
     return AP_OK;
 }
 
@@ -1298,7 +1301,13 @@ int ap_net_set_fuse_ds(ap_net* h, int on) {
 
 int ap_net_set_fuse_block(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->fuse_block = on != 0;
+    h->fuse_block = on < 0 ? 0 : (on > 2 ? 2 : on);
+    return AP_OK;
+}
+
+int ap_set_bottleneck_cut(int cut) {
+    if (cut != 1 && cut != 2) return fail(AP_EINVAL, "ap_set_bottleneck_cut: 1 or 2");
+    g_bneck_cut.store(cut);
     return AP_OK;
 }
 

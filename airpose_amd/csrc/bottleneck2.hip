@@ -1,0 +1,432 @@
+// Identity bottleneck of layer1 (256 -> 64 -> 64 -> 256, 56 x 56) as ONE persistent kernel, second cut (bf16, gfx950).
+//
+//   out = relu(bn3(conv3(relu(bn2(conv2_3x3(relu(bn1(conv1(x))))))) + x)          Bottleneck.forward, model_copenet.py:27-45
+//
+// Same tiling as bottleneck.hip (14 x 14 output pixels, 16 x 16 halo, one workgroup of 8 waves per CU walking tiles), cut
+// differently inside the tile:
+//   * ALL weights stay in LDS: W1 (32 KB) and W2 (72 KB) for the whole kernel, W3 (32 KB) half resident (chunks 0, 1 in two
+//     8-KB slots) and half (chunks 2, 3) fetched by LDS-DMA into the t1 buffer while that is dead (conv3 time).  The first cut
+//     re-streamed all 136 KB of weights per tile through the texture path -- more than the 128 KB of x it read; this one
+//     moves 32 KB per tile (four 1-KB pieces per wave).
+//   * a wave owns two halo ROWS (16 pixels each, lane = column) from the x load to the store:
+//       - x of its rows: 2 x 8 MFMA B fragments = 64 VGPRs, loaded global -> registers one tile AHEAD into a second set of
+//         64, in four parts spread over the tile (nothing of x ever crosses LDS);
+//       - conv1 on them, BN + ReLU, zero outside the image, t1 to LDS (the only tensor the waves exchange: conv2 needs the
+//         rows above / below and the columns left / right);
+//       - conv2 for the same two rows as OUTPUT rows (B fragments gathered from t1 with the tap's shift; the first / last halo
+//         row and column give junk that is computed and never stored), BN + ReLU in registers;
+//       - the packed result is the B fragment of conv3 (weight rows permuted so that a lane owns 8 consecutive channels per
+//         fragment pair, conv_pair.hip's trick), conv3 in four chunks of 64 channels, + identity = THE SAME x FRAGMENT REGISTERS
+//         conv1 consumed (B-fragment k of the x row and the 8 output channels a lane holds in chunk k/2, pair k&1 are the same
+//         16 bytes of the same pixel), ReLU, 16-byte stores.
+//   * 4 barriers per tile (t1 region free / t1 ready / conv2 done + W3 chunks 0,1 landed / W3 chunks 2,3 landed); no barrier
+//     inside conv1 (64 MFMAs per wave), conv2 (144) or a conv3 chunk (16).
+//   * every vmcnt hand-counted: per tile and wave the queue sees exactly  4 4 4 x loads | 2 DMA | 4 x loads | 8 stores | 2 DMA | 8 stores
+//     (stores of junk lanes go to a dump line instead of being masked, so the count never depends on the data).
+// Results are bit-identical to conv1 -> conv2 -> conv3(+identity) through conv_pipe.hip (same K order per output element,
+// same epilogue expression, same bf16 rounding points): tests/test_gpu_parity.py.
+#include <type_traits>
+
+#include "ap_common.h"
+#include "kernels.h"
+
+#ifndef B2_SAFE
+#define B2_SAFE 0
+#endif
+// timing-only builds (results wrong): 1 no x loads after the prologue | 2 no stores | 4 no W3 DMA | 8 no MFMAs | 16 no epilogue math
+#ifndef B2_ABLATE
+#define B2_ABLATE 0
+#endif
+
+namespace {
+
+constexpr int B2_TS = 14;
+// LDS map (bytes)
+constexpr int L_W1 = 0;            // [4 K chunks][64 rows][128 B]
+constexpr int L_W2 = 32768;        // [9 taps][64 rows][128 B]
+constexpr int L_T1 = 106496;       // [16 x 16 halo pixels][128 B]; W3 chunks 2, 3 during conv3
+constexpr int L_W3 = 139264;       // [2 slots][64 rows][128 B]: W3 chunks 0, 1
+constexpr int L_TAB = 155648;      // s1 h1 s2 h2 (64 floats each), s3 h3 (256 each)
+constexpr int L_TOTAL = 158720;
+constexpr int T_S1 = 0, T_H1 = 256, T_S2 = 512, T_H2 = 768, T_S3 = 1024, T_H3 = 2048;
+
+template <int N> __device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B2_SAFE ? 0 : N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr) {
+    u32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ f32x4 lds_read_f32x4(uint32_t addr) {
+    f32x4 r;
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+    return r;
+}
+template <int OFF> __device__ __forceinline__ void lds_write_b128(uint32_t addr, const u32x4& v) {
+    asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(addr), "v"(v), "n"(OFF) : "memory");
+}
+template <int OFF> __device__ __forceinline__ u32x4 gload_b128(const unsigned char* p) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+    return r;
+}
+template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+__device__ __forceinline__ void mm(f32x4& c, const u32x4& w, const u32x4& x) {
+    if (B2_ABLATE & 8) asm volatile("" : "+v"(c) : "v"(w), "v"(x));
+    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t u) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(u));
+    return r;
+}
+// channel (within its 64) of row rho of a 64-row weight tile: fragment f = rho >> 4, row i of it; lane group g4 of fragment
+// pair q = f >> 1 owns channels q*32 + g4*8 .. + 7 (conv_pair.hip: pr_row_channel)
+__host__ __device__ __forceinline__ int b2_row_channel(int rho) {
+    const int f = rho >> 4, i = rho & 15;
+    return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3);
+}
+// BN (+ identity) + ReLU + bf16 of the 8 consecutive channels a lane holds in fragments (2q, 2q+1): the expression of the
+// stand-alone kernels' epilogue (fma, add, max, round), two values per instruction
+__device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32x4& s0, const f32x4& s1, const f32x4& h0,
+                                     const f32x4& h1, const u32x4* res) {
+    if (B2_ABLATE & 16) {
+        u32x4 o = res ? *res : u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+        asm volatile("" : "+v"(o) : "v"(lo), "v"(hi), "v"(s0), "v"(s1), "v"(h0), "v"(h1));
+        return o;
+    }
+    f32x2 v0 = __builtin_elementwise_fma(lo.xy, s0.xy, h0.xy), v1 = __builtin_elementwise_fma(lo.zw, s0.zw, h0.zw);
+    f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
+    if (res) {
+        const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
+        v0 += f32x2{__builtin_bit_cast(float, r0 << 16), __builtin_bit_cast(float, r0 & 0xffff0000u)};
+        v1 += f32x2{__builtin_bit_cast(float, r1 << 16), __builtin_bit_cast(float, r1 & 0xffff0000u)};
+        v2 += f32x2{__builtin_bit_cast(float, r2 << 16), __builtin_bit_cast(float, r2 & 0xffff0000u)};
+        v3 += f32x2{__builtin_bit_cast(float, r3 << 16), __builtin_bit_cast(float, r3 & 0xffff0000u)};
+    }
+    u32x4 o;
+    o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));
+    o.z = relu_pk_bf16(cvt_pk_bf16(v2.x, v2.y)); o.w = relu_pk_bf16(cvt_pk_bf16(v3.x, v3.y));
+    return o;
+}
+
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g4 = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+
+    // ---------------------------------------------------------------- once per workgroup: W1, W2, BatchNorm tables -> LDS
+    // tile = 64 rows x 128 B, row rho = channel b2_row_channel(rho), 16-byte chunk c at position c ^ (rho & 7)
+    {
+        const unsigned char* w1 = (const unsigned char*)a.w1;
+        const unsigned char* w2 = (const unsigned char*)a.w2;
+        for (int idx = tid; idx < 2048; idx += 512) {
+            const int kc = idx >> 9, rho = (idx >> 3) & 63, c = (idx & 7) ^ (rho & 7);
+            *(u32x4*)(smem + L_W1 + idx * 16) = *(const u32x4*)(w1 + ((size_t)b2_row_channel(rho) * 256 + kc * 64 + c * 8) * 2);
+        }
+        for (int idx = tid; idx < 4608; idx += 512) {
+            const int tap = idx >> 9, rho = (idx >> 3) & 63, c = (idx & 7) ^ (rho & 7);
+            *(u32x4*)(smem + L_W2 + idx * 16) = *(const u32x4*)(w2 + ((size_t)b2_row_channel(rho) * 576 + tap * 64 + c * 8) * 2);
+        }
+        float* tb = (float*)(smem + L_TAB);
+        if (tid < 64) {
+            tb[T_S1 / 4 + tid] = a.s1[tid]; tb[T_H1 / 4 + tid] = a.h1[tid];
+            tb[T_S2 / 4 + tid] = a.s2[tid]; tb[T_H2 / 4 + tid] = a.h2[tid];
+        }
+        if (tid < 256) { tb[T_S3 / 4 + tid] = a.s3[tid]; tb[T_H3 / 4 + tid] = a.h3[tid]; }
+    }
+    // W3 by LDS-DMA: chunk cc = channels cc*64 .. +63 (rows permuted), one 1-KB piece (8 rows) per wave
+    const int prow = lane >> 3;
+    const unsigned char* w3src =
+        (const unsigned char*)a.w3 + ((size_t)b2_row_channel(wave * 8 + prow) * 64 + (((lane & 7) ^ prow) * 8)) * 2;
+    auto dma3 = [&](auto CC) {
+        constexpr int cc = CC;
+        if (B2_ABLATE & 4) return;
+        constexpr int off = cc < 2 ? L_W3 + cc * 8192 : L_T1 + (cc - 2) * 8192;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3src + cc * 8192),
+                                         (__attribute__((address_space(3))) void*)(smem + off + wave * 1024), 16, 0, 0);
+    };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
+
+    // ---------------------------------------------------------------- lane constants
+    const uint32_t swz = (uint32_t)((g4 ^ (lr & 7)) << 4);
+    const uint32_t aW1_ = lds0 + L_W1 + lr * 128 + swz;       // A fragment f of a tile: + f*2048; K half 1: ^ 64
+    const uint32_t aW2_ = lds0 + L_W2 + lr * 128 + swz;
+    const uint32_t aW3_ = lds0 + L_W3 + lr * 128 + swz, aW3b_ = lds0 + L_T1 + lr * 128 + swz;
+    const uint32_t tw_ = lds0 + L_T1 + wave * 4096 + lr * 128 + swz;   // t1 of halo row 2*wave (+2048: the next row), pair 1: ^ 64
+    uint32_t tbc_[3];                                        // t1 B fragment of column lr + dc (clamped), row 0, K half 0
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        int cx = lr + j - 1;
+        cx = cx < 0 ? 0 : (cx > 15 ? 15 : cx);
+        tbc_[j] = lds0 + L_T1 + cx * 128 + ((g4 ^ (cx & 7)) << 4);
+    }
+    int rowoff[4];                                           // halo rows 2*wave - 1 .. 2*wave + 2, clamped (junk rows only)
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        int r = 2 * wave - 1 + k;
+        r = r < 0 ? 0 : (r > 15 ? 15 : r);
+        rowoff[k] = r * 2048;
+    }
+    const uint32_t tab_ = lds0 + L_TAB + g4 * 32;
+
+    const int H = a.H, W = a.W;
+    const unsigned char* xg = (const unsigned char*)a.x;
+    unsigned char* yg = (unsigned char*)a.y;
+    unsigned char* dumpl = dump + tid * 16;
+    // every kernel-argument load completes here (a scalar load pending inside the loop would share lgkmcnt with the counted
+    // fragment reads, and scalar loads return out of order)
+    const int tpi = a.tiles_per_img, tlx = a.tiles_x, total = a.total;
+    asm volatile("" ::"s"(tpi), "s"(tlx), "s"(total), "s"(H), "s"(W), "s"(xg), "s"(yg), "s"(dump), "s"(a.w3));
+
+    // x of the wave's two halo rows of tile T as B fragments: xs[g*8 + k] = channels k*32 + g4*8 .. + 7 of pixel (row g, col lr).
+    // xptr: the two row pointers; xpart<KK>: fragments 2KK, 2KK+1 of both rows (4 loads: one 128-byte line per pixel)
+    auto xptr = [&](int T, const unsigned char* (&xp)[2]) {
+        const int n = T / tpi, r = T - n * tpi, ty = r / tlx, tx = r - ty * tlx;
+        int cx = tx * B2_TS - 1 + lr;
+        cx = cx < 0 ? 0 : (cx >= W ? W - 1 : cx);
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            int cy = ty * B2_TS - 1 + 2 * wave + g;
+            cy = cy < 0 ? 0 : (cy >= H ? H - 1 : cy);
+            xp[g] = xg + ((((size_t)n * H + cy) * W + cx) * 256 + g4 * 8) * 2;
+        }
+    };
+    auto xpart = [&](u32x4 (&xs)[16], const unsigned char* (&xp)[2], auto KK) {
+        constexpr int k = 2 * decltype(KK)::value;
+        if (B2_ABLATE & 1) return;
+        xs[k] = gload_b128<k * 64>(xp[0]); xs[k + 1] = gload_b128<k * 64 + 64>(xp[0]);
+        xs[8 + k] = gload_b128<k * 64>(xp[1]); xs[9 + k] = gload_b128<k * 64 + 64>(xp[1]);
+    };
+    auto rdA = [&](u32x4 (&w)[4], uint32_t addr) {
+        w[0] = lds_read_b128<0>(addr); w[1] = lds_read_b128<2048>(addr);
+        w[2] = lds_read_b128<4096>(addr); w[3] = lds_read_b128<6144>(addr);
+    };
+
+    // ---------------------------------------------------------------- one tile.  xc: its x fragments (requested a tile ago),
+    // xn: the set the next tile's are requested into
+    auto tile = [&](int T, int Tn, u32x4 (&xc)[16], u32x4 (&xn)[16]) {
+        // the lane constants pass through an empty asm per tile: derived addresses (36 of them in conv2 alone) are then
+        // recomputed where they are used (one VALU each) instead of being hoisted out of the tile loop and spilled
+        uint32_t aW1 = aW1_, aW2 = aW2_, aW3 = aW3_, aW3b = aW3b_, tw = tw_, tab = tab_;
+        uint32_t tbc[3] = {tbc_[0], tbc_[1], tbc_[2]};
+        asm volatile("" : "+v"(aW1), "+v"(aW2), "+v"(aW3), "+v"(aW3b), "+v"(tw), "+v"(tab), "+v"(tbc[0]), "+v"(tbc[1]), "+v"(tbc[2]));
+        const int n = T / tpi, r = T - n * tpi, ty = r / tlx, tx = r - ty * tlx;
+        const int hx = tx * B2_TS - 1 + lr;
+        const bool colin = hx >= 0 && hx < W, colout = lr >= 1 && lr <= 14;
+        bool inimg[2];
+        unsigned char* op[2];
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R;
+            inimg[g] = colin && hy >= 0 && hy < H;
+            const bool ok = colout && R >= 1 && R <= 14;
+            op[g] = ok ? yg + ((((size_t)n * H + hy) * W + hx) * 256 + g4 * 8) * 2 : dumpl;
+        }
+        // The x fragments of the NEXT tile are requested in four parts spread over this tile (a burst of 128 KB per CU at the
+        // tile start left HBM idle for the rest of the tile), so the queue of a wave per tile is
+        //     Xa 4 | Xb 4 | Xc 4 | DMA 2 | Xd 4 | stores 8 | DMA 2 | stores 8
+        // and conv1 waits for its fragments part by part (they were requested one tile ago)
+        const unsigned char* xp[2];
+        xptr(Tn, xp);
+        auto xwait = [](u32x4 (&xc)[16], auto KK) {      // (the array as a parameter: asm operands on a captured array reference do not compile)
+            constexpr int kk = decltype(KK)::value;
+            if constexpr (kk == 0) wait_vmcnt<32>();         // behind Xa of the last tile: 4+4+2+4+8+2+8
+            else if constexpr (kk == 1) wait_vmcnt<32>();    // behind Xb: 4+2+4+8+2+8 and this tile's Xa
+            else if constexpr (kk == 2) wait_vmcnt<28>();    // behind Xc: 2+4+8+2+8 + Xa
+            else wait_vmcnt<22>();                           // behind Xd: 8+2+8 + Xa
+            asm volatile("" : "+v"(xc[2 * kk]), "+v"(xc[2 * kk + 1]), "+v"(xc[8 + 2 * kk]), "+v"(xc[9 + 2 * kk]));
+        };
+        xwait(xc, I0{});
+        xpart(xn, xp, I0{});
+
+        f32x4 acc[8];
+        u32x4 wf[2][4];
+        // ------------------------------------------------------------ conv1: 8 K groups of 32, 4 row fragments x 2 pixel rows
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rdA(wf[0], aW1);
+        sfor<0, 8>([&](auto K) {
+            constexpr int k = K;
+            if constexpr (k + 1 < 8) {
+                rdA(wf[(k + 1) & 1], (aW1 + ((k + 1) >> 1) * 8192) ^ (((k + 1) & 1) ? 64u : 0u));
+                wait_lgkmcnt<4>();
+            } else wait_lgkmcnt<0>();
+            if constexpr (k == 2 || k == 4 || k == 6) xwait(xc, std::integral_constant<int, k / 2>{});
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[k & 1][f], xc[k]); mm(acc[4 + f], wf[k & 1][f], xc[8 + k]); }
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        xpart(xn, xp, I1{});
+        // every wave is done with W3 chunks 2, 3 of the last tile (they lie in the t1 region)
+        __builtin_amdgcn_s_barrier();
+        sfor<0, 2>([&](auto Q) {                             // (one table read serves both pixel rows)
+            constexpr int q = Q;
+            const f32x4 s0 = lds_read_f32x4<T_S1 + q * 128>(tab), s1 = lds_read_f32x4<T_S1 + q * 128 + 16>(tab);
+            const f32x4 h0 = lds_read_f32x4<T_H1 + q * 128>(tab), h1 = lds_read_f32x4<T_H1 + q * 128 + 16>(tab);
+            wait_lgkmcnt<0>();
+            sfor<0, 2>([&](auto GG) {
+                constexpr int g = GG;
+                u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], s0, s1, h0, h1, nullptr);
+                if (!inimg[g]) o = u32x4{0u, 0u, 0u, 0u};    // conv2 pads t1 with zeros, not with conv1 of zeros
+                lds_write_b128<g * 2048>(q ? tw ^ 64u : tw, o);
+            });
+        });
+        wait_lgkmcnt<0>();
+        __builtin_amdgcn_s_barrier();                        // t1 complete
+
+        // ------------------------------------------------------------ conv2: 9 taps x 2 K halves; output rows = the same two
+        // halo rows (row 0 / 15 and column 0 / 15 of the halo give junk)
+        u32x4 bfr[2][2];
+        auto rdB = [&](u32x4 (&b)[2], auto TT, auto SS) {
+            constexpr int t = TT, s = SS, dr = t / 3 - 1, dc = t % 3 - 1;
+            b[0] = lds_read_b128<0>((tbc[dc + 1] + rowoff[dr + 1]) ^ (s ? 64u : 0u));
+            b[1] = lds_read_b128<0>((tbc[dc + 1] + rowoff[dr + 2]) ^ (s ? 64u : 0u));
+        };
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        rdA(wf[0], aW2);
+        rdB(bfr[0], I0{}, I0{});
+        sfor<0, 18>([&](auto J) {
+            constexpr int j = J;
+            if constexpr (j + 1 < 18) {
+                constexpr int t1 = (j + 1) >> 1, s1 = (j + 1) & 1;
+                rdA(wf[(j + 1) & 1], (aW2 + t1 * 8192) ^ (s1 ? 64u : 0u));
+                rdB(bfr[(j + 1) & 1], std::integral_constant<int, t1>{}, std::integral_constant<int, s1>{});
+                wait_lgkmcnt<6>();
+            } else wait_lgkmcnt<0>();
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[j & 1][f], bfr[j & 1][0]); mm(acc[4 + f], wf[j & 1][f], bfr[j & 1][1]); }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (j == 8) xpart(xn, xp, I2{});
+        });
+        u32x4 y[4];                                          // t2 of the two rows = conv3's B fragments (row g, K half q)
+        sfor<0, 2>([&](auto Q) {
+            constexpr int q = Q;
+            const f32x4 s0 = lds_read_f32x4<T_S2 + q * 128>(tab), s1 = lds_read_f32x4<T_S2 + q * 128 + 16>(tab);
+            const f32x4 h0 = lds_read_f32x4<T_H2 + q * 128>(tab), h1 = lds_read_f32x4<T_H2 + q * 128 + 16>(tab);
+            wait_lgkmcnt<0>();
+            y[q] = bn8(acc[2 * q], acc[2 * q + 1], s0, s1, h0, h1, nullptr);
+            y[2 + q] = bn8(acc[4 + 2 * q], acc[4 + 2 * q + 1], s0, s1, h0, h1, nullptr);
+        });
+
+        // ------------------------------------------------------------ conv3 in four chunks of 64 channels
+        // own pieces of W3 chunks 0, 1 (requested in the last tile, behind them: 8 stores, Xa Xb Xc of this tile); the barrier also says
+        // every wave is done reading t1
+        wait_vmcnt<20>();
+        __builtin_amdgcn_s_barrier();
+        dma3(I2{}); dma3(I3{});
+        xpart(xn, xp, I3{});
+        sfor<0, 4>([&](auto CC) {
+            constexpr int cc = CC;
+            if constexpr (cc == 2) {
+                wait_vmcnt<12>();                            // own pieces of chunks 2, 3; behind them Xd and the stores of chunks 0, 1
+                __builtin_amdgcn_s_barrier();                // ... everybody's; and the slots of chunks 0, 1 are free
+                dma3(I0{}); dma3(I1{});                      // for the next tile
+            }
+            const uint32_t base = cc < 2 ? aW3 + cc * 8192 : aW3b + (cc - 2) * 8192;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            rdA(wf[0], base);
+            rdA(wf[1], base ^ 64u);
+            wait_lgkmcnt<4>();
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[0][f], y[0]); mm(acc[4 + f], wf[0][f], y[2]); }
+            __builtin_amdgcn_sched_barrier(0);
+            wait_lgkmcnt<0>();
+#pragma unroll
+            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[1][f], y[1]); mm(acc[4 + f], wf[1][f], y[3]); }
+            __builtin_amdgcn_sched_barrier(0);
+            sfor<0, 2>([&](auto Q) {
+                constexpr int q = Q;
+                constexpr int to = cc * 256 + q * 128;
+                const f32x4 s0 = lds_read_f32x4<T_S3 + to>(tab), s1 = lds_read_f32x4<T_S3 + to + 16>(tab);
+                const f32x4 h0 = lds_read_f32x4<T_H3 + to>(tab), h1 = lds_read_f32x4<T_H3 + to + 16>(tab);
+                wait_lgkmcnt<0>();
+                sfor<0, 2>([&](auto GG) {
+                    constexpr int g = GG;
+                    const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], s0, s1, h0, h1, &xc[g * 8 + cc * 2 + q]);
+                    if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(op[g]));
+                    else *(u32x4*)(op[g] + cc * 128 + q * 64) = o;
+                });
+            });
+        });
+    };
+
+    // ---------------------------------------------------------------- prologue + tile loop (two x register sets, alternating)
+    const int G = gridDim.x;
+    int T = blockIdx.x;
+    u32x4 xa[16], xb[16];
+    {
+        const unsigned char* xp0[2];
+        xptr(T, xp0);
+        if (B2_ABLATE & 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { xa[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; xb[i] = xa[i]; }
+        }
+        sfor<0, 4>([&](auto KK) { xpart(xa, xp0, KK); });
+    }
+    dma3(I0{}); dma3(I1{});
+    wait_vmcnt<0>();
+    __syncthreads();
+    while (true) {
+        int Tn = T + G;
+        bool more = Tn < total;
+        tile(T, more ? Tn : T, xa, xb);
+        if (!more) break;
+        T = Tn; Tn = T + G; more = Tn < total;
+        tile(T, more ? Tn : T, xb, xa);
+        if (!more) break;
+        T = Tn;
+    }
+    wait_vmcnt<0>();                                         // no LDS-DMA may be in flight when the LDS is released
+}
+
+}  // namespace
+
+// identity block of layer1 (cin = 256), second cut
+hipError_t ap_launch_bneck2(BneckArgs a, hipStream_t st) {
+    static int n_cu_dev[AP_MAX_DEVICES] = {};
+    static unsigned char* dump_dev[AP_MAX_DEVICES] = {};
+    if (a.H % B2_TS || a.W % B2_TS || a.N <= 0) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!n_cu_dev[dev]) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)bneck2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+        if (e != hipSuccess) return e;
+        e = hipMalloc((void**)&dump_dev[dev], 16384);       // junk lanes store here: 512 lanes x 16 B + 512 B of chunk offsets
+        if (e != hipSuccess) return e;
+        n_cu_dev[dev] = n;
+    }
+    a.tiles_x = a.W / B2_TS;
+    a.tiles_per_img = a.tiles_x * (a.H / B2_TS);
+    a.total = a.N * a.tiles_per_img;
+    const int grid = a.total < n_cu_dev[dev] ? a.total : n_cu_dev[dev];
+    hipLaunchKernelGGL(bneck2_kernel, dim3(grid), dim3(512), L_TOTAL, st, a, dump_dev[dev]);
+    return hipGetLastError();
+}

@@ -281,6 +281,8 @@ def main():
         body.set_fused(int(os.environ["AIRPOSE_SMPLX_FUSED"]))
     if os.environ.get("AIRPOSE_FUSE_PAIR"):                 # A/B aid: fused conv3 -> conv1 pairs on (default) / off
         net.set_fuse_pair(int(os.environ["AIRPOSE_FUSE_PAIR"]))
+    if os.environ.get("AIRPOSE_FUSE_BLOCK"):                # A/B aid: layer1 blocks: 0 separate convs, 1 first cut, 2 second cut
+        net.set_fuse_block(int(os.environ["AIRPOSE_FUSE_BLOCK"]))
     if os.environ.get("AIRPOSE_CONV_CONFIG"):                # A/B aid: tile configuration of the conv kernels (ap_set_conv_config)
         from airpose_amd import _native as Nn
         Nn.check(Nn.lib().ap_set_conv_config(int(os.environ["AIRPOSE_CONV_CONFIG"])), "ap_set_conv_config")

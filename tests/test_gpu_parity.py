@@ -474,9 +474,20 @@ def _bneck_case(dev, N, H, ds, seed):
     return y.float().cpu().permute(0, 3, 1, 2).double(), ref
 
 
+@pytest.fixture(params=[1, 2])
+def bneck_cut(request):
+    """Both cuts of the fused identity bottleneck (bottleneck.hip / bottleneck2.hip) behind ap_bottleneck64_nhwc."""
+    from airpose_amd import _native as Nn
+    Nn.check(Nn.lib().ap_set_bottleneck_cut(request.param), "ap_set_bottleneck_cut")
+    yield request.param
+    Nn.lib().ap_set_bottleneck_cut(1)
+
+
 @pytest.mark.parametrize("ds", [0, 1])
 @pytest.mark.parametrize("N,H", [(2, 56), (3, 14), (1, 28), (5, 56), (21, 56)])   # 21*16 = 336 tiles > 256 CUs: persistent loop
-def test_fused_bottleneck_primitive(dev, N, H, ds):
+def test_fused_bottleneck_primitive(dev, N, H, ds, bneck_cut):
+    if ds and bneck_cut == 2:
+        pytest.skip("the second cut covers identity blocks")
     got, ref = _bneck_case(dev, N, H, ds, seed=100 * N + H + ds)
     assert torch.isfinite(got).all()
     # same operands and the same bf16 rounding points: what differs is the fp32 accumulation order (an intermediate
@@ -484,7 +495,7 @@ def test_fused_bottleneck_primitive(dev, N, H, ds):
     assert rel_err(got.numpy(), ref.numpy()) < 8e-3
 
 
-def test_fused_bottleneck_persistent_loop_equals_three_convs(dev):
+def test_fused_bottleneck_persistent_loop_equals_three_convs(dev, bneck_cut):
     """More tiles than CUs (and not a multiple): every workgroup of the persistent kernel walks several tiles, the
     last round is partial.  The fused block must equal conv1 -> conv2 -> conv3(+identity) bit for bit (same operands,
     same bf16 rounding points, same K order per output element)."""
@@ -516,10 +527,41 @@ def test_fused_bottleneck_persistent_loop_equals_three_convs(dev):
     assert torch.equal(y.view(torch.int16), y2.view(torch.int16))
 
 
-def test_fused_bottleneck_is_deterministic(dev):
+def test_fused_bottleneck_is_deterministic(dev, bneck_cut):
     a, _ = _bneck_case(dev, 4, 56, 0, seed=9)
     b, _ = _bneck_case(dev, 4, 56, 0, seed=9)
     assert torch.equal(a, b)
+
+
+def test_fused_bottleneck_cuts_agree_at_full_size(dev):
+    """512 images (32 tiles per workgroup: the steady state of both register sets, every hand-counted wait met many
+    times over): the two cuts give the same bits, run to run."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    bf = torch.bfloat16
+    g = torch.Generator().manual_seed(5)
+    N, H = 512, 56
+    x = torch.randn(N, H, H, 256, generator=g, dtype=torch.float32).to(bf).to(dev)
+    w1 = (torch.randn(128, 256, generator=g) * (2.0 / 256) ** 0.5).to(bf).to(dev)
+    w2 = (torch.randn(128, 576, generator=g) * (2.0 / 576) ** 0.5).to(bf).to(dev)
+    w3 = (torch.randn(256, 64, generator=g) * (2.0 / 64) ** 0.5).to(bf).to(dev)
+    sc = [(torch.rand(c, generator=g) + 0.5).to(dev) for c in (128, 128, 256)]
+    sh = [(torch.randn(c, generator=g) * 0.1).to(dev) for c in (128, 128, 256)]
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = Nn.stream_ptr(dev)
+    outs = []
+    try:
+        for cut in (1, 2, 2, 2):
+            Nn.check(L.ap_set_bottleneck_cut(cut), "cut")
+            y = torch.full((N, H, H, 256), float("nan"), dtype=bf, device=dev)
+            Nn.check(L.ap_bottleneck64_nhwc(p(x), p(w1), p(sc[0]), p(sh[0]), p(w2), p(sc[1]), p(sh[1]), p(w3), p(sc[2]),
+                                            p(sh[2]), p(y), N, H, H, 256, 0, st), "ap_bottleneck64_nhwc")
+            torch.cuda.synchronize()
+            outs.append(y)
+    finally:
+        L.ap_set_bottleneck_cut(1)
+    for o in outs[1:]:
+        assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16))
 
 
 def test_fused_layer1_matches_separate_convs(netbf, golden, copenet_inputs, dev):
@@ -529,8 +571,11 @@ def test_fused_layer1_matches_separate_convs(netbf, golden, copenet_inputs, dev)
     a = netbf.forward_feat_ext(x)
     netbf.set_fuse_block(0)
     b = netbf.forward_feat_ext(x)
+    netbf.set_fuse_block(2)            # identity blocks through the second cut (bottleneck2.hip)
+    c = netbf.forward_feat_ext(x)
     netbf.set_fuse_block(1)
     assert torch.equal(a, b)           # same operands, rounding points and K order per output element
+    assert torch.equal(a, c)
     assert rel_err(a.cpu().numpy(), golden["copenet_b2"]["xf0"]) < 3e-2
 
 
