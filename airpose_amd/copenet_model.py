@@ -294,7 +294,7 @@ class copenet(nn.Module):
         self._set_knob("ap_net_set_fuse_ds", on)
 
     def set_fuse_block(self, on):
-        """bf16: run each layer1 bottleneck as one fused kernel (default) or as separate convolutions."""
+        """bf16: layer1 bottlenecks as one fused kernel each: 2 (default) bottleneck2.hip, 1 the first cut, 0 separate convolutions."""
         self._set_knob("ap_net_set_fuse_block", on)
 
     def set_fuse_pair(self, on):

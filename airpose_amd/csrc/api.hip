@@ -136,7 +136,7 @@ unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_
 // without the slab / lean kernels, -5 automatic without the lean kernel, 0..14 / 17 / 100 one explicit configuration);
 // dispatch_conv reads it once per launch and decodes it, so handles on different threads never see a torn setting.
 std::atomic<int> g_conv_mode{-1};
-std::atomic<int> g_bneck_cut{1};   // ap_bottleneck64_nhwc: 1 = bottleneck.hip, 2 = bottleneck2.hip for identity blocks
+std::atomic<int> g_bneck_cut{2};   // ap_bottleneck64_nhwc: 2 = bottleneck2.hip (default), 1 = bottleneck.hip (the first cut)
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -231,7 +231,7 @@ struct ap_net {
     bool fuse_ief = true;          // folded map: one split-K feature kernel + one kernel for all IEF iterations
     bool fold = true;
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
-    int fuse_block = 1;            // bf16: layer1 bottlenecks as one kernel each: 1 bottleneck.hip, 2 identity blocks through bottleneck2.hip
+    int fuse_block = 2;            // bf16: layer1 bottlenecks as one kernel each: 2 bottleneck2.hip (default), 1 bottleneck.hip (first cut), 0 separate convs
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape, mean_cam;
@@ -442,7 +442,7 @@ int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, cons
     a.N = N; a.H = H; a.W = H;
     HIP_TRY(zero_line(&a.zero));
     a.dbg = g_conv_dbg;
-    if (cut == 2 && !ds && c1.cin == 256) HIP_TRY(ap_launch_bneck2(a, st));
+    if (cut == 2 && ((!ds && c1.cin == 256) || (ds && c1.cin == 64))) HIP_TRY(ap_launch_bneck2(a, ds ? 1 : 0, st));
     else HIP_TRY(ap_launch_bneck64(a, c1.cin, ds ? 1 : 0, st));
     return AP_OK;
 }
@@ -1159,7 +1159,7 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
     a.N = N; a.H = H; a.W = W;
     HIP_TRY(zero_line(&a.zero));
     a.dbg = g_conv_dbg;
-    if (g_bneck_cut.load() == 2 && Cin == 256 && !downsample) HIP_TRY(ap_launch_bneck2(a, (hipStream_t)stream));
+    if (g_bneck_cut.load() == 2) HIP_TRY(ap_launch_bneck2(a, downsample ? 1 : 0, (hipStream_t)stream));
     else HIP_TRY(ap_launch_bneck64(a, Cin, downsample ? 1 : 0, (hipStream_t)stream));
     return AP_OK;
 }

@@ -10,7 +10,7 @@
 //     moves 32 KB per tile (four 1-KB pieces per wave).
 //   * a wave owns two halo ROWS (16 pixels each, lane = column) from the x load to the store:
 //       - x of its rows: 2 x 8 MFMA B fragments = 64 VGPRs, loaded global -> registers one tile AHEAD into a second set of
-//         64, in four parts spread over the tile (nothing of x ever crosses LDS);
+//         64, one instruction per MFMA group (nothing of x ever crosses LDS);
 //       - conv1 on them, BN + ReLU, zero outside the image, t1 to LDS (the only tensor the waves exchange: conv2 needs the
 //         rows above / below and the columns left / right);
 //       - conv2 for the same two rows as OUTPUT rows (B fragments gathered from t1 with the tap's shift; the first / last halo
@@ -21,7 +21,7 @@
 //         16 bytes of the same pixel), ReLU, 16-byte stores.
 //   * 4 barriers per tile (t1 region free / t1 ready / conv2 done + W3 chunks 0,1 landed / W3 chunks 2,3 landed); no barrier
 //     inside conv1 (64 MFMAs per wave), conv2 (144) or a conv3 chunk (16).
-//   * every vmcnt hand-counted: per tile and wave the queue sees exactly  4 4 4 x loads | 2 DMA | 4 x loads | 8 stores | 2 DMA | 8 stores
+//   * every vmcnt hand-counted: per tile and wave the queue sees exactly  16 x loads | 2 DMA | 8 stores | 2 DMA | 8 stores
 //     (stores of junk lanes go to a dump line instead of being masked, so the count never depends on the data).
 // Results are bit-identical to conv1 -> conv2 -> conv3(+identity) through conv_pipe.hip (same K order per output element,
 // same epilogue expression, same bf16 rounding points): tests/test_gpu_parity.py.
@@ -41,13 +41,22 @@
 namespace {
 
 constexpr int B2_TS = 14;
-// LDS map (bytes)
-constexpr int L_W1 = 0;            // [4 K chunks][64 rows][128 B]
-constexpr int L_W2 = 32768;        // [9 taps][64 rows][128 B]
-constexpr int L_T1 = 106496;       // [16 x 16 halo pixels][128 B]; W3 chunks 2, 3 during conv3
-constexpr int L_W3 = 139264;       // [2 slots][64 rows][128 B]: W3 chunks 0, 1
-constexpr int L_TAB = 155648;      // s1 h1 s2 h2 (64 floats each), s3 h3 (256 each)
-constexpr int L_TOTAL = 158720;
+// LDS map (bytes), per variant.  DS = first block of layer1: cin = 64, conv3 carries the folded downsample branch as a second
+// K segment of 64 (W3 rows of 128), no identity
+template <bool DS> struct B2Map {
+    static constexpr int CIN = DS ? 64 : 256;
+    static constexpr int NK1 = CIN / 32;                     // K groups of conv1 = x fragments per pixel row
+    static constexpr int CH3 = DS ? 16384 : 8192;            // one W3 chunk (64 channels x K3): [K3 / 64 halves][64 rows][128 B]
+    static constexpr int NP3 = CH3 / 8192;                   // DMA pieces per wave and chunk
+    static constexpr int W1 = 0;                             // [CIN / 64 K chunks][64 rows][128 B]
+    static constexpr int W2 = CIN * 128;                     // [9 taps][64 rows][128 B]
+    static constexpr int T1 = W2 + 73728;                    // [16 x 16 halo pixels][128 B]; W3 chunks 2, 3 during conv3
+    static constexpr int W3 = T1 + 32768;                    // W3 chunks 0, 1
+    static constexpr int TAB = W3 + 2 * CH3;                 // s1 h1 s2 h2 (64 floats each), s3 h3 (256 each)
+    static constexpr int TOTAL = TAB + 3072;
+    static constexpr int Q = 2 * NK1 + 4 * NP3 + 16;         // vector-memory operations of a wave per tile
+    static_assert(2 * CH3 <= 32768 && TOTAL <= 160 * 1024, "chunks 2, 3 fit the t1 buffer; LDS per CU");
+};
 constexpr int T_S1 = 0, T_H1 = 256, T_S2 = 512, T_H2 = 768, T_S3 = 1024, T_H3 = 2048;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
@@ -127,8 +136,12 @@ __device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32
     return o;
 }
 
+template <bool DS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
+    using M = B2Map<DS>;
+    constexpr int L_W1 = M::W1, L_W2 = M::W2, L_T1 = M::T1, L_W3 = M::W3, L_TAB = M::TAB, CIN = M::CIN, NK1 = M::NK1, NX = 2 * M::NK1;
+    constexpr int CH3 = M::CH3, K3 = DS ? 128 : 64, Q = M::Q;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -140,9 +153,9 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
     {
         const unsigned char* w1 = (const unsigned char*)a.w1;
         const unsigned char* w2 = (const unsigned char*)a.w2;
-        for (int idx = tid; idx < 2048; idx += 512) {
+        for (int idx = tid; idx < CIN * 8; idx += 512) {
             const int kc = idx >> 9, rho = (idx >> 3) & 63, c = (idx & 7) ^ (rho & 7);
-            *(u32x4*)(smem + L_W1 + idx * 16) = *(const u32x4*)(w1 + ((size_t)b2_row_channel(rho) * 256 + kc * 64 + c * 8) * 2);
+            *(u32x4*)(smem + L_W1 + idx * 16) = *(const u32x4*)(w1 + ((size_t)b2_row_channel(rho) * CIN + kc * 64 + c * 8) * 2);
         }
         for (int idx = tid; idx < 4608; idx += 512) {
             const int tap = idx >> 9, rho = (idx >> 3) & 63, c = (idx & 7) ^ (rho & 7);
@@ -155,16 +168,18 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
         }
         if (tid < 256) { tb[T_S3 / 4 + tid] = a.s3[tid]; tb[T_H3 / 4 + tid] = a.h3[tid]; }
     }
-    // W3 by LDS-DMA: chunk cc = channels cc*64 .. +63 (rows permuted), one 1-KB piece (8 rows) per wave
+    // W3 by LDS-DMA: chunk cc = channels cc*64 .. +63 (rows permuted); per 64-wide K half one 1-KB piece (8 rows) per wave
     const int prow = lane >> 3;
     const unsigned char* w3src =
-        (const unsigned char*)a.w3 + ((size_t)b2_row_channel(wave * 8 + prow) * 64 + (((lane & 7) ^ prow) * 8)) * 2;
+        (const unsigned char*)a.w3 + ((size_t)b2_row_channel(wave * 8 + prow) * K3 + (((lane & 7) ^ prow) * 8)) * 2;
     auto dma3 = [&](auto CC) {
         constexpr int cc = CC;
         if (B2_ABLATE & 4) return;
-        constexpr int off = cc < 2 ? L_W3 + cc * 8192 : L_T1 + (cc - 2) * 8192;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3src + cc * 8192),
-                                         (__attribute__((address_space(3))) void*)(smem + off + wave * 1024), 16, 0, 0);
+        constexpr int off = cc < 2 ? L_W3 + cc * CH3 : L_T1 + (cc - 2) * CH3;
+#pragma unroll
+        for (int kh = 0; kh < K3 / 64; ++kh)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3src + cc * (64 * K3 * 2) + kh * 128),
+                                             (__attribute__((address_space(3))) void*)(smem + off + kh * 8192 + wave * 1024), 16, 0, 0);
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -200,8 +215,8 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
     const int tpi = a.tiles_per_img, tlx = a.tiles_x, total = a.total;
     asm volatile("" ::"s"(tpi), "s"(tlx), "s"(total), "s"(H), "s"(W), "s"(xg), "s"(yg), "s"(dump), "s"(a.w3));
 
-    // x of the wave's two halo rows of tile T as B fragments: xs[g*8 + k] = channels k*32 + g4*8 .. + 7 of pixel (row g, col lr).
-    // xptr: the two row pointers; xpart<KK>: fragments 2KK, 2KK+1 of both rows (4 loads: one 128-byte line per pixel)
+    // x of the wave's two halo rows of tile T as B fragments: xs[g*NK1 + k] = channels k*32 + g4*8 .. + 7 of pixel (row g, col lr).
+    // xptr: the two row pointers; xone<i>: one 16-byte piece per lane (fragment i/2 of row i%2; fragments 2m, 2m+1 of a pixel share a 128-byte line)
     auto xptr = [&](int T, const unsigned char* (&xp)[2]) {
         const int n = T / tpi, r = T - n * tpi, ty = r / tlx, tx = r - ty * tlx;
         int cx = tx * B2_TS - 1 + lr;
@@ -210,14 +225,13 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
         for (int g = 0; g < 2; ++g) {
             int cy = ty * B2_TS - 1 + 2 * wave + g;
             cy = cy < 0 ? 0 : (cy >= H ? H - 1 : cy);
-            xp[g] = xg + ((((size_t)n * H + cy) * W + cx) * 256 + g4 * 8) * 2;
+            xp[g] = xg + ((((size_t)n * H + cy) * W + cx) * CIN + g4 * 8) * 2;
         }
     };
-    auto xpart = [&](u32x4 (&xs)[16], const unsigned char* (&xp)[2], auto KK) {
-        constexpr int k = 2 * decltype(KK)::value;
+    auto xone = [&](u32x4 (&xs)[NX], const unsigned char* (&xp)[2], auto II) {      // load i: fragment i/2 of row i%2
+        constexpr int i = decltype(II)::value, k = i / 2, g = i % 2;
         if (B2_ABLATE & 1) return;
-        xs[k] = gload_b128<k * 64>(xp[0]); xs[k + 1] = gload_b128<k * 64 + 64>(xp[0]);
-        xs[8 + k] = gload_b128<k * 64>(xp[1]); xs[9 + k] = gload_b128<k * 64 + 64>(xp[1]);
+        xs[g * NK1 + k] = gload_b128<k * 64>(xp[g]);
     };
     auto rdA = [&](u32x4 (&w)[4], uint32_t addr) {
         w[0] = lds_read_b128<0>(addr); w[1] = lds_read_b128<2048>(addr);
@@ -226,7 +240,7 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
 
     // ---------------------------------------------------------------- one tile.  xc: its x fragments (requested a tile ago),
     // xn: the set the next tile's are requested into
-    auto tile = [&](int T, int Tn, u32x4 (&xc)[16], u32x4 (&xn)[16]) {
+    auto tile = [&](int T, int Tn, u32x4 (&xc)[NX], u32x4 (&xn)[NX]) {
         // the lane constants pass through an empty asm per tile: derived addresses (36 of them in conv2 alone) are then
         // recomputed where they are used (one VALU each) instead of being hoisted out of the tile loop and spilled
         uint32_t aW1 = aW1_, aW2 = aW2_, aW3 = aW3_, aW3b = aW3b_, tw = tw_, tab = tab_;
@@ -244,41 +258,37 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
             const bool ok = colout && R >= 1 && R <= 14;
             op[g] = ok ? yg + ((((size_t)n * H + hy) * W + hx) * 256 + g4 * 8) * 2 : dumpl;
         }
-        // The x fragments of the NEXT tile are requested in four parts spread over this tile (a burst of 128 KB per CU at the
-        // tile start left HBM idle for the rest of the tile), so the queue of a wave per tile is
-        //     Xa 4 | Xb 4 | Xc 4 | DMA 2 | Xd 4 | stores 8 | DMA 2 | stores 8
-        // and conv1 waits for its fragments part by part (they were requested one tile ago)
+        // The x fragments of the NEXT tile are requested ONE instruction at a time behind the first 16 MFMA groups of this tile
+        // (conv1: 8, conv2: 8): a burst of 128 KB per CU at the tile start left HBM idle for the rest of the tile, and bursts of
+        // 4 x 8 waves still stalled the issuing waves on a full memory pipe.  The queue of a wave per tile is
+        //     16 x loads (conv1, conv2) | DMA 2 | stores 8 | DMA 2 | stores 8
+        // and conv1 waits for its fragments pair by pair (they were requested one tile ago)
         const unsigned char* xp[2];
         xptr(Tn, xp);
-        auto xwait = [](u32x4 (&xc)[16], auto KK) {      // (the array as a parameter: asm operands on a captured array reference do not compile)
-            constexpr int kk = decltype(KK)::value;
-            if constexpr (kk == 0) wait_vmcnt<32>();         // behind Xa of the last tile: 4+4+2+4+8+2+8
-            else if constexpr (kk == 1) wait_vmcnt<32>();    // behind Xb: 4+2+4+8+2+8 and this tile's Xa
-            else if constexpr (kk == 2) wait_vmcnt<28>();    // behind Xc: 2+4+8+2+8 + Xa
-            else wait_vmcnt<22>();                           // behind Xd: 8+2+8 + Xa
-            asm volatile("" : "+v"(xc[2 * kk]), "+v"(xc[2 * kk + 1]), "+v"(xc[8 + 2 * kk]), "+v"(xc[9 + 2 * kk]));
+        auto xwait = [](u32x4 (&xc)[NX], auto KK) {      // (the array as a parameter: asm operands on a captured array reference do not compile)
+            constexpr int k = decltype(KK)::value;
+            wait_vmcnt<Q - 2 - k>();                         // behind loads 2k, 2k+1 of the last tile: Q - 2k - 2 of that tile, k of this one
+            asm volatile("" : "+v"(xc[k]), "+v"(xc[NK1 + k]));
         };
-        xwait(xc, I0{});
-        xpart(xn, xp, I0{});
 
         f32x4 acc[8];
         u32x4 wf[2][4];
-        // ------------------------------------------------------------ conv1: 8 K groups of 32, 4 row fragments x 2 pixel rows
+        // ------------------------------------------------------------ conv1: NK1 K groups of 32, 4 row fragments x 2 pixel rows
 #pragma unroll
         for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
         rdA(wf[0], aW1);
-        sfor<0, 8>([&](auto K) {
+        sfor<0, NK1>([&](auto K) {
             constexpr int k = K;
-            if constexpr (k + 1 < 8) {
+            if constexpr (k + 1 < NK1) {
                 rdA(wf[(k + 1) & 1], (aW1 + ((k + 1) >> 1) * 8192) ^ (((k + 1) & 1) ? 64u : 0u));
                 wait_lgkmcnt<4>();
             } else wait_lgkmcnt<0>();
-            if constexpr (k == 2 || k == 4 || k == 6) xwait(xc, std::integral_constant<int, k / 2>{});
+            xwait(xc, K);
 #pragma unroll
-            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[k & 1][f], xc[k]); mm(acc[4 + f], wf[k & 1][f], xc[8 + k]); }
+            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[k & 1][f], xc[k]); mm(acc[4 + f], wf[k & 1][f], xc[NK1 + k]); }
             __builtin_amdgcn_sched_barrier(0);
+            xone(xn, xp, K);
         });
-        xpart(xn, xp, I1{});
         // every wave is done with W3 chunks 2, 3 of the last tile (they lie in the t1 region)
         __builtin_amdgcn_s_barrier();
         sfor<0, 2>([&](auto Q) {                             // (one table read serves both pixel rows)
@@ -319,7 +329,7 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) { mm(acc[f], wf[j & 1][f], bfr[j & 1][0]); mm(acc[4 + f], wf[j & 1][f], bfr[j & 1][1]); }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j == 8) xpart(xn, xp, I2{});
+            if constexpr (j < NK1) xone(xn, xp, std::integral_constant<int, NK1 + j>{});
         });
         u32x4 y[4];                                          // t2 of the two rows = conv3's B fragments (row g, K half q)
         sfor<0, 2>([&](auto Q) {
@@ -332,32 +342,38 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
         });
 
         // ------------------------------------------------------------ conv3 in four chunks of 64 channels
-        // own pieces of W3 chunks 0, 1 (requested in the last tile, behind them: 8 stores, Xa Xb Xc of this tile); the barrier also says
+        // own pieces of W3 chunks 0, 1 (requested in the last tile, behind them: 8 stores, 16 x loads); the barrier also says
         // every wave is done reading t1
-        wait_vmcnt<20>();
+        wait_vmcnt<8 + NX>();
         __builtin_amdgcn_s_barrier();
         dma3(I2{}); dma3(I3{});
-        xpart(xn, xp, I3{});
         sfor<0, 4>([&](auto CC) {
             constexpr int cc = CC;
             if constexpr (cc == 2) {
-                wait_vmcnt<12>();                            // own pieces of chunks 2, 3; behind them Xd and the stores of chunks 0, 1
+                wait_vmcnt<8>();                             // own pieces of chunks 2, 3; behind them the stores of chunks 0, 1
                 __builtin_amdgcn_s_barrier();                // ... everybody's; and the slots of chunks 0, 1 are free
                 dma3(I0{}); dma3(I1{});                      // for the next tile
             }
-            const uint32_t base = cc < 2 ? aW3 + cc * 8192 : aW3b + (cc - 2) * 8192;
+            const uint32_t base = cc < 2 ? aW3 + cc * CH3 : aW3b + (cc - 2) * CH3;
 #pragma unroll
             for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // K groups of 32: 0, 1 = t2 (the packed conv2 result); DS: 2, 3 = x of the pixel (the folded downsample branch,
+            // model_copenet.py:41-42 -- the x fragments conv1 consumed)
+            constexpr int NG = K3 / 32;
             rdA(wf[0], base);
-            rdA(wf[1], base ^ 64u);
-            wait_lgkmcnt<4>();
+            sfor<0, NG>([&](auto S) {
+                constexpr int sg = S;
+                if constexpr (sg + 1 < NG) {
+                    rdA(wf[(sg + 1) & 1], (base + ((sg + 1) >> 1) * 8192) ^ (((sg + 1) & 1) ? 64u : 0u));
+                    wait_lgkmcnt<4>();
+                } else wait_lgkmcnt<0>();
 #pragma unroll
-            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[0][f], y[0]); mm(acc[4 + f], wf[0][f], y[2]); }
-            __builtin_amdgcn_sched_barrier(0);
-            wait_lgkmcnt<0>();
-#pragma unroll
-            for (int f = 0; f < 4; ++f) { mm(acc[f], wf[1][f], y[1]); mm(acc[4 + f], wf[1][f], y[3]); }
-            __builtin_amdgcn_sched_barrier(0);
+                for (int f = 0; f < 4; ++f) {
+                    if constexpr (sg < 2) { mm(acc[f], wf[sg & 1][f], y[sg]); mm(acc[4 + f], wf[sg & 1][f], y[2 + sg]); }
+                    else { mm(acc[f], wf[sg & 1][f], xc[sg - 2]); mm(acc[4 + f], wf[sg & 1][f], xc[NK1 + sg - 2]); }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            });
             sfor<0, 2>([&](auto Q) {
                 constexpr int q = Q;
                 constexpr int to = cc * 256 + q * 128;
@@ -366,7 +382,7 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
                 wait_lgkmcnt<0>();
                 sfor<0, 2>([&](auto GG) {
                     constexpr int g = GG;
-                    const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], s0, s1, h0, h1, &xc[g * 8 + cc * 2 + q]);
+                    const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], s0, s1, h0, h1, DS ? nullptr : &xc[DS ? 0 : g * 8 + cc * 2 + q]);
                     if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(op[g]));
                     else *(u32x4*)(op[g] + cc * 128 + q * 64) = o;
                 });
@@ -375,17 +391,21 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
     };
 
     // ---------------------------------------------------------------- prologue + tile loop (two x register sets, alternating)
+    // Round r gives tile r*G + t to the workgroup whose slot is t.  Workgroups are dealt to the 8 XCDs round-robin
+    // (blockIdx % 8), each XCD has its own L2, and neighbouring tiles share halo rows / columns: slot = (b % 8) * (G / 8) + b / 8
+    // puts 32 CONSECUTIVE tiles (two whole images at 256 workgroups) on one XCD per round, so the halo is re-read from that
+    // XCD's L2 instead of from HBM
     const int G = gridDim.x;
-    int T = blockIdx.x;
-    u32x4 xa[16], xb[16];
+    int T = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
+    u32x4 xa[NX], xb[NX];
     {
         const unsigned char* xp0[2];
         xptr(T, xp0);
         if (B2_ABLATE & 1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { xa[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; xb[i] = xa[i]; }
+            for (int i = 0; i < NX; ++i) { xa[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; xb[i] = xa[i]; }
         }
-        sfor<0, 4>([&](auto KK) { xpart(xa, xp0, KK); });
+        sfor<0, NX>([&](auto II) { xone(xa, xp0, II); });
     }
     dma3(I0{}); dma3(I1{});
     wait_vmcnt<0>();
@@ -405,8 +425,8 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
 
 }  // namespace
 
-// identity block of layer1 (cin = 256), second cut
-hipError_t ap_launch_bneck2(BneckArgs a, hipStream_t st) {
+// layer1 bottleneck, second cut: ds = 0 identity block (cin = 256), ds = 1 first block (cin = 64, W3 rows = [conv3 | downsample])
+hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st) {
     static int n_cu_dev[AP_MAX_DEVICES] = {};
     static unsigned char* dump_dev[AP_MAX_DEVICES] = {};
     if (a.H % B2_TS || a.W % B2_TS || a.N <= 0) return hipErrorInvalidValue;
@@ -417,7 +437,9 @@ hipError_t ap_launch_bneck2(BneckArgs a, hipStream_t st) {
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)bneck2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, L_TOTAL);
+        e = hipFuncSetAttribute((const void*)bneck2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2Map<false>::TOTAL);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)bneck2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B2Map<true>::TOTAL);
         if (e != hipSuccess) return e;
         e = hipMalloc((void**)&dump_dev[dev], 16384);       // junk lanes store here: 512 lanes x 16 B + 512 B of chunk offsets
         if (e != hipSuccess) return e;
@@ -427,6 +449,7 @@ hipError_t ap_launch_bneck2(BneckArgs a, hipStream_t st) {
     a.tiles_per_img = a.tiles_x * (a.H / B2_TS);
     a.total = a.N * a.tiles_per_img;
     const int grid = a.total < n_cu_dev[dev] ? a.total : n_cu_dev[dev];
-    hipLaunchKernelGGL(bneck2_kernel, dim3(grid), dim3(512), L_TOTAL, st, a, dump_dev[dev]);
+    if (ds) hipLaunchKernelGGL(bneck2_kernel<true>, dim3(grid), dim3(512), B2Map<true>::TOTAL, st, a, dump_dev[dev]);
+    else hipLaunchKernelGGL(bneck2_kernel<false>, dim3(grid), dim3(512), B2Map<false>::TOTAL, st, a, dump_dev[dev]);
     return hipGetLastError();
 }

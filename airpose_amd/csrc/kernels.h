@@ -72,8 +72,8 @@ struct BneckArgs {
     int tiles_x, tiles_per_img, total;   // filled by the launcher
 };
 hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st);
-// identity block (cin = 256), second cut: weights resident in LDS, x in registers (bottleneck2.hip)
-hipError_t ap_launch_bneck2(BneckArgs a, hipStream_t st);
+// second cut: weights resident in LDS, x in registers (bottleneck2.hip); ds = 0 identity block, 1 first block of layer1
+hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st);
 
 // ---- stem / pooling (stem.hip)
 // conv 7x7/2 p3 (3->64) + BN + ReLU from NCHW fp32 into NHWC T [N][112][112][64]

@@ -392,7 +392,7 @@ def main():
                          "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of the trunk in %d launches per step: conv_pipe_kernel "
                                    "(dominant instance <T,128,128,2,4,2>; stride-1 3x3 layers in bf16: conv_slab_kernel; conv3 of layer2-3 blocks together with the next block's conv1: conv_pair_kernel; "
                                    "conv3 of the layer4 identity blocks: conv_lean_kernel) + the fused layer1 bottlenecks in bf16 "
-                                   "(bneck64ds_kernel, bneck256_kernel); time = HIP-event span of the conv stack "
+                                   "(bneck2_kernel<ds> / <identity>); time = HIP-event span of the conv stack "
                                    "(over both concurrent passes when the two views run on two streams)" % launches,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
                          "traffic": pmc_traffic(),

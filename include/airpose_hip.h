@@ -198,12 +198,12 @@ int ap_net_set_fuse_ds(ap_net* h, int on);
 /* bf16 mode: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool kernels
  * (bit-identical results; kept for A/B measurement). */
 int ap_net_set_fuse_stem(ap_net* h, int on);
-/* bf16 mode: on = 1 runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel intermediates
- * never leave the CU), on = 2 the same with the identity blocks through the second cut of that kernel (bottleneck2.hip:
- * weights resident in LDS, x in registers), on = 0 as its three (two + folded-downsample) convolutions.  All three give
- * the same bits (parity-tested). */
+/* bf16 mode: on = 2 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
+ * intermediates never leave the CU; bottleneck2.hip: weights resident in LDS, x in registers), on = 1 the same through
+ * the first cut of that kernel (bottleneck.hip: weights re-streamed per tile, x through LDS; kept for A/B), on = 0 as its
+ * three (two + folded-downsample) convolutions.  All three give the same bits (parity-tested). */
 int ap_net_set_fuse_block(ap_net* h, int on);
-/* which kernel ap_bottleneck64_nhwc runs for identity blocks: 1 bottleneck.hip, 2 bottleneck2.hip (process-wide; a test /
+/* which kernel ap_bottleneck64_nhwc runs: 2 bottleneck2.hip (default), 1 bottleneck.hip (process-wide; a test /
  * measurement switch for the stand-alone operator -- handles use ap_net_set_fuse_block) */
 int ap_set_bottleneck_cut(int cut);
 /* bf16: conv3 (+ identity, ReLU) of an identity bottleneck and conv1 of the NEXT bottleneck as one pixel-local kernel

@@ -480,14 +480,12 @@ def bneck_cut(request):
     from airpose_amd import _native as Nn
     Nn.check(Nn.lib().ap_set_bottleneck_cut(request.param), "ap_set_bottleneck_cut")
     yield request.param
-    Nn.lib().ap_set_bottleneck_cut(1)
+    Nn.lib().ap_set_bottleneck_cut(2)
 
 
 @pytest.mark.parametrize("ds", [0, 1])
 @pytest.mark.parametrize("N,H", [(2, 56), (3, 14), (1, 28), (5, 56), (21, 56)])   # 21*16 = 336 tiles > 256 CUs: persistent loop
 def test_fused_bottleneck_primitive(dev, N, H, ds, bneck_cut):
-    if ds and bneck_cut == 2:
-        pytest.skip("the second cut covers identity blocks")
     got, ref = _bneck_case(dev, N, H, ds, seed=100 * N + H + ds)
     assert torch.isfinite(got).all()
     # same operands and the same bf16 rounding points: what differs is the fp32 accumulation order (an intermediate
@@ -559,7 +557,7 @@ def test_fused_bottleneck_cuts_agree_at_full_size(dev):
             torch.cuda.synchronize()
             outs.append(y)
     finally:
-        L.ap_set_bottleneck_cut(1)
+        L.ap_set_bottleneck_cut(2)
     for o in outs[1:]:
         assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16))
 
@@ -567,13 +565,12 @@ def test_fused_bottleneck_cuts_agree_at_full_size(dev):
 def test_fused_layer1_matches_separate_convs(netbf, golden, copenet_inputs, dev):
     """Whole-bottleneck fusion of layer1 (default) vs its separate convolutions, through the trunk."""
     x = copenet_inputs["im0"].to(dev)
-    netbf.set_fuse_block(1)
+    netbf.set_fuse_block(1)            # first cut (bottleneck.hip)
     a = netbf.forward_feat_ext(x)
     netbf.set_fuse_block(0)
     b = netbf.forward_feat_ext(x)
-    netbf.set_fuse_block(2)            # identity blocks through the second cut (bottleneck2.hip)
+    netbf.set_fuse_block(2)            # second cut (bottleneck2.hip), the default
     c = netbf.forward_feat_ext(x)
-    netbf.set_fuse_block(1)
     assert torch.equal(a, b)           # same operands, rounding points and K order per output element
     assert torch.equal(a, c)
     assert rel_err(a.cpu().numpy(), golden["copenet_b2"]["xf0"]) < 3e-2
@@ -1205,9 +1202,10 @@ def test_full_size_properties_bf16(netbf, body, dev):
     x = d(torch.cat([im0, im1]))
     netbf.set_fuse_block(0)
     ref = netbf.forward_feat_ext(x)
-    netbf.set_fuse_block(1)
-    for _ in range(3):
-        assert torch.equal(netbf.forward_feat_ext(x), ref)
+    for cut in (1, 2):                 # first cut, then the default (bottleneck2.hip) -- which stays set
+        netbf.set_fuse_block(cut)
+        for _ in range(3):
+            assert torch.equal(netbf.forward_feat_ext(x), ref)
 
 
 def test_hmr_config1_on_gpu_matches_reference(golden, dev):
