@@ -22,7 +22,8 @@
 //   * 4 barriers per tile (t1 region free / t1 ready / conv2 done + W3 chunks 0,1 landed / W3 chunks 2,3 landed); no barrier
 //     inside conv1 (64 MFMAs per wave), conv2 (144) or a conv3 chunk (16).
 //   * every vmcnt hand-counted: per tile and wave the queue sees exactly  16 x loads | 2 DMA | 8 stores | 2 DMA | 8 stores
-//     (stores of junk lanes go to a dump line instead of being masked, so the count never depends on the data).
+//     (stores of junk lanes carry an out-of-range buffer offset and are dropped by the hardware instead of being masked, so the
+//     count never depends on the data).
 // Results are bit-identical to conv1 -> conv2 -> conv3(+identity) through conv_pipe.hip (same K order per output element,
 // same epilogue expression, same bf16 rounding points): tests/test_gpu_parity.py.
 #include <type_traits>
@@ -33,10 +34,12 @@
 #ifndef B2_SAFE
 #define B2_SAFE 0
 #endif
-// timing-only builds (results wrong): 1 no x loads after the prologue | 2 no stores | 4 no W3 DMA | 8 no MFMAs | 16 no epilogue math
+// timing-only builds (results wrong): 1 no x loads after the prologue | 2 no stores | 4 no W3 DMA | 8 no MFMAs | 16 no epilogue math |
+// 32 every store is issued out of range (dropped: no write traffic)
 #ifndef B2_ABLATE
 #define B2_ABLATE 0
 #endif
+
 
 namespace {
 
@@ -54,7 +57,7 @@ template <bool DS> struct B2Map {
     static constexpr int W3 = T1 + 32768;                    // W3 chunks 0, 1
     static constexpr int TAB = W3 + 2 * CH3;                 // s1 h1 s2 h2 (64 floats each), s3 h3 (256 each)
     static constexpr int TOTAL = TAB + 3072;
-    static constexpr int Q = 2 * NK1 + 4 * NP3 + 16;         // vector-memory operations of a wave per tile
+    static constexpr int Q = 2 * NK1 + 4 * NP3 + 16;         // vector-memory operations of a wave per tile: NX loads, 16 stores, 4 NP3 DMA pieces
     static_assert(2 * CH3 <= 32768 && TOTAL <= 160 * 1024, "chunks 2, 3 fit the t1 buffer; LDS per CU");
 };
 constexpr int T_S1 = 0, T_H1 = 256, T_S2 = 512, T_H2 = 768, T_S3 = 1024, T_H3 = 2048;
@@ -84,6 +87,15 @@ template <int OFF> __device__ __forceinline__ u32x4 gload_b128(const unsigned ch
     u32x4 r;
     asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
     return r;
+}
+// SGPR base + 32-bit lane offset (one VGPR per address instead of two; the launcher keeps every tensor below 4 GB)
+template <int OFF> __device__ __forceinline__ u32x4 gload_b128_s(uint32_t off, const unsigned char* base) {
+    u32x4 r;
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(off), "s"(base), "n"(OFF) : "memory");
+    return r;
+}
+template <int OFF> __device__ __forceinline__ void gstore_b128_s(uint32_t off, unsigned char* base, const u32x4& v) {
+    asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ::"v"(off), "v"(v), "s"(base), "n"(OFF) : "memory");
 }
 template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) {
@@ -138,7 +150,7 @@ __device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32
 
 template <bool DS>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
+bneck2_kernel(const BneckArgs a) {
     using M = B2Map<DS>;
     constexpr int L_W1 = M::W1, L_W2 = M::W2, L_T1 = M::T1, L_W3 = M::W3, L_TAB = M::TAB, CIN = M::CIN, NK1 = M::NK1, NX = 2 * M::NK1;
     constexpr int CH3 = M::CH3, K3 = DS ? 128 : 64, Q = M::Q;
@@ -184,19 +196,23 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
-    // ---------------------------------------------------------------- lane constants
-    const uint32_t swz = (uint32_t)((g4 ^ (lr & 7)) << 4);
-    const uint32_t aW1_ = lds0 + L_W1 + lr * 128 + swz;       // A fragment f of a tile: + f*2048; K half 1: ^ 64
-    const uint32_t aW2_ = lds0 + L_W2 + lr * 128 + swz;
-    const uint32_t aW3_ = lds0 + L_W3 + lr * 128 + swz, aW3b_ = lds0 + L_T1 + lr * 128 + swz;
-    const uint32_t tw_ = lds0 + L_T1 + wave * 4096 + lr * 128 + swz;   // t1 of halo row 2*wave (+2048: the next row), pair 1: ^ 64
-    uint32_t tbc_[3];                                        // t1 B fragment of column lr + dc (clamped), row 0, K half 0
+    // ---------------------------------------------------------------- lane constants: derived per tile from the lane id
+    // (lane_consts below) -- kept in registers across the tile loop they cost ~20 VGPRs the kernel does not have
+    struct LaneC { uint32_t aW1, aW2, aW3, aW3b, tw, tab, tbc[3]; };
+    auto lane_consts = [&](int ll, LaneC& c) {
+        const int lr = ll & 15, g4 = ll >> 4;
+        const uint32_t fb = lds0 + lr * 128 + (uint32_t)((g4 ^ (lr & 7)) << 4);
+        c.aW1 = fb + L_W1; c.aW2 = fb + L_W2;                // A fragment f of a tile: + f*2048; K half 1: ^ 64
+        c.aW3 = fb + L_W3; c.aW3b = fb + L_T1;
+        c.tw = fb + L_T1 + wave * 4096;                      // t1 of halo row 2*wave (+2048: the next row), pair 1: ^ 64
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        int cx = lr + j - 1;
-        cx = cx < 0 ? 0 : (cx > 15 ? 15 : cx);
-        tbc_[j] = lds0 + L_T1 + cx * 128 + ((g4 ^ (cx & 7)) << 4);
-    }
+        for (int j = 0; j < 3; ++j) {                        // t1 B fragment of column lr + dc (clamped), row 0, K half 0
+            int cx = lr + j - 1;
+            cx = cx < 0 ? 0 : (cx > 15 ? 15 : cx);
+            c.tbc[j] = lds0 + L_T1 + cx * 128 + ((g4 ^ (cx & 7)) << 4);
+        }
+        c.tab = lds0 + L_TAB + g4 * 32;
+    };
     int rowoff[4];                                           // halo rows 2*wave - 1 .. 2*wave + 2, clamped (junk rows only)
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
@@ -204,20 +220,19 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
         r = r < 0 ? 0 : (r > 15 ? 15 : r);
         rowoff[k] = r * 2048;
     }
-    const uint32_t tab_ = lds0 + L_TAB + g4 * 32;
 
     const int H = a.H, W = a.W;
     const unsigned char* xg = (const unsigned char*)a.x;
     unsigned char* yg = (unsigned char*)a.y;
-    unsigned char* dumpl = dump + tid * 16;
     // every kernel-argument load completes here (a scalar load pending inside the loop would share lgkmcnt with the counted
     // fragment reads, and scalar loads return out of order)
     const int tpi = a.tiles_per_img, tlx = a.tiles_x, total = a.total;
-    asm volatile("" ::"s"(tpi), "s"(tlx), "s"(total), "s"(H), "s"(W), "s"(xg), "s"(yg), "s"(dump), "s"(a.w3));
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, a.N * H * W * 512, 0x00020000);
+    asm volatile("" ::"s"(tpi), "s"(tlx), "s"(total), "s"(H), "s"(W), "s"(xg), "s"(yg), "s"(a.w3));
 
     // x of the wave's two halo rows of tile T as B fragments: xs[g*NK1 + k] = channels k*32 + g4*8 .. + 7 of pixel (row g, col lr).
     // xptr: the two row pointers; xone<i>: one 16-byte piece per lane (fragment i/2 of row i%2; fragments 2m, 2m+1 of a pixel share a 128-byte line)
-    auto xptr = [&](int T, const unsigned char* (&xp)[2]) {
+    auto xptr = [&](int T, uint32_t (&xp)[2], int lr, int g4) {
         const int n = T / tpi, r = T - n * tpi, ty = r / tlx, tx = r - ty * tlx;
         int cx = tx * B2_TS - 1 + lr;
         cx = cx < 0 ? 0 : (cx >= W ? W - 1 : cx);
@@ -225,46 +240,83 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
         for (int g = 0; g < 2; ++g) {
             int cy = ty * B2_TS - 1 + 2 * wave + g;
             cy = cy < 0 ? 0 : (cy >= H ? H - 1 : cy);
-            xp[g] = xg + ((((size_t)n * H + cy) * W + cx) * CIN + g4 * 8) * 2;
+            xp[g] = (uint32_t)((((n * H + cy) * W + cx) * CIN + g4 * 8) * 2);
         }
     };
-    auto xone = [&](u32x4 (&xs)[NX], const unsigned char* (&xp)[2], auto II) {      // load i: fragment i/2 of row i%2
+    auto xone = [&](u32x4 (&xs)[NX], uint32_t (&xp)[2], auto II) {      // load i: fragment i/2 of row i%2
         constexpr int i = decltype(II)::value, k = i / 2, g = i % 2;
         if (B2_ABLATE & 1) return;
-        xs[g * NK1 + k] = gload_b128<k * 64>(xp[g]);
+        xs[g * NK1 + k] = gload_b128_s<k * 64>(xp[g], xg);
+    };
+    // where the output rows of tile T go.  Stores go through a buffer descriptor over y: lanes that have
+    // nothing to store -- junk columns (lane 0 / 15), junk rows (halo row 0 / 15) -- carry an offset behind
+    // the end of the buffer and the hardware drops them, so every wave ISSUES the same 16 stores per tile whatever it holds
+    // (the hand-counted vmcnt waits depend on that) without a branch or a dump line
+    struct OutRows { uint32_t off[2]; };
+    constexpr uint32_t OOB = 0xffff0000u;
+    auto optr = [&](int T, OutRows& o, int lr, int g4) {
+        const int n = T / tpi, r = T - n * tpi, ty = r / tlx, tx = r - ty * tlx;
+        const int hx = tx * B2_TS - 1 + lr;
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R;
+            const bool ok = R >= 1 && R <= 14 && lr >= 1 && lr <= 14 && !(B2_ABLATE & 32);
+            o.off[g] = ok ? (uint32_t)((((n * H + hy) * W + hx) * 256 + g4 * 8) * 2) : OOB;
+        }
     };
     auto rdA = [&](u32x4 (&w)[4], uint32_t addr) {
         w[0] = lds_read_b128<0>(addr); w[1] = lds_read_b128<2048>(addr);
         w[2] = lds_read_b128<4096>(addr); w[3] = lds_read_b128<6144>(addr);
     };
 
+    // scale / shift of the 8 channels a lane holds in fragment pair q: t = {s[0..3], s[4..7], h[0..3], h[4..7]}
+    auto rdT = [&](f32x4 (&t)[4], uint32_t tabq, auto OS, auto OH) {
+        constexpr int os = decltype(OS)::value, oh = decltype(OH)::value;
+        t[0] = lds_read_f32x4<os>(tabq); t[1] = lds_read_f32x4<os + 16>(tabq);
+        t[2] = lds_read_f32x4<oh>(tabq); t[3] = lds_read_f32x4<oh + 16>(tabq);
+    };
     // ---------------------------------------------------------------- one tile.  xc: its x fragments (requested a tile ago),
     // xn: the set the next tile's are requested into
+#ifdef AP_TRACE   // cycle stamps of waves 0 and 4 of workgroup 0, sixth tile (16 slots each): tools/probes/bneck2_trace.py
+    int tile_no = 0;
+    unsigned long long stamps[13];
+#define B2STAMP(i) do { if (a.dbg && blockIdx.x == 0 && tile_no == 5 && (wave & 3) == 0) { \
+        stamps[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
+#else
+#define B2STAMP(i) do { } while (0)
+#endif
     auto tile = [&](int T, int Tn, u32x4 (&xc)[NX], u32x4 (&xn)[NX]) {
-        // the lane constants pass through an empty asm per tile: derived addresses (36 of them in conv2 alone) are then
-        // recomputed where they are used (one VALU each) instead of being hoisted out of the tile loop and spilled
-        uint32_t aW1 = aW1_, aW2 = aW2_, aW3 = aW3_, aW3b = aW3b_, tw = tw_, tab = tab_;
-        uint32_t tbc[3] = {tbc_[0], tbc_[1], tbc_[2]};
-        asm volatile("" : "+v"(aW1), "+v"(aW2), "+v"(aW3), "+v"(aW3b), "+v"(tw), "+v"(tab), "+v"(tbc[0]), "+v"(tbc[1]), "+v"(tbc[2]));
+        // the lane id passes through an empty asm per tile: what derives from it (36 addresses in conv2 alone) is then
+        // recomputed where it is used (one VALU each) instead of being hoisted out of the tile loop and spilled
+        int ll = lane;
+        asm volatile("" : "+v"(ll));
+        LaneC lc;
+        lane_consts(ll, lc);
+        const uint32_t aW1 = lc.aW1, aW2 = lc.aW2, aW3 = lc.aW3, aW3b = lc.aW3b, tw = lc.tw, tab = lc.tab;
+        const uint32_t tbc[3] = {lc.tbc[0], lc.tbc[1], lc.tbc[2]};
+        const int lr = ll & 15, g4 = ll >> 4;
         const int n = T / tpi, r = T - n * tpi, ty = r / tlx, tx = r - ty * tlx;
         const int hx = tx * B2_TS - 1 + lr;
-        const bool colin = hx >= 0 && hx < W, colout = lr >= 1 && lr <= 14;
+        const bool colin = hx >= 0 && hx < W;
         bool inimg[2];
-        unsigned char* op[2];
 #pragma unroll
         for (int g = 0; g < 2; ++g) {
-            const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R;
+            const int hy = ty * B2_TS - 1 + 2 * wave + g;
             inimg[g] = colin && hy >= 0 && hy < H;
-            const bool ok = colout && R >= 1 && R <= 14;
-            op[g] = ok ? yg + ((((size_t)n * H + hy) * W + hx) * 256 + g4 * 8) * 2 : dumpl;
         }
-        // The x fragments of the NEXT tile are requested ONE instruction at a time behind the first 16 MFMA groups of this tile
-        // (conv1: 8, conv2: 8): a burst of 128 KB per CU at the tile start left HBM idle for the rest of the tile, and bursts of
+        OutRows opp;
+        optr(T, opp, lr, g4);
+        // The x fragments of the NEXT tile are requested ONE instruction at a time behind the first NX MFMA groups of this tile
+        // (conv1, then conv2): a burst of 128 KB per CU at the tile start left HBM idle for the rest of the tile, and bursts of
         // 4 x 8 waves still stalled the issuing waves on a full memory pipe.  The queue of a wave per tile is
-        //     16 x loads (conv1, conv2) | DMA 2 | stores 8 | DMA 2 | stores 8
-        // and conv1 waits for its fragments pair by pair (they were requested one tile ago)
-        const unsigned char* xp[2];
-        xptr(Tn, xp);
+        //     NX x loads | DMA | 8 stores | DMA | 8 stores                                         (Q operations)
+        // and conv1 waits for its fragments pair by pair (they were requested one tile ago).
+        // (Measured and not kept: the 16 output pieces held in registers and stored one per MFMA group during the next tile's
+        // conv1 / conv2 -- the first block, which has the registers, ran 4-10 % slower: what the 822 MB of output cost is the
+        // write bandwidth itself (3.5 TB/s store-only in this kernel's skeleton), not the moment the stores are issued.)
+        uint32_t xp[2];
+        xptr(Tn, xp, lr, g4);
+        B2STAMP(0);
         auto xwait = [](u32x4 (&xc)[NX], auto KK) {      // (the array as a parameter: asm operands on a captured array reference do not compile)
             constexpr int k = decltype(KK)::value;
             wait_vmcnt<Q - 2 - k>();                         // behind loads 2k, 2k+1 of the last tile: Q - 2k - 2 of that tile, k of this one
@@ -289,22 +341,26 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
             __builtin_amdgcn_sched_barrier(0);
             xone(xn, xp, K);
         });
+        B2STAMP(1);
         // every wave is done with W3 chunks 2, 3 of the last tile (they lie in the t1 region)
         __builtin_amdgcn_s_barrier();
+        B2STAMP(2);
+        f32x4 tq[4];
         sfor<0, 2>([&](auto Q) {                             // (one table read serves both pixel rows)
             constexpr int q = Q;
-            const f32x4 s0 = lds_read_f32x4<T_S1 + q * 128>(tab), s1 = lds_read_f32x4<T_S1 + q * 128 + 16>(tab);
-            const f32x4 h0 = lds_read_f32x4<T_H1 + q * 128>(tab), h1 = lds_read_f32x4<T_H1 + q * 128 + 16>(tab);
+            rdT(tq, tab, std::integral_constant<int, T_S1 + q * 128>{}, std::integral_constant<int, T_H1 + q * 128>{});
             wait_lgkmcnt<0>();
             sfor<0, 2>([&](auto GG) {
                 constexpr int g = GG;
-                u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], s0, s1, h0, h1, nullptr);
+                u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr);
                 if (!inimg[g]) o = u32x4{0u, 0u, 0u, 0u};    // conv2 pads t1 with zeros, not with conv1 of zeros
                 lds_write_b128<g * 2048>(q ? tw ^ 64u : tw, o);
             });
         });
         wait_lgkmcnt<0>();
+        B2STAMP(3);
         __builtin_amdgcn_s_barrier();                        // t1 complete
+        B2STAMP(4);
 
         // ------------------------------------------------------------ conv2: 9 taps x 2 K halves; output rows = the same two
         // halo rows (row 0 / 15 and column 0 / 15 of the halo give junk)
@@ -329,30 +385,36 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
 #pragma unroll
             for (int f = 0; f < 4; ++f) { mm(acc[f], wf[j & 1][f], bfr[j & 1][0]); mm(acc[4 + f], wf[j & 1][f], bfr[j & 1][1]); }
             __builtin_amdgcn_sched_barrier(0);
-            if constexpr (j < NK1) xone(xn, xp, std::integral_constant<int, NK1 + j>{});
+            if constexpr (NK1 + j < NX) xone(xn, xp, std::integral_constant<int, NK1 + j>{});
         });
+        B2STAMP(5);
         u32x4 y[4];                                          // t2 of the two rows = conv3's B fragments (row g, K half q)
         sfor<0, 2>([&](auto Q) {
             constexpr int q = Q;
-            const f32x4 s0 = lds_read_f32x4<T_S2 + q * 128>(tab), s1 = lds_read_f32x4<T_S2 + q * 128 + 16>(tab);
-            const f32x4 h0 = lds_read_f32x4<T_H2 + q * 128>(tab), h1 = lds_read_f32x4<T_H2 + q * 128 + 16>(tab);
+            rdT(tq, tab, std::integral_constant<int, T_S2 + q * 128>{}, std::integral_constant<int, T_H2 + q * 128>{});
             wait_lgkmcnt<0>();
-            y[q] = bn8(acc[2 * q], acc[2 * q + 1], s0, s1, h0, h1, nullptr);
-            y[2 + q] = bn8(acc[4 + 2 * q], acc[4 + 2 * q + 1], s0, s1, h0, h1, nullptr);
+            y[q] = bn8(acc[2 * q], acc[2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr);
+            y[2 + q] = bn8(acc[4 + 2 * q], acc[4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr);
         });
 
         // ------------------------------------------------------------ conv3 in four chunks of 64 channels
-        // own pieces of W3 chunks 0, 1 (requested in the last tile, behind them: 8 stores, 16 x loads); the barrier also says
+        // own pieces of W3 chunks 0, 1 (requested in the last tile, behind them: 8 stores, NX x loads); the barrier also says
         // every wave is done reading t1
+        B2STAMP(6);
         wait_vmcnt<8 + NX>();
         __builtin_amdgcn_s_barrier();
+        B2STAMP(7);
         dma3(I2{}); dma3(I3{});
         sfor<0, 4>([&](auto CC) {
             constexpr int cc = CC;
+            if constexpr (cc == 1) B2STAMP(8);
+            if constexpr (cc == 3) B2STAMP(11);
             if constexpr (cc == 2) {
+                B2STAMP(9);
                 wait_vmcnt<8>();                             // own pieces of chunks 2, 3; behind them the stores of chunks 0, 1
                 __builtin_amdgcn_s_barrier();                // ... everybody's; and the slots of chunks 0, 1 are free
                 dma3(I0{}); dma3(I1{});                      // for the next tile
+                B2STAMP(10);
             }
             const uint32_t base = cc < 2 ? aW3 + cc * CH3 : aW3b + (cc - 2) * CH3;
 #pragma unroll
@@ -360,34 +422,40 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
             // K groups of 32: 0, 1 = t2 (the packed conv2 result); DS: 2, 3 = x of the pixel (the folded downsample branch,
             // model_copenet.py:41-42 -- the x fragments conv1 consumed)
             constexpr int NG = K3 / 32;
+            auto grp = [&](uint32_t b, auto G) -> uint32_t { constexpr int g = decltype(G)::value; return (b + (g >> 1) * 8192) ^ ((g & 1) ? 64u : 0u); };
             rdA(wf[0], base);
+            rdA(wf[1], base ^ 64u);
             sfor<0, NG>([&](auto S) {
                 constexpr int sg = S;
-                if constexpr (sg + 1 < NG) {
-                    rdA(wf[(sg + 1) & 1], (base + ((sg + 1) >> 1) * 8192) ^ (((sg + 1) & 1) ? 64u : 0u));
-                    wait_lgkmcnt<4>();
-                } else wait_lgkmcnt<0>();
+                if constexpr (sg + 1 < NG) wait_lgkmcnt<4>(); else wait_lgkmcnt<0>();     // younger: the next group's fragments
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
                     if constexpr (sg < 2) { mm(acc[f], wf[sg & 1][f], y[sg]); mm(acc[4 + f], wf[sg & 1][f], y[2 + sg]); }
                     else { mm(acc[f], wf[sg & 1][f], xc[sg - 2]); mm(acc[4 + f], wf[sg & 1][f], xc[NK1 + sg - 2]); }
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (sg + 2 < NG) rdA(wf[sg & 1], grp(base, std::integral_constant<int, sg + 2>{}));
             });
             sfor<0, 2>([&](auto Q) {
                 constexpr int q = Q;
                 constexpr int to = cc * 256 + q * 128;
-                const f32x4 s0 = lds_read_f32x4<T_S3 + to>(tab), s1 = lds_read_f32x4<T_S3 + to + 16>(tab);
-                const f32x4 h0 = lds_read_f32x4<T_H3 + to>(tab), h1 = lds_read_f32x4<T_H3 + to + 16>(tab);
+                rdT(tq, tab, std::integral_constant<int, T_S3 + to>{}, std::integral_constant<int, T_H3 + to>{});
                 wait_lgkmcnt<0>();
                 sfor<0, 2>([&](auto GG) {
                     constexpr int g = GG;
-                    const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], s0, s1, h0, h1, DS ? nullptr : &xc[DS ? 0 : g * 8 + cc * 2 + q]);
-                    if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(op[g]));
-                    else *(u32x4*)(op[g] + cc * 128 + q * 64) = o;
+                    const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3],
+                                        DS ? nullptr : &xc[DS ? 0 : g * 8 + cc * 2 + q]);
+                    if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(opp.off[g]));
+                    else __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, opp.off[g] + cc * 128 + q * 64, 0, 0);
                 });
             });
         });
+#ifdef AP_TRACE
+        B2STAMP(12);
+        if (a.dbg && blockIdx.x == 0 && tile_no == 5 && (wave & 3) == 0 && lane == 0)
+            for (int i = 0; i < 13; ++i) a.dbg[(wave >> 2) * 16 + i] = stamps[i];
+        ++tile_no;
+#endif
     };
 
     // ---------------------------------------------------------------- prologue + tile loop (two x register sets, alternating)
@@ -399,8 +467,8 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
     int T = (G & 7) == 0 ? (int)(blockIdx.x & 7) * (G >> 3) + (int)(blockIdx.x >> 3) : (int)blockIdx.x;
     u32x4 xa[NX], xb[NX];
     {
-        const unsigned char* xp0[2];
-        xptr(T, xp0);
+        uint32_t xp0[2];
+        xptr(T, xp0, lr, g4);
         if (B2_ABLATE & 1) {
 #pragma unroll
             for (int i = 0; i < NX; ++i) { xa[i] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u}; xb[i] = xa[i]; }
@@ -428,8 +496,8 @@ bneck2_kernel(const BneckArgs a, unsigned char* __restrict__ dump) {
 // layer1 bottleneck, second cut: ds = 0 identity block (cin = 256), ds = 1 first block (cin = 64, W3 rows = [conv3 | downsample])
 hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st) {
     static int n_cu_dev[AP_MAX_DEVICES] = {};
-    static unsigned char* dump_dev[AP_MAX_DEVICES] = {};
     if (a.H % B2_TS || a.W % B2_TS || a.N <= 0) return hipErrorInvalidValue;
+    if ((size_t)a.N * a.H * a.W * 512 >= 0xffff0000ull) return hipErrorInvalidValue;      // 32-bit offsets, out-of-range marker
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
@@ -441,15 +509,13 @@ hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st) {
         if (e != hipSuccess) return e;
         e = hipFuncSetAttribute((const void*)bneck2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B2Map<true>::TOTAL);
         if (e != hipSuccess) return e;
-        e = hipMalloc((void**)&dump_dev[dev], 16384);       // junk lanes store here: 512 lanes x 16 B + 512 B of chunk offsets
-        if (e != hipSuccess) return e;
         n_cu_dev[dev] = n;
     }
     a.tiles_x = a.W / B2_TS;
     a.tiles_per_img = a.tiles_x * (a.H / B2_TS);
     a.total = a.N * a.tiles_per_img;
     const int grid = a.total < n_cu_dev[dev] ? a.total : n_cu_dev[dev];
-    if (ds) hipLaunchKernelGGL(bneck2_kernel<true>, dim3(grid), dim3(512), B2Map<true>::TOTAL, st, a, dump_dev[dev]);
-    else hipLaunchKernelGGL(bneck2_kernel<false>, dim3(grid), dim3(512), B2Map<false>::TOTAL, st, a, dump_dev[dev]);
+    if (ds) hipLaunchKernelGGL(bneck2_kernel<true>, dim3(grid), dim3(512), B2Map<true>::TOTAL, st, a);
+    else hipLaunchKernelGGL(bneck2_kernel<false>, dim3(grid), dim3(512), B2Map<false>::TOTAL, st, a);
     return hipGetLastError();
 }
