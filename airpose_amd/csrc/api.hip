@@ -233,7 +233,7 @@ struct ap_net {
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
     int fuse_block = 2;            // bf16: layer1 bottlenecks as one kernel each: 2 bottleneck2.hip (default), 1 bottleneck.hip (first cut), 0 separate convs
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
-    bool fuse_stem = true;         // bf16: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
+    bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape, mean_cam;
     // workspace
     int chunk = 0;
@@ -710,7 +710,7 @@ int finalize_regressor(ap_net* h) {
 int reserve_trunk_ws(ap_net* h, ap_net::TrunkWs& w, int n) {
     const bool bf = h->prec == AP_PREC_BF16;
     const size_t es = h->esize();
-    if (!(bf && h->fuse_stem)) HIP_TRY(w.ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
+    if (!(h->fuse_stem && (bf || h->prec == AP_PREC_BF16X2))) HIP_TRY(w.ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
     HIP_TRY(w.ws_a.reserve((size_t)n * 802816 * es));
     HIP_TRY(w.ws_b.reserve((size_t)n * 802816 * es));
     HIP_TRY(w.ws_ds.reserve((size_t)n * 802816 * es));
@@ -735,6 +735,9 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     } else if (bf) {
         HIP_TRY(ap_launch_stem_conv_mfma(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
                                          h->stem_shift.as<float>(), w.ws_stem.p, n, st));
+    } else if (kind == AP_PREC_BF16X2 && h->fuse_stem) {
+        HIP_TRY(ap_launch_stem_pool_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
+                                          h->stem_shift.as<float>(), w.ws_a.p, n, st));
     } else if (kind == AP_PREC_BF16X2) {
         HIP_TRY(ap_launch_stem_conv_mfma_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
                                                h->stem_shift.as<float>(), w.ws_stem.p, n, st));
@@ -746,7 +749,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             HIP_TRY(ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
                                         (char*)w.ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, kind, st));
     }
-    if (!(bf && h->fuse_stem)) HIP_TRY(ap_launch_maxpool(w.ws_stem.p, w.ws_a.p, n, kind, st));
+    if (!(h->fuse_stem && (bf || kind == AP_PREC_BF16X2))) HIP_TRY(ap_launch_maxpool(w.ws_stem.p, w.ws_a.p, n, kind, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
     if (signal_at == 1) HIP_TRY(hipEventRecord(h->ev_skew, st));
     void *cur = w.ws_a.p, *nxt = w.ws_b.p;

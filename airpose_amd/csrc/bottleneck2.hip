@@ -35,7 +35,7 @@
 #define B2_SAFE 0
 #endif
 // timing-only builds (results wrong): 1 no x loads after the prologue | 2 no stores | 4 no W3 DMA | 8 no MFMAs | 16 no epilogue math |
-// 32 every store is issued out of range (dropped: no write traffic)
+// 32 every store is issued out of range (dropped: no write traffic) | 64 stores as 8 consecutive lanes per 128-byte line
 #ifndef B2_ABLATE
 #define B2_ABLATE 0
 #endif
@@ -446,7 +446,12 @@ bneck2_kernel(const BneckArgs a) {
                     const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3],
                                         DS ? nullptr : &xc[DS ? 0 : g * 8 + cc * 2 + q]);
                     if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(opp.off[g]));
-                    else __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, opp.off[g] + cc * 128 + q * 64, 0, 0);
+                    else if (B2_ABLATE & 64) {               // shape experiment (data of the wrong pixels): 8 CONSECUTIVE lanes = one 128-byte line
+                        const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R, p = (ll >> 3) + 8 * q;
+                        const bool ok = R >= 1 && R <= 14 && p >= 1 && p <= 14;
+                        const uint32_t off = ok ? (uint32_t)((((n * H + hy) * W + tx * B2_TS - 1 + p) * 256) * 2 + (ll & 7) * 16) : 0xffff0000u;
+                        __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, off + cc * 128, 0, 0);
+                    } else __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, opp.off[g] + cc * 128 + q * 64, 0, 0);
                 });
             });
         });

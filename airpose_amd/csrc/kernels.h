@@ -86,6 +86,9 @@ hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_spli
 // split-bf16 MFMA stem (bf16x2 mode): w_hi / w_lo: [64][232] bf16 planes of the packed weights; y: split pairs
 hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
                                           const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
+// fused split-bf16 stem + max-pool (bf16x2 mode): conv1 + bn1 + relu + maxpool, pooled split pairs [N][56][56][64]
+hipError_t ap_launch_stem_pool_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
+                                     const float* scale, const float* shift, void* y_pooled, int n_img, hipStream_t st);
 // fused bf16 MFMA stem + maxpool: NCHW fp32 crops -> [N][56][56][64] bf16
 hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
                                 const float* shift, void* y_pooled, int n_img, hipStream_t st);

@@ -422,6 +422,164 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// Fused split-bf16 MFMA stem + 3x3/2 max-pool (bf16x2 parity mode): stem_pool_kernel's strip program with every operand as a
+// (hi, lo) pair -- two weight images, two input patches, three MFMAs per product in stem_mfma_split_kernel's order (so the
+// fp32 accumulators hold the same bits) -- the vertically pooled rows in fp32 and the split rounding AFTER the 3x3 maximum:
+// v -> hi + lo (hi = bf16(v), lo = bf16(v - hi)) is monotonic in v (checked exhaustively over an exponent range on the host)
+// and post-ReLU values are >= 0, so the maximum of the rounded values is the rounded maximum; packed the way
+// maxpool_split_kernel packs it (see the store below) the result equals the split stem followed by that kernel bit for bit.  The 112 x 112 x 64 pairs (3.2 MB per image) never touch HBM; the two-kernel path was
+// 11 % of a parity-mode step.  LDS 114 KiB: one workgroup (7 waves) per CU.
+__global__ void __launch_bounds__(448) stem_pool_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
+                                                              int n_split, const bf16_t* __restrict__ wpk_hi,
+                                                              const bf16_t* __restrict__ wpk_lo, const float* __restrict__ scale,
+                                                              const float* __restrict__ shift, bsplit_t* __restrict__ y) {
+    constexpr int WBYTES = 64 * SWLD * 2, PEL = FROWS * FPW * 4 + 32, PBYTES = PEL * 2;
+    constexpr int VBYTES = 2 * SO * SC * 4;                  // [2][112][64] fp32
+    constexpr int PVBYTES = 2 * PBYTES > VBYTES ? 2 * PBYTES : VBYTES;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    bf16_t* wsm_hi = (bf16_t*)lds;
+    bf16_t* wsm_lo = (bf16_t*)(lds + WBYTES);
+    bf16_t* patch_hi = (bf16_t*)(lds + 2 * WBYTES);
+    bf16_t* patch_lo = patch_hi + PEL;
+    float* vm = (float*)(lds + 2 * WBYTES);                  // vertically pooled rows, over the dead patches
+    float* sbn = (float*)(lds + 2 * WBYTES + PVBYTES);       // BatchNorm scale | shift
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int strip = blockIdx.x, n = blockIdx.y, py0 = strip * 2;
+    constexpr int XIT = (FROWS * 56 + 447) / 448;
+    const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
+    const int iy0 = 4 * py0 - 5;
+    float4 xin0[XIT], xin1[XIT], xin2[XIT];
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {                         // (row, 4 pixels) of the three channel planes; addresses clamped
+        const int i0 = tid + k * 448, i = i0 < FROWS * 56 ? i0 : FROWS * 56 - 1;
+        const int x4 = i % 56, row = i / 56, iy = iy0 + row, iyc = iy < 0 ? 0 : iy > IMG - 1 ? IMG - 1 : iy;
+        const float* src = xin + (size_t)iyc * IMG + 4 * x4;
+        xin0[k] = *(const float4*)src;
+        xin1[k] = *(const float4*)(src + (size_t)IMG * IMG);
+        xin2[k] = *(const float4*)(src + (size_t)2 * IMG * IMG);
+    }
+    if (tid < 128) sbn[tid] = tid < 64 ? scale[tid] : shift[tid & 63];
+    for (int i = tid; i < WBYTES / 16; i += 448) {
+        ((u32x4*)wsm_hi)[i] = ((const u32x4*)wpk_hi)[i];
+        ((u32x4*)wsm_lo)[i] = ((const u32x4*)wpk_lo)[i];
+    }
+    auto split2 = [](float a, float b, uint32_t& hi, uint32_t& lo) {      // two values -> packed hi pair, packed lo pair
+        const bf16_t ha = f32_to_bf16(a), hb = f32_to_bf16(b);
+        hi = (uint32_t)ha | ((uint32_t)hb << 16);
+        lo = (uint32_t)f32_to_bf16(a - bf16_to_f32(ha)) | ((uint32_t)f32_to_bf16(b - bf16_to_f32(hb)) << 16);
+    };
+#pragma unroll
+    for (int k = 0; k < XIT; ++k) {                         // three channel planes -> 4 x [c0 c1 c2 0], hi and lo
+        const int i = tid + k * 448, x4 = i % 56, row = i / 56;
+        if (i >= FROWS * 56) continue;
+        const bool inside = (unsigned)(iy0 + row) < (unsigned)IMG;
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        const float4 v0 = inside ? xin0[k] : zero4, v1 = inside ? xin1[k] : zero4, v2 = inside ? xin2[k] : zero4;
+        const int o = (row * FPW + 4 * x4 + 3) * 4;
+        const float c0[4] = {v0.x, v0.y, v0.z, v0.w}, c1[4] = {v1.x, v1.y, v1.z, v1.w}, c2[4] = {v2.x, v2.y, v2.z, v2.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            uint32_t h01, l01, h2z, l2z;
+            split2(c0[e], c1[e], h01, l01);
+            split2(c2[e], 0.f, h2z, l2z);
+            *(uint2*)(patch_hi + o + e * 4) = make_uint2(h01, h2z);
+            *(uint2*)(patch_lo + o + e * 4) = make_uint2(l01, l2z);
+        }
+    }
+    for (int i = tid; i < FROWS * 8; i += 448) {           // left 3 / right 5 pad pixels of every row
+        const int q = i % 8, row = i / 8;
+        const int px = q < 3 ? q : 227 + (q - 3);
+        *(uint2*)(patch_hi + (row * FPW + px) * 4) = make_uint2(0u, 0u);
+        *(uint2*)(patch_lo + (row * FPW + px) * 4) = make_uint2(0u, 0u);
+    }
+    if (tid < 32) { patch_hi[FROWS * FPW * 4 + tid] = 0; patch_lo[FROWS * FPW * 4 + tid] = 0; }
+    __syncthreads();
+
+    const int lr = lane & 15, g = lane >> 4;
+    const int xo = wave * 16 + lr;                          // conv column of this lane
+    const bool row0_valid = py0 > 0;                        // conv row 2*py0-1 exists
+    f32x4 acc[5][4];
+#pragma unroll
+    for (int fm = 0; fm < 5; ++fm)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1
+    for (int kb = 0; kb < SKB; ++kb) {                      // k-block = kernel row; lane group g = taps 2g, 2g+1
+        u32x4 wh[4], wl[4], xh[5], xl[5];
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) {
+            wh[fn] = *(const u32x4*)(wsm_hi + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
+            wl[fn] = *(const u32x4*)(wsm_lo + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
+        }
+#pragma unroll
+        for (int fm = 0; fm < 5; ++fm) {
+            xh[fm] = *(const u32x4*)(patch_hi + ((2 * fm + kb) * FPW + 2 * xo + 2 * g) * 4);
+            xl[fm] = *(const u32x4*)(patch_lo + ((2 * fm + kb) * FPW + 2 * xo + 2 * g) * 4);
+        }
+#pragma unroll
+        for (int pass = 0; pass < 3; ++pass)                 // hi*hi, w_hi*x_lo, w_lo*x_hi: stem_mfma_split_kernel's order
+#pragma unroll
+            for (int fm = 0; fm < 5; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn)
+                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                        __builtin_bit_cast(bf16x8, pass == 2 ? wl[fn] : wh[fn]),
+                        __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn], 0, 0, 0);
+    }
+    __syncthreads();                                         // every wave is done with the patches: vm may overwrite them
+#pragma unroll
+    for (int fn = 0; fn < 4; ++fn) {
+        const int ch = fn * 16 + g * 4;
+        const float4 sc = *(const float4*)(sbn + ch), sh = *(const float4*)(sbn + 64 + ch);
+        float v[5][4];
+#pragma unroll
+        for (int fm = 0; fm < 5; ++fm) {
+            v[fm][0] = fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f);
+            v[fm][1] = fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f);
+            v[fm][2] = fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f);
+            v[fm][3] = fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f);
+        }
+        if (!row0_valid) { v[0][0] = v[0][1] = v[0][2] = v[0][3] = 0.f; }
+#pragma unroll
+        for (int pr = 0; pr < 2; ++pr) {
+            float4 o;
+            o.x = fmaxf(fmaxf(v[2 * pr][0], v[2 * pr + 1][0]), v[2 * pr + 2][0]);
+            o.y = fmaxf(fmaxf(v[2 * pr][1], v[2 * pr + 1][1]), v[2 * pr + 2][1]);
+            o.z = fmaxf(fmaxf(v[2 * pr][2], v[2 * pr + 1][2]), v[2 * pr + 2][2]);
+            o.w = fmaxf(fmaxf(v[2 * pr][3], v[2 * pr + 1][3]), v[2 * pr + 2][3]);
+            // rows of 256 B: the 16-byte chunk index (4 channels) XOR-swizzled by the pixel
+            *(float4*)(vm + ((pr * SO + xo) * SC + ((((ch >> 2) ^ (xo & 15)) << 2)))) = o;
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < 2 * PO * 8; i += 448) {           // (pr, px, 8-channel group)
+        const int c8 = i & 7, t = i >> 3, px = t % PO, pr = t / PO;
+        float m[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = 0.f;
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int cx = 2 * px + dx;
+            if (cx < 0) continue;
+            const float4 a = *(const float4*)(vm + ((pr * SO + cx) * SC + (((2 * c8) ^ (cx & 15)) << 2)));
+            const float4 b = *(const float4*)(vm + ((pr * SO + cx) * SC + (((2 * c8 + 1) ^ (cx & 15)) << 2)));
+            m[0] = fmaxf(m[0], a.x); m[1] = fmaxf(m[1], a.y); m[2] = fmaxf(m[2], a.z); m[3] = fmaxf(m[3], a.w);
+            m[4] = fmaxf(m[4], b.x); m[5] = fmaxf(m[5], b.y); m[6] = fmaxf(m[6], b.z); m[7] = fmaxf(m[7], b.w);
+        }
+        // split, rebuild hi + lo, split again: the two-kernel path rounds every conv output to a pair, takes the maximum of
+        // the VALUES and packs that again -- where lo rounded up to half an ulp of hi (value = the midpoint of two hi
+        // neighbours) the second packing picks the even neighbour, the same value as another pair.  One packing here would
+        // give equal values in a few different bit patterns (seen as 2e-6 relative after 52 more layers)
+        u32x4 hi, lo;
+        split8_pack(m, hi, lo);
+        split8_unpack(hi, lo, m);
+        split8_pack(m, hi, lo);
+        u32x4* dst = (u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8);
+        dst[0] = hi; dst[1] = lo;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 template <typename T>
 __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int total) {
     constexpr int EPC = 16 / sizeof(T), CPP = SC / EPC;          // chunks per pixel
@@ -659,6 +817,24 @@ hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, co
                                 const float* shift, void* y_pooled, int n_img, hipStream_t st) {
     hipLaunchKernelGGL(stem_pool_kernel, dim3(PO / 2, n_img), dim3(448), 0, st, x0, x1, n_split,
                        (const bf16_t*)w_packed, scale, shift, (bf16_t*)y_pooled);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_stem_pool_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
+                                     const float* scale, const float* shift, void* y_pooled, int n_img, hipStream_t st) {
+    static bool attr_set[AP_MAX_DEVICES] = {};
+    constexpr int pb = 2 * (FROWS * FPW * 4 + 32) * 2, vb = 2 * SO * SC * 4;
+    constexpr int lds = 2 * 64 * SWLD * 2 + (pb > vb ? pb : vb) + 128 * 4;
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)stem_pool_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (e != hipSuccess) return e;
+        attr_set[dev] = true;
+    }
+    hipLaunchKernelGGL(stem_pool_split_kernel, dim3(PO / 2, n_img), dim3(448), lds, st, x0, x1, n_split, (const bf16_t*)w_hi,
+                       (const bf16_t*)w_lo, scale, shift, (bsplit_t*)y_pooled);
     return hipGetLastError();
 }
 

@@ -195,8 +195,8 @@ int ap_net_set_fuse_ief(ap_net* h, int on);
  * fp64, no downsample tensor written or re-read); on = 0 runs the two convolutions of Bottleneck.forward
  * (model_copenet.py:38-45) separately.  Both are parity-tested. */
 int ap_net_set_fuse_ds(ap_net* h, int on);
-/* bf16 mode: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool kernels
- * (bit-identical results; kept for A/B measurement). */
+/* bf16 and bf16x2 modes: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool
+ * kernels (bit-identical results; kept for A/B measurement). */
 int ap_net_set_fuse_stem(ap_net* h, int on);
 /* bf16 mode: on = 2 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
  * intermediates never leave the CU; bottleneck2.hip: weights resident in LDS, x in registers), on = 1 the same through

@@ -639,6 +639,20 @@ def test_fused_stem_pool_is_bit_identical(netbf, dev):
     assert torch.equal(a, b)
 
 
+def test_fused_split_stem_pool_is_bit_identical(netx2, dev):
+    """bf16x2: the fused split stem + max-pool (split rounding after the 3x3 maximum) == the split stem followed by the split
+    max-pool, bit for bit, for the first / last strips (padding rows) and both views of a batch."""
+    from airpose_amd import weights as W
+    x = torch.from_numpy(W.synthetic_inputs(5, 3)["im1"]).to(dev)
+    netx2.set_fuse_stem(1)
+    a = netx2.forward_feat_ext(x)
+    netx2.set_fuse_stem(0)
+    b = netx2.forward_feat_ext(x)
+    netx2.set_fuse_stem(1)
+    assert torch.isfinite(a).all()
+    assert torch.equal(a, b)
+
+
 def test_folded_downsample_matches_separate_convs(net32, netbf, golden, copenet_inputs, dev):
     """Downsample branch folded into conv3 (second K segment) vs the two separate convolutions."""
     x = copenet_inputs["im0"].to(dev)
