@@ -277,9 +277,9 @@ bneck2_kernel(const BneckArgs a) {
     };
     // ---------------------------------------------------------------- one tile.  xc: its x fragments (requested a tile ago),
     // xn: the set the next tile's are requested into
-#ifdef AP_TRACE   // cycle stamps of waves 0 and 4 of workgroup 0, sixth tile (16 slots each): tools/probes/bneck2_trace.py
+#ifdef AP_TRACE   // cycle stamps of waves 0 and 4 of workgroup 0, sixth tile (24 slots each): tools/probes/bneck2_trace.py
     int tile_no = 0;
-    unsigned long long stamps[13];
+    unsigned long long stamps[17];
 #define B2STAMP(i) do { if (a.dbg && blockIdx.x == 0 && tile_no == 5 && (wave & 3) == 0) { \
         stamps[i] = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); } } while (0)
 #else
@@ -436,11 +436,13 @@ bneck2_kernel(const BneckArgs a) {
                 __builtin_amdgcn_sched_barrier(0);
                 if constexpr (sg + 2 < NG) rdA(wf[sg & 1], grp(base, std::integral_constant<int, sg + 2>{}));
             });
+            if constexpr (cc == 1) B2STAMP(13);              // chunk 1 in detail: MFMAs issued | tables of pair 0 | pair 0 done | tables of pair 1
             sfor<0, 2>([&](auto Q) {
                 constexpr int q = Q;
                 constexpr int to = cc * 256 + q * 128;
                 rdT(tq, tab, std::integral_constant<int, T_S3 + to>{}, std::integral_constant<int, T_H3 + to>{});
                 wait_lgkmcnt<0>();
+                if constexpr (cc == 1) B2STAMP(14 + 2 * q);
                 sfor<0, 2>([&](auto GG) {
                     constexpr int g = GG;
                     const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3],
@@ -453,12 +455,13 @@ bneck2_kernel(const BneckArgs a) {
                         __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, off + cc * 128, 0, 0);
                     } else __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, opp.off[g] + cc * 128 + q * 64, 0, 0);
                 });
+                if constexpr (cc == 1 && q == 0) B2STAMP(15);
             });
         });
 #ifdef AP_TRACE
         B2STAMP(12);
         if (a.dbg && blockIdx.x == 0 && tile_no == 5 && (wave & 3) == 0 && lane == 0)
-            for (int i = 0; i < 13; ++i) a.dbg[(wave >> 2) * 16 + i] = stamps[i];
+            for (int i = 0; i < 17; ++i) a.dbg[(wave >> 2) * 24 + i] = stamps[i];
         ++tile_no;
 #endif
     };

@@ -32,6 +32,8 @@ for rep in range(3):
     L.ap_debug_set_trace(p(buf)); run(); torch.cuda.synchronize(); L.ap_debug_set_trace(None)
     b = buf.cpu()
     for wv in (0, 1):
-        t = b[wv * 16: wv * 16 + 13]
+        t = b[wv * 24: wv * 24 + 17]
         d = [int(t[i + 1] - t[i]) for i in range(12)]
         print("ds=%d wave %d tile total %6d cycles (100 MHz ticks x clock ratio): " % (ds, wv * 4, int(t[12] - t[0])) + "  ".join("%s=%d" % (names[i], d[i]) for i in range(12)))
+        print("      chunk 1 in detail: fragment reads + 16 MFMAs issued=%d  tables of pair 0=%d  pair 0 arithmetic + 2 stores=%d  tables of pair 1=%d  pair 1 arithmetic + 2 stores=%d" % (
+            int(t[13] - t[8]), int(t[14] - t[13]), int(t[15] - t[14]), int(t[16] - t[15]), int(t[9] - t[16])))
