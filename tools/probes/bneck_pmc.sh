@@ -1,14 +1,14 @@
 #!/bin/bash
 # write-path counters of the fused layer1 kernels (stand-alone bench, 512 images): tools/probes/bneck_pmc.sh
+# (every pass under its own timeout: a pass with the TA_* counters aborted inside rocprofv3 and then sat until the box's limit)
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/bneck_pmc; rm -rf $O; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 i=0
 for C in "SQ_VMEM_WR_TA_DATA_FIFO_FULL SQ_VMEM_TA_ADDR_FIFO_FULL SQ_VMEM_TA_CMD_FIFO_FULL SQ_WAVE_CYCLES SQ_BUSY_CYCLES" \
-         "TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_BUFFER_COALESCED_WRITE_CYCLES_sum TA_BUFFER_WRITE_WAVEFRONTS_sum TA_BUSY_avr GRBM_GUI_ACTIVE" \
          "TCP_TCC_WRITE_REQ_sum TCP_PENDING_STALL_CYCLES_sum TCP_TCC_READ_REQ_sum TCP_TA_TCP_STATE_READ_sum" \
          "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum TCC_EA0_RDREQ_sum TCC_TAG_STALL_sum"; do
   i=$((i+1))
   for ds in 0 1; do
-    rocprofv3 --pmc $C --output-format csv -d $O/p${i}_ds$ds -- python $R/tools/bneck_bench.py --images 512 --cuts 2 --ds $ds --iters 3 > $O/p${i}_ds$ds.log 2>&1
+    timeout 150 rocprofv3 --pmc $C --output-format csv -d $O/p${i}_ds$ds -- python $R/tools/bneck_bench.py --images 512 --cuts 2 --ds $ds --iters 3 > $O/p${i}_ds$ds.log 2>&1
     python - "$O/p${i}_ds$ds" "$ds" <<'PY'
 import csv, glob, sys, collections
 d, ds = sys.argv[1], sys.argv[2]
