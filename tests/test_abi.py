@@ -110,3 +110,18 @@ def test_conv_config_knob_validates_on_the_host():
             assert L.ap_set_conv_config(c) != 0, c
     finally:
         assert L.ap_set_conv_config(-1) == 0
+
+
+def test_bottleneck_cut_knob_validates_on_the_host():
+    """ap_set_bottleneck_cut is host-only state: 1 (first cut) and 2 (second cut, the default) are accepted, anything else
+    is refused and leaves the selection alone."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    try:
+        for c in (1, 2):
+            assert L.ap_set_bottleneck_cut(c) == 0, c
+        for c in (0, 3, -1, 17):
+            assert L.ap_set_bottleneck_cut(c) != 0, c
+    finally:
+        assert L.ap_set_bottleneck_cut(2) == 0
+
