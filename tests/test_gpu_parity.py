@@ -436,14 +436,15 @@ def test_conv_configs_agree_bitwise(dev):
 
 
 # ------------------------------------------------------------------------------------------------ fused bottleneck
-def _bneck_case(dev, N, H, ds, seed):
+def _bneck_case(dev, N, H, ds, seed, W=None):
     """Bottleneck.forward (model_copenet.py:27-47) for planes = 64 on bf16 operands: fp64 oracle that rounds the two
     64-channel intermediates to bf16 exactly where the kernel (and the three-convolution path) does."""
     from airpose_amd import _native as Nn
     g = torch.Generator().manual_seed(seed)
     cin = 64 if ds else 256
     bf = torch.bfloat16
-    x = torch.randn(N, cin, H, H, generator=g).to(bf)
+    W = H if W is None else W
+    x = torch.randn(N, cin, H, W, generator=g).to(bf)
     w1 = (torch.randn(64, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(bf)
     w2 = (torch.randn(64, 64, 3, 3, generator=g) * (2.0 / 576) ** 0.5).to(bf)
     w3 = (torch.randn(256, 64, 1, 1, generator=g) * (2.0 / 64) ** 0.5).to(bf)
@@ -464,11 +465,11 @@ def _bneck_case(dev, N, H, ds, seed):
         return o.contiguous().to(dev)
     w3p = torch.cat([w3, wd], 1) if ds else w3
     xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
-    y = torch.full((N, H, H, 256), float("nan"), dtype=bf, device=dev)
+    y = torch.full((N, H, W, 256), float("nan"), dtype=bf, device=dev)
     dv = [rows(w1, 128), rows(w2, 128), rows(w3p, 256)] + [t.to(dev) for t in sc + sh]
     p = lambda t: ctypes.c_void_p(t.data_ptr())
     rc = Nn.lib().ap_bottleneck64_nhwc(p(xd), p(dv[0]), p(dv[3]), p(dv[6]), p(dv[1]), p(dv[4]), p(dv[7]), p(dv[2]),
-                                       p(dv[5]), p(dv[8]), p(y), N, H, H, cin, int(ds), Nn.stream_ptr(dev))
+                                       p(dv[5]), p(dv[8]), p(y), N, H, W, cin, int(ds), Nn.stream_ptr(dev))
     Nn.check(rc, "ap_bottleneck64_nhwc")
     torch.cuda.synchronize()
     return y.float().cpu().permute(0, 3, 1, 2).double(), ref
@@ -490,6 +491,14 @@ def test_fused_bottleneck_primitive(dev, N, H, ds, bneck_cut):
     assert torch.isfinite(got).all()
     # same operands and the same bf16 rounding points: what differs is the fp32 accumulation order (an intermediate
     # may round to the neighbouring bf16 value) and the bf16 rounding of the output
+    assert rel_err(got.numpy(), ref.numpy()) < 8e-3
+
+
+@pytest.mark.parametrize("ds", [0, 1])
+def test_fused_bottleneck_rectangular_image(dev, ds, bneck_cut):
+    """H != W (2 x 3 tiles): tile rows / columns and the image border masks are not interchangeable."""
+    got, ref = _bneck_case(dev, 3, 28, ds, seed=31 + ds, W=42)
+    assert torch.isfinite(got).all()
     assert rel_err(got.numpy(), ref.numpy()) < 8e-3
 
 
