@@ -273,6 +273,10 @@ __global__ void __launch_bounds__(256) stem_mfma_split_kernel(const float* __res
 #ifndef AP_STEM_PASSES
 #define AP_STEM_PASSES 1
 #endif
+// timing-only builds (results wrong): 1 no input loads | 2 no weight loads | 4 no MFMAs | 8 no output stores
+#ifndef STEM_ABLATE
+#define STEM_ABLATE 0
+#endif
 constexpr int FPW = 232;                                   // patch row stride in pixels (230 used, even)
 constexpr int FROWS = 15;                                  // input rows of a strip
 __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
@@ -303,13 +307,15 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
 #pragma unroll
     for (int k = 0; k < WIT; ++k) {
         const int i = tid + k * 448;
-        wreg[k] = ((const u32x4*)wpk)[i < WBYTES / 16 ? i : WBYTES / 16 - 1];
+        if (STEM_ABLATE & 2) wreg[k] = u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        else wreg[k] = ((const u32x4*)wpk)[i < WBYTES / 16 ? i : WBYTES / 16 - 1];
     }
 #pragma unroll
     for (int k = 0; k < XIT; ++k) {                         // (row, 4 pixels) of the three channel planes
         const int i0 = tid + k * 448, i = i0 < FROWS * 56 ? i0 : FROWS * 56 - 1;
         const int x4 = i % 56, row = i / 56, iy = iy0 + row, iyc = iy < 0 ? 0 : iy > IMG - 1 ? IMG - 1 : iy;
         const float* src = xin + (size_t)iyc * IMG + 4 * x4;
+        if (STEM_ABLATE & 1) { xin0[k] = xin1[k] = xin2[k] = make_float4(0.5f, 0.25f, 0.125f, 1.f); continue; }
         xin0[k] = *(const float4*)src;
         xin1[k] = *(const float4*)(src + (size_t)IMG * IMG);
         xin2[k] = *(const float4*)(src + (size_t)2 * IMG * IMG);
@@ -367,9 +373,11 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
 #pragma unroll
             for (int fm = 0; fm < 5; ++fm)
 #pragma unroll
-                for (int fn = 0; fn < FNH; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                for (int fn = 0; fn < FNH; ++fn) {
+                    if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[fm]));
+                    else acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
                         __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+                }
         }
         __syncthreads();                                     // every wave is done with the patch: vm may overwrite it
 #pragma unroll
@@ -417,6 +425,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         u32x4 o;
         o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
         o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
+        if (STEM_ABLATE & 8) asm volatile("" ::"v"(o)); else
         *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
     }
 }
