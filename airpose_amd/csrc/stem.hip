@@ -273,7 +273,8 @@ __global__ void __launch_bounds__(256) stem_mfma_split_kernel(const float* __res
 #ifndef AP_STEM_PASSES
 #define AP_STEM_PASSES 1
 #endif
-// timing-only builds (results wrong): 1 no input loads | 2 no weight loads | 4 no MFMAs | 8 no output stores
+// timing-only builds (results wrong): 1 no input loads | 2 no weight loads | 4 no MFMAs | 8 no output stores | 16 no horizontal
+// pooling pass | 32 no epilogue (BatchNorm, ReLU, vertical maximum, pooled rows to LDS) | 128 no fragment reads in the K loop
 #ifndef STEM_ABLATE
 #define STEM_ABLATE 0
 #endif
@@ -366,10 +367,15 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         for (int kb = 0; kb < SKB; ++kb) {                  // k-block = kernel row; lane group g = taps 2g, 2g+1
             u32x4 wf[FNH], xf[5];
 #pragma unroll
-            for (int fn = 0; fn < FNH; ++fn)
-                wf[fn] = *(const u32x4*)(wsm + ((half * FNH + fn) * 16 + lr) * SWLD + kb * 32 + g * 8);
+            for (int fn = 0; fn < FNH; ++fn) {
+                if (STEM_ABLATE & 128) wf[fn] = u32x4{0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                else wf[fn] = *(const u32x4*)(wsm + ((half * FNH + fn) * 16 + lr) * SWLD + kb * 32 + g * 8);
+            }
 #pragma unroll
-            for (int fm = 0; fm < 5; ++fm) xf[fm] = *(const u32x4*)(patch + ((2 * fm + kb) * FPW + 2 * xo + 2 * g) * 4);
+            for (int fm = 0; fm < 5; ++fm) {
+                if (STEM_ABLATE & 128) xf[fm] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
+                else xf[fm] = *(const u32x4*)(patch + ((2 * fm + kb) * FPW + 2 * xo + 2 * g) * 4);
+            }
 #pragma unroll
             for (int fm = 0; fm < 5; ++fm)
 #pragma unroll
@@ -382,6 +388,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         __syncthreads();                                     // every wave is done with the patch: vm may overwrite it
 #pragma unroll
         for (int fn = 0; fn < FNH; ++fn) {
+            if (STEM_ABLATE & 32) { asm volatile("" ::"v"(acc[0][fn]), "v"(acc[1][fn]), "v"(acc[2][fn]), "v"(acc[3][fn]), "v"(acc[4][fn])); continue; }
             const int ch = (half * FNH + fn) * 16 + g * 4;
             const float4 sc = *(const float4*)(sbn + ch), sh = *(const float4*)(sbn + 64 + ch);
             float v[5][4];
@@ -407,6 +414,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
     }
     __syncthreads();
     for (int i = tid; i < 2 * PO * 8; i += 448) {           // (pr, px, 8-channel chunk)
+        if (STEM_ABLATE & 16) break;
         const int c8 = i & 7, t = i >> 3, px = t % PO, pr = t / PO;
         float m[8];
 #pragma unroll
