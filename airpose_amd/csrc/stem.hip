@@ -670,67 +670,65 @@ __global__ void __launch_bounds__(256) maxpool_split_kernel(const bsplit_t* __re
     dst[0] = hi; dst[1] = lo;
 }
 
-__global__ void __launch_bounds__(256) avgpool_split_kernel(const bsplit_t* __restrict__ x, float* __restrict__ y, int C, int total) {
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int gpr = C / 8, gc = idx % gpr, n = idx / gpr;
-    float s[8];
+// AvgPool2d(7) over the 49 pixels of an image, all three storage kinds.  One workgroup = 32 consecutive channel groups (16-byte
+// pieces: 4 fp32 / 8 bf16 / 8 split pairs) x 8 pixel partitions: thread (part, gl) sums pixels part, part + 8, ... of its
+// group in that order, the 8 partial sums meet in LDS and are added in partition order -- a fixed association, the same on
+// every run.  (One thread per group walking all 49 pixels left the chip at 4 waves per CU and the stage at 0.6-1.5 TB/s.)
+template <int EPC, typename LOAD>
+__device__ __forceinline__ void avgpool_body(LOAD&& load, float* __restrict__ y, int C, int n_img) {
+    __shared__ float part_sum[8][32][EPC];
+    const int gl = threadIdx.x & 31, part = threadIdx.x >> 5;
+    const int gpr = C / EPC, tiles = gpr / 32, n = blockIdx.x / tiles, g0 = (blockIdx.x % tiles) * 32;
+    float s[EPC];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) s[e] = 0.f;
-    const bsplit_t* src = x + (size_t)n * 49 * C + gc * 8;
-    for (int p0 = 0; p0 < 49; p0 += 7) {                    // 7 x 2 loads in flight per thread, summed in pixel order
-        u32x4 vh[7], vl[7];
+    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
+    float v[7][EPC];
 #pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            const u32x4* q = (const u32x4*)(src + (size_t)(p0 + u) * C);
-            vh[u] = q[0]; vl[u] = q[1];
-        }
-#pragma unroll
-        for (int u = 0; u < 7; ++u) {
-            float v[8];
-            split8_unpack(vh[u], vl[u], v);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) s[e] += v[e];
-        }
+    for (int j = 0; j < 7; ++j) {                           // pixels part + 8 j (49 = 6 x 8 + 1: partition 0 has a seventh)
+        const int p = part + 8 * j;
+        load(n, p < 49 ? p : 48, g0 + gl, v[j]);
     }
-    float* dst = y + (size_t)n * C + gc * 8;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) dst[e] = s[e] / 49.0f;
+    for (int j = 0; j < 7; ++j)
+        if (part + 8 * j < 49) {
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += v[j][e];
+        }
+#pragma unroll
+    for (int e = 0; e < EPC; ++e) part_sum[part][gl][e] = s[e];
+    __syncthreads();
+    if (part == 0) {
+#pragma unroll
+        for (int k = 1; k < 8; ++k)
+#pragma unroll
+            for (int e = 0; e < EPC; ++e) s[e] += part_sum[k][gl][e];
+        float* dst = y + (size_t)n * C + (size_t)(g0 + gl) * EPC;
+#pragma unroll
+        for (int e = 0; e < EPC; ++e) dst[e] = s[e] / 49.0f;
+    }
+}
+
+__global__ void __launch_bounds__(256) avgpool_split_kernel(const bsplit_t* __restrict__ x, float* __restrict__ y, int C, int n_img) {
+    avgpool_body<8>([&](int n, int p, int g, float (&v)[8]) {
+        const u32x4* q = (const u32x4*)(x + ((size_t)n * 49 + p) * C + (size_t)g * 8);
+        split8_unpack(q[0], q[1], v);
+    }, y, C, n_img);
 }
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int total) {
+__global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int n_img) {
     constexpr int EPC = 16 / sizeof(T);
-    const int idx = blockIdx.x * 256 + threadIdx.x;
-    if (idx >= total) return;
-    const int cpr = C / EPC, cc = idx % cpr, n = idx / cpr;
-    float s[EPC];
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) s[e] = 0.f;
-    const T* src = x + (size_t)n * 49 * C + cc * EPC;
-    for (int p0 = 0; p0 < 49; p0 += 7) {                    // 7 loads in flight per thread, summed in pixel order
-      uint4 vv[7];
-#pragma unroll
-      for (int u = 0; u < 7; ++u) vv[u] = *(const uint4*)(src + (size_t)(p0 + u) * C);
-#pragma unroll
-      for (int u = 0; u < 7; ++u) {
-        const uint4 v = vv[u];
+    avgpool_body<EPC>([&](int n, int p, int g, float (&v)[EPC]) {
+        const uint4 q = *(const uint4*)(x + ((size_t)n * 49 + p) * C + (size_t)g * EPC);
         if constexpr (sizeof(T) == 2) {
-            float lo, hi;
-            unpack_bf16x2(v.x, lo, hi); s[0] += lo; s[1] += hi;
-            unpack_bf16x2(v.y, lo, hi); s[2] += lo; s[3] += hi;
-            unpack_bf16x2(v.z, lo, hi); s[4] += lo; s[5] += hi;
-            unpack_bf16x2(v.w, lo, hi); s[6] += lo; s[7] += hi;
+            unpack_bf16x2(q.x, v[0], v[1]); unpack_bf16x2(q.y, v[2], v[3]);
+            unpack_bf16x2(q.z, v[4], v[5]); unpack_bf16x2(q.w, v[6], v[7]);
         } else {
-            s[0] += __builtin_bit_cast(float, v.x); s[1] += __builtin_bit_cast(float, v.y);
-            s[2] += __builtin_bit_cast(float, v.z); s[3] += __builtin_bit_cast(float, v.w);
+            v[0] = __builtin_bit_cast(float, q.x); v[1] = __builtin_bit_cast(float, q.y);
+            v[2] = __builtin_bit_cast(float, q.z); v[3] = __builtin_bit_cast(float, q.w);
         }
-      }
-    }
-    float* dst = y + (size_t)n * C + cc * EPC;
-#pragma unroll
-    for (int e = 0; e < EPC; ++e) dst[e] = s[e] / 49.0f;
+    }, y, C, n_img);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -873,18 +871,11 @@ hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStr
 }
 
 hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int kind, hipStream_t st) {
-    if (kind == K_SPLIT) {
-        const int total = n_img * (C / 8);
-        hipLaunchKernelGGL(avgpool_split_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x, y, C,
-                           total);
-    } else if (kind == K_BF16) {
-        const int total = n_img * (C / 8);
-        hipLaunchKernelGGL(avgpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)x, y, C,
-                           total);
-    } else {
-        const int total = n_img * (C / 4);
-        hipLaunchKernelGGL(avgpool_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)x, y, C,
-                           total);
-    }
+    const int epc = kind == K_F32 ? 4 : 8;
+    if (n_img <= 0 || C % (32 * epc)) return hipErrorInvalidValue;          // workgroup = 32 groups of epc channels
+    const dim3 grid((unsigned)(n_img * (C / epc / 32)));
+    if (kind == K_SPLIT) hipLaunchKernelGGL(avgpool_split_kernel, grid, dim3(256), 0, st, (const bsplit_t*)x, y, C, n_img);
+    else if (kind == K_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, y, C, n_img);
+    else hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, y, C, n_img);
     return hipGetLastError();
 }
