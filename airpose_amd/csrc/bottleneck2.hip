@@ -227,7 +227,7 @@ bneck2_kernel(const BneckArgs a) {
     // every kernel-argument load completes here (a scalar load pending inside the loop would share lgkmcnt with the counted
     // fragment reads, and scalar loads return out of order)
     const int tpi = a.tiles_per_img, tlx = a.tiles_x, total = a.total;
-    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, a.N * H * W * 512, 0x00020000);
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, (int)((uint32_t)a.N * H * W * 512u), 0x00020000);   // (< 0xffff0000: launcher)
     asm volatile("" ::"s"(tpi), "s"(tlx), "s"(total), "s"(H), "s"(W), "s"(xg), "s"(yg), "s"(a.w3));
 
     // x of the wave's two halo rows of tile T as B fragments: xs[g*NK1 + k] = channels k*32 + g4*8 .. + 7 of pixel (row g, col lr).
@@ -240,7 +240,7 @@ bneck2_kernel(const BneckArgs a) {
         for (int g = 0; g < 2; ++g) {
             int cy = ty * B2_TS - 1 + 2 * wave + g;
             cy = cy < 0 ? 0 : (cy >= H ? H - 1 : cy);
-            xp[g] = (uint32_t)((((n * H + cy) * W + cx) * CIN + g4 * 8) * 2);
+            xp[g] = ((((uint32_t)n * H + cy) * W + cx) * CIN + g4 * 8) * 2;          // (unsigned: up to 4 GB of x)
         }
     };
     auto xone = [&](u32x4 (&xs)[NX], uint32_t (&xp)[2], auto II) {      // load i: fragment i/2 of row i%2
@@ -261,7 +261,7 @@ bneck2_kernel(const BneckArgs a) {
         for (int g = 0; g < 2; ++g) {
             const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R;
             const bool ok = R >= 1 && R <= 14 && lr >= 1 && lr <= 14 && !(B2_ABLATE & 32);
-            o.off[g] = ok ? (uint32_t)((((n * H + hy) * W + hx) * 256 + g4 * 8) * 2) : OOB;
+            o.off[g] = ok ? ((((uint32_t)n * H + hy) * W + hx) * 256 + g4 * 8) * 2 : OOB;
         }
     };
     auto rdA = [&](u32x4 (&w)[4], uint32_t addr) {
@@ -451,7 +451,7 @@ bneck2_kernel(const BneckArgs a) {
                     else if (B2_ABLATE & 64) {               // shape experiment (data of the wrong pixels): 8 CONSECUTIVE lanes = one 128-byte line
                         const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R, p = (ll >> 3) + 8 * q;
                         const bool ok = R >= 1 && R <= 14 && p >= 1 && p <= 14;
-                        const uint32_t off = ok ? (uint32_t)((((n * H + hy) * W + tx * B2_TS - 1 + p) * 256) * 2 + (ll & 7) * 16) : 0xffff0000u;
+                        const uint32_t off = ok ? ((((uint32_t)n * H + hy) * W + tx * B2_TS - 1 + p) * 256) * 2 + (ll & 7) * 16 : 0xffff0000u;
                         __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, off + cc * 128, 0, 0);
                     } else __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, opp.off[g] + cc * 128 + q * 64, 0, 0);
                 });
