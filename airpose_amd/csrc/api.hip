@@ -780,7 +780,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.t2 = w.ws_t2.p; a.wstream = B.pair.p;
             a.s3 = L3.scale.as<float>(); a.h3 = L3.shift.as<float>();
             a.s1 = Nx.c1.scale.as<float>(); a.h1 = Nx.c1.shift.as<float>();
-            a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho;
+            a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg;
             if (B.has_down) { a.x2 = cur; a.Ho = a.Wo = Ho; a.H2 = a.W2 = H; a.stride2 = L3.stride2; }
             else a.res = cur;
             HIP_TRY(ap_launch_conv_pair(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
@@ -1185,6 +1185,7 @@ int ap_conv_pair_nhwc(const void* t2, const void* w3, const float* s3, const flo
     }
     PairArgs a{};
     a.t2 = t2; a.res = res; a.wstream = ws.p; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n; a.M = M;
+    a.dbg = g_conv_dbg;
     HIP_TRY(ap_launch_conv_pair(a, P, 0, 4 * P, N1, st));
     return AP_OK;
 }

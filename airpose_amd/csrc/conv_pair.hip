@@ -299,6 +299,13 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         return;
     }
     // one 128-channel chunk of conv3 + its share of conv1; cur: this chunk's identity / result, nxt: the next chunk's identity
+#ifdef AP_TRACE   // cycle stamps of wave 0 of workgroups 0 and 300, chunk 1 (32 slots each): tools/probes/pair_trace.py
+#define PRSTAMP(i) do { if (p.dbg && nb == 1 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 300)) { \
+        const unsigned long long t_ = __builtin_readcyclecounter(); asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+        if (lane == 0) p.dbg[(blockIdx.x ? 32 : 0) + (i)] = t_; } } while (0)
+#else
+#define PRSTAMP(i) do { } while (0)
+#endif
     auto chunk = [&](int nb, u32x4 (&cur)[4], u32x4 (&nxt)[IDB ? 4 : 1]) {
         const bool lastc = nb == NB - 1;
         f32x4 acc3[8];
@@ -311,8 +318,14 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
             // conservative.  After the barrier everybody's pieces of that tile have landed and the slot read last step is free.
             constexpr int rem = SPC - 1 - j;                 // steps after this one in the chunk
             constexpr int yl = rem - 1 < S - 3 ? (rem - 1 > 0 ? rem - 1 : 0) : S - 3;
+            PRSTAMP(3 * j);
+            // (measured, tools/probes/pair_trace.py: counting the identity loads / the next chunk's operations into these waits moves
+            //  the 1.2-2.5k-cycle stall of step 1 into the epilogue's wait for the identity and changes nothing: the loads themselves
+            //  take that long under this kernel's own HBM traffic)
             if (lastc) { if constexpr (rem > 0) wait_vmcnt<LPW * yl>(); } else wait_vmcnt<LPW * (S - 3)>();
+            PRSTAMP(3 * j + 1);
             __builtin_amdgcn_s_barrier();
+            PRSTAMP(3 * j + 2);
             const bool issue = !(PR_ABLATE & 4) && !(lastc && rem < S - 1);
             const bool pre = !(lastc && rem == 0);
             if constexpr (j < KP) {
@@ -326,6 +339,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
                 else load_identity(nb, cur);
             }
             if constexpr (j == KP - 1) {
+                PRSTAMP(28);
                 // ---------------------------------------------------- conv3 epilogue of chunk nb, in registers.
                 // Certainly younger than this chunk's identity loads -- IDB: the DMA pieces of steps 1 .. SPC-1 of the previous
                 // chunk (S-1 <= SPC: every step of a chunk that is not the last one issues), of the prologue for chunk 0;
@@ -353,7 +367,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
                         *(u32x4*)oq = cur[q];
                     } else if (mok) *(u32x4*)(outp + nb * 256 + q * 64) = cur[q];
                 });
+                PRSTAMP(29);
             }
+            if constexpr (j == SPC - 1) PRSTAMP(30);
         });
     };
     for (int nb = 0; nb < NB; nb += 2) {

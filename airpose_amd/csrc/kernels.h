@@ -53,6 +53,7 @@ struct PairArgs {
     // stage-first block: second K segment = the block input x2 [N][H2][W2][P2] sampled at (ho*stride2, wo*stride2)
     const void* x2;
     int Ho, Wo, H2, W2, stride2;
+    unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
 };
 bool ap_conv_pair_supported(int P, int P2, int C3, int N1);
 size_t ap_conv_pair_stream_bytes(int P, int P2, int C3, int N1);
