@@ -118,6 +118,9 @@ __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&w
     }
 }
 
+#ifndef X2_DROP
+#define X2_DROP 0      // experiment: 1 drops w_hi * x_lo (activations as plain bf16), 2 drops w_lo * x_hi (weights as plain bf16)
+#endif
 // split-bf16 (planar) second cluster of a K step: w_hi * x_lo over all accumulators, then w_lo * x_hi (the first cluster
 // is the plain mma_issue on the hi fragments), the two MFMAs of one accumulator FM*FN instructions apart
 template <int FM, int FN, int NP, typename F>
@@ -128,7 +131,8 @@ __device__ __forceinline__ void mma_issue_cross(const u32x4 (&xh)[FM], const u32
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
         const int jj = j % (FM * FN), fm = jj / FN, fn = jj % FN;
-        acc[fm][fn] = rp_mfma_bf16(j < FM * FN ? wh[fn] : wl[fn], j < FM * FN ? xl[fm] : xh[fm], acc[fm][fn]);
+        if (!((X2_DROP == 1 && j < FM * FN) || (X2_DROP == 2 && j >= FM * FN)))
+            acc[fm][fn] = rp_mfma_bf16(j < FM * FN ? wh[fn] : wl[fn], j < FM * FN ? xl[fm] : xh[fm], acc[fm][fn]);
 #pragma unroll
         for (int k = 0; k < NP; ++k)
             if ((k + 1) * NM / (NP + 1) == j + 1) {
