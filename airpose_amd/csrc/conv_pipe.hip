@@ -121,17 +121,20 @@ __device__ __forceinline__ void mma_issue(const u32x4 (&xf)[FM], const u32x4 (&w
 #ifndef X2_DROP
 #define X2_DROP 0      // experiment: 1 drops w_hi * x_lo (activations as plain bf16), 2 drops w_lo * x_hi (weights as plain bf16)
 #endif
+#ifndef X2_MINH
+#define X2_MINH 0       // ... X2_DROP = 1 only in layers whose input has at least this many rows (0: everywhere)
+#endif
 // split-bf16 (planar) second cluster of a K step: w_hi * x_lo over all accumulators, then w_lo * x_hi (the first cluster
 // is the plain mma_issue on the hi fragments), the two MFMAs of one accumulator FM*FN instructions apart
 template <int FM, int FN, int NP, typename F>
 __device__ __forceinline__ void mma_issue_cross(const u32x4 (&xh)[FM], const u32x4 (&xl)[FM], const u32x4 (&wh)[FN],
-                                                const u32x4 (&wl)[FN], f32x4 (&acc)[FM][FN], F&& piece) {
+                                                const u32x4 (&wl)[FN], f32x4 (&acc)[FM][FN], F&& piece, bool drop_here = true) {
     constexpr int NM = 2 * FM * FN;
     static_assert(NM >= NP + 1, "need more MFMAs than DMA pieces per cluster");
 #pragma unroll
     for (int j = 0; j < NM; ++j) {
         const int jj = j % (FM * FN), fm = jj / FN, fn = jj % FN;
-        if (!((X2_DROP == 1 && j < FM * FN) || (X2_DROP == 2 && j >= FM * FN)))
+        if (!((X2_DROP == 1 && drop_here && j < FM * FN) || (X2_DROP == 2 && j >= FM * FN)))
             acc[fm][fn] = rp_mfma_bf16(j < FM * FN ? wh[fn] : wl[fn], j < FM * FN ? xl[fm] : xh[fm], acc[fm][fn]);
 #pragma unroll
         for (int k = 0; k < NP; ++k)
@@ -390,7 +393,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
         }
         AP_STAMP(7);
         if constexpr (SPLIT)
-            mma_issue_cross<FM, FN, LPW>(xf0, xf1, wf0, wf1, acc, [&](int i) { if (refill && !(RP_ABLATE & 1)) issue_piece(i, cs); });
+            mma_issue_cross<FM, FN, LPW>(xf0, xf1, wf0, wf1, acc, [&](int i) { if (refill && !(RP_ABLATE & 1)) issue_piece(i, cs); }, p.H >= X2_MINH);
         else
             mma_issue<T, FM, FN, LPW>(xf1, wf1, acc, [&](int i) { if (refill && !(RP_ABLATE & 1)) issue_piece(i, cs); });
         if (++cs == S) cs = 0;
