@@ -12,10 +12,14 @@ import torch  # noqa: F401  (must be imported first so that libamdhip64 is the o
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIRPOSE_HIP_LIB", os.path.join(_HERE, "libairpose_hip.so"))   # override: profiling builds
+# the fp16 flavour: the same sources built with -DAP_F16 (fp16 instead of bf16 as the 16-bit storage / MFMA type)
+LIB_PATH_F16 = os.environ.get("AIRPOSE_HIP_LIB_F16", os.path.join(_HERE, "libairpose_hip_f16.so"))
 
 AP_PREC_FP32, AP_PREC_BF16, AP_PREC_BF16X2 = 0, 1, 2
-# fp32: exact fp32 MFMA chain | bf16: throughput mode | bf16x2: split-bf16 pairs, the fast parity mode
-PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16, "bf16x2": AP_PREC_BF16X2}
+# fp32: exact fp32 MFMA chain | bf16: throughput mode, bf16 storage | f16: throughput mode, fp16 storage (the kernels of the bf16
+# mode from the fp16 flavour of the library: 11 significand bits instead of 8 at the same MFMA rate) | bf16x2: split-bf16 pairs
+PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16, "f16": AP_PREC_BF16, "bf16x2": AP_PREC_BF16X2}
+FLAVOUR = {"f16": "f16"}                                    # precision -> library flavour ("" = libairpose_hip.so)
 
 _c = ctypes
 _vp, _i, _f, _i64p = _c.c_void_p, _c.c_int, _c.c_float, _c.POINTER(_c.c_int64)
@@ -86,31 +90,38 @@ SIGNATURES = {
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }
 
-_lib = None
+_libs = {}
 _lib_lock = threading.Lock()
 
 
-def lib():
-    """Load (once) and return the shared library; raises if it has not been built."""
-    global _lib
-    if _lib is None:
+def lib(flavour=""):
+    """Load (once) and return the shared library of that flavour ("" = bf16 storage, "f16" = fp16 storage); raises if it has
+    not been built."""
+    L = _libs.get(flavour)
+    if L is None:
         with _lib_lock:
-            if _lib is None:
-                if not os.path.isfile(LIB_PATH):
+            L = _libs.get(flavour)
+            if L is None:
+                path = LIB_PATH_F16 if flavour == "f16" else LIB_PATH
+                if not os.path.isfile(path):
                     raise RuntimeError(
                         "airpose_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
-                        "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
-                L = ctypes.CDLL(LIB_PATH)
+                        "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % path)
+                L = ctypes.CDLL(path)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)
                     fn.restype, fn.argtypes = res, args
-                _lib = L
-    return _lib
+                _libs[flavour] = L
+    return L
 
 
-def check(rc, what):
+def lib_for(precision):
+    return lib(FLAVOUR.get(precision, ""))
+
+
+def check(rc, what, L=None):
     if rc != 0:
-        msg = lib().ap_last_error().decode("utf-8", "replace")
+        msg = (L or lib()).ap_last_error().decode("utf-8", "replace")
         raise RuntimeError("airpose_hip %s failed (status %d): %s" % (what, rc, msg))
 
 

@@ -50,7 +50,7 @@ class copenet(nn.Module):
         if tuple(layers) != (3, 4, 6, 3):
             raise ValueError("only the ResNet-50 layout [3, 4, 6, 3] of the reference is supported")
         if precision not in N.PRECISIONS:
-            raise ValueError("precision must be 'bf16' (throughput), 'bf16x2' (split-bf16: fast parity mode) or "
+            raise ValueError("precision must be 'bf16' / 'f16' (throughput; bf16 or fp16 storage), 'bf16x2' (split-bf16: fast parity mode) or "
                              "'fp32' (exact fp32 MFMA chain)")
         self.precision = precision
         self.inplanes = 64
@@ -125,7 +125,7 @@ class copenet(nn.Module):
         sig = (device.index, self._signature())
         if self._handle is not None and sig == self._packed_sig:
             return self._handle
-        L = N.lib()
+        L = self._L()
         if self._handle is not None and getattr(self, "_hdev", device.index) != device.index:
             # the handle (packed weights, workspace, per-device launch state) belongs to the device of the first call
             L.ap_net_destroy(self._handle)
@@ -151,7 +151,7 @@ class copenet(nn.Module):
     def __del__(self):
         try:
             if getattr(self, "_handle", None) is not None:
-                N.lib().ap_net_destroy(self._handle)
+                self._L().ap_net_destroy(self._handle)
                 self._handle = None
         except Exception:
             pass
@@ -178,7 +178,7 @@ class copenet(nn.Module):
         out = torch.empty(x.shape[0], 2048, device=dev, dtype=torch.float32)
         with self._lock, torch.cuda.device(dev):
             h = self._native(dev)
-            N.check(N.lib().ap_trunk_fwd(h, N.dptr(x, "x"), x.shape[0], N.dptr(out), N.stream_ptr(dev)), "ap_trunk_fwd")
+            N.check(self._L().ap_trunk_fwd(h, N.dptr(x, "x"), x.shape[0], N.dptr(out), N.stream_ptr(dev)), "ap_trunk_fwd")
         return out
 
     @staticmethod
@@ -207,7 +207,7 @@ class copenet(nn.Module):
         betas = torch.empty(2, B, 10, device=dev, dtype=torch.float32)
         with self._lock, torch.cuda.device(dev):
             h = self._native(dev)
-            fn = getattr(N.lib(), entry)
+            fn = getattr(self._L(), entry)
             N.check(fn(h, N.dptr(a0), N.dptr(a1), N.dptr(bb0), N.dptr(bb1), N.dptr(pos0), N.dptr(pos1),
                        N.dptr(th0), th0s, N.dptr(th1), th1s, N.dptr(sh0), sh0s, N.dptr(sh1), sh1s, B, int(iters),
                        N.dptr(pose[0]), N.dptr(betas[0]), N.dptr(pose[1]), N.dptr(betas[1]), N.stream_ptr(dev)), entry)
@@ -257,21 +257,25 @@ class copenet(nn.Module):
         betas_out = torch.empty(B, 10, device=dev, dtype=torch.float32)
         with self._lock, torch.cuda.device(dev):
             h = self._native(dev)
-            N.check(N.lib().ap_regressor_step(h, N.dptr(xf), N.dptr(bb), N.dptr(pose), N.dptr(betas), N.dptr(partner),
+            N.check(self._L().ap_regressor_step(h, N.dptr(xf), N.dptr(bb), N.dptr(pose), N.dptr(betas), N.dptr(partner),
                                               136, B, N.dptr(pose_out), N.dptr(betas_out), N.stream_ptr(dev)),
                     "ap_regressor_step")
         return pose_out, betas_out
 
     # ------------------------------------------------------------------ measurement hooks (bench.py)
     def enable_timing(self, on=True):
-        N.check(N.lib().ap_net_enable_timing(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
+        N.check(self._L().ap_net_enable_timing(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_net_enable_timing")
 
     def timing(self, reset=True):
         ms = (ctypes.c_double * 4)()
         n = ctypes.c_int64()
-        N.check(N.lib().ap_net_timing(self._handle, ms, ctypes.byref(n), int(reset)), "ap_net_timing")
+        N.check(self._L().ap_net_timing(self._handle, ms, ctypes.byref(n), int(reset)), "ap_net_timing")
         return {"stem_ms": ms[0], "conv_ms": ms[1], "avgpool_ms": ms[2], "regressor_ms": ms[3], "passes": n.value}
+
+    def _L(self):
+        """The native library this model's handle lives in ("f16": the fp16 flavour)."""
+        return N.lib_for(self.precision)
 
     def _set_knob(self, entry, value):
         """Per-handle knob: remembered on the module and re-applied whenever the native handle is re-created (a call
@@ -280,7 +284,7 @@ class copenet(nn.Module):
         self._knobs[entry] = int(value)
         with self._lock:
             h = self._native(torch.device("cuda", torch.cuda.current_device()))
-            N.check(getattr(N.lib(), entry)(h, int(value)), entry)
+            N.check(getattr(self._L(), entry)(h, int(value)), entry)
 
     def set_fold(self, on):
         """Evaluate fc1 -> fc2 -> dec as one folded affine map (default) or as the literal chain."""

@@ -3,19 +3,36 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// -DAP_F16 (experiment build, libairpose_hip_f16.so): the 16-bit storage type of the "bf16" mode becomes IEEE fp16 everywhere --
+// same MFMA rate, 11 instead of 8 significand bits, 5 exponent bits (activations and weights of this network stay far inside).
+// The names keep "bf16"; only this header, the MFMA mnemonic and the pack instruction change.
+#ifdef AP_F16
+typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
+#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 __builtin_amdgcn_mfma_f32_16x16x32_f16
+#define AP_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
+#define AP_CVTPK_ASM "v_cvt_pk_f16_f32"
+#else
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+#define AP_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
+#define AP_CVTPK_ASM "v_cvt_pk_bf16_f32"
+#endif
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
 typedef uint16_t bf16_t;   // storage type of a bf16 activation / weight
 
 #define AP_WAVE 64
 
+#ifdef AP_F16
+__device__ __forceinline__ float bf16_to_f32(bf16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) { return __builtin_bit_cast(bf16_t, (_Float16)f); }
+#else
 __device__ __forceinline__ float bf16_to_f32(bf16_t h) {
     return __builtin_bit_cast(float, (uint32_t)h << 16);
 }
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-even
     return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
+#endif
 // two fp32 -> one dword of two bf16, round to nearest even.  One v_cvt_pk_bf16_f32 for the PAIR: written as two (__bf16) casts
 // and an or, hipcc emits the same instruction once per VALUE (second source a dummy) plus a shift / or to merge them -- three
 // VALU instructions per pair in every epilogue of the trunk instead of one (identical results: it is the same conversion).
@@ -24,12 +41,17 @@ __device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
     return (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
 #endif
     uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    asm(AP_CVTPK_ASM " %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
 __device__ __forceinline__ void unpack_bf16x2(uint32_t u, float& lo, float& hi) {
+#ifdef AP_F16
+    lo = bf16_to_f32((bf16_t)(u & 0xffffu));
+    hi = bf16_to_f32((bf16_t)(u >> 16));
+#else
     lo = __builtin_bit_cast(float, u << 16);
     hi = __builtin_bit_cast(float, u & 0xffff0000u);
+#endif
 }
 
 // Split-bf16 storage ("bf16x2" precision): one value as two bf16, hi = rne(x) and lo = rne(x - hi), value = hi + lo
@@ -56,8 +78,11 @@ __device__ __forceinline__ void split8_unpack(const u32x4& hi, const u32x4& lo, 
     const uint32_t hh[4] = {hi.x, hi.y, hi.z, hi.w}, ll[4] = {lo.x, lo.y, lo.z, lo.w};
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        v[2 * i] = __builtin_bit_cast(float, hh[i] << 16) + __builtin_bit_cast(float, ll[i] << 16);
-        v[2 * i + 1] = __builtin_bit_cast(float, hh[i] & 0xffff0000u) + __builtin_bit_cast(float, ll[i] & 0xffff0000u);
+        float h0, h1, l0, l1;
+        unpack_bf16x2(hh[i], h0, h1);
+        unpack_bf16x2(ll[i], l0, l1);
+        v[2 * i] = h0 + l0;
+        v[2 * i + 1] = h1 + l1;
     }
 }
 // bf16 positions (in units of 2 bytes from the start of a row of 4-byte elements) of element i
@@ -95,15 +120,21 @@ static inline hipError_t ap_current_device(int* dev) {
 }
 
 // host-side bf16 helpers (weights packing)
+#ifdef AP_F16
+static inline uint16_t host_f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // RNE
+static inline float host_bf16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
+#else
+static inline float host_bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 static inline uint16_t host_f32_to_bf16(float f) {
     uint32_t u = __builtin_bit_cast(uint32_t, f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
+#endif
 static inline void host_split_parts(float f, uint16_t* hi, uint16_t* lo) {
     *hi = host_f32_to_bf16(f);
-    *lo = host_f32_to_bf16(f - __builtin_bit_cast(float, (uint32_t)*hi << 16));
+    *lo = host_f32_to_bf16(f - host_bf16_to_f32(*hi));
 }
 // n floats (n % 8 == 0, rows are multiples of 8) -> planar split-bf16: dst holds 2n uint16, group g at [16g, 16g + 16)
 static inline void host_split_pack_planar(const float* src, size_t n, uint16_t* dst) {

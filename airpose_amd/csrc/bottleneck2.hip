@@ -110,7 +110,7 @@ __device__ __forceinline__ void mm(f32x4& c, const u32x4& w, const u32x4& x) {
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm(AP_CVTPK_ASM " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 __device__ __forceinline__ uint32_t relu_pk_bf16(uint32_t u) {
@@ -137,10 +137,10 @@ __device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32
     f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
     if (res) {
         const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
-        v0 += f32x2{__builtin_bit_cast(float, r0 << 16), __builtin_bit_cast(float, r0 & 0xffff0000u)};
-        v1 += f32x2{__builtin_bit_cast(float, r1 << 16), __builtin_bit_cast(float, r1 & 0xffff0000u)};
-        v2 += f32x2{__builtin_bit_cast(float, r2 << 16), __builtin_bit_cast(float, r2 & 0xffff0000u)};
-        v3 += f32x2{__builtin_bit_cast(float, r3 << 16), __builtin_bit_cast(float, r3 & 0xffff0000u)};
+        { float a_, b_; unpack_bf16x2(r0, a_, b_); v0 += f32x2{a_, b_}; }
+        { float a_, b_; unpack_bf16x2(r1, a_, b_); v1 += f32x2{a_, b_}; }
+        { float a_, b_; unpack_bf16x2(r2, a_, b_); v2 += f32x2{a_, b_}; }
+        { float a_, b_; unpack_bf16x2(r3, a_, b_); v3 += f32x2{a_, b_}; }
     }
     u32x4 o;
     o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));

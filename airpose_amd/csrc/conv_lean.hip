@@ -35,7 +35,7 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr)
     return r;
 }
 __device__ __forceinline__ void mfma_acc(f32x4& c, const u32x4& w, const u32x4& x) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
+    asm volatile(AP_MFMA16_ASM " %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
 }
 
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) conv_lean_kernel(const ConvArgs p) {

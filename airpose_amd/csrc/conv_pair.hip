@@ -82,7 +82,7 @@ typedef __attribute__((ext_vector_type(2))) float f32x2;
 // once per PAIR -- the cast gives one v_cvt_pk per value plus shifts / ors to merge)
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
     uint32_t r;
-    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    asm(AP_CVTPK_ASM " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
 // ReLU on two packed bf16: as signed 16-bit integers negative values (sign bit set, -0 included) are below zero, positive
@@ -226,10 +226,10 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
         if (res) {
             const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
-            v0 += f32x2{__builtin_bit_cast(float, r0 << 16), __builtin_bit_cast(float, r0 & 0xffff0000u)};
-            v1 += f32x2{__builtin_bit_cast(float, r1 << 16), __builtin_bit_cast(float, r1 & 0xffff0000u)};
-            v2 += f32x2{__builtin_bit_cast(float, r2 << 16), __builtin_bit_cast(float, r2 & 0xffff0000u)};
-            v3 += f32x2{__builtin_bit_cast(float, r3 << 16), __builtin_bit_cast(float, r3 & 0xffff0000u)};
+            { float a_, b_; unpack_bf16x2(r0, a_, b_); v0 += f32x2{a_, b_}; }
+            { float a_, b_; unpack_bf16x2(r1, a_, b_); v1 += f32x2{a_, b_}; }
+            { float a_, b_; unpack_bf16x2(r2, a_, b_); v2 += f32x2{a_, b_}; }
+            { float a_, b_; unpack_bf16x2(r3, a_, b_); v3 += f32x2{a_, b_}; }
         }
         u32x4 o;
         o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));

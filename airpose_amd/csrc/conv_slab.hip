@@ -62,7 +62,7 @@ template <int OFF> __device__ __forceinline__ u32x4 lds_read_b128(uint32_t addr)
 // here never share an accumulator back to back with different operands, and the epilogue's first VALU read of an
 // accumulator is fenced by s_nop below.)
 __device__ __forceinline__ void mfma_acc(f32x4& c, const u32x4& w, const u32x4& x) {
-    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
+    asm volatile(AP_MFMA16_ASM " %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
 }
 
 // 8 MFMAs with NP callbacks spread evenly between them

@@ -35,7 +35,7 @@ class copenet(_copenet_base):
         cam = torch.empty(B, 3, device=dev, dtype=torch.float32)
         with self._lock, torch.cuda.device(dev):
             h = self._native(dev)
-            N.check(N.lib().ap_hmr_fwd(h, N.dptr(x), B, int(iters), N.dptr(th), ths, N.dptr(sh), shs, N.dptr(cm), cms,
+            N.check(self._L().ap_hmr_fwd(h, N.dptr(x), B, int(iters), N.dptr(th), ths, N.dptr(sh), shs, N.dptr(cm), cms,
                                        N.dptr(rot), N.dptr(betas), N.dptr(cam), N.stream_ptr(dev)), "ap_hmr_fwd")
         return rot, betas, cam
 
@@ -51,7 +51,7 @@ class copenet(_copenet_base):
         po, so, co = (torch.empty(B, n, device=dev, dtype=torch.float32) for n in (132, 10, 3))
         with self._lock, torch.cuda.device(dev):
             h = self._native(dev)
-            N.check(N.lib().ap_hmr_reg(h, N.dptr(xf), B, int(iters), N.dptr(p), 132, N.dptr(s), 10, N.dptr(c), 3, N.dptr(po),
+            N.check(self._L().ap_hmr_reg(h, N.dptr(xf), B, int(iters), N.dptr(p), 132, N.dptr(s), 10, N.dptr(c), 3, N.dptr(po),
                                        N.dptr(so), N.dptr(co), N.stream_ptr(dev)), "ap_hmr_reg")
         return po, so, co
 

@@ -128,11 +128,12 @@ def parity_block(args, sd, body, batch, net_bf, sample, want, dev):
     the checker; the oracle is not run again here)."""
     import torch
     from airpose_amd import copenet_model, pipeline
-    if args.parity_steps <= 0 or args.precision != "bf16":
+    if args.parity_steps <= 0 or args.precision not in ("bf16", "f16"):
         return None
     gin = {k: v.to(dev) for k, v in sample.items()} if want is not None else None
     modes = {}
-    for prec, steps in (("bf16x2", 2 * args.parity_steps), ("fp32", args.parity_steps)):
+    other16 = "bf16" if args.precision == "f16" else "f16"    # the throughput kernels with the other 16-bit storage type
+    for prec, steps in (("bf16x2", 2 * args.parity_steps), ("fp32", args.parity_steps), (other16, 4 * args.parity_steps)):
         net = copenet_model.getcopenet(MEAN, precision=prec).eval()
         net.load_state_dict(sd)
         if args.chunk:
@@ -157,7 +158,9 @@ def parity_block(args, sd, body, batch, net_bf, sample, want, dev):
     res.update({"dtype": "bf16x2", "bar": 1e-4,
                 "arithmetic": "split-bf16 storage (hi + lo bf16 per value, planar groups of 8 channels, fp32 bytes); each product as "
                               "hi*hi + hi*lo + lo*hi in three v_mfma_f32_16x16x32_bf16 per 8 K elements, fp32 accumulate",
-                "fp32_mode": dict(modes["fp32"], arithmetic="fp32 storage, v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain)")})
+                "fp32_mode": dict(modes["fp32"], arithmetic="fp32 storage, v_mfma_f32_16x16x4_f32 (exact fp32 FMA chain)"),
+                other16 + "_mode": dict(modes[other16], arithmetic="the timed mode's kernels with %s storage and "
+                                        "v_mfma_f32_16x16x32_%s" % (("bf16", "bf16") if other16 == "bf16" else ("fp16", "f16")))})
     if gin is not None:
         ebf = slice_errs({k: v.float().cpu() for k, v in
                           pipeline.TwoViewInference(net_bf, body, iters=3)(gin, want_rotmat=True).items()}, want)
@@ -225,7 +228,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=256, help="pairs per GPU")
-    ap.add_argument("--precision", default="bf16", choices=["bf16", "bf16x2", "fp32"])
+    ap.add_argument("--precision", default="f16", choices=["f16", "bf16", "bf16x2", "fp32"],
+                    help="f16 (default) / bf16: the throughput kernels with fp16 / bf16 storage; bf16x2, fp32: the parity-grade modes")
     ap.add_argument("--chunk", type=int, default=0, help="images per depth-first trunk chunk (0 = default)")
     ap.add_argument("--cpu-sample", type=int, default=16, help="pairs in the CPU baseline sample (0 = skip)")
     ap.add_argument("--no-tail", action="store_true", help="time the network only (BASELINE config 2 shape)")
@@ -368,8 +372,9 @@ def main():
         dual = bool(args.dual_stream) and B >= 64 and 2 * B <= chunk
         # bf16: 3 fused layer1 bottlenecks + 13 blocks x 3 convs = 42 launches per pass, minus the 8 conv1 layers that ride in a
         # fused conv3 -> conv1 pair (layer2.0-2.3, layer3.1-3.4 as producers): 34
-        pairs_on = args.precision == "bf16" and os.environ.get("AIRPOSE_FUSE_PAIR", "1") != "0"
-        launches = ((34 if pairs_on else 42) if args.precision == "bf16" else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
+        half = args.precision in ("bf16", "f16")               # the throughput kernels (either 16-bit storage type)
+        pairs_on = half and os.environ.get("AIRPOSE_FUSE_PAIR", "1") != "0"
+        launches = ((34 if pairs_on else 42) if half else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
         # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
@@ -381,6 +386,10 @@ def main():
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": args.precision, "data": "synthetic",
+            "arithmetic": {"f16": "fp16 storage, v_mfma_f32_16x16x32_f16, fp32 accumulate and epilogues",
+                           "bf16": "bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate and epilogues",
+                           "bf16x2": "split-bf16 pairs, three bf16 MFMA products per product, fp32 accumulate",
+                           "fp32": "fp32 storage, v_mfma_f32_16x16x4_f32"}[args.precision],
             "config": {"workload": "copenet_twoview forward (ResNet-50 x2 views, 3 IEF iterations) + SMPL-X LBS tail "
                                    "(10475 verts, 127 joints, projection)" if not args.no_tail else
                                    "copenet_twoview forward only (ResNet-50 x2 views, 3 IEF iterations)",
@@ -390,8 +399,8 @@ def main():
                        "sharding": "whole pairs per GPU, no data-path collective"},
             "roofline": {"bound": "mfma",
                          "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of the trunk in %d launches per step: conv_pipe_kernel "
-                                   "(dominant instance <T,128,128,2,4,2>; stride-1 3x3 layers in bf16: conv_slab_kernel; conv3 of layer2-3 blocks together with the next block's conv1: conv_pair_kernel; "
-                                   "conv3 of the layer4 identity blocks: conv_lean_kernel) + the fused layer1 bottlenecks in bf16 "
+                                   "(dominant instance <T,128,128,2,4,2>; stride-1 3x3 layers in the 16-bit modes: conv_slab_kernel; conv3 of layer2-3 blocks together with the next block's conv1: conv_pair_kernel; "
+                                   "conv3 of the layer4 identity blocks: conv_lean_kernel) + the fused layer1 bottlenecks in the 16-bit modes "
                                    "(bneck2_kernel<ds> / <identity>); time = HIP-event span of the conv stack "
                                    "(over both concurrent passes when the two views run on two streams)" % launches,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,

@@ -112,6 +112,16 @@ def test_conv_config_knob_validates_on_the_host():
         assert L.ap_set_conv_config(-1) == 0
 
 
+def test_f16_flavour_exports_every_declared_symbol():
+    """libairpose_hip_f16.so (the same sources with -DAP_F16) carries the same C ABI."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib("f16")
+    assert L is not Nn.lib()
+    for name in Nn.SIGNATURES:
+        assert hasattr(L, name), name
+    assert Nn.lib_for("f16") is L and Nn.lib_for("bf16") is Nn.lib()
+
+
 def test_bottleneck_cut_knob_validates_on_the_host():
     """ap_set_bottleneck_cut is host-only state: 1 (first cut) and 2 (second cut, the default) are accepted, anything else
     is refused and leaves the selection alone."""

@@ -6,6 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r01_x}; O=$R/gpurun_out; mkdir -p $O
 cd /tmp; export TMPDIR=/tmp
 python $R/bench.py --steps 20 --warmup 5 > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err
 python $R/bench.py --steps 20 --warmup 5 --batch 64 --no-tail --cpu-sample 0 --parity-steps 0 > $O/${TAG}_bench_b64.json 2>> $O/${TAG}_bench.err
+python $R/bench.py --steps 20 --warmup 5 --precision bf16 --cpu-sample 0 --parity-steps 0 --repeat-blocks 2 > $O/${TAG}_bench_bf16.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --steps 10 --warmup 2 --precision bf16x2 --cpu-sample 0 --parity-steps 0 --repeat-blocks 1 > $O/${TAG}_bench_x2.json 2>> $O/${TAG}_bench.err
 python $R/bench.py --steps 5 --warmup 2 --precision fp32 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 > $O/${TAG}_bench_fp32.json 2>> $O/${TAG}_bench.err
 rm -rf $O/${TAG}_trace $O/${TAG}_pmc_FETCH_SIZE $O/${TAG}_pmc_WRITE_SIZE

@@ -99,7 +99,7 @@ if macc:
         if tg:
             f.write('"conv stack (all bf16 conv kernels)",,%.0f,,%.0f,%.2f\n' % (tb, tg, 100 * tb / (tg * 1024)))
             print("conv stack MFMA busy %.2f %%" % (100 * tb / (tg * 1024)))
-for f in ("bench", "bench_b64", "bench_x2", "bench_fp32"):
+for f in ("bench", "bench_bf16", "bench_b64", "bench_x2", "bench_fp32"):
     p = os.path.join(O, "%s_%s.json" % (tag, f))
     if os.path.exists(p) and os.path.getsize(p):
         d = json.loads(open(p).read().strip().splitlines()[-1])
