@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Soak of the bf16 trunk with every hand-counted kernel on (bottleneck2, pair, slab, lean, fused stem): N forward passes over
 512 images (256 per view, two concurrent passes), each compared bit for bit with the separate-convolution path of the first
-pass.  A rare miss of a counted wait shows up as a mismatch.   python tools/probes/soak_trunk.py [iterations]"""
+pass.  A rare miss of a counted wait shows up as a mismatch.   python tools/probes/soak_trunk.py [iterations] [f16|bf16]"""
 import os
 import sys
 
@@ -11,9 +11,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 from airpose_amd import copenet_model, weights as W  # noqa: E402
 
 it = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+prec = sys.argv[2] if len(sys.argv) > 2 else "f16"          # "f16" / "bf16": the storage type of the throughput kernels
 dev = torch.device("cuda", 0)
 mean = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "airpose_amd", "data", "smpl_mean_params.npz")
-net = copenet_model.getcopenet(mean, precision="bf16").eval()
+net = copenet_model.getcopenet(mean, precision=prec).eval()
 net.load_state_dict(W.to_torch(W.copenet_state_dict(3, mean)))
 g = torch.Generator().manual_seed(1)
 x = torch.randn(512, 3, 224, 224, generator=g).to(dev)
