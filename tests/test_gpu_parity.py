@@ -117,7 +117,7 @@ def _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed):
     shift = torch.randn(Cout, generator=g) * 0.1
     Ho = (H + 2 * pad - k) // stride + 1
     res = torch.randn(N, Cout, Ho, Ho, generator=g) if use_res else None
-    tdt = torch.bfloat16 if prec == "bf16" else torch.float32
+    tdt = {"bf16": torch.bfloat16, "f16": torch.float16}.get(prec, torch.float32)      # "f16": the fp16 flavour of the library
     xq, wq = x.to(tdt), w.to(tdt)
     resq = res.to(tdt) if use_res else None
     # oracle on the SAME (rounded) operands, fp64 accumulate
@@ -137,9 +137,9 @@ def _conv_case(dev, prec, N, H, Cin, Cout, k, stride, pad, relu, use_res, seed):
     wd, sd_, hd = wp.to(dev), sp.to(dev), hp.to(dev)
     y = torch.full((N, Ho, Ho, Cout), float("nan"), dtype=tdt, device=dev)
     p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
-    rc = Nn.lib().ap_conv2d_nhwc(Nn.PRECISIONS[prec], p(xd), p(wd), p(sd_), p(hd), p(rd), p(y), N, H, H, Cin, Cout, k,
-                                 stride, pad, int(relu), Nn.stream_ptr(dev))
-    Nn.check(rc, "ap_conv2d_nhwc")
+    rc = Nn.lib_for(prec).ap_conv2d_nhwc(Nn.PRECISIONS[prec], p(xd), p(wd), p(sd_), p(hd), p(rd), p(y), N, H, H, Cin, Cout, k,
+                                         stride, pad, int(relu), Nn.stream_ptr(dev))
+    Nn.check(rc, "ap_conv2d_nhwc", Nn.lib_for(prec))
     torch.cuda.synchronize()
     got = y.float().cpu().permute(0, 3, 1, 2).double()
     return got, ref
@@ -445,13 +445,13 @@ def test_conv_configs_agree_bitwise(dev):
 
 
 # ------------------------------------------------------------------------------------------------ fused bottleneck
-def _bneck_case(dev, N, H, ds, seed, W=None):
+def _bneck_case(dev, N, H, ds, seed, W=None, prec="bf16"):
     """Bottleneck.forward (model_copenet.py:27-47) for planes = 64 on bf16 operands: fp64 oracle that rounds the two
     64-channel intermediates to bf16 exactly where the kernel (and the three-convolution path) does."""
     from airpose_amd import _native as Nn
     g = torch.Generator().manual_seed(seed)
     cin = 64 if ds else 256
-    bf = torch.bfloat16
+    bf = torch.float16 if prec == "f16" else torch.bfloat16
     W = H if W is None else W
     x = torch.randn(N, cin, H, W, generator=g).to(bf)
     w1 = (torch.randn(64, cin, 1, 1, generator=g) * (2.0 / cin) ** 0.5).to(bf)
@@ -477,9 +477,9 @@ def _bneck_case(dev, N, H, ds, seed, W=None):
     y = torch.full((N, H, W, 256), float("nan"), dtype=bf, device=dev)
     dv = [rows(w1, 128), rows(w2, 128), rows(w3p, 256)] + [t.to(dev) for t in sc + sh]
     p = lambda t: ctypes.c_void_p(t.data_ptr())
-    rc = Nn.lib().ap_bottleneck64_nhwc(p(xd), p(dv[0]), p(dv[3]), p(dv[6]), p(dv[1]), p(dv[4]), p(dv[7]), p(dv[2]),
-                                       p(dv[5]), p(dv[8]), p(y), N, H, W, cin, int(ds), Nn.stream_ptr(dev))
-    Nn.check(rc, "ap_bottleneck64_nhwc")
+    rc = Nn.lib_for(prec).ap_bottleneck64_nhwc(p(xd), p(dv[0]), p(dv[3]), p(dv[6]), p(dv[1]), p(dv[4]), p(dv[7]), p(dv[2]),
+                                               p(dv[5]), p(dv[8]), p(y), N, H, W, cin, int(ds), Nn.stream_ptr(dev))
+    Nn.check(rc, "ap_bottleneck64_nhwc", Nn.lib_for(prec))
     torch.cuda.synchronize()
     return y.float().cpu().permute(0, 3, 1, 2).double(), ref
 
@@ -655,6 +655,34 @@ def test_f16_whole_pipeline_matches_oracle(netf16, body, copenet_sd, copenet_inp
         for nm, (x, y) in parts.items():
             e = float(np.abs(x - y).max() / np.abs(y).max())
             assert e < 1e-4, "%s %s rel err %.3e" % (k, nm, e)
+
+
+F16_CONV_CASES = [
+    # N, H, Cin, Cout, k, stride, pad, relu, residual     (one per kernel family of the throughput mode)
+    (2, 28, 256, 128, 1, 1, 0, True, False),     # ring kernel, 1x1
+    (2, 28, 128, 128, 3, 1, 1, True, False),     # slab kernel, 3x3 stride 1
+    (2, 28, 128, 128, 3, 2, 1, True, False),     # ring kernel, 3x3 stride 2
+    (2, 14, 256, 1024, 1, 1, 0, True, True),     # pointwise + residual (lean kernel at full size)
+    (3, 56, 64, 64, 3, 1, 1, True, False),       # 64-wide tile
+]
+
+
+@pytest.mark.parametrize("case", F16_CONV_CASES)
+def test_conv_primitive_f16_matches_fp64(dev, case):
+    """ap_conv2d_nhwc of the fp16 flavour against fp64 on the same fp16 operands: fp32 accumulation order and the fp16 rounding
+    of the output are what is left (2^-11 per value)."""
+    N, H, Cin, Cout, k, stride, pad, relu, use_res = case
+    got, ref = _conv_case(dev, "f16", N, H, Cin, Cout, k, stride, pad, relu, use_res, seed=7 * Cin + Cout + k)
+    assert torch.isfinite(got).all()
+    assert rel_err(got.numpy(), ref.numpy()) < 1e-3
+
+
+@pytest.mark.parametrize("ds", [0, 1])
+def test_fused_bottleneck_f16_matches_fp64(dev, ds):
+    """The fused layer1 block of the fp16 flavour (second cut) against the fp64 oracle with fp16 rounding points."""
+    got, ref = _bneck_case(dev, 3, 56, ds, seed=61 + ds, prec="f16")
+    assert torch.isfinite(got).all()
+    assert rel_err(got.numpy(), ref.numpy()) < 1.5e-3
 
 
 def test_f16_fused_paths_are_bitwise(netf16, dev):
