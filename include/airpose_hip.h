@@ -30,7 +30,9 @@ extern "C" {
 #define AP_ENOMEM (-4)
 
 #define AP_PREC_FP32 0 /* fp32 storage, v_mfma_f32_16x16x4_f32: parity mode (1e-4 vs the CPU reference) */
-#define AP_PREC_BF16 1 /* bf16 storage, v_mfma_f32_16x16x32_bf16, fp32 accumulate: throughput mode */
+#define AP_PREC_BF16 1 /* 16-bit storage, fp32 accumulate: throughput mode.  libairpose_hip.so: bf16 (v_mfma_f32_16x16x32_bf16);
+                        * libairpose_hip_f16.so (the same sources, -DAP_F16): fp16 (v_mfma_f32_16x16x32_f16) -- same rate, 11
+                        * significand bits: 5.5e-5 instead of 3.0e-4 against the reference's CPU path; stored activations < 65504 */
 #define AP_PREC_BF16X2 2 /* split-bf16 storage: every value as hi = rne(x), lo = rne(x - hi) in bf16 (16 mantissa bits, fp32
                           * bytes), planar in groups of 8 channels (32 bytes = 8 hi | 8 lo); every product as
                           * hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (three MFMAs per 8 K elements), fp32 accumulate:
