@@ -1362,6 +1362,12 @@ def test_hmr_config1_on_gpu_matches_reference(golden, dev):
     netb.load_state_dict(sd, strict=True)
     rotb, betasb, camb = netb(x, iters=3)
     assert rel_err(betasb.cpu().numpy(), g["betas"]) < TOLBF and rel_err(rotb.cpu().numpy(), g["rotmat"]) < TOLBF
+    neth = hmr_model.getcopenet(MEAN_PARAMS, precision="f16").eval()      # the fp16 flavour: under north_star's bar
+    neth.load_state_dict(sd, strict=True)
+    roth, betash, camh = neth(x, iters=3)
+    errh = [rel_err(roth.cpu().numpy(), g["rotmat"]), rel_err(betash.cpu().numpy(), g["betas"]), rel_err(camh.cpu().numpy(), g["cam"])]
+    print("hmr f16 rel errs", errh)
+    assert max(errh) < 1e-4
 
 
 def test_errors_are_loud(net32, dev):
