@@ -121,7 +121,12 @@ def lib_for(precision):
 
 def check(rc, what, L=None):
     if rc != 0:
-        msg = (L or lib()).ap_last_error().decode("utf-8", "replace")
+        # the message lives in the library (flavour) that failed: the one named, else the first loaded one that has a message
+        msg = ""
+        for cand in ([L] if L is not None else list(_libs.values()) or [lib()]):
+            msg = cand.ap_last_error().decode("utf-8", "replace")
+            if msg:
+                break
         raise RuntimeError("airpose_hip %s failed (status %d): %s" % (what, rc, msg))
 
 
