@@ -121,9 +121,16 @@ static inline hipError_t ap_current_device(int* dev) {
 
 // host-side bf16 helpers (weights packing)
 #ifdef AP_F16
-static inline uint16_t host_f32_to_bf16(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }      // RNE
+// (a finite weight that leaves the fp16 range is recorded: ap_net_finalize of this flavour refuses the checkpoint)
+static inline bool& host_h16_overflow() { static thread_local bool f = false; return f; }
+static inline uint16_t host_f32_to_bf16(float f) {                                                           // RNE
+    const uint16_t h = __builtin_bit_cast(uint16_t, (_Float16)f);
+    if ((h & 0x7fffu) == 0x7c00u && f == f && f - f == 0.f) host_h16_overflow() = true;
+    return h;
+}
 static inline float host_bf16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 #else
+static inline bool& host_h16_overflow() { static thread_local bool f = false; return f; }   // (bf16 has fp32's range: never set)
 static inline float host_bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
 static inline uint16_t host_f32_to_bf16(float f) {
     uint32_t u = __builtin_bit_cast(uint32_t, f);

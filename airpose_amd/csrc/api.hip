@@ -1024,9 +1024,14 @@ int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const
 int ap_net_finalize(ap_net* h) {
     if (!h) return fail(AP_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device));
+    host_h16_overflow() = false;
     int rc = finalize_trunk(h);
     if (rc) return rc;
     if ((rc = finalize_regressor(h))) return rc;
+    // fp16 flavour (-DAP_F16): a BatchNorm-folded weight above 65 504 would become inf on the device
+    if (host_h16_overflow() && h->prec == AP_PREC_BF16)
+        return fail(AP_ESHAPE, "ap_net_finalize: a (BatchNorm-folded) weight exceeds the fp16 range of this flavour of the library; "
+                               "use the bf16 flavour (libairpose_hip.so, precision='bf16')");
     h->finalized = true;
     return AP_OK;
 }

@@ -685,6 +685,22 @@ def test_fused_bottleneck_f16_matches_fp64(dev, ds):
     assert rel_err(got.numpy(), ref.numpy()) < 1.5e-3
 
 
+def test_f16_flavour_refuses_weights_outside_the_fp16_range(copenet_sd, dev):
+    """A (BatchNorm-folded) weight above 65 504 would be inf in fp16 storage: the fp16 flavour refuses the checkpoint when it
+    packs it, the bf16 flavour (fp32's exponent range) takes it."""
+    from airpose_amd import copenet_model
+    sd = {k: v.clone() for k, v in copenet_sd.items()}
+    sd["layer3.2.conv2.weight"][5, 7, 1, 1] = 3.0e5
+    x = torch.zeros(1, 3, 224, 224, device=dev)
+    bad = copenet_model.getcopenet(MEAN_PARAMS, precision="f16").eval()
+    bad.load_state_dict(sd)
+    with pytest.raises(RuntimeError, match="fp16 range"):
+        bad.forward_feat_ext(x)
+    ok = copenet_model.getcopenet(MEAN_PARAMS, precision="bf16").eval()
+    ok.load_state_dict(sd)
+    assert torch.isfinite(ok.forward_feat_ext(x)).all()
+
+
 def test_f16_fused_paths_are_bitwise(netf16, dev):
     """Every fused kernel of the fp16 flavour (both cuts of the layer1 block, the conv3 -> conv1 pairs, the folded downsample,
     the fused stem) against its separate-kernel path through the trunk: same bits, as in the bf16 flavour."""
