@@ -12,14 +12,13 @@ import torch  # noqa: F401  (must be imported first so that libamdhip64 is the o
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("AIRPOSE_HIP_LIB", os.path.join(_HERE, "libairpose_hip.so"))   # override: profiling builds
-# the fp16 flavour: the same sources built with -DAP_F16 (fp16 instead of bf16 as the 16-bit storage / MFMA type)
-LIB_PATH_F16 = os.environ.get("AIRPOSE_HIP_LIB_F16", os.path.join(_HERE, "libairpose_hip_f16.so"))
 
-AP_PREC_FP32, AP_PREC_BF16, AP_PREC_BF16X2 = 0, 1, 2
-# fp32: exact fp32 MFMA chain | bf16: throughput mode, bf16 storage | f16: throughput mode, fp16 storage (the kernels of the bf16
-# mode from the fp16 flavour of the library: 11 significand bits instead of 8 at the same MFMA rate) | bf16x2: split-bf16 pairs
-PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16, "f16": AP_PREC_BF16, "bf16x2": AP_PREC_BF16X2}
-FLAVOUR = {"f16": "f16"}                                    # precision -> library flavour ("" = libairpose_hip.so)
+AP_PREC_FP32, AP_PREC_BF16, AP_PREC_BF16X2, AP_PREC_F16 = 0, 1, 2, 3
+AP_ERANGE = -5
+# fp32: exact fp32 MFMA chain | bf16: throughput kernels, bf16 storage | f16: the same kernels with fp16 storage (11 significand
+# bits instead of 8 at the same MFMA rate: under the 1e-4 bar; |value| <= 65504) | bf16x2: split-bf16 pairs (fast parity mode)
+PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16, "f16": AP_PREC_F16, "bf16x2": AP_PREC_BF16X2}
+HALF_PRECISIONS = ("bf16", "f16")                          # the 16-bit throughput modes (fused layer1 / pair / slab / lean kernels)
 
 _c = ctypes
 _vp, _i, _f, _i64p = _c.c_void_p, _c.c_int, _c.c_float, _c.POINTER(_c.c_int64)
@@ -42,6 +41,8 @@ SIGNATURES = {
     "ap_net_set_tensor": (_i, [_vp, _c.c_char_p, _vp, _i64p, _i]),
     "ap_net_finalize": (_i, [_vp]),
     "ap_net_precision": (_i, [_vp]),
+    "ap_net_set_range_check": (_i, [_vp, _i]),
+    "ap_net_range_status": (_i, [_vp, _vp, _i]),
     "ap_trunk_fwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "ap_regressor_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_regressor_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
@@ -59,15 +60,18 @@ SIGNATURES = {
     "ap_net_set_chunk": (_i, [_vp, _i]),
     "ap_net_set_dual_stream": (_i, [_vp, _i]),
     "ap_net_set_fold": (_i, [_vp, _i]),
+    "ap_net_fold_status": (_i, [_vp, _c.POINTER(_c.c_double)]),
+    "ap_net_set_fold_bar": (_i, [_vp, _c.c_double]),
     "ap_net_set_fuse_ief": (_i, [_vp, _i]),
     "ap_net_set_fuse_stem": (_i, [_vp, _i]),
     "ap_net_set_fuse_ds": (_i, [_vp, _i]),
     "ap_net_set_fuse_block": (_i, [_vp, _i]),
-    "ap_set_bottleneck_cut": (_i, [_i]),
     "ap_net_set_fuse_pair": (_i, [_vp, _i]),
-    "ap_conv_pair_nhwc": (_i, [_vp] * 10 + [_i] * 3 + [_vp]),
-    "ap_conv_pair_ds_nhwc": (_i, [_vp] * 9 + [_i] * 6 + [_vp]),
-    "ap_bottleneck64_nhwc": (_i, [_vp] * 11 + [_i] * 5 + [_vp]),
+    "ap_conv_pair_stream_bytes": (_c.c_int64, [_i, _i, _i]),
+    "ap_conv_pair_pack": (_i, [_i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ap_conv_pair_nhwc": (_i, [_i] + [_vp] * 9 + [_i] * 3 + [_vp]),
+    "ap_conv_pair_ds_nhwc": (_i, [_i] + [_vp] * 9 + [_i] * 6 + [_vp]),
+    "ap_bottleneck64_nhwc": (_i, [_i] + [_vp] * 11 + [_i] * 5 + [_vp]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),
     "ap_smplx_destroy": (None, [_vp]),
     "ap_smplx_num_joints_out": (_i, [_vp]),
@@ -90,44 +94,36 @@ SIGNATURES = {
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }
 
-_libs = {}
+_lib = None
 _lib_lock = threading.Lock()
 
 
-def lib(flavour=""):
-    """Load (once) and return the shared library of that flavour ("" = bf16 storage, "f16" = fp16 storage); raises if it has
-    not been built."""
-    L = _libs.get(flavour)
-    if L is None:
+def lib():
+    """Load (once) and return the shared library; raises if it has not been built."""
+    global _lib
+    if _lib is None:
         with _lib_lock:
-            L = _libs.get(flavour)
-            if L is None:
-                path = LIB_PATH_F16 if flavour == "f16" else LIB_PATH
-                if not os.path.isfile(path):
+            if _lib is None:
+                if not os.path.isfile(LIB_PATH):
                     raise RuntimeError(
                         "airpose_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
-                        "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % path)
-                L = ctypes.CDLL(path)
+                        "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
+                L = ctypes.CDLL(LIB_PATH)
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)
                     fn.restype, fn.argtypes = res, args
-                _libs[flavour] = L
-    return L
+                _lib = L
+    return _lib
 
 
-def lib_for(precision):
-    return lib(FLAVOUR.get(precision, ""))
+class RangeError(RuntimeError):
+    """AP_ERANGE: a stored activation left the fp16 range (precision="f16"); use precision="bf16" for that checkpoint."""
 
 
-def check(rc, what, L=None):
+def check(rc, what):
     if rc != 0:
-        # the message lives in the library (flavour) that failed: the one named, else the first loaded one that has a message
-        msg = ""
-        for cand in ([L] if L is not None else list(_libs.values()) or [lib()]):
-            msg = cand.ap_last_error().decode("utf-8", "replace")
-            if msg:
-                break
-        raise RuntimeError("airpose_hip %s failed (status %d): %s" % (what, rc, msg))
+        msg = lib().ap_last_error().decode("utf-8", "replace")
+        raise (RangeError if rc == AP_ERANGE else RuntimeError)("airpose_hip %s failed (status %d): %s" % (what, rc, msg))
 
 
 def require_gpu():

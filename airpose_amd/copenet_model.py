@@ -45,7 +45,7 @@ class copenet(nn.Module):
     variant = 0            # ap_net_create variant (0: two-view copenet)
     fc1_extra = 3 + 3 + 6 + 21 * 6 + 10 + 21 * 6 + 10
 
-    def __init__(self, block=Bottleneck, layers=(3, 4, 6, 3), smpl_mean_params=None, precision="bf16"):
+    def __init__(self, block=Bottleneck, layers=(3, 4, 6, 3), smpl_mean_params=None, precision="f16"):
         super().__init__()
         if tuple(layers) != (3, 4, 6, 3):
             raise ValueError("only the ResNet-50 layout [3, 4, 6, 3] of the reference is supported")
@@ -273,9 +273,22 @@ class copenet(nn.Module):
         N.check(self._L().ap_net_timing(self._handle, ms, ctypes.byref(n), int(reset)), "ap_net_timing")
         return {"stem_ms": ms[0], "conv_ms": ms[1], "avgpool_ms": ms[2], "regressor_ms": ms[3], "passes": n.value}
 
-    def _L(self):
-        """The native library this model's handle lives in ("f16": the fp16 flavour)."""
-        return N.lib_for(self.precision)
+    @staticmethod
+    def _L():
+        return N.lib()
+
+    def set_range_check(self, mode):
+        """precision="f16": 1 (default) deferred -- a non-finite trunk feature makes the NEXT call raise RangeError; 2 -- every
+        forward synchronises its stream and raises for its own pass; 0 off."""
+        self._set_knob("ap_net_set_range_check", mode)
+
+    def range_status(self, reset=False):
+        """Synchronise the current stream and raise RangeError if a trunk pass of this handle produced non-finite features
+        (precision="f16": a stored activation left the fp16 range).  No-op for the other precisions."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(self._L().ap_net_range_status(h, N.stream_ptr(dev), int(bool(reset))), "ap_net_range_status")
 
     def _set_knob(self, entry, value):
         """Per-handle knob: remembered on the module and re-applied whenever the native handle is re-created (a call
@@ -290,6 +303,15 @@ class copenet(nn.Module):
         """Evaluate fc1 -> fc2 -> dec as one folded affine map (default) or as the literal chain."""
         self._set_knob("ap_net_set_fold", on)
 
+    def fold_status(self):
+        """(state, probe_rel_err): state 1 = folded regressor map in use, 2 = literal chain by choice, 0 = literal chain because
+        ap_net_finalize found the fold of THIS checkpoint off by more than 1e-5 on its probe batch."""
+        err = ctypes.c_double()
+        with self._lock:
+            h = self._native(torch.device("cuda", torch.cuda.current_device()))
+            st = self._L().ap_net_fold_status(h, ctypes.byref(err))
+        return st, err.value
+
     def set_fuse_ief(self, on):
         """Folded map: all IEF iterations in one kernel (default) or one GEMM per iteration."""
         self._set_knob("ap_net_set_fuse_ief", on)
@@ -298,11 +320,11 @@ class copenet(nn.Module):
         self._set_knob("ap_net_set_fuse_ds", on)
 
     def set_fuse_block(self, on):
-        """bf16: layer1 bottlenecks as one fused kernel each: 2 (default) bottleneck2.hip, 1 the first cut, 0 separate convolutions."""
+        """bf16 / f16: each layer1 bottleneck as one fused kernel (default, bottleneck2.hip) or as separate convolutions."""
         self._set_knob("ap_net_set_fuse_block", on)
 
     def set_fuse_pair(self, on):
-        """bf16: conv3 of an identity block and conv1 of the next block as one pixel-local kernel (default) or two."""
+        """bf16 / f16: conv3 of an identity block and conv1 of the next block as one pixel-local kernel (default) or two."""
         self._set_knob("ap_net_set_fuse_pair", on)
 
     def set_fuse_stem(self, on):
@@ -316,7 +338,7 @@ class copenet(nn.Module):
         self._set_knob("ap_net_set_chunk", images)
 
 
-def getcopenet(smpl_mean_params, pretrained=True, precision="bf16", **kwargs):
+def getcopenet(smpl_mean_params, pretrained=True, precision="f16", **kwargs):
     """model_copenet.getcopenet (:229-239).  ImageNet initialisation needs torchvision + network, neither
     of which exists here; weights arrive through load_state_dict / load_from_checkpoint instead."""
     return copenet(Bottleneck, [3, 4, 6, 3], smpl_mean_params, precision=precision, **kwargs)

@@ -15,7 +15,7 @@ from .copenet_model import Bottleneck, copenet
 
 
 class copenet_sep(nn.Module):
-    def __init__(self, block, layers, smpl_mean_params, precision="bf16"):
+    def __init__(self, block, layers, smpl_mean_params, precision="f16"):
         super().__init__()
         self.copenet0 = copenet(block, layers, smpl_mean_params, precision=precision)
         self.copenet1 = copenet(block, layers, smpl_mean_params, precision=precision)
@@ -59,5 +59,5 @@ class copenet_sep(nn.Module):
         return new_pose0, new_shape0, new_pose1, new_shape1
 
 
-def getcopenet_sep(smpl_mean_params, precision="bf16", **kwargs):
+def getcopenet_sep(smpl_mean_params, precision="f16", **kwargs):
     return copenet_sep(Bottleneck, [3, 4, 6, 3], smpl_mean_params, precision=precision, **kwargs)

@@ -65,6 +65,6 @@ class copenet(_copenet_base):
     regressor_step = forward_ief
 
 
-def getcopenet(smpl_mean_params, pretrained=True, precision="bf16", **kwargs):
+def getcopenet(smpl_mean_params, pretrained=True, precision="f16", **kwargs):
     """model_copenet_singleview.getcopenet; weights arrive through load_state_dict (no torchvision / network here)."""
     return copenet(Bottleneck, [3, 4, 6, 3], smpl_mean_params, precision=precision, **kwargs)

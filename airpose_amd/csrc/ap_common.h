@@ -3,22 +3,38 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-// -DAP_F16 (experiment build, libairpose_hip_f16.so): the 16-bit storage type of the "bf16" mode becomes IEEE fp16 everywhere --
-// same MFMA rate, 11 instead of 8 significand bits, 5 exponent bits (activations and weights of this network stay far inside).
-// The names keep "bf16"; only this header, the MFMA mnemonic and the pack instruction change.
+// The 16-bit storage type of the throughput kernels is a property of the TRANSLATION UNIT: every kernel source that touches 16-bit
+// activations / weights (conv_*.hip, bottleneck2.hip, stem.hip) is compiled twice into the ONE library -- plainly (bf16 storage,
+// v_mfma_f32_16x16x32_bf16, namespace k_bf16) and with -DAP_F16 (IEEE fp16 storage, v_mfma_f32_16x16x32_f16, namespace k_f16: same
+// MFMA rate, 11 instead of 8 significand bits, 5 exponent bits) -- and api.hip picks the set by the handle's precision
+// (AP_PREC_BF16 / AP_PREC_F16).  Two translation units instead of one template parameter on purpose: the hand-counted kernels sit
+// at their register budgets, and co-compiled instantiations of one template perturb each other's register allocation.
+// In a kernel source, "h16" / bf16_t / bf16x8 / K_BF16 mean "the 16-bit type of this translation unit".
 #ifdef AP_F16
+#define AP_NS k_f16
 typedef __attribute__((ext_vector_type(8))) _Float16 bf16x8;
-#define __builtin_amdgcn_mfma_f32_16x16x32_bf16 __builtin_amdgcn_mfma_f32_16x16x32_f16
 #define AP_MFMA16_ASM "v_mfma_f32_16x16x32_f16"
 #define AP_CVTPK_ASM "v_cvt_pk_f16_f32"
 #else
+#define AP_NS k_bf16
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 #define AP_MFMA16_ASM "v_mfma_f32_16x16x32_bf16"
 #define AP_CVTPK_ASM "v_cvt_pk_bf16_f32"
 #endif
+#define AP_NS_BEGIN namespace AP_NS {
+#define AP_NS_END }
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
-typedef uint16_t bf16_t;   // storage type of a bf16 activation / weight
+typedef uint16_t bf16_t;   // storage type of a 16-bit activation / weight (bf16, or fp16 in the -DAP_F16 translation units)
+
+// D = A (16 x 32) B (32 x 16) + C on the matrix pipe, operands in the 16-bit type of this translation unit
+__device__ __forceinline__ f32x4 ap_mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+#ifdef AP_F16
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+#else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+#endif
+}
 
 #define AP_WAVE 64
 
@@ -119,26 +135,21 @@ static inline hipError_t ap_current_device(int* dev) {
     return (*dev < 0 || *dev >= AP_MAX_DEVICES) ? hipErrorInvalidDevice : hipSuccess;
 }
 
-// host-side bf16 helpers (weights packing)
-#ifdef AP_F16
-// (a finite weight that leaves the fp16 range is recorded: ap_net_finalize of this flavour refuses the checkpoint)
-static inline bool& host_h16_overflow() { static thread_local bool f = false; return f; }
-static inline uint16_t host_f32_to_bf16(float f) {                                                           // RNE
-    const uint16_t h = __builtin_bit_cast(uint16_t, (_Float16)f);
-    if ((h & 0x7fffu) == 0x7c00u && f == f && f - f == 0.f) host_h16_overflow() = true;
-    return h;
-}
-static inline float host_bf16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
-#else
-static inline bool& host_h16_overflow() { static thread_local bool f = false; return f; }   // (bf16 has fp32's range: never set)
+// host-side 16-bit helpers (weight packing; api.hip packs for either storage type)
 static inline float host_bf16_to_f32(uint16_t h) { return __builtin_bit_cast(float, (uint32_t)h << 16); }
-static inline uint16_t host_f32_to_bf16(float f) {
+static inline uint16_t host_f32_to_bf16(float f) {                                                           // RNE
     uint32_t u = __builtin_bit_cast(uint32_t, f);
     if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);   // NaN
     u += 0x7fffu + ((u >> 16) & 1u);
     return (uint16_t)(u >> 16);
 }
-#endif
+// fp16 (RNE); a finite value that leaves the fp16 range sets *overflow (ap_net_finalize refuses such a checkpoint in AP_PREC_F16)
+static inline uint16_t host_f32_to_f16(float f, bool* overflow) {
+    const uint16_t h = __builtin_bit_cast(uint16_t, (_Float16)f);
+    if ((h & 0x7fffu) == 0x7c00u && f == f && f - f == 0.f) *overflow = true;
+    return h;
+}
+static inline float host_f16_to_f32(uint16_t h) { return (float)__builtin_bit_cast(_Float16, h); }
 static inline void host_split_parts(float f, uint16_t* hi, uint16_t* lo) {
     *hi = host_f32_to_bf16(f);
     *lo = host_f32_to_bf16(f - host_bf16_to_f32(*hi));

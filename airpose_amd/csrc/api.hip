@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/airpose_hip.h"
+#define AP_API_TU   // kernels.h: declare the launchers of BOTH 16-bit storage flavours (k_bf16:: / k_f16::)
 #include "ap_common.h"
 #include "kernels.h"
 
@@ -22,6 +23,11 @@ int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
 }
+// launcher of the 16-bit kernel set the precision selects: fp16 storage (AP_PREC_F16) or bf16 storage / fp32 / split-bf16
+#define H16(prec, fn) ((prec) == AP_PREC_F16 ? k_f16::fn : k_bf16::fn)
+inline bool prec_half(int prec) { return prec == AP_PREC_BF16 || prec == AP_PREC_F16; }   // the throughput kernels
+inline int prec_kind(int prec) { return prec == AP_PREC_F16 ? K_BF16 : prec; }             // storage kind inside a kernel set
+inline bool prec_valid(int prec) { return prec == AP_PREC_FP32 || prec == AP_PREC_BF16 || prec == AP_PREC_BF16X2 || prec == AP_PREC_F16; }
 #define HIP_TRY(expr)                                                                              \
     do {                                                                                           \
         hipError_t _e = (expr);                                                                    \
@@ -136,7 +142,6 @@ unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_
 // without the slab / lean kernels, -5 automatic without the lean kernel, 0..14 / 17 / 100 one explicit configuration);
 // dispatch_conv reads it once per launch and decodes it, so handles on different threads never see a torn setting.
 std::atomic<int> g_conv_mode{-1};
-std::atomic<int> g_bneck_cut{2};   // ap_bottleneck64_nhwc: 2 = bottleneck2.hip (default), 1 = bottleneck.hip (the first cut)
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -168,7 +173,8 @@ hipError_t device_cus(int* n) {
 }
 
 // choose the tile configuration: large tiles need enough tiles to fill 256 CUs (1 workgroup per CU)
-hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipStream_t st) {
+hipError_t dispatch_conv(ConvArgs& a, int prec /* AP_PREC_* */, hipStream_t st) {
+    const int is_bf16 = prec_kind(prec);                     // storage kind inside the kernel set: K_F32 / K_BF16 (16-bit) / K_SPLIT
     const int mode = g_conv_mode.load(std::memory_order_relaxed);
     const bool use_slab = mode == -1 || mode == -5, use_lean = mode == -1;
     int cfg = mode < 0 ? -1 : mode;
@@ -190,26 +196,26 @@ hipError_t dispatch_conv(ConvArgs& a, int is_bf16 /* = kind: AP_PREC_* */, hipSt
         //   17  pointwise layers with a short contraction and several channel tiles (conv3 of layer2-4, layer3.0 conv1: K <= 512,
         //       C_out >= 256)
         //       on three lean workgroups per CU (conv_lean.hip, bit-identical to 11): -4..6 % there, +20 % on K >= 1024
-        if (use_slab && ap_conv_slab_supported(a, is_bf16)) cfg = 14;
-        else if (use_lean && a.Cin <= 512 && a.Cout >= 256 && mt128 * nt128 >= 768 && ap_conv_lean_supported(a, is_bf16)) cfg = 17;
+        if (use_slab && k_bf16::ap_conv_slab_supported(a, is_bf16)) cfg = 14;
+        else if (use_lean && a.Cin <= 512 && a.Cout >= 256 && mt128 * nt128 >= 768 && k_bf16::ap_conv_lean_supported(a, is_bf16)) cfg = 17;
         else if (mt128 * nt128 >= 256) cfg = a.Cout <= 64 ? 12 : 11;
         else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
     }
-    if (cfg == 100) return ap_launch_conv(a, is_bf16, st);
+    if (cfg == 100) return H16(prec, ap_launch_conv)(a, is_bf16, st);
     hipError_t e = zero_line(&a.zero);
     if (e != hipSuccess) return e;
     a.dbg = g_conv_dbg;
     if (cfg == 17) {                                         // lean pointwise kernel; other shapes: the ring kernel's tile
-        if (!ap_conv_lean_supported(a, is_bf16)) return ap_launch_conv_pipe(a, is_bf16, 11, st);
-        return ap_launch_conv_lean(a, st);
+        if (!k_bf16::ap_conv_lean_supported(a, is_bf16)) return H16(prec, ap_launch_conv_pipe)(a, is_bf16, 11, st);
+        return H16(prec, ap_launch_conv_lean)(a, st);
     }
     if (cfg == 14) {
         // explicit 14 on a shape the slab kernel cannot run: the ring kernel's tile of the same shape
-        if (!ap_conv_slab_supported(a, is_bf16)) return ap_launch_conv_pipe(a, is_bf16, 11, st);
-        return ap_launch_conv_slab(a, st);
+        if (!k_bf16::ap_conv_slab_supported(a, is_bf16)) return H16(prec, ap_launch_conv_pipe)(a, is_bf16, 11, st);
+        return H16(prec, ap_launch_conv_slab)(a, st);
     }
-    return ap_launch_conv_pipe(a, is_bf16, cfg, st);
+    return H16(prec, ap_launch_conv_pipe)(a, is_bf16, cfg, st);
 }
 constexpr int ST = 148, SLD = 288, DLD = 148;
 
@@ -230,8 +236,11 @@ struct ap_net {
     DevBuf foldT_feat, foldT_state, fold_bias;   // the same map k-major ([k][148]) for the fused IEF kernel (copenet head)
     bool fuse_ief = true;          // folded map: one split-K feature kernel + one kernel for all IEF iterations
     bool fold = true;
+    double fold_check_err = 0.0;   // ap_net_finalize: folded vs literal chain on the probe batch (max |diff| / max |literal|)
+    bool fold_rejected = false;    // ... above fold_bar: fold forced off for this checkpoint
+    double fold_bar = 1e-5;        // (ap_net_set_fold_bar: test aid)
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
-    int fuse_block = 2;            // bf16: layer1 bottlenecks as one kernel each: 2 bottleneck2.hip (default), 1 bottleneck.hip (first cut), 0 separate convs
+    bool fuse_block = true;        // 16-bit modes: each layer1 bottleneck as one kernel (bottleneck2.hip); off: separate convs
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     DevBuf mean_pose, mean_shape, mean_cam;
@@ -250,7 +259,16 @@ struct ap_net {
     int passes_per_view = 1;       // experiment: 2 = each view as two concurrent half passes (four streams)
     DevBuf ws_H, ws_S, ws_T1, ws_T2, ws_D, ws_state;
     Timing tm;
-    size_t esize() const { return prec == AP_PREC_BF16 ? 2 : 4; }   // fp32 and split-bf16 pairs: 4 bytes
+    bool half() const { return prec_half(prec); }            // the throughput kernels (bf16 or fp16 storage)
+    int kind() const { return prec_kind(prec); }
+    size_t esize() const { return half() ? 2 : 4; }          // fp32 and split-bf16 pairs: 4 bytes
+    // AP_PREC_F16 range sentinel: host-mapped word the pooling stage sets when a trunk feature is not finite (NULL otherwise).
+    // range_mode 1 (default): sticky, reported by the NEXT call on the handle and by ap_net_range_status (no sync on the hot path);
+    // 2: every trunk-running call synchronises its stream and reports its own pass
+    int* range_flag = nullptr;
+    int range_mode = 1;
+    bool f16_overflow = false;                               // AP_PREC_F16: a packed weight left the fp16 range (ap_net_finalize refuses)
+    uint16_t h16(float f) { return prec == AP_PREC_F16 ? host_f32_to_f16(f, &f16_overflow) : host_f32_to_bf16(f); }
 };
 
 struct ap_smplx {
@@ -313,14 +331,14 @@ int pack_conv(ap_net* h, const std::string& wname, const std::string& bnname, in
     int rc = bn_fold(h, bnname, cout, scale, shift);
     if (rc) return rc;
     const size_t n = (size_t)L.cout_pad * L.wld;
-    if (h->prec == AP_PREC_BF16) {
+    if (h->half()) {
         std::vector<uint16_t> pk(n, 0);
         for (int o = 0; o < cout; ++o)
             for (int c = 0; c < cin; ++c)
                 for (int r = 0; r < k; ++r)
                     for (int s = 0; s < k; ++s)
                         pk[(size_t)o * L.wld + (r * k + s) * cin + c] =
-                            host_f32_to_bf16(w->data[(((size_t)o * cin + c) * k + r) * k + s]);
+                            h->h16(w->data[(((size_t)o * cin + c) * k + r) * k + s]);
         HIP_TRY(upload(L.w, pk.data(), n * 2));
     } else {
         std::vector<float> pk(n, 0.f);
@@ -365,9 +383,9 @@ int pack_c3_ds(ap_net* h, const std::string& P, int planes, int inplanes, int st
         for (int c = 0; c < K2; ++c) pk[(size_t)o * L.wld + K1 + c] = (float)((double)wd->data[(size_t)o * K2 + c] * (double)sd[o]);
         shift[o] = h3[o] + hd[o];
     }
-    if (h->prec == AP_PREC_BF16) {
+    if (h->half()) {
         std::vector<uint16_t> pb(n);
-        for (size_t i = 0; i < n; ++i) pb[i] = host_f32_to_bf16(pk[i]);
+        for (size_t i = 0; i < n; ++i) pb[i] = h->h16(pk[i]);
         HIP_TRY(upload(L.w, pb.data(), n * 2));
     } else if (h->prec == AP_PREC_BF16X2) {
         std::vector<uint16_t> ps(2 * n);
@@ -399,7 +417,7 @@ int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const
     return AP_OK;
 }
 
-int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int is_bf16,
+int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int prec,
              hipStream_t st) {
     ConvArgs a{};
     a.x = x; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = res; a.y = y;
@@ -411,13 +429,13 @@ int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const 
     a.M = N * a.Ho * a.Wo;
     a.ldx = L.cin; a.ldy = L.cout; a.ldr = L.cout; a.wld = L.wld;
     a.relu = relu;
-    HIP_TRY(dispatch_conv(a, is_bf16, st));
+    HIP_TRY(dispatch_conv(a, prec, st));
     return AP_OK;
 }
 
 // fused conv3 + downsample of a stage's first block: t [N][Ho][Ho][cin] (pointwise) and x [N][Hin][Hin][cin2]
 // sampled with stride2, concatenated along K
-int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int Hin, void* y, int is_bf16,
+int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int Hin, void* y, int prec,
               hipStream_t st) {
     ConvArgs a{};
     a.x = t; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = nullptr; a.y = y;
@@ -426,13 +444,13 @@ int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int H
     a.M = N * Ho * Ho;
     a.ldx = L.cin; a.ldy = L.cout; a.ldr = L.cout; a.wld = L.wld; a.relu = 1;
     a.x2 = x; a.H2 = Hin; a.W2 = Hin; a.Cin2 = L.cin2; a.stride2 = L.stride2; a.ldx2 = L.cin2;
-    HIP_TRY(dispatch_conv(a, is_bf16, st));
+    HIP_TRY(dispatch_conv(a, prec, st));
     return AP_OK;
 }
 
 // fused layer1 bottleneck (bf16): x [N][H][H][c1.cin] -> y [N][H][H][256]
 int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, const void* x, int N, int H, void* y,
-                int cut, hipStream_t st) {
+                int prec, hipStream_t st) {
     BneckArgs a{};
     a.x = x; a.y = y;
     a.w1 = c1.w.p; a.w2 = c2.w.p; a.w3 = c3.w.p;
@@ -442,8 +460,8 @@ int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, cons
     a.N = N; a.H = H; a.W = H;
     HIP_TRY(zero_line(&a.zero));
     a.dbg = g_conv_dbg;
-    if (cut == 2 && ((!ds && c1.cin == 256) || (ds && c1.cin == 64))) HIP_TRY(ap_launch_bneck2(a, ds ? 1 : 0, st));
-    else HIP_TRY(ap_launch_bneck64(a, c1.cin, ds ? 1 : 0, st));
+    if (!((!ds && c1.cin == 256) || (ds && c1.cin == 64))) return fail(AP_ESHAPE, "fused layer1 bottleneck: C_in 256 (identity) or 64 (first block)");
+    HIP_TRY(H16(prec, ap_launch_bneck2)(a, ds ? 1 : 0, st));
     return AP_OK;
 }
 
@@ -479,7 +497,7 @@ int finalize_trunk(ap_net* h) {
             for (int c = 0; c < 3; ++c)
                 for (int r = 0; r < 7; ++r)
                     for (int s2 = 0; s2 < 7; ++s2)
-                        pk[o * 232 + r * 32 + s2 * 4 + c] = host_f32_to_bf16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
+                        pk[o * 232 + r * 32 + s2 * 4 + c] = h->h16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
         HIP_TRY(upload(h->stem_wpk, pk.data(), pk.size() * 2));
         if (h->prec == AP_PREC_BF16X2) {                    // low plane: bf16(w - hi) at the same positions
             std::vector<uint16_t> pl(64 * 232, 0);
@@ -528,17 +546,17 @@ int finalize_trunk(ap_net* h) {
     // the order the fused kernel consumes them, built on the device from the rows packed above.  Identity blocks: conv3 +
     // identity; stage-first blocks: conv3 with the downsample branch folded in as a second K segment (pack_c3_ds), with the
     // next conv1 where the registers allow, alone otherwise
-    if (h->prec == AP_PREC_BF16)
+    if (h->half())
         for (size_t b = 0; b + 1 < h->blocks.size(); ++b) {
             ap_net::Block &A = h->blocks[b], &N = h->blocks[b + 1];
             const Layer& L3 = A.has_down ? A.c3ds : A.c3;
             const int P = L3.cin, P2 = A.has_down ? L3.cin2 : 0, C3 = L3.cout;
             int N1 = N.c1.cout;
             if (N.c1.cin != C3) continue;
-            if (!ap_conv_pair_supported(P, P2, C3, N1)) N1 = 0;
-            if (!ap_conv_pair_supported(P, P2, C3, N1)) continue;
-            HIP_TRY(A.pair.reserve(ap_conv_pair_stream_bytes(P, P2, C3, N1)));
-            HIP_TRY(ap_launch_pair_pack(L3.w.p, N1 ? N.c1.w.p : nullptr, A.pair.p, P, P2, C3, N1, nullptr));
+            if (!k_bf16::ap_conv_pair_supported(P, P2, C3, N1)) N1 = 0;
+            if (!k_bf16::ap_conv_pair_supported(P, P2, C3, N1)) continue;
+            HIP_TRY(A.pair.reserve(k_bf16::ap_conv_pair_stream_bytes(P, P2, C3, N1)));
+            HIP_TRY(H16(h->prec, ap_launch_pair_pack)(L3.w.p, N1 ? N.c1.w.p : nullptr, A.pair.p, P, P2, C3, N1, nullptr));
             A.pair_p = P; A.pair_p2 = P2; A.pair_c3 = C3; A.pair_n1 = N1;
         }
     HIP_TRY(hipDeviceSynchronize());
@@ -682,6 +700,56 @@ int finalize_regressor(ap_net* h) {
         }
         if ((rc = pack_linear(wf.data(), 2332, 0, 2048, 145, bfv.data(), h->fold_feat))) return rc;
         if ((rc = pack_linear(wf.data(), 2332, 2048, 284, 145, nullptr, h->fold_state))) return rc;
+        {   // Guard of the fold on THIS checkpoint: the fp32-rounded folded map against the literal fc1 -> fc2 -> dec chain, both
+            // evaluated in fp64 on a fixed probe batch (post-pooling-like features, states around the mean parameters).  The
+            // fold is exact algebra; what can go wrong is cancellation -- folded rows whose fp32 rounding error, summed over the
+            // 2332 inputs, is visible in the small decoder outputs.  Above 1e-5 of the output scale the handle evaluates the
+            // literal chain instead (ap_net_fold_status reports which and why).
+            const int NP = 8;
+            uint64_t lcg = 0x9E3779B97F4A7C15ull;
+            auto unif = [&]() { lcg = lcg * 6364136223846793005ull + 1442695040888963407ull; return (double)(lcg >> 11) * (1.0 / 9007199254740992.0); };
+            auto gauss = [&]() { const double u = std::max(unif(), 1e-300), v = unif(); return std::sqrt(-2.0 * std::log(u)) * std::cos(6.283185307179586 * v); };
+            double worst = 0.0, scale = 0.0;
+            std::vector<double> x(2332), t1(1024), t2(1024);
+            std::vector<double> ylit((size_t)NP * 145), yfold((size_t)NP * 145);
+            for (int r = 0; r < NP; ++r) {
+                for (int j = 0; j < 2048; ++j) x[j] = std::fabs(gauss()) * 0.8;               // pooled post-ReLU features
+                for (int j = 2048; j < 2332; ++j) x[j] = 0.3 * gauss();                        // bb / position / 6-D pose / shape
+                for (int j = 0; j < 132 && 2054 + j < 2332; ++j) x[2054 + j] += ip->data[j];  // around the mean pose
+                for (int o = 0; o < 1024; ++o) {
+                    double acc = b1->data[o];
+                    const float* wr = &w1->data[(size_t)o * 2332];
+                    for (int j = 0; j < 2332; ++j) acc += (double)wr[j] * x[j];
+                    t1[o] = acc;
+                }
+                for (int o = 0; o < 1024; ++o) {
+                    double acc = b2->data[o];
+                    const float* wr = &w2->data[(size_t)o * 1024];
+                    for (int j = 0; j < 1024; ++j) acc += (double)wr[j] * t1[j];
+                    t2[o] = acc;
+                }
+                for (int o = 0; o < 145; ++o) {
+                    double acc = bd[o], accf = bfv[o];
+                    const float* wr = &wd[(size_t)o * 1024];
+                    for (int j = 0; j < 1024; ++j) acc += (double)wr[j] * t2[j];
+                    const float* fr = &wf[(size_t)o * 2332];
+                    for (int j = 0; j < 2332; ++j) accf += (double)fr[j] * x[j];
+                    ylit[(size_t)r * 145 + o] = acc;
+                    yfold[(size_t)r * 145 + o] = accf;
+                    scale = std::max(scale, std::fabs(acc));
+                    worst = std::max(worst, std::fabs(acc - accf));
+                }
+            }
+            h->fold_check_err = scale > 0.0 ? worst / scale : 0.0;
+            const bool was_rejected = h->fold_rejected;
+            h->fold_rejected = !(h->fold_check_err <= h->fold_bar);
+            if (was_rejected && !h->fold_rejected) h->fold = true;      // re-packed weights pass: back to the default
+            if (h->fold_rejected) {
+                h->fold = false;
+                fprintf(stderr, "airpose_hip: the folded regressor map differs from the literal fc1 -> fc2 -> dec chain by %.3e of the "
+                                "output scale on the probe batch (bar %.1e): this handle evaluates the literal chain\n", h->fold_check_err, h->fold_bar);
+            }
+        }
         {   // k-major copies for the fused IEF kernel
             std::vector<float> tf((size_t)2048 * 148, 0.f), ts((size_t)288 * 148, 0.f), tb(148, 0.f);   // (k padded to 288 with zero rows)
             for (int o = 0; o < 145; ++o) {
@@ -708,7 +776,7 @@ int finalize_regressor(ap_net* h) {
 
 // workspace of one pass over n images (a grow may synchronise the device and free: never while a sibling pass is in flight)
 int reserve_trunk_ws(ap_net* h, ap_net::TrunkWs& w, int n) {
-    const bool bf = h->prec == AP_PREC_BF16;
+    const bool bf = h->half();
     const size_t es = h->esize();
     if (!(h->fuse_stem && (bf || h->prec == AP_PREC_BF16X2))) HIP_TRY(w.ws_stem.reserve((size_t)n * 112 * 112 * 64 * es));
     HIP_TRY(w.ws_a.reserve((size_t)n * 802816 * es));
@@ -722,34 +790,35 @@ int reserve_trunk_ws(ap_net* h, ap_net::TrunkWs& w, int n) {
 // one depth-first pass over n = n0 + n1 images: the first n0 from x0, the rest from x1 (two views, one pass)
 int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st,
                 size_t* ev_out = nullptr, int signal_at = 0) {
-    const int bf = h->prec == AP_PREC_BF16;                  // gates the bf16-only fused kernels
-    const int kind = h->prec;                                // storage kind of every generic kernel
+    const int bf = h->half();                                // gates the fused kernels of the 16-bit throughput modes
+    const int prec = h->prec;                                // selects the kernel set (H16) and, as prec_kind, the storage kind
+    const int kind = h->kind();
     const size_t es = h->esize();
     const int n = n0 + n1;
     { int rc0 = reserve_trunk_ws(h, w, n); if (rc0) return rc0; }
     size_t e0 = 0, e1 = 0, e2 = 0, e3 = 0;
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
-        HIP_TRY(ap_launch_stem_pool(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                    w.ws_a.p, n, st));
+        HIP_TRY(H16(prec, ap_launch_stem_pool)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
+                                               w.ws_a.p, n, st));
     } else if (bf) {
-        HIP_TRY(ap_launch_stem_conv_mfma(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
-                                         h->stem_shift.as<float>(), w.ws_stem.p, n, st));
+        HIP_TRY(H16(prec, ap_launch_stem_conv_mfma)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
+                                                    h->stem_shift.as<float>(), w.ws_stem.p, n, st));
     } else if (kind == AP_PREC_BF16X2 && h->fuse_stem) {
-        HIP_TRY(ap_launch_stem_pool_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
+        HIP_TRY(k_bf16::ap_launch_stem_pool_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
                                           h->stem_shift.as<float>(), w.ws_a.p, n, st));
     } else if (kind == AP_PREC_BF16X2) {
-        HIP_TRY(ap_launch_stem_conv_mfma_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
+        HIP_TRY(k_bf16::ap_launch_stem_conv_mfma_split(x0, x1, n0, h->stem_wpk.p, h->stem_wpk_lo.p, h->stem_scale.as<float>(),
                                                h->stem_shift.as<float>(), w.ws_stem.p, n, st));
     } else {
         if (n0)
-            HIP_TRY(ap_launch_stem_conv(x0, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
+            HIP_TRY(k_bf16::ap_launch_stem_conv(x0, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
                                         w.ws_stem.p, n0, kind, st));
         if (n1)
-            HIP_TRY(ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
+            HIP_TRY(k_bf16::ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
                                         (char*)w.ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, kind, st));
     }
-    if (!(h->fuse_stem && (bf || kind == AP_PREC_BF16X2))) HIP_TRY(ap_launch_maxpool(w.ws_stem.p, w.ws_a.p, n, kind, st));
+    if (!(h->fuse_stem && (bf || kind == AP_PREC_BF16X2))) HIP_TRY(H16(prec, ap_launch_maxpool)(w.ws_stem.p, w.ws_a.p, n, kind, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
     if (signal_at == 1) HIP_TRY(hipEventRecord(h->ev_skew, st));
     void *cur = w.ws_a.p, *nxt = w.ws_b.p;
@@ -763,13 +832,13 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         if (bf && h->fuse_block && B.c2.cout == 64 && B.c2.stride == 1 && H % 14 == 0 && (!B.has_down || B.c1.cin == 64)) {
             // layer1: conv1 -> conv2 -> conv3 (+identity | folded downsample) in one kernel, intermediates in LDS
             const Layer& L3 = B.has_down ? B.c3ds : B.c3;
-            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, h->fuse_block, st))) return rc;
+            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, prec, st))) return rc;
             std::swap(cur, nxt);
             continue;
         }
-        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, kind, st))) return rc;
+        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st))) return rc;
         t1_ready = false;
-        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, kind, st))) return rc;
+        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st))) return rc;
         if (bf && h->fuse_pair && B.pair_p && &B != &h->blocks.back() && (!B.has_down || h->fuse_ds)) {
             // conv3 (+ identity | + folded downsample, ReLU) AND -- where the pair carries it -- the next block's conv1 in one
             // kernel: the block output is written once and not read back for conv1 (model_copenet.py:38-45 of this block,
@@ -783,23 +852,23 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg;
             if (B.has_down) { a.x2 = cur; a.Ho = a.Wo = Ho; a.H2 = a.W2 = H; a.stride2 = L3.stride2; }
             else a.res = cur;
-            HIP_TRY(ap_launch_conv_pair(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
+            HIP_TRY(H16(prec, ap_launch_conv_pair)(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
             t1_ready = B.pair_n1 > 0;
         } else if (B.has_down && h->fuse_ds) {
-            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, kind, st))) return rc;
+            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st))) return rc;
         } else {
             const void* res = cur;
             if (B.has_down) {
-                if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, kind, st))) return rc;
+                if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, prec, st))) return rc;
                 res = w.ws_ds.p;
             }
-            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, kind, st))) return rc;
+            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st))) return rc;
         }
         std::swap(cur, nxt);
         H = Ho;
     }
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e2));
-    HIP_TRY(ap_launch_avgpool(cur, feat, n, 2048, kind, st));
+    HIP_TRY(H16(prec, ap_launch_avgpool)(cur, feat, n, 2048, kind, h->range_flag, st));
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e3));
     if (ev_out) {                                            // the caller combines the events of two concurrent passes
         ev_out[0] = e0; ev_out[1] = e1; ev_out[2] = e2; ev_out[3] = e3;
@@ -814,10 +883,26 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
 }
 
 // trunk over the concatenation [x0 (n0 images) | x1 (n1 images)]; feat rows follow the same order
+int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st);
 int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
     if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
-    const int n_img = n0 + n1;
     if (n0 <= 0 || n1 < 0 || !x0 || (n1 && !x1) || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
+    if (h->range_flag && h->range_mode && __atomic_load_n(h->range_flag, __ATOMIC_RELAXED))
+        return fail(AP_ERANGE, "AP_PREC_F16: an earlier trunk pass of this handle produced non-finite features (a stored activation left "
+                               "the fp16 range); clear with ap_net_range_status(h, stream, 1) and use AP_PREC_BF16 for this checkpoint");
+    int rc_pass = trunk_passes(h, x0, n0, x1, n1, feat, st);
+    if (rc_pass) return rc_pass;
+    if (h->range_flag && h->range_mode == 2) {
+        HIP_TRY(hipStreamSynchronize(st));
+        if (__atomic_load_n(h->range_flag, __ATOMIC_RELAXED))
+            return fail(AP_ERANGE, "AP_PREC_F16: non-finite trunk features (a stored activation left the fp16 range); use AP_PREC_BF16 "
+                                   "for this checkpoint");
+    }
+    return AP_OK;
+}
+
+int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
+    const int n_img = n0 + n1;
     const int chunk = h->chunk > 0 ? h->chunk : 512;
     const size_t IMG_ELEMS = (size_t)3 * 224 * 224;
     // (measured: +4..5 % at 64 images per view, -4 % at 32, where the launches no longer fill the chip)
@@ -972,11 +1057,16 @@ const char* ap_version(void) { return "airpose_hip 0.1 (gfx950)"; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
 int ap_net_create(ap_net** out, int device, int precision, int variant) {
-    if (!out || (precision != AP_PREC_FP32 && precision != AP_PREC_BF16 && precision != AP_PREC_BF16X2) || (variant < 0 || variant > 3))
+    if (!out || !prec_valid(precision) || (variant < 0 || variant > 3))
         return fail(AP_EINVAL, "ap_net_create: bad arguments");
     HIP_TRY(hipSetDevice(device));
     ap_net* h = new ap_net();
     h->device = device; h->prec = precision; h->variant = variant;
+    if (precision == AP_PREC_F16) {
+        hipError_t e = hipHostMalloc((void**)&h->range_flag, sizeof(int), hipHostMallocMapped);
+        if (e != hipSuccess) { delete h; return fail((int)e, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+        *h->range_flag = 0;
+    }
     *out = h;
     return AP_OK;
 }
@@ -1003,6 +1093,7 @@ void ap_net_destroy(ap_net* h) {
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
     if (h->ev_skew) (void)hipEventDestroy(h->ev_skew);
+    if (h->range_flag) (void)hipHostFree(h->range_flag);
     delete h;
 }
 
@@ -1024,19 +1115,36 @@ int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const
 int ap_net_finalize(ap_net* h) {
     if (!h) return fail(AP_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device));
-    host_h16_overflow() = false;
+    h->f16_overflow = false;
     int rc = finalize_trunk(h);
     if (rc) return rc;
     if ((rc = finalize_regressor(h))) return rc;
-    // fp16 flavour (-DAP_F16): a BatchNorm-folded weight above 65 504 would become inf on the device
-    if (host_h16_overflow() && h->prec == AP_PREC_BF16)
-        return fail(AP_ESHAPE, "ap_net_finalize: a (BatchNorm-folded) weight exceeds the fp16 range of this flavour of the library; "
-                               "use the bf16 flavour (libairpose_hip.so, precision='bf16')");
+    // fp16 storage: a BatchNorm-folded weight above 65 504 would become inf on the device
+    if (h->f16_overflow)
+        return fail(AP_ESHAPE, "ap_net_finalize: a (BatchNorm-folded) weight exceeds the fp16 range of AP_PREC_F16; "
+                               "use AP_PREC_BF16 (precision='bf16': fp32's exponent range)");
     h->finalized = true;
     return AP_OK;
 }
 
 int ap_net_precision(const ap_net* h) { return h ? h->prec : AP_EINVAL; }
+
+int ap_net_set_range_check(ap_net* h, int mode) {
+    if (!h || mode < 0 || mode > 2) return fail(AP_EINVAL, "ap_net_set_range_check: handle, mode in {0, 1, 2}");
+    h->range_mode = mode;
+    return AP_OK;
+}
+
+int ap_net_range_status(ap_net* h, void* stream, int reset) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    if (!h->range_flag) return AP_OK;                        // only fp16 storage has a range to leave
+    HIP_TRY(hipSetDevice(h->device));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    const int bad = __atomic_load_n(h->range_flag, __ATOMIC_RELAXED);
+    if (reset) __atomic_store_n(h->range_flag, 0, __ATOMIC_RELAXED);
+    if (bad) return fail(AP_ERANGE, "AP_PREC_F16: a trunk pass produced non-finite features (a stored activation left the fp16 range)");
+    return AP_OK;
+}
 
 int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* stream) {
     if (!h) return fail(AP_EINVAL, "null handle");
@@ -1134,8 +1242,8 @@ int ap_copenet_fwd(ap_net* h, const float* x0, const float* x1, const float* bb0
 int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* scale, const float* shift,
                    const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
                    int relu, void* stream) {
-    const int bf = precision == AP_PREC_BF16;
-    if ((precision != AP_PREC_BF16 && precision != AP_PREC_FP32 && precision != AP_PREC_BF16X2) || !x || !w || !scale ||
+    const int bf = prec_half(precision);
+    if (!prec_valid(precision) || !x || !w || !scale ||
         !shift || !y || N <= 0 ||
         H <= 0 || W <= 0 || ksize <= 0 || stride <= 0 || pad < 0)
         return fail(AP_EINVAL, "ap_conv2d_nhwc: bad argument");
@@ -1154,11 +1262,11 @@ int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* sca
     return AP_OK;
 }
 
-int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
+int ap_bottleneck64_nhwc(int precision, const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
                          const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
                          int N, int H, int W, int Cin, int downsample, void* stream) {
-    if (!x || !w1 || !s1 || !h1 || !w2 || !s2 || !h2 || !w3 || !s3 || !h3 || !y || N <= 0)
-        return fail(AP_EINVAL, "ap_bottleneck64_nhwc: bad argument");
+    if (!prec_half(precision) || !x || !w1 || !s1 || !h1 || !w2 || !s2 || !h2 || !w3 || !s3 || !h3 || !y || N <= 0)
+        return fail(AP_EINVAL, "ap_bottleneck64_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
     if (H <= 0 || W <= 0 || H % 14 || W % 14 || !((Cin == 256 && !downsample) || (Cin == 64 && downsample)))
         return fail(AP_ESHAPE, "ap_bottleneck64_nhwc: H, W multiples of 14; Cin 256 (identity) or 64 (downsample)");
     BneckArgs a{};
@@ -1167,57 +1275,52 @@ int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const f
     a.N = N; a.H = H; a.W = W;
     HIP_TRY(zero_line(&a.zero));
     a.dbg = g_conv_dbg;
-    if (g_bneck_cut.load() == 2) HIP_TRY(ap_launch_bneck2(a, downsample ? 1 : 0, (hipStream_t)stream));
-    else HIP_TRY(ap_launch_bneck64(a, Cin, downsample ? 1 : 0, (hipStream_t)stream));
+    HIP_TRY(H16(precision, ap_launch_bneck2)(a, downsample ? 1 : 0, (hipStream_t)stream));
     return AP_OK;
 }
 
-int ap_conv_pair_nhwc(const void* t2, const void* w3, const float* s3, const float* h3, const void* res, const void* w1,
+// The fused pair kernel consumes its two weight matrices as ONE stream of 16-KiB tiles in consumption order.  The stream is
+// CALLER-OWNED: packed once by ap_conv_pair_pack into a buffer of ap_conv_pair_stream_bytes, handed to every launch -- the
+// library keeps no hidden copy keyed by weight addresses (an allocator may reuse an address for new contents).
+int64_t ap_conv_pair_stream_bytes(int P, int P2, int N1) {
+    if (!k_bf16::ap_conv_pair_supported(P, P2, 4 * P, N1)) return AP_ESHAPE;
+    return (int64_t)k_bf16::ap_conv_pair_stream_bytes(P, P2, 4 * P, N1);
+}
+
+int ap_conv_pair_pack(int precision, const void* w3, const void* w1, int P, int P2, int N1, void* wstream, void* stream) {
+    if (!prec_half(precision) || !w3 || !wstream || (N1 > 0 && !w1))
+        return fail(AP_EINVAL, "ap_conv_pair_pack: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
+    if (!k_bf16::ap_conv_pair_supported(P, P2, 4 * P, N1))
+        return fail(AP_ESHAPE, "ap_conv_pair_pack: (P, P2, N1) must be (128,0,128), (128,0,256), (256,0,256), (128,256,128) or (256,512,0)");
+    HIP_TRY(H16(precision, ap_launch_pair_pack)(w3, N1 ? w1 : nullptr, wstream, P, P2, 4 * P, N1, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_conv_pair_nhwc(int precision, const void* t2, const void* wstream, const float* s3, const float* h3, const void* res,
                       const float* s1, const float* h1, void* out, void* t1n, int M, int P, int N1, void* stream) {
-    if (!t2 || !w3 || !s3 || !h3 || !res || !w1 || !s1 || !h1 || !out || !t1n || M <= 0)
-        return fail(AP_EINVAL, "ap_conv_pair_nhwc: bad argument");
-    if (!ap_conv_pair_supported(P, 0, 4 * P, N1)) return fail(AP_ESHAPE, "ap_conv_pair_nhwc: (P, N1) must be (128,128), (128,256) or (256,256)");
-    // the weight stream of the last (w3, w1) pair is kept (tools/pair_bench.py times repeated calls)
-    static const void *k3 = nullptr, *k1 = nullptr;
-    static int kp = 0, kn = 0;
-    static DevBuf ws;
-    hipStream_t st = (hipStream_t)stream;
-    if (k3 != w3 || k1 != w1 || kp != P || kn != N1) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(ws.reserve(ap_conv_pair_stream_bytes(P, 0, 4 * P, N1)));
-        HIP_TRY(ap_launch_pair_pack(w3, w1, ws.p, P, 0, 4 * P, N1, st));
-        k3 = w3; k1 = w1; kp = P; kn = N1;
-    }
+    if (!prec_half(precision) || !t2 || !wstream || !s3 || !h3 || !res || !s1 || !h1 || !out || !t1n || M <= 0)
+        return fail(AP_EINVAL, "ap_conv_pair_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
+    if (!k_bf16::ap_conv_pair_supported(P, 0, 4 * P, N1)) return fail(AP_ESHAPE, "ap_conv_pair_nhwc: (P, N1) must be (128,128), (128,256) or (256,256)");
     PairArgs a{};
-    a.t2 = t2; a.res = res; a.wstream = ws.p; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n; a.M = M;
+    a.t2 = t2; a.res = res; a.wstream = wstream; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n; a.M = M;
     a.dbg = g_conv_dbg;
-    HIP_TRY(ap_launch_conv_pair(a, P, 0, 4 * P, N1, st));
+    HIP_TRY(H16(precision, ap_launch_conv_pair)(a, P, 0, 4 * P, N1, (hipStream_t)stream));
     return AP_OK;
 }
 
-int ap_conv_pair_ds_nhwc(const void* t2, const void* x, const void* w3d, const float* h3, const void* w1, const float* s1,
-                         const float* h1, void* out, void* t1n, int N, int Ho, int P, int P2, int stride, int N1, void* stream) {
-    if (!t2 || !x || !w3d || !h3 || !out || N <= 0 || Ho <= 0 || (N1 > 0 && (!w1 || !s1 || !h1 || !t1n)))
-        return fail(AP_EINVAL, "ap_conv_pair_ds_nhwc: bad argument");
+int ap_conv_pair_ds_nhwc(int precision, const void* t2, const void* x, const void* wstream, const float* s3, const float* h3,
+                         const float* s1, const float* h1, void* out, void* t1n, int N, int Ho, int P, int P2, int stride, int N1,
+                         void* stream) {
+    if (!prec_half(precision) || !t2 || !x || !wstream || !s3 || !h3 || !out || N <= 0 || Ho <= 0 || (N1 > 0 && (!s1 || !h1 || !t1n)))
+        return fail(AP_EINVAL, "ap_conv_pair_ds_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
     const int C3 = 4 * P;
-    if (!ap_conv_pair_supported(P, P2, C3, N1) || stride < 1 || stride > 2)
+    if (!k_bf16::ap_conv_pair_supported(P, P2, C3, N1) || stride < 1 || stride > 2)
         return fail(AP_ESHAPE, "ap_conv_pair_ds_nhwc: (P, P2, N1) must be (128,256,128) or (256,512,0); stride 1 or 2");
-    static const void *k3 = nullptr, *k1 = nullptr;
-    static int kp = 0, kn = 0;
-    static DevBuf ws, ones;
-    hipStream_t st = (hipStream_t)stream;
-    if (k3 != w3d || k1 != w1 || kp != P || kn != N1) {
-        HIP_TRY(hipDeviceSynchronize());
-        HIP_TRY(ws.reserve(ap_conv_pair_stream_bytes(P, P2, C3, N1)));
-        HIP_TRY(ap_launch_pair_pack(w3d, w1, ws.p, P, P2, C3, N1, st));
-        std::vector<float> one(C3, 1.f);                    // the BatchNorm scales are folded into w3d (pack_c3_ds)
-        HIP_TRY(upload(ones, one.data(), one.size() * 4));
-        k3 = w3d; k1 = w1; kp = P; kn = N1;
-    }
     PairArgs a{};
-    a.t2 = t2; a.x2 = x; a.wstream = ws.p; a.s3 = ones.as<float>(); a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n;
+    a.t2 = t2; a.x2 = x; a.wstream = wstream; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n;
     a.M = N * Ho * Ho; a.Ho = a.Wo = Ho; a.H2 = a.W2 = Ho * stride; a.stride2 = stride;
-    HIP_TRY(ap_launch_conv_pair(a, P, P2, C3, N1, st));
+    a.dbg = g_conv_dbg;
+    HIP_TRY(H16(precision, ap_launch_conv_pair)(a, P, P2, C3, N1, (hipStream_t)stream));
     return AP_OK;
 }
 
@@ -1310,13 +1413,7 @@ int ap_net_set_fuse_ds(ap_net* h, int on) {
 
 int ap_net_set_fuse_block(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->fuse_block = on < 0 ? 0 : (on > 2 ? 2 : on);
-    return AP_OK;
-}
-
-int ap_set_bottleneck_cut(int cut) {
-    if (cut != 1 && cut != 2) return fail(AP_EINVAL, "ap_set_bottleneck_cut: 1 or 2");
-    g_bneck_cut.store(cut);
+    h->fuse_block = on != 0;
     return AP_OK;
 }
 
@@ -1340,8 +1437,23 @@ int ap_net_set_fuse_stem(ap_net* h, int on) {
 
 int ap_net_set_fold(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
+    if (on && h->fold_rejected)
+        return fail(AP_ESTATE, "ap_net_set_fold: the fold was rejected for this checkpoint by ap_net_finalize (ap_net_fold_status)");
     h->fold = on != 0;
     return AP_OK;
+}
+
+int ap_net_set_fold_bar(ap_net* h, double bar) {
+    if (!h || !(bar >= 0.0)) return fail(AP_EINVAL, "ap_net_set_fold_bar: handle, bar >= 0");
+    h->fold_bar = bar;
+    h->finalized = false;                                    // takes effect at the next ap_net_finalize
+    return AP_OK;
+}
+
+int ap_net_fold_status(const ap_net* h, double* probe_rel_err) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    if (probe_rel_err) *probe_rel_err = h->fold_check_err;
+    return h->fold_rejected ? 0 : (h->fold ? 1 : 2);
 }
 
 int ap_net_set_dual_stream(ap_net* h, int on) {
@@ -1716,7 +1828,7 @@ int ap_preprocess_crops(const unsigned char* frames, int64_t frame_stride_bytes,
     if (!frames || !crop_y0y1x0x1 || !out_nchw || !scale_out || !pad_left_top_out || n <= 0 || H <= 0 || W <= 0 ||
         frame_stride_bytes < 0)
         return fail(AP_EINVAL, "ap_preprocess_crops: bad argument");
-    HIP_TRY(ap_launch_preprocess(frames, (size_t)frame_stride_bytes, n, H, W, bgr, crop_y0y1x0x1, out_nchw, scale_out,
+    HIP_TRY(k_bf16::ap_launch_preprocess(frames, (size_t)frame_stride_bytes, n, H, W, bgr, crop_y0y1x0x1, out_nchw, scale_out,
                                  pad_left_top_out, (hipStream_t)stream));
     return AP_OK;
 }

@@ -31,6 +31,8 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+AP_NS_BEGIN
+
 #ifndef B2_SAFE
 #define B2_SAFE 0
 #endif
@@ -105,7 +107,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) 
 }
 __device__ __forceinline__ void mm(f32x4& c, const u32x4& w, const u32x4& x) {
     if (B2_ABLATE & 8) asm volatile("" : "+v"(c) : "v"(w), "v"(x));
-    else c = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+    else c = ap_mfma16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c);
 }
 typedef __attribute__((ext_vector_type(2))) float f32x2;
 __device__ __forceinline__ uint32_t cvt_pk_bf16(float a, float b) {
@@ -527,3 +529,5 @@ hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st) {
     else hipLaunchKernelGGL(bneck2_kernel<false>, dim3(grid), dim3(512), B2Map<false>::TOTAL, st, a);
     return hipGetLastError();
 }
+
+AP_NS_END

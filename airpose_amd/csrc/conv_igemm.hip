@@ -23,6 +23,8 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+AP_NS_BEGIN
+
 namespace {
 
 template <typename T> using Elem = ElemKind<T>;
@@ -34,8 +36,8 @@ __device__ __forceinline__ void mma_chunk(const u32x4 (&xf)[FM], const u32x4 (&w
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+                acc[fm][fn] = ap_mfma16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn]);
     } else {
         // lane group g holds k = 4g..4g+3 of a 16-deep slab; MFMA t contracts {4g'+t : g'=0..3}
 #pragma unroll
@@ -63,9 +65,9 @@ __device__ __forceinline__ void mma_split3(const u32x4 (&xh)[FM], const u32x4 (&
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                acc[fm][fn] = ap_mfma16(
                     __builtin_bit_cast(bf16x8, pass == 2 ? wl[fn] : wh[fn]),
-                    __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn], 0, 0, 0);
+                    __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn]);
 }
 
 template <typename T, int BM, int BN, int WAVES_M, int WAVES_N>
@@ -344,6 +346,11 @@ int ap_conv_cout_pad(void) { return 128; }
 
 hipError_t ap_launch_conv(const ConvArgs& a, int kind, hipStream_t st) {
     if (kind == K_BF16) return launch_T<bf16_t>(a, st);
+#ifndef AP_F16                                               // (the fp16 set carries the 16-bit kind only)
     if (kind == K_SPLIT) return launch_T<bsplit_t>(a, st);
-    return kind == K_F32 ? launch_T<float>(a, st) : hipErrorInvalidValue;
+    if (kind == K_F32) return launch_T<float>(a, st);
+#endif
+    return hipErrorInvalidValue;
 }
+
+AP_NS_END

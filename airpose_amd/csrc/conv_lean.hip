@@ -16,6 +16,8 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+AP_NS_BEGIN
+
 namespace {
 
 constexpr int BM = 128, BN = 128, NT = 512, FM = 4, FN = 2, WAVES_N = 4;
@@ -197,3 +199,5 @@ hipError_t ap_launch_conv_lean(ConvArgs a, hipStream_t st) {
     hipLaunchKernelGGL(conv_lean_kernel, dim3(a.mtiles * a.ntiles), dim3(NT), LDS_BYTES, st, a);
     return hipGetLastError();
 }
+
+AP_NS_END

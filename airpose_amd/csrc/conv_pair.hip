@@ -32,6 +32,8 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+AP_NS_BEGIN
+
 #ifndef PR_SAFE
 #define PR_SAFE 0
 #endif
@@ -74,7 +76,7 @@ template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) 
     }
 }
 __device__ __forceinline__ f32x4 mfma16(const u32x4& w, const u32x4& x, const f32x4& c) {
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+    return ap_mfma16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c);
 }
 
 typedef __attribute__((ext_vector_type(2))) float f32x2;
@@ -442,3 +444,5 @@ hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int P2, int C3, int N1,
     if (P == 256 && P2 == 512 && C3 == 1024 && N1 == 0) return launch_pair<256, 512, 1024, 0, false, 4, 4, 8, false>(a, st);
     return hipErrorInvalidValue;
 }
+
+AP_NS_END

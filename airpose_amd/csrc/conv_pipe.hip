@@ -18,6 +18,8 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+AP_NS_BEGIN
+
 // Timing-only builds for tuning (results WRONG, times valid): -DRP_ABLATE=<bits>
 //   1 no DMA in the K loop | 2 no fragment reads in the K loop | 4 no MFMAs | 8 no barrier in the K loop
 #ifndef RP_ABLATE
@@ -59,7 +61,7 @@ __device__ __forceinline__ f32x4 rp_mfma_bf16(const u32x4& w, const u32x4& x, co
     asm volatile("" : "+v"(r) : "v"(w), "v"(x));
     return r;
 #else
-    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c, 0, 0, 0);
+    return ap_mfma16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c);
 #endif
 }
 
@@ -70,8 +72,8 @@ __device__ __forceinline__ void mma_chunk2(const u32x4 (&xf)[FM], const u32x4 (&
         for (int fm = 0; fm < FM; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+                acc[fm][fn] = ap_mfma16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn]);
     } else {
 #pragma unroll
         for (int t = 0; t < 4; ++t)
@@ -629,10 +631,14 @@ hipError_t launch_pipe_cfg(const ConvArgs& a, int cfg, hipStream_t st) {
 hipError_t ap_launch_conv_pipe(const ConvArgs& a, int kind, int cfg, hipStream_t st) {
     if (!a.zero) return hipErrorInvalidValue;
     if (kind == K_BF16) return launch_pipe_cfg<bf16_t>(a, cfg, st);
+#ifndef AP_F16                                               // (the fp16 set carries the 16-bit kind only)
     if (kind == K_F32) return launch_pipe_cfg<float>(a, cfg, st);
     if (kind == K_SPLIT) {
         if (cfg == 11) return launch_pipe<bsplit_t, 128, 128, 2, 4, 2, false>(a, st);
         if (cfg == 12) return launch_pipe<bsplit_t, 128, 64, 4, 2, 2, false>(a, st);
     }
+#endif
     return hipErrorInvalidValue;
 }
+
+AP_NS_END

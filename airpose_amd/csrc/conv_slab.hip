@@ -22,6 +22,8 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+AP_NS_BEGIN
+
 // Timing-only builds (results WRONG, times valid): -DSL_ABLATE=<bits>
 //   1 no slab DMA in the K loop | 2 fragment addresses computed once | 4 weight rows walked sequentially (the ring kernel's
 //   order) | 8 no weight DMA in the K loop | 16 slab pieces of the K loop issued, but from the zero line
@@ -404,3 +406,5 @@ hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st) {
     hipLaunchKernelGGL(conv_slab_kernel, dim3(a.mtiles * a.ntiles), dim3(NT), LDS_BYTES, st, a);
     return hipGetLastError();
 }
+
+AP_NS_END

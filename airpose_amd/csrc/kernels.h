@@ -27,18 +27,7 @@ struct ConvArgs {
     int out_f32;          // split-bf16 kind only: y (and res) are plain fp32 [M][ldy] instead of split pairs
 };
 
-int ap_conv_cout_pad(void);
-hipError_t ap_launch_conv(const ConvArgs& a, int kind, hipStream_t st);   // kind = AP_PREC_*: 0 fp32, 1 bf16, 2 split-bf16
-// software-pipelined (LDS-DMA ring) variant; cfg: 0 = 256x128, 1 = 128x128, 2 = 128x64, 3 = 256x64
-hipError_t ap_launch_conv_pipe(const ConvArgs& a, int kind, int cfg, hipStream_t st);
-
-// stride-1 3x3 with the nine taps read from one LDS slab per 64-channel chunk (conv_slab.hip); bf16, 128x128 tiles
-bool ap_conv_slab_supported(const ConvArgs& a, int kind);
-hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st);
-
-// pointwise convolutions on three workgroups per CU (conv_lean.hip); bf16, 128x128 tiles, bit-identical to conv_pipe
-bool ap_conv_lean_supported(const ConvArgs& a, int kind);
-hipError_t ap_launch_conv_lean(ConvArgs a, hipStream_t st);
+// (launchers of the 16-bit-flavoured kernel sources: kernels_h16.inc, included at the end of this file)
 
 // ---- conv3 (+ identity | + folded downsample) of a block + conv1 of the next block in one pixel-local kernel (conv_pair.hip)
 struct PairArgs {
@@ -55,11 +44,6 @@ struct PairArgs {
     int Ho, Wo, H2, W2, stride2;
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
 };
-bool ap_conv_pair_supported(int P, int P2, int C3, int N1);
-size_t ap_conv_pair_stream_bytes(int P, int P2, int C3, int N1);
-// w3 [C3][P + P2], w1 [N1][C3]: K-contiguous bf16 rows as packed for the stand-alone kernels
-hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P, int P2, int C3, int N1, hipStream_t st);
-hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int P2, int C3, int N1, hipStream_t st);
 
 // ---- fused layer1 bottleneck (bottleneck.hip); bf16 only
 struct BneckArgs {
@@ -72,35 +56,8 @@ struct BneckArgs {
     int N, H, W;                  // H, W multiples of 14
     int tiles_x, tiles_per_img, total;   // filled by the launcher
 };
-hipError_t ap_launch_bneck64(BneckArgs a, int cin, int ds, hipStream_t st);
-// second cut: weights resident in LDS, x in registers (bottleneck2.hip); ds = 0 identity block, 1 first block of layer1
-hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st);
 
 // ---- stem / pooling (stem.hip)
-// conv 7x7/2 p3 (3->64) + BN + ReLU from NCHW fp32 into NHWC T [N][112][112][64]
-hipError_t ap_launch_stem_conv(const float* x_nchw, const float* w_k147x64, const float* scale, const float* shift,
-                               void* y, int n_img, int kind, hipStream_t st);
-// bf16 MFMA stem: images [0, n_split) come from x0, the rest from x1 (both views in one pass);
-// w_packed: [64][232] bf16, k' = r*32 + s*4 + c
-hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_split, const void* w_packed,
-                                    const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
-// split-bf16 MFMA stem (bf16x2 mode): w_hi / w_lo: [64][232] bf16 planes of the packed weights; y: split pairs
-hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
-                                          const float* scale, const float* shift, void* y, int n_img, hipStream_t st);
-// fused split-bf16 stem + max-pool (bf16x2 mode): conv1 + bn1 + relu + maxpool, pooled split pairs [N][56][56][64]
-hipError_t ap_launch_stem_pool_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
-                                     const float* scale, const float* shift, void* y_pooled, int n_img, hipStream_t st);
-// fused bf16 MFMA stem + maxpool: NCHW fp32 crops -> [N][56][56][64] bf16
-hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
-                                const float* shift, void* y_pooled, int n_img, hipStream_t st);
-// maxpool 3x3/2 p1: [N][112][112][64] -> [N][56][56][64]
-hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStream_t st);
-// global 7x7 average: [N][49][C] T -> [N][C] fp32
-hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int kind, hipStream_t st);
-
-// crop + letter-box resize + /255 + normalise: uint8 HWC frames -> [n][3][224][224] fp32 (stem.hip)
-hipError_t ap_launch_preprocess(const unsigned char* frames, size_t frame_stride, int n, int H, int W, int bgr,
-                                const int* crop, float* out, float* scale_out, int* pad_out, hipStream_t st);
 
 // ---- regressor glue (regressor.hip); all fp32
 struct RegInitArgs {
@@ -248,3 +205,18 @@ hipError_t ap_launch_fit_decode(const float* z, int L, const float* w1t, const f
                                 const float* w3t, const float* b3, float* H1, float* H2, float* O, float* aa, hipStream_t st);
 hipError_t ap_launch_fit_backprop_adam(const FitArgs& a, const float* w3, const float* w2, const float* w1, const float* H1,
                                        const float* H2, int step, hipStream_t st);
+
+// ---- launchers that exist once per 16-bit storage flavour (ap_common.h: AP_NS).  A kernel source sees its own set; api.hip
+// (AP_API_TU) sees both and picks by the handle's precision
+#ifdef AP_API_TU
+namespace k_bf16 {
+#include "kernels_h16.inc"
+}
+namespace k_f16 {
+#include "kernels_h16.inc"
+}
+#else
+namespace AP_NS {
+#include "kernels_h16.inc"
+}
+#endif

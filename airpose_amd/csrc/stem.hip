@@ -7,6 +7,8 @@
 #include "ap_common.h"
 #include "kernels.h"
 
+AP_NS_BEGIN
+
 namespace {
 
 constexpr int IMG = 224, SO = 112, PO = 56, SC = 64;
@@ -142,8 +144,8 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
         for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
             for (int fn = 0; fn < 4; ++fn)
-                acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+                acc[fm][fn] = ap_mfma16(
+                    __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn]);
     }
     // epilogue: lane = pixel (tile row wave*4+fm, col lr), channels fn*16 + g*4 .. +3
 #pragma unroll
@@ -231,9 +233,9 @@ __global__ void __launch_bounds__(256) stem_mfma_split_kernel(const float* __res
             for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
                 for (int fn = 0; fn < 4; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    acc[fm][fn] = ap_mfma16(
                         __builtin_bit_cast(bf16x8, pass == 2 ? wl[fn] : wh[fn]),
-                        __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn]);
     }
 #pragma unroll
     for (int fn = 0; fn < 4; ++fn) {
@@ -381,8 +383,8 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
 #pragma unroll
                 for (int fn = 0; fn < FNH; ++fn) {
                     if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[fm]));
-                    else acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
-                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn], 0, 0, 0);
+                    else acc[fm][fn] = ap_mfma16(
+                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn]);
                 }
         }
         __syncthreads();                                     // every wave is done with the patch: vm may overwrite it
@@ -539,9 +541,9 @@ __global__ void __launch_bounds__(448) stem_pool_split_kernel(const float* __res
             for (int fm = 0; fm < 5; ++fm)
 #pragma unroll
                 for (int fn = 0; fn < 4; ++fn)
-                    acc[fm][fn] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+                    acc[fm][fn] = ap_mfma16(
                         __builtin_bit_cast(bf16x8, pass == 2 ? wl[fn] : wh[fn]),
-                        __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn], 0, 0, 0);
+                        __builtin_bit_cast(bf16x8, pass == 1 ? xl[fm] : xh[fm]), acc[fm][fn]);
     }
     __syncthreads();                                         // every wave is done with the patches: vm may overwrite them
 #pragma unroll
@@ -674,8 +676,10 @@ __global__ void __launch_bounds__(256) maxpool_split_kernel(const bsplit_t* __re
 // pieces: 4 fp32 / 8 bf16 / 8 split pairs) x 8 pixel partitions: thread (part, gl) sums pixels part, part + 8, ... of its
 // group in that order, the 8 partial sums meet in LDS and are added in partition order -- a fixed association, the same on
 // every run.  (One thread per group walking all 49 pixels left the chip at 4 waves per CU and the stage at 0.6-1.5 TB/s.)
+// range_flag (optional, fp16 storage): a non-finite pooled value -- an activation that left the fp16 range somewhere in the stack
+// reaches the last layer as inf / NaN, and a sum with a non-finite term is non-finite -- sets *range_flag (host-mapped word)
 template <int EPC, typename LOAD>
-__device__ __forceinline__ void avgpool_body(LOAD&& load, float* __restrict__ y, int C, int n_img) {
+__device__ __forceinline__ void avgpool_body(LOAD&& load, float* __restrict__ y, int C, int n_img, int* range_flag = nullptr) {
     __shared__ float part_sum[8][32][EPC];
     const int gl = threadIdx.x & 31, part = threadIdx.x >> 5;
     const int gpr = C / EPC, tiles = gpr / 32, n = blockIdx.x / tiles, g0 = (blockIdx.x % tiles) * 32;
@@ -703,8 +707,13 @@ __device__ __forceinline__ void avgpool_body(LOAD&& load, float* __restrict__ y,
 #pragma unroll
             for (int e = 0; e < EPC; ++e) s[e] += part_sum[k][gl][e];
         float* dst = y + (size_t)n * C + (size_t)(g0 + gl) * EPC;
+        bool bad = false;
 #pragma unroll
-        for (int e = 0; e < EPC; ++e) dst[e] = s[e] / 49.0f;
+        for (int e = 0; e < EPC; ++e) {
+            dst[e] = s[e] / 49.0f;
+            bad |= !(fabsf(s[e]) <= 3.0e38f);               // inf or NaN
+        }
+        if (range_flag && bad) __hip_atomic_store(range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -717,7 +726,7 @@ __global__ void __launch_bounds__(256) avgpool_split_kernel(const bsplit_t* __re
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int n_img) {
+__global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, float* __restrict__ y, int C, int n_img, int* range_flag) {
     constexpr int EPC = 16 / sizeof(T);
     avgpool_body<EPC>([&](int n, int p, int g, float (&v)[EPC]) {
         const uint4 q = *(const uint4*)(x + ((size_t)n * 49 + p) * C + (size_t)g * EPC);
@@ -728,7 +737,7 @@ __global__ void __launch_bounds__(256) avgpool_kernel(const T* __restrict__ x, f
             v[0] = __builtin_bit_cast(float, q.x); v[1] = __builtin_bit_cast(float, q.y);
             v[2] = __builtin_bit_cast(float, q.z); v[3] = __builtin_bit_cast(float, q.w);
         }
-    }, y, C, n_img);
+    }, y, C, n_img, range_flag);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -785,22 +794,27 @@ __global__ void preprocess_kernel(const unsigned char* __restrict__ frames, size
 
 }  // namespace
 
+#ifndef AP_F16
 hipError_t ap_launch_preprocess(const unsigned char* frames, size_t frame_stride, int n, int H, int W, int bgr,
                                 const int* crop, float* out, float* scale_out, int* pad_out, hipStream_t st) {
     hipLaunchKernelGGL(preprocess_kernel, dim3((224 * 224 + 255) / 256, n), dim3(256), 0, st, frames, frame_stride, H, W,
                        bgr, crop, out, scale_out, pad_out);
     return hipGetLastError();
 }
+#endif
 
 hipError_t ap_launch_stem_conv(const float* x, const float* w, const float* scale, const float* shift, void* y,
                                int n_img, int kind, hipStream_t st) {
     dim3 grid(SO / 16, SO / 16, n_img);
     if (kind == K_BF16)
         hipLaunchKernelGGL(stem_direct_kernel<bf16_t>, grid, dim3(256), 0, st, x, w, scale, shift, (bf16_t*)y);
+#ifndef AP_F16                                               // (the fp16 set carries the 16-bit kind only)
     else if (kind == K_SPLIT)
         hipLaunchKernelGGL(stem_direct_kernel<bsplit_t>, grid, dim3(256), 0, st, x, w, scale, shift, (bsplit_t*)y);
-    else
+    else if (kind == K_F32)
         hipLaunchKernelGGL(stem_direct_kernel<float>, grid, dim3(256), 0, st, x, w, scale, shift, (float*)y);
+#endif
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
@@ -811,6 +825,7 @@ hipError_t ap_launch_stem_conv_mfma(const float* x0, const float* x1, int n_spli
     return hipGetLastError();
 }
 
+#ifndef AP_F16
 hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
                                           const float* scale, const float* shift, void* y, int n_img, hipStream_t st) {
     static bool attr_set[AP_MAX_DEVICES] = {};
@@ -827,6 +842,7 @@ hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int 
                        (const bf16_t*)w_hi, (const bf16_t*)w_lo, scale, shift, (bsplit_t*)y);
     return hipGetLastError();
 }
+#endif
 
 hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
                                 const float* shift, void* y_pooled, int n_img, hipStream_t st) {
@@ -835,6 +851,7 @@ hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, co
     return hipGetLastError();
 }
 
+#ifndef AP_F16
 hipError_t ap_launch_stem_pool_split(const float* x0, const float* x1, int n_split, const void* w_hi, const void* w_lo,
                                      const float* scale, const float* shift, void* y_pooled, int n_img, hipStream_t st) {
     static bool attr_set[AP_MAX_DEVICES] = {};
@@ -852,30 +869,40 @@ hipError_t ap_launch_stem_pool_split(const float* x0, const float* x1, int n_spl
                        (const bf16_t*)w_lo, scale, shift, (bsplit_t*)y_pooled);
     return hipGetLastError();
 }
+#endif
 
 hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStream_t st) {
-    if (kind == K_SPLIT) {
-        const int total = n_img * PO * PO * (SC / 8);
-        hipLaunchKernelGGL(maxpool_split_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x,
-                           (bsplit_t*)y, total);
-    } else if (kind == K_BF16) {
+    if (kind == K_BF16) {
         const int total = n_img * PO * PO * (SC / 8);
         hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)x,
                            (bf16_t*)y, total);
-    } else {
+    }
+#ifndef AP_F16                                               // (the fp16 set carries the 16-bit kind only)
+    else if (kind == K_SPLIT) {
+        const int total = n_img * PO * PO * (SC / 8);
+        hipLaunchKernelGGL(maxpool_split_kernel, dim3((total + 255) / 256), dim3(256), 0, st, (const bsplit_t*)x,
+                           (bsplit_t*)y, total);
+    } else if (kind == K_F32) {
         const int total = n_img * PO * PO * (SC / 4);
         hipLaunchKernelGGL(maxpool_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)x,
                            (float*)y, total);
     }
+#endif
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
 
-hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int kind, hipStream_t st) {
+hipError_t ap_launch_avgpool(const void* x, float* y, int n_img, int C, int kind, int* range_flag, hipStream_t st) {
     const int epc = kind == K_F32 ? 4 : 8;
     if (n_img <= 0 || C % (32 * epc)) return hipErrorInvalidValue;          // workgroup = 32 groups of epc channels
     const dim3 grid((unsigned)(n_img * (C / epc / 32)));
-    if (kind == K_SPLIT) hipLaunchKernelGGL(avgpool_split_kernel, grid, dim3(256), 0, st, (const bsplit_t*)x, y, C, n_img);
-    else if (kind == K_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, y, C, n_img);
-    else hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, y, C, n_img);
+    if (kind == K_BF16) hipLaunchKernelGGL(avgpool_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, y, C, n_img, range_flag);
+#ifndef AP_F16                                               // (the fp16 set carries the 16-bit kind only)
+    else if (kind == K_SPLIT) hipLaunchKernelGGL(avgpool_split_kernel, grid, dim3(256), 0, st, (const bsplit_t*)x, y, C, n_img);
+    else if (kind == K_F32) hipLaunchKernelGGL(avgpool_kernel<float>, grid, dim3(256), 0, st, (const float*)x, y, C, n_img, range_flag);
+#endif
+    else return hipErrorInvalidValue;
     return hipGetLastError();
 }
+
+AP_NS_END

@@ -80,8 +80,15 @@ class ViewSplitIEF(object):
         return dist.all_gather_into_tensor(both.view(2 * both.shape[1], 136), mine, group=self.group, async_op=True)
 
     def exchange_wait(self, work):
+        """The partner's (B, 136) rows as a tensor the CALLER owns: a copy, never a view of the cached gather buffer (the
+        next exchange_start overwrites that buffer in place; 544 B per sample)."""
         work.wait()                                                       # RCCL: orders the current stream behind the collective
-        return self._both[1 - self.me].to(self._dev, non_blocking=True)
+        part = self._both[1 - self.me]
+        if self._host_staged:
+            # host-staged (gloo) message: a synchronous copy out of the reused pageable buffer -- an asynchronous H2D from it
+            # could still be reading when the next all_gather writes it
+            return part.to(self._dev, non_blocking=False) if self._dev.type != "cpu" else part.clone()
+        return part.clone()
 
     def exchange(self, pose, betas):
         return self.exchange_wait(self.exchange_start(pose, betas))

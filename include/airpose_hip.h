@@ -28,15 +28,21 @@ extern "C" {
 #define AP_ESHAPE (-2)  /* tensor name / shape mismatch */
 #define AP_ESTATE (-3)  /* handle not finalised, missing tensors */
 #define AP_ENOMEM (-4)
+#define AP_ERANGE (-5)  /* AP_PREC_F16: a stored activation left the fp16 range (non-finite trunk features) */
 
 #define AP_PREC_FP32 0 /* fp32 storage, v_mfma_f32_16x16x4_f32: parity mode (1e-4 vs the CPU reference) */
-#define AP_PREC_BF16 1 /* 16-bit storage, fp32 accumulate: throughput mode.  libairpose_hip.so: bf16 (v_mfma_f32_16x16x32_bf16);
-                        * libairpose_hip_f16.so (the same sources, -DAP_F16): fp16 (v_mfma_f32_16x16x32_f16) -- same rate, 11
-                        * significand bits: 5.5e-5 instead of 3.0e-4 against the reference's CPU path; stored activations < 65504 */
+#define AP_PREC_BF16 1 /* bf16 storage (v_mfma_f32_16x16x32_bf16), fp32 accumulate and epilogues: throughput mode with fp32's
+                        * exponent range; 3.0e-4 against the reference's CPU path (8 significand bits through 53 convolutions) */
 #define AP_PREC_BF16X2 2 /* split-bf16 storage: every value as hi = rne(x), lo = rne(x - hi) in bf16 (16 mantissa bits, fp32
                           * bytes), planar in groups of 8 channels (32 bytes = 8 hi | 8 lo); every product as
                           * hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (three MFMAs per 8 K elements), fp32 accumulate:
                           * the fast parity mode (meets the 1e-4 bar at ~5x the fp32-MFMA rate) */
+#define AP_PREC_F16 3 /* IEEE fp16 storage (v_mfma_f32_16x16x32_f16), fp32 accumulate and epilogues: the throughput kernels of
+                       * AP_PREC_BF16 at the same MFMA rate with 11 instead of 8 significand bits -- 5.5e-5 against the reference's
+                       * CPU path, under the 1e-4 bar.  Range: |stored value| <= 65504.  ap_net_finalize refuses a checkpoint whose
+                       * (BatchNorm-folded) weights leave that range, and every trunk pass checks its pooled features: a non-finite
+                       * value (an activation that overflowed to inf somewhere in the stack reaches them as inf / NaN) makes
+                       * ap_trunk_fwd and every forward built on it return AP_ERANGE (see there) */
 
 typedef struct ap_net ap_net;     /* ResNet-50 trunk + IEF regressor */
 typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
@@ -59,6 +65,19 @@ void ap_net_destroy(ap_net* h);
 int ap_net_set_tensor(ap_net* h, const char* name, const float* host_data, const int64_t* shape, int ndim);
 int ap_net_finalize(ap_net* h);
 int ap_net_precision(const ap_net* h);
+/* AP_PREC_F16 range sentinel (no-ops returning AP_OK for the other precisions).  The pooling stage of every trunk pass sets a
+ * per-handle, host-mapped flag when a trunk feature is not finite.
+ *   ap_net_set_range_check  mode 1 (default): deferred -- nothing is added to the hot path; the flag is sticky and the NEXT
+ *                           trunk-running call on the handle returns AP_ERANGE, as does ap_net_range_status;
+ *                           mode 2: synchronous -- every trunk-running call (ap_trunk_fwd, ap_copenet_fwd, ap_hmr_fwd, ...)
+ *                           synchronises its stream after the trunk and returns AP_ERANGE for its OWN pass; mode 0: off
+ *   ap_net_range_status     synchronises `stream` and returns AP_OK or AP_ERANGE; reset != 0 clears the flag
+ * What the sentinel sees: inf / NaN that reach the last layer.  An overflowed (+inf) activation propagates through the following
+ * convolutions as +-inf / NaN; ReLU clears -inf and, in the kernels that clamp with v_max_f32, NaN -- so the sentinel is a strong
+ * indicator, not a proof (an overflow all of whose descendants are clamped goes unseen).  The weight check of ap_net_finalize is
+ * exact. */
+int ap_net_set_range_check(ap_net* h, int mode);
+int ap_net_range_status(ap_net* h, void* stream, int reset);
 
 /* copenet.forward_feat_ext (model_copenet.py:161-176).
  * x: [n_img][3][224][224] NCHW fp32 (the reference input contract); feat: [n_img][2048] fp32. */
@@ -131,34 +150,44 @@ int ap_singleview_reg(ap_net* h, const float* xf, const float* bb, const float* 
  * Bottleneck.forward (model_copenet.py:27-47: conv -> BN -> [+ residual] -> ReLU).  Exposed so the kernel can be
  * unit-tested and reused.  NHWC activations x [N][H][W][Cin], y/res [N][Ho][Wo][Cout]; w [Cout_pad][k][k][Cin]
  * with Cout_pad = Cout rounded up to 128 (zero rows), scale/shift [Cout_pad]; element type of x/w/res/y is
- * bf16 (AP_PREC_BF16), float (AP_PREC_FP32) or split-bf16 (AP_PREC_BF16X2: 4 bytes per element, planar groups of 8
- * channels = 8 bf16 hi parts then 8 bf16 lo parts); Cin a multiple of 64 (bf16) / 32 (fp32, bf16x2), Cout of 8 (4: fp32). */
+ * bf16 (AP_PREC_BF16), fp16 (AP_PREC_F16), float (AP_PREC_FP32) or split-bf16 (AP_PREC_BF16X2: 4 bytes per element, planar groups of 8
+ * channels = 8 bf16 hi parts then 8 bf16 lo parts); Cin a multiple of 64 (bf16, fp16) / 32 (fp32, bf16x2), Cout of 8 (4: fp32). */
 int ap_conv2d_nhwc(int precision, const void* x, const void* w, const float* scale, const float* shift,
                    const void* res, void* y, int N, int H, int W, int Cin, int Cout, int ksize, int stride, int pad,
                    int relu, void* stream);
 
-/* Fused 64-plane bottleneck (layer1 of the trunk, bf16 only): Bottleneck.forward, model_copenet.py:27-47, as ONE
- * kernel with both intermediates resident in LDS.  x [N][H][W][Cin] bf16, y [N][H][W][256] bf16; H, W multiples of 14.
+/* Fused 64-plane bottleneck (layer1 of the trunk; precision = AP_PREC_BF16 or AP_PREC_F16: the storage type of x, y and the
+ * weights): Bottleneck.forward, model_copenet.py:27-47, as ONE kernel with both intermediates resident in LDS.
+ * x [N][H][W][Cin], y [N][H][W][256]; H, W multiples of 14.
  *   downsample = 0: Cin = 256, w1 [64..][256], w2 [64..][3][3][64], w3 [256][64];  y = relu(bn3(conv3(..)) + x)
  *   downsample = 1: Cin = 64,  w1 [64..][64],  w3 [256][128] = [conv3 | downsample conv] (K-concatenated, BN scales
  *                   folded into the weights, s3 = 1, h3 = shift3 + shift_ds);           y = relu(W3 . [mid2 | x] + h3)
  * Weight rows are K-contiguous bf16 as for ap_conv2d_nhwc; s*, h* are fp32 BatchNorm scale / shift.  Matches the
  * three-convolution path to bf16 rounding of the fp32 accumulations. */
-int ap_bottleneck64_nhwc(const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
+int ap_bottleneck64_nhwc(int precision, const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
                          const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
                          int N, int H, int W, int Cin, int downsample, void* stream);
 
-/* Test / tuning entry of the fused pair kernel on NHWC bf16 tensors: t2 [M][P] (conv2 output), res [M][4P] (block input),
- * w3 [4P][P] + s3/h3 (conv3 + bn3 of the block), w1 [N1][4P] + s1/h1 (conv1 + bn1 of the next block); writes
- * out [M][4P] = relu(bn3(conv3 t2) + res) and t1n [M][N1] = relu(bn1(conv1 out)).  (P, N1) in {(128,128), (128,256), (256,256)}. */
-int ap_conv_pair_nhwc(const void* t2, const void* w3, const float* s3, const float* h3, const void* res, const void* w1,
+/* Fused pair kernel on NHWC 16-bit tensors (precision = AP_PREC_BF16 or AP_PREC_F16): conv3 (+ identity | + folded downsample,
+ * ReLU) of a bottleneck and conv1 (+ ReLU) of the NEXT bottleneck as one pixel-local kernel (conv_pair.hip; replaces
+ * model_copenet.py:38-45 of one block and :29-31 of the next per launch).  The two weight matrices are consumed as ONE stream of
+ * 16-KiB tiles; the stream is caller-owned: ap_conv_pair_stream_bytes gives its size (negative = unsupported shape),
+ * ap_conv_pair_pack builds it on the device from w3 [4P][P + P2] and w1 [N1][4P] (K-contiguous rows as for ap_conv2d_nhwc; w1 NULL
+ * when N1 = 0) -- re-pack whenever the weights change; the library caches nothing.
+ *   ap_conv_pair_nhwc     identity block: t2 [M][P] (conv2 output), res [M][4P] (block input), s3/h3 (bn3), s1/h1 (next bn1);
+ *                         out [M][4P] = relu(bn3(conv3 t2) + res), t1n [M][N1] = relu(bn1(conv1 out)).
+ *                         (P, N1) in {(128,128), (128,256), (256,256)}
+ *   ap_conv_pair_ds_nhwc  stage-first block: w3 = [conv3 | downsample conv] with both BatchNorm scales folded into the rows
+ *                         (s3 = ones [4P], h3 = shift3 + shift_ds); x [N][Ho*stride][Ho*stride][P2] = the block input, read at
+ *                         the strided pixel as a second K segment; no identity; with the next conv1 (N1 > 0) or alone (N1 = 0:
+ *                         s1 / h1 / t1n NULL).  (P, P2, N1) in {(128,256,128), (256,512,0)} */
+int64_t ap_conv_pair_stream_bytes(int P, int P2, int N1);
+int ap_conv_pair_pack(int precision, const void* w3, const void* w1, int P, int P2, int N1, void* wstream, void* stream);
+int ap_conv_pair_nhwc(int precision, const void* t2, const void* wstream, const float* s3, const float* h3, const void* res,
                       const float* s1, const float* h1, void* out, void* t1n, int M, int P, int N1, void* stream);
-/* The same kernel on a stage's first block: conv3 with the downsample branch folded in as a second K segment (w3d [4P][P + P2] =
- * [conv3 | downsample conv], BatchNorm scales folded into the rows, h3 = shift3 + shift_ds; x [N][Ho*stride][Ho*stride][P2] is the
- * block input, read at the strided pixel), no identity; with the next block's conv1 (N1 > 0) or alone (N1 = 0, w1 / s1 / h1 /
- * t1n NULL).  (P, P2, N1) in {(128,256,128), (256,512,0)}.  Replaces model_copenet.py:38-45 with :41-42,97-102 per launch. */
-int ap_conv_pair_ds_nhwc(const void* t2, const void* x, const void* w3d, const float* h3, const void* w1, const float* s1,
-                         const float* h1, void* out, void* t1n, int N, int Ho, int P, int P2, int stride, int N1, void* stream);
+int ap_conv_pair_ds_nhwc(int precision, const void* t2, const void* x, const void* wstream, const float* s3, const float* h3,
+                         const float* s1, const float* h1, void* out, void* t1n, int N, int Ho, int P, int P2, int stride, int N1,
+                         void* stream);
 
 /* Tuning/testing knob (process-wide, one atomic word: safe to set while handles run on other threads; a launch sees the
  * old or the new value): tile configuration of the convolution kernels.  -1 = automatic, 0..13 = software-pipelined
@@ -188,6 +217,14 @@ int ap_net_timing(ap_net* h, double ms[4], int64_t* passes, int reset);
  * (like the BatchNorm fold).  on = 1 (default) evaluates the folded map, on = 0 the literal three-GEMM chain;
  * both are parity-tested against the reference. */
 int ap_net_set_fold(ap_net* h, int on);
+/* The fold is exact algebra but not unconditionally well-conditioned: ap_net_finalize (copenet-layout handles) evaluates the
+ * fp32-rounded folded map and the literal chain in fp64 on a fixed probe batch and, when they differ by more than 1e-5 of the
+ * output scale, switches THIS handle to the literal chain (a line on stderr says so; ap_net_set_fold(h, 1) is then refused).
+ * Returns 1 = folded map in use, 2 = literal chain by the caller's choice, 0 = literal chain because the fold was rejected;
+ * *probe_rel_err (optional) = the measured difference. */
+int ap_net_fold_status(const ap_net* h, double* probe_rel_err);
+/* Test aid: the bar of that check (default 1e-5); the handle must be finalised again for it to take effect. */
+int ap_net_set_fold_bar(ap_net* h, double bar);
 /* With the folded map (ap_net_set_fold(1)): on = 1 (default) runs a whole IEF forward as two launches (split-K feature
  * GEMM + ONE kernel for initialisation, all iterations with the cross-view swap, and the pose/betas split: the swap only
  * couples the two views of a pair, which one workgroup owns); on = 0 as one GEMM per iteration plus glue kernels. */
@@ -200,15 +237,11 @@ int ap_net_set_fuse_ds(ap_net* h, int on);
 /* bf16 and bf16x2 modes: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool
  * kernels (bit-identical results; kept for A/B measurement). */
 int ap_net_set_fuse_stem(ap_net* h, int on);
-/* bf16 mode: on = 2 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
- * intermediates never leave the CU; bottleneck2.hip: weights resident in LDS, x in registers), on = 1 the same through
- * the first cut of that kernel (bottleneck.hip: weights re-streamed per tile, x through LDS; kept for A/B), on = 0 as its
- * three (two + folded-downsample) convolutions.  All three give the same bits (parity-tested). */
+/* 16-bit modes: on = 1 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
+ * intermediates never leave the CU; bottleneck2.hip: weights resident in LDS, x in registers), on = 0 as its three
+ * (two + folded-downsample) convolutions.  Both give the same bits (parity-tested). */
 int ap_net_set_fuse_block(ap_net* h, int on);
-/* which kernel ap_bottleneck64_nhwc runs: 2 bottleneck2.hip (default), 1 bottleneck.hip (process-wide; a test /
- * measurement switch for the stand-alone operator -- handles use ap_net_set_fuse_block) */
-int ap_set_bottleneck_cut(int cut);
-/* bf16: conv3 (+ identity, ReLU) of an identity bottleneck and conv1 of the NEXT bottleneck as one pixel-local kernel
+/* 16-bit modes: conv3 (+ identity, ReLU) of an identity bottleneck and conv1 of the NEXT bottleneck as one pixel-local kernel
  * (conv_pair.hip; layer2 and layer3 identity blocks, layer2 -> layer3, and the first blocks of layer2 / layer3 with their
  * downsample branch as a second K segment): the block output makes one HBM trip less per block boundary.  Bit-identical to the two stand-alone kernels.  Default on; replaces model_copenet.py:38-45 (+ :29-31 of the
  * next block) per launch. */

@@ -112,26 +112,21 @@ def test_conv_config_knob_validates_on_the_host():
         assert L.ap_set_conv_config(-1) == 0
 
 
-def test_f16_flavour_exports_every_declared_symbol():
-    """libairpose_hip_f16.so (the same sources with -DAP_F16) carries the same C ABI."""
+def test_one_library_carries_both_16bit_storage_types():
+    """AP_PREC_F16 is a precision of the ONE library (no second .so, no flavour switch): the enum values are distinct, the
+    f16 kernel set (namespace k_f16) is linked in, and the host-only entry points validate the precision argument."""
+    import subprocess
     from airpose_amd import _native as Nn
-    L = Nn.lib("f16")
-    assert L is not Nn.lib()
-    for name in Nn.SIGNATURES:
-        assert hasattr(L, name), name
-    assert Nn.lib_for("f16") is L and Nn.lib_for("bf16") is Nn.lib()
-
-
-def test_bottleneck_cut_knob_validates_on_the_host():
-    """ap_set_bottleneck_cut is host-only state: 1 (first cut) and 2 (second cut, the default) are accepted, anything else
-    is refused and leaves the selection alone."""
-    from airpose_amd import _native as Nn
+    assert sorted(Nn.PRECISIONS.values()) == [0, 1, 2, 3] and Nn.PRECISIONS["f16"] == 3 and Nn.PRECISIONS["bf16"] == 1
+    assert not os.path.exists(os.path.join(REPO, "airpose_amd", "libairpose_hip_f16.so"))
+    syms = subprocess.run(["nm", "-D", "--defined-only", Nn.LIB_PATH], check=True, capture_output=True, text=True).stdout
+    for ns in ("k_bf16", "k_f16"):
+        for fn in ("ap_launch_conv_pipe", "ap_launch_conv_pair", "ap_launch_bneck2", "ap_launch_stem_pool", "ap_launch_conv_slab"):
+            assert re.search(r"_ZN%d%s\d+%s" % (len(ns), ns, fn), syms), (ns, fn)
     L = Nn.lib()
-    try:
-        for c in (1, 2):
-            assert L.ap_set_bottleneck_cut(c) == 0, c
-        for c in (0, 3, -1, 17):
-            assert L.ap_set_bottleneck_cut(c) != 0, c
-    finally:
-        assert L.ap_set_bottleneck_cut(2) == 0
-
+    # pair-stream size: a host-only query; unsupported shapes are refused
+    assert L.ap_conv_pair_stream_bytes(128, 0, 128) > 0 and L.ap_conv_pair_stream_bytes(256, 512, 0) > 0
+    assert L.ap_conv_pair_stream_bytes(64, 0, 64) < 0
+    # the stand-alone 16-bit operators take AP_PREC_BF16 / AP_PREC_F16 only (argument check comes before any launch)
+    assert L.ap_conv_pair_pack(Nn.AP_PREC_FP32, None, None, 128, 0, 128, None, None) == -1
+    assert L.ap_net_range_status(None, None, 0) == -1 and L.ap_net_set_range_check(None, 1) == -1

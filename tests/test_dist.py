@@ -75,6 +75,13 @@ def _worker(rank, world, port, out_dir):
         assert ief.n_exchanges == 4
         want_c = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], init_theta0=th[0], init_theta1=th[1],
                                  init_shape0=sh[0], init_shape1=sh[1], iters=2)
+        # the partner rows handed out by exchange() belong to the caller: a later exchange must not change them
+        # (they used to be a view of the cached gather buffer)
+        p1 = ief.exchange(pose, betas)
+        keep = p1.clone()
+        p2 = ief.exchange(pose + 1.0, betas + 1.0)
+        assert torch.equal(p1, keep) and not torch.equal(p1, p2)
+        assert p1.data_ptr() != p2.data_ptr()
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), pose=pose.numpy(), betas=betas.numpy(),
              want_pose=want[2 * rank].numpy(), want_betas=want[2 * rank + 1].numpy(),
              pose_c=pose_c.numpy(), betas_c=betas_c.numpy(),

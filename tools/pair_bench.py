@@ -40,9 +40,11 @@ def main():
         out, t1n = torch.empty(M, C3, dtype=torch.bfloat16, device=dev), torch.empty(M, N1, dtype=torch.bfloat16, device=dev)
         out2, t1b = torch.empty_like(out), torch.empty_like(t1n)
         st = N.stream_ptr(dev)
+        ws = torch.empty(L.ap_conv_pair_stream_bytes(P, 0, N1), dtype=torch.uint8, device=dev)   # caller-owned weight stream
+        N.check(L.ap_conv_pair_pack(bf, p(w3), p(w1), P, 0, N1, p(ws), st), "pack")
 
         def fused():
-            N.check(L.ap_conv_pair_nhwc(p(t2), p(w3), p(s3), p(h3), p(x), p(w1), p(s1), p(h1), p(out), p(t1n), M, P, N1, st), "pair")
+            N.check(L.ap_conv_pair_nhwc(bf, p(t2), p(ws), p(s3), p(h3), p(x), p(s1), p(h1), p(out), p(t1n), M, P, N1, st), "pair")
 
         def two():
             N.check(L.ap_conv2d_nhwc(bf, p(t2), p(w3), p(s3), p(h3), p(x), p(out2), n, H, H, P, C3, 1, 1, 0, 1, st), "c3")

@@ -20,9 +20,8 @@ sc = [torch.ones(c, device=dev) for c in (128, 128, 256)]
 sh = [torch.zeros(c, device=dev) for c in (128, 128, 256)]
 y = torch.empty(n, H, H, 256, device=dev, dtype=bf)
 buf = torch.zeros(64, dtype=torch.int64, device=dev)
-N.check(L.ap_set_bottleneck_cut(2), "cut")
 def run():
-    N.check(L.ap_bottleneck64_nhwc(p(x), p(w1), p(sc[0]), p(sh[0]), p(w2), p(sc[1]), p(sh[1]), p(w3), p(sc[2]), p(sh[2]),
+    N.check(L.ap_bottleneck64_nhwc(N.PRECISIONS["bf16"], p(x), p(w1), p(sc[0]), p(sh[0]), p(w2), p(sc[1]), p(sh[1]), p(w3), p(sc[2]), p(sh[2]),
                                    p(y), n, H, H, cin, ds, N.stream_ptr(dev)), "bneck")
 for _ in range(3): run()
 names = ["conv1", "barrier A", "epi1 + t1 write", "barrier B", "conv2", "epi2", "wait W3 + barrier C", "chunk 0", "chunk 1",

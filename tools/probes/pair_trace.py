@@ -20,8 +20,11 @@ s3, h3 = torch.rand(C3, device=dev) + 0.5, torch.randn(C3, device=dev) * 0.1
 s1, h1 = torch.rand(N1, device=dev) + 0.5, torch.randn(N1, device=dev) * 0.1
 out, t1n = torch.empty(M, C3, dtype=torch.bfloat16, device=dev), torch.empty(M, N1, dtype=torch.bfloat16, device=dev)
 buf = torch.zeros(160, dtype=torch.int64, device=dev)
+BF = N.PRECISIONS["bf16"]
+ws = torch.empty(L.ap_conv_pair_stream_bytes(P, 0, N1), dtype=torch.uint8, device=dev)
+N.check(L.ap_conv_pair_pack(BF, p(w3), p(w1), P, 0, N1, p(ws), N.stream_ptr(dev)), "pack")
 def run():
-    N.check(L.ap_conv_pair_nhwc(p(t2), p(w3), p(s3), p(h3), p(x), p(w1), p(s1), p(h1), p(out), p(t1n), M, P, N1, N.stream_ptr(dev)), "pair")
+    N.check(L.ap_conv_pair_nhwc(BF, p(t2), p(ws), p(s3), p(h3), p(x), p(s1), p(h1), p(out), p(t1n), M, P, N1, N.stream_ptr(dev)), "pair")
 for _ in range(3): run()
 KP, SPC = P // 64, P // 64 + 2 * (N1 // 128)
 for rep in range(2):

@@ -20,7 +20,7 @@ g = torch.Generator().manual_seed(1)
 x = torch.randn(512, 3, 224, 224, generator=g).to(dev)
 net.set_fuse_block(0); net.set_fuse_pair(0)
 ref = net.forward_feat_ext(x).clone()
-net.set_fuse_block(2); net.set_fuse_pair(1)
+net.set_fuse_block(1); net.set_fuse_pair(1)
 bad = 0
 for i in range(it):
     y = net.forward_feat_ext(x)
@@ -34,7 +34,7 @@ bb = torch.rand(B, 3, generator=g).to(dev)
 pos = torch.zeros(B, 3, device=dev)
 net.set_fuse_block(0); net.set_fuse_pair(0)
 ref2 = [t.clone() for t in net(x[:B], x[B:], bb, bb, pos, pos, iters=3)]
-net.set_fuse_block(2); net.set_fuse_pair(1)
+net.set_fuse_block(1); net.set_fuse_pair(1)
 bad2 = 0
 for i in range(it):
     out = net(x[:B], x[B:], bb, bb, pos, pos, iters=3)
