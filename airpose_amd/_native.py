@@ -54,6 +54,7 @@ SIGNATURES = {
     "ap_hmr_fwd": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ap_conv2d_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 9 + [_vp]),
     "ap_set_conv_config": (_i, [_i]),
+    "ap_set_pair_groups": (_i, [_i]),
     "ap_debug_set_trace": (_i, [_vp]),
     "ap_net_enable_timing": (_i, [_vp, _i]),
     "ap_net_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
@@ -64,6 +65,7 @@ SIGNATURES = {
     "ap_net_set_fold_bar": (_i, [_vp, _c.c_double]),
     "ap_net_set_fuse_ief": (_i, [_vp, _i]),
     "ap_net_set_fuse_stem": (_i, [_vp, _i]),
+    "ap_net_set_fuse_pool": (_i, [_vp, _i]),
     "ap_net_set_fuse_ds": (_i, [_vp, _i]),
     "ap_net_set_fuse_block": (_i, [_vp, _i]),
     "ap_net_set_fuse_pair": (_i, [_vp, _i]),

@@ -327,6 +327,10 @@ class copenet(nn.Module):
         """bf16 / f16: conv3 of an identity block and conv1 of the next block as one pixel-local kernel (default) or two."""
         self._set_knob("ap_net_set_fuse_pair", on)
 
+    def set_fuse_pool(self, on):
+        """bf16 / f16: AvgPool2d(7) in the epilogue of the last convolution (default) or as its own kernel."""
+        self._set_knob("ap_net_set_fuse_pool", on)
+
     def set_fuse_stem(self, on):
         self._set_knob("ap_net_set_fuse_stem", on)
 

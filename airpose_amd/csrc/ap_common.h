@@ -49,6 +49,42 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {   // round-to-nearest-e
     return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 #endif
+// ReLU that KEEPS a (positive-signed) NaN and +inf: max on the bit pattern as a signed integer -- every value with the sign bit
+// set (negative numbers, -0, -inf) becomes +0, everything else is untouched.  One v_max_i32, like fmaxf's one v_max_f32, and the
+// same result for every finite input (up to the sign of zero); but fmaxf(NaN, 0) = 0 would swallow the NaN an overflowed (+inf)
+// fp16 activation turns into in the next convolution -- and with it the evidence the fp16 range sentinel looks for at the end of
+// the trunk (ap_net_set_range_check).  The register epilogues of conv_pair.hip / bottleneck2.hip do the same on packed pairs
+// (v_pk_max_i16).
+__device__ __forceinline__ float ap_relu(float x) {
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+}
+
+// fp16 range sentinel (AP_PREC_F16 only; compiled out of the bf16 translation units).  A stored activation can only leave the fp16
+// range where an fp32 result is converted for storage, and every stored activation of the trunk is post-ReLU, i.e. an overflow is
+// born as +inf = 0x7c00.  Every epilogue therefore folds the packed dwords it stores into a per-thread running maximum over signed
+// 16-bit halves (ONE v_pk_max_i16 per two stored values: +inf is the largest positive pattern below the NaNs, negative patterns
+// never win) and, once per thread at the end of the kernel, sets the handle's host-mapped flag if either half reached 0x7c00.
+// (Checking only the pooled features at the end of the trunk is not enough: the NaNs an inf turns into downstream carry a set
+// sign bit on this hardware and every ReLU clears them -- measured, tests/test_gpu_parity.py::test_f16_activation_overflow_is_reported.)
+// Use: `uint32_t rng = 0u;` per thread, ap_rng_note(rng, packed_dword) at every store of packed values, ap_rng_flush(flag, rng)
+// at the end of the kernel.  All three compile to nothing in the bf16 translation units.
+#ifdef AP_F16
+__device__ __forceinline__ void ap_rng_note(uint32_t& m, uint32_t packed) {
+    asm("v_pk_max_i16 %0, %0, %1" : "+v"(m) : "v"(packed));
+}
+// epilogues WITHOUT a ReLU (stand-alone operator, unfused downsample branch) can also overflow to -inf: sign bits masked first
+__device__ __forceinline__ void ap_rng_note_signed(uint32_t& m, uint32_t packed) { ap_rng_note(m, packed & 0x7fff7fffu); }
+__device__ __forceinline__ void ap_rng_flush(int* flag, uint32_t m) {
+    if (flag && ((m & 0xffffu) >= 0x7c00u || (m >> 16) >= 0x7c00u))
+        __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+#else
+__device__ __forceinline__ void ap_rng_note(uint32_t&, uint32_t) {}
+__device__ __forceinline__ void ap_rng_note_signed(uint32_t&, uint32_t) {}
+__device__ __forceinline__ void ap_rng_flush(int*, uint32_t) {}
+#endif
+
 // two fp32 -> one dword of two bf16, round to nearest even.  One v_cvt_pk_bf16_f32 for the PAIR: written as two (__bf16) casts
 // and an or, hipcc emits the same instruction once per VALUE (second source a dummy) plus a shift / or to merge them -- three
 // VALU instructions per pair in every epilogue of the trunk instead of one (identical results: it is the same conversion).

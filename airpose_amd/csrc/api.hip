@@ -142,6 +142,12 @@ unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_
 // without the slab / lean kernels, -5 automatic without the lean kernel, 0..14 / 17 / 100 one explicit configuration);
 // dispatch_conv reads it once per launch and decodes it, so handles on different threads never see a torn setting.
 std::atomic<int> g_conv_mode{-1};
+// ap_set_pair_groups: 16-pixel groups per wave of the fused pair kernel on the layer3 shapes (P = 256): -1 automatic, 1, 2
+std::atomic<int> g_pair_groups{-1};
+inline int pair_groups(int P) {
+    const int v = g_pair_groups.load(std::memory_order_relaxed);
+    return P == 256 ? (v < 0 ? 1 : v) : 1;
+}
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -243,6 +249,8 @@ struct ap_net {
     bool fuse_block = true;        // 16-bit modes: each layer1 bottleneck as one kernel (bottleneck2.hip); off: separate convs
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
+    bool fuse_pool = false;        // 16-bit modes: AvgPool2d(7) in the epilogue of layer4.2 conv3 (conv_lean.hip POOL variant; bit-identical).
+                                   // Off by default: measured neutral (fp16) to -0.5 % (bf16) in the two-stream trunk, profiles/r04_fuse_pool_ab.txt
     DevBuf mean_pose, mean_shape, mean_cam;
     // workspace
     int chunk = 0;
@@ -279,6 +287,7 @@ struct ap_smplx {
     DevBuf dirs_frag, jv_slot, skin_idx8, skin_w4, ws_side;   // fused contraction + skinning: directions in MFMA fragment order, joint-vertex slots / buffer
     bool blend_split = true;
     bool fused = true;          // body-only pose feature, 4 bones per vertex, split-bf16 blend: one kernel for contraction + skinning
+    int fused_cut = 2;          // ... 2 = smplx_lbs_tail_kernel (round 4), 1 = smplx_lbs_fused_kernel (round 3; ap_smplx_set_fused(h, 3))
     DevBuf j_template, j_shapedirs, parents, depth, skin_idx, skin_w, extra_verts, lmk_tri, lmk_bary;
     DevBuf ws_coef, ws_A, ws_jposed, ws_post, ws_vposed, ws_cc;
     int n_out_joints = 0;
@@ -418,8 +427,9 @@ int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const
 }
 
 int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int prec,
-             hipStream_t st) {
+             hipStream_t st, int* rflag = nullptr) {
     ConvArgs a{};
+    a.range_flag = rflag;
     a.x = x; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = res; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = L.cin;
     a.Ho = (H + 2 * L.pad - L.k) / L.stride + 1;
@@ -436,8 +446,9 @@ int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const 
 // fused conv3 + downsample of a stage's first block: t [N][Ho][Ho][cin] (pointwise) and x [N][Hin][Hin][cin2]
 // sampled with stride2, concatenated along K
 int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int Hin, void* y, int prec,
-              hipStream_t st) {
+              hipStream_t st, int* rflag = nullptr) {
     ConvArgs a{};
+    a.range_flag = rflag;
     a.x = t; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = nullptr; a.y = y;
     a.N = N; a.H = Ho; a.W = Ho; a.Cin = L.cin; a.Ho = Ho; a.Wo = Ho; a.Cout = L.cout;
     a.KH = a.KW = 1; a.stride = 1; a.pad = 0;
@@ -450,8 +461,9 @@ int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int H
 
 // fused layer1 bottleneck (bf16): x [N][H][H][c1.cin] -> y [N][H][H][256]
 int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, const void* x, int N, int H, void* y,
-                int prec, hipStream_t st) {
+                int prec, hipStream_t st, int* rflag = nullptr) {
     BneckArgs a{};
+    a.range_flag = rflag;
     a.x = x; a.y = y;
     a.w1 = c1.w.p; a.w2 = c2.w.p; a.w3 = c3.w.p;
     a.s1 = c1.scale.as<float>(); a.h1 = c1.shift.as<float>();
@@ -800,7 +812,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
         HIP_TRY(H16(prec, ap_launch_stem_pool)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                               w.ws_a.p, n, st));
+                                               w.ws_a.p, n, h->range_flag, st));
     } else if (bf) {
         HIP_TRY(H16(prec, ap_launch_stem_conv_mfma)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
                                                     h->stem_shift.as<float>(), w.ws_stem.p, n, st));
@@ -818,7 +830,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             HIP_TRY(k_bf16::ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
                                         (char*)w.ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, kind, st));
     }
-    if (!(h->fuse_stem && (bf || kind == AP_PREC_BF16X2))) HIP_TRY(H16(prec, ap_launch_maxpool)(w.ws_stem.p, w.ws_a.p, n, kind, st));
+    if (!(h->fuse_stem && (bf || kind == AP_PREC_BF16X2))) HIP_TRY(H16(prec, ap_launch_maxpool)(w.ws_stem.p, w.ws_a.p, n, kind, h->range_flag, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
     if (signal_at == 1) HIP_TRY(hipEventRecord(h->ev_skew, st));
     void *cur = w.ws_a.p, *nxt = w.ws_b.p;
@@ -826,19 +838,20 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     int rc;
     int blk = 0;
     bool t1_ready = false;                                   // ws_t1 already holds this block's conv1 output (fused pair)
+    bool pooled = false;                                     // the last convolution wrote the pooled features itself
     for (auto& B : h->blocks) {
         if (signal_at >= 2 && blk++ == signal_at - 2) HIP_TRY(hipEventRecord(h->ev_skew, st));
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
         if (bf && h->fuse_block && B.c2.cout == 64 && B.c2.stride == 1 && H % 14 == 0 && (!B.has_down || B.c1.cin == 64)) {
             // layer1: conv1 -> conv2 -> conv3 (+identity | folded downsample) in one kernel, intermediates in LDS
             const Layer& L3 = B.has_down ? B.c3ds : B.c3;
-            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, prec, st))) return rc;
+            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, prec, st, h->range_flag))) return rc;
             std::swap(cur, nxt);
             continue;
         }
-        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st))) return rc;
+        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, h->range_flag))) return rc;
         t1_ready = false;
-        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st))) return rc;
+        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, h->range_flag))) return rc;
         if (bf && h->fuse_pair && B.pair_p && &B != &h->blocks.back() && (!B.has_down || h->fuse_ds)) {
             // conv3 (+ identity | + folded downsample, ReLU) AND -- where the pair carries it -- the next block's conv1 in one
             // kernel: the block output is written once and not read back for conv1 (model_copenet.py:38-45 of this block,
@@ -849,26 +862,42 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.t2 = w.ws_t2.p; a.wstream = B.pair.p;
             a.s3 = L3.scale.as<float>(); a.h3 = L3.shift.as<float>();
             a.s1 = Nx.c1.scale.as<float>(); a.h1 = Nx.c1.shift.as<float>();
-            a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg;
+            a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg; a.range_flag = h->range_flag;
+            a.groups = pair_groups(B.pair_p);
             if (B.has_down) { a.x2 = cur; a.Ho = a.Wo = Ho; a.H2 = a.W2 = H; a.stride2 = L3.stride2; }
             else a.res = cur;
             HIP_TRY(H16(prec, ap_launch_conv_pair)(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
             t1_ready = B.pair_n1 > 0;
         } else if (B.has_down && h->fuse_ds) {
-            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st))) return rc;
+            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st, h->range_flag))) return rc;
+        } else if (bf && h->fuse_pool && &B == &h->blocks.back() && !B.has_down && Ho == 7 &&
+                   g_conv_mode.load(std::memory_order_relaxed) == -1) {
+            // last convolution of the trunk: conv3 + bn3 + identity + ReLU AND AvgPool2d(7) + view in one kernel
+            // (model_copenet.py:38-47 of layer4.2, then :173-175); the block output is never written
+            ConvArgs a{};
+            a.x = w.ws_t2.p; a.w = B.c3.w.p; a.scale = B.c3.scale.as<float>(); a.shift = B.c3.shift.as<float>(); a.res = cur; a.y = nullptr;
+            a.N = n; a.H = a.W = a.Ho = a.Wo = Ho; a.Cin = B.c3.cin; a.Cout = B.c3.cout;
+            a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.M = n * Ho * Ho;
+            a.ldx = B.c3.cin; a.ldy = B.c3.cout; a.ldr = B.c3.cout; a.wld = B.c3.wld; a.relu = 1;
+            a.pool_out = feat; a.range_flag = h->range_flag;
+            HIP_TRY(zero_line(&a.zero));
+            if (k_bf16::ap_conv_lean_supported(a, kind)) {
+                HIP_TRY(H16(prec, ap_launch_conv_lean)(a, st));
+                pooled = true;
+            } else if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, cur, 1, prec, st, h->range_flag))) return rc;
         } else {
             const void* res = cur;
             if (B.has_down) {
-                if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, prec, st))) return rc;
+                if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, prec, st, h->range_flag))) return rc;
                 res = w.ws_ds.p;
             }
-            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st))) return rc;
+            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st, h->range_flag))) return rc;
         }
         std::swap(cur, nxt);
         H = Ho;
     }
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e2));
-    HIP_TRY(H16(prec, ap_launch_avgpool)(cur, feat, n, 2048, kind, h->range_flag, st));
+    if (!pooled) HIP_TRY(H16(prec, ap_launch_avgpool)(cur, feat, n, 2048, kind, h->range_flag, st));
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e3));
     if (ev_out) {                                            // the caller combines the events of two concurrent passes
         ev_out[0] = e0; ev_out[1] = e1; ev_out[2] = e2; ev_out[3] = e3;
@@ -1303,7 +1332,7 @@ int ap_conv_pair_nhwc(int precision, const void* t2, const void* wstream, const 
     if (!k_bf16::ap_conv_pair_supported(P, 0, 4 * P, N1)) return fail(AP_ESHAPE, "ap_conv_pair_nhwc: (P, N1) must be (128,128), (128,256) or (256,256)");
     PairArgs a{};
     a.t2 = t2; a.res = res; a.wstream = wstream; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n; a.M = M;
-    a.dbg = g_conv_dbg;
+    a.dbg = g_conv_dbg; a.groups = pair_groups(P);
     HIP_TRY(H16(precision, ap_launch_conv_pair)(a, P, 0, 4 * P, N1, (hipStream_t)stream));
     return AP_OK;
 }
@@ -1319,13 +1348,19 @@ int ap_conv_pair_ds_nhwc(int precision, const void* t2, const void* x, const voi
     PairArgs a{};
     a.t2 = t2; a.x2 = x; a.wstream = wstream; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n;
     a.M = N * Ho * Ho; a.Ho = a.Wo = Ho; a.H2 = a.W2 = Ho * stride; a.stride2 = stride;
-    a.dbg = g_conv_dbg;
+    a.dbg = g_conv_dbg; a.groups = pair_groups(P);
     HIP_TRY(H16(precision, ap_launch_conv_pair)(a, P, P2, C3, N1, (hipStream_t)stream));
     return AP_OK;
 }
 
 int ap_debug_set_trace(void* device_buf_160_u64) {
     g_conv_dbg = (unsigned long long*)device_buf_160_u64;
+    return AP_OK;
+}
+
+int ap_set_pair_groups(int groups) {
+    if (groups != -1 && groups != 1 && groups != 2) return fail(AP_EINVAL, "ap_set_pair_groups: -1 (automatic), 1 or 2");
+    g_pair_groups.store(groups, std::memory_order_relaxed);
     return AP_OK;
 }
 
@@ -1426,6 +1461,12 @@ int ap_net_set_fuse_pair(ap_net* h, int on) {
 int ap_net_set_fuse_ief(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_ief = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_fuse_pool(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fuse_pool = on != 0;
     return AP_OK;
 }
 
@@ -1687,7 +1728,7 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     if (fused) {
         int n_cu = 0;
         HIP_TRY(device_cus(&n_cu));
-        HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, st));
+        HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, h->fused_cut, st));
         if (h->tm.on) { HIP_TRY(h->tm.rec(st, &ev[2])); ev[3] = ev[2]; }     // stage 1 = the fused kernel, stage 2 empty
     } else {
         // v_posed = v_template + [betas | expr | pose_feature] . dirs^T; hand/face rows of the pose feature are
@@ -1782,6 +1823,7 @@ int ap_smplx_debug_poison_workspace(ap_smplx* h, int n) {
 int ap_smplx_set_fused(ap_smplx* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fused = on != 0;
+    h->fused_cut = on == 3 ? 1 : 2;                          // 3: the first cut of the fused kernel (A/B)
     return AP_OK;
 }
 

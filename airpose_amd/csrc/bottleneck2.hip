@@ -129,7 +129,7 @@ __host__ __device__ __forceinline__ int b2_row_channel(int rho) {
 // BN (+ identity) + ReLU + bf16 of the 8 consecutive channels a lane holds in fragments (2q, 2q+1): the expression of the
 // stand-alone kernels' epilogue (fma, add, max, round), two values per instruction
 __device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32x4& s0, const f32x4& s1, const f32x4& h0,
-                                     const f32x4& h1, const u32x4* res) {
+                                     const f32x4& h1, const u32x4* res, uint32_t& rng) {
     if (B2_ABLATE & 16) {
         u32x4 o = res ? *res : u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
         asm volatile("" : "+v"(o) : "v"(lo), "v"(hi), "v"(s0), "v"(s1), "v"(h0), "v"(h1));
@@ -147,6 +147,7 @@ __device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32
     u32x4 o;
     o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));
     o.z = relu_pk_bf16(cvt_pk_bf16(v2.x, v2.y)); o.w = relu_pk_bf16(cvt_pk_bf16(v3.x, v3.y));
+    ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);   // fp16 range sentinel (ap_common.h)
     return o;
 }
 
@@ -161,6 +162,7 @@ bneck2_kernel(const BneckArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g4 = lane >> 4;
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the bf16 set
 
     // ---------------------------------------------------------------- once per workgroup: W1, W2, BatchNorm tables -> LDS
     // tile = 64 rows x 128 B, row rho = channel b2_row_channel(rho), 16-byte chunk c at position c ^ (rho & 7)
@@ -354,7 +356,7 @@ bneck2_kernel(const BneckArgs a) {
             wait_lgkmcnt<0>();
             sfor<0, 2>([&](auto GG) {
                 constexpr int g = GG;
-                u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr);
+                u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr, rng);
                 if (!inimg[g]) o = u32x4{0u, 0u, 0u, 0u};    // conv2 pads t1 with zeros, not with conv1 of zeros
                 lds_write_b128<g * 2048>(q ? tw ^ 64u : tw, o);
             });
@@ -395,8 +397,8 @@ bneck2_kernel(const BneckArgs a) {
             constexpr int q = Q;
             rdT(tq, tab, std::integral_constant<int, T_S2 + q * 128>{}, std::integral_constant<int, T_H2 + q * 128>{});
             wait_lgkmcnt<0>();
-            y[q] = bn8(acc[2 * q], acc[2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr);
-            y[2 + q] = bn8(acc[4 + 2 * q], acc[4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr);
+            y[q] = bn8(acc[2 * q], acc[2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr, rng);
+            y[2 + q] = bn8(acc[4 + 2 * q], acc[4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr, rng);
         });
 
         // ------------------------------------------------------------ conv3 in four chunks of 64 channels
@@ -448,7 +450,7 @@ bneck2_kernel(const BneckArgs a) {
                 sfor<0, 2>([&](auto GG) {
                     constexpr int g = GG;
                     const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3],
-                                        DS ? nullptr : &xc[DS ? 0 : g * 8 + cc * 2 + q]);
+                                        DS ? nullptr : &xc[DS ? 0 : g * 8 + cc * 2 + q], rng);
                     if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(opp.off[g]));
                     else if (B2_ABLATE & 64) {               // shape experiment (data of the wrong pixels): 8 CONSECUTIVE lanes = one 128-byte line
                         const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R, p = (ll >> 3) + 8 * q;
@@ -499,6 +501,7 @@ bneck2_kernel(const BneckArgs a) {
         T = Tn;
     }
     wait_vmcnt<0>();                                         // no LDS-DMA may be in flight when the LDS is released
+    ap_rng_flush(a.range_flag, rng);
 }
 
 }  // namespace

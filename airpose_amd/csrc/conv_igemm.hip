@@ -235,6 +235,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     constexpr int CPR = BN / EPO;
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the other kinds
+    const uint32_t smask = p.relu ? 0xffffffffu : 0x7fff7fffu;
     for (int q = tid; q < BM * CPR; q += 256) {
         const int px = q / CPR, cc = q - px * CPR;
         const int m = bm * BM + px, ch = bn * BN + cc * EPO;
@@ -251,12 +253,13 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
                 unpack_bf16x2(rv.w, lo, hi); b.z += lo; b.w += hi;
             }
             if (p.relu) {
-                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-                b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+                a.x = ap_relu(a.x); a.y = ap_relu(a.y); a.z = ap_relu(a.z); a.w = ap_relu(a.w);
+                b.x = ap_relu(b.x); b.y = ap_relu(b.y); b.z = ap_relu(b.z); b.w = ap_relu(b.w);
             }
             u32x4 o;
             o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w);
             o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
+            ap_rng_note(rng, o.x & smask); ap_rng_note(rng, o.y & smask); ap_rng_note(rng, o.z & smask); ap_rng_note(rng, o.w & smask);
             *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
         } else if constexpr (KIND == K_SPLIT) {
             float v[8];
@@ -278,7 +281,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             }
             if (p.relu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = ap_relu(v[e]);
             }
             if (p.out_f32) {
                 float* yp = (float*)yg + (size_t)m * p.ldy + ch;
@@ -296,10 +299,11 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
                 const float4 rv = *(const float4*)(rg + (size_t)m * p.ldr + ch);
                 a.x += rv.x; a.y += rv.y; a.z += rv.z; a.w += rv.w;
             }
-            if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            if (p.relu) { a.x = ap_relu(a.x); a.y = ap_relu(a.y); a.z = ap_relu(a.z); a.w = ap_relu(a.w); }
             *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
         }
     }
+    if constexpr (KIND == K_BF16) ap_rng_flush(p.range_flag, rng);
 }
 
 template <int BM, int BN>

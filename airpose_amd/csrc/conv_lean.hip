@@ -13,6 +13,14 @@
 // the 16-byte chunk c of row p sits at slot 4p + (c ^ h[p >> 2]), h = {0, 3, 2, 1}: a ds_read_b128 group (16 lanes = chunk a of
 // rows 0-3 and 12-15 plus chunk a^1 of rows 4-11) then covers the 16 bank quads exactly once.  The swizzle lives on the DMA
 // SOURCE address (LDS-DMA writes lane-linearly).
+//
+// POOL variant (the last convolution of the trunk, layer4.2 conv3: model_copenet.py:38-47 followed by AvgPool2d(7) + view,
+// :173-175): the 231 MB block output is never written.  A workgroup owns a SUPER-TILE of 5 images = 245 pixel rows x 128 channels,
+// computed as two 128-row sub-tiles through the same K loop; the epilogue (BatchNorm, + identity, ReLU, rounding to the 16-bit
+// storage type -- the values the stand-alone path would have stored) reduces the pixels of every image per channel IN THE ORDER OF
+// avgpool_kernel (stem.hip): eight partitions p, p + 8, ... summed serially, then the partitions in order, / 49 -- so the features
+// are bit-identical to conv + avgpool_kernel, for every batch size and position of the image in the batch.  The image that
+// straddles the two sub-tiles (rows 98..146) carries its eight partial sums in LDS from the first sub-tile to the second.
 #include "ap_common.h"
 #include "kernels.h"
 
@@ -25,6 +33,13 @@ constexpr int SLOTS = 3, TILE_BYTES = 16384, A_BYTES = 8192;
 constexpr int HALF = 64, CLD = HALF + 4;                   // epilogue stage: 128 x 68 floats per half
 constexpr int LDS_BYTES = SLOTS * TILE_BYTES;               // 49152 (>= 128 * 68 * 4 = 34816)
 static_assert(BM * CLD * 4 <= LDS_BYTES, "the epilogue stage reuses the ring");
+// POOL variant: 5 images (49 pixels each) per super-tile; partial sums of a sub-tile's <= 3 image segments behind the stage
+// (inside the ring), the straddling image's carried partials behind the ring
+constexpr int POOL_IMGS = 5, POOL_PIX = 49, POOL_ROWS = POOL_IMGS * POOL_PIX;       // 245 of 2 x 128 rows
+constexpr int PSUM_OFF = BM * CLD * 4, PSUM_BYTES = 3 * 8 * HALF * 4;                // [seg 3][part 8][64] floats
+constexpr int CARRY_BYTES = 2 * 8 * HALF * 4;                                        // [half 2][part 8][64] floats
+static_assert(PSUM_OFF + PSUM_BYTES <= LDS_BYTES, "partial sums fit behind the stage");
+static_assert(3 * (LDS_BYTES + CARRY_BYTES) <= 160 * 1024, "three workgroups per CU");
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 template <int N> __device__ __forceinline__ void wait_lgkmcnt() {
@@ -40,26 +55,37 @@ __device__ __forceinline__ void mfma_acc(f32x4& c, const u32x4& w, const u32x4& 
     asm volatile(AP_MFMA16_ASM " %0, %1, %2, %0" : "+v"(c) : "v"(w), "v"(x));
 }
 
+template <bool POOL>
 __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6))) conv_lean_kernel(const ConvArgs p) {
     typedef bf16_t T;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int wm = wave / WAVES_N, wn = wave % WAVES_N;
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-    const int bm = tile / p.ntiles, bn = tile % p.ntiles;
+    const int bm = tile / p.ntiles, bn = tile % p.ntiles;      // POOL: bm = super-tile (5 images)
     const int KT = p.Cin / 32;
     const unsigned char* zg = (const unsigned char*)p.zero;
     const unsigned char* xg = (const unsigned char*)p.x;
     const unsigned char* wg = (const unsigned char*)p.w;
     asm volatile("" ::"s"(zg), "s"(xg), "s"(wg));           // kernel-argument loads complete here (see conv_slab.hip)
 
+    constexpr int NSUB = POOL ? 2 : 1;
+    const int row0 = POOL ? bm * POOL_ROWS : bm * BM;         // first pixel row of the (super-)tile
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    for (int sub = 0; sub < NSUB; ++sub) {
+    if (POOL && sub) __syncthreads();                        // the previous sub-tile's stage / partial sums are read: the ring is free
+    // per-lane state is derived from an opaque copy of the thread id inside the sub-tile loop: it is recomputed for the second
+    // sub-tile instead of being kept alive across the first one's epilogue (80 registers: three workgroups per CU)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
+    const int lane = tid & 63;
     // ---------------------------------------------------------------- DMA: wave w carries activation piece w (pixels
     // 16w .. 16w+15 of the tile) and weight piece w (channels 16w .. 16w+15) of every K step; lane l fills slot l of the piece
     const int prow = lane >> 2;                              // row of the piece this lane's slot belongs to
     const int pchunk = (lane & 3) ^ ((0x1230 >> ((prow >> 2) * 4)) & 3);   // h = {0, 3, 2, 1}
-    const int m = bm * BM + wave * 16 + prow;
-    const bool a_ok = m < p.M;
+    // operand rows of this sub-tile (POOL: rows past the 245th of the super-tile are zero rows)
+    const int rl_dma = sub * BM + wave * 16 + prow, m = row0 + rl_dma;
+    const bool a_ok = m < p.M && (!POOL || rl_dma < POOL_ROWS);
     uint32_t aoff = a_ok ? (uint32_t)(((size_t)m * p.ldx + pchunk * 8) * sizeof(T)) : 0u;
     uint32_t woff = (uint32_t)(((size_t)(bn * BN + wave * 16 + prow) * p.wld + pchunk * 8) * sizeof(T));   // rows padded to 128: valid
     auto issue_tile = [&](int slot) {
@@ -75,7 +101,6 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
 
     // ---------------------------------------------------------------- MFMA state
     const int lr = lane & 15, g4 = lane >> 4;
-    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     const uint32_t fslot = (uint32_t)(lr * 4 + (g4 ^ ((0x1230 >> ((lr >> 2) * 4)) & 3))) * 16u;
     const uint32_t xa = lds0 + wm * 4096 + fslot;            // fragment fm at + fm * 1024
     const uint32_t wa = lds0 + A_BYTES + wn * 2048 + fslot;  // fragment fn at + fn * 1024
@@ -125,6 +150,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
     constexpr int CPR = HALF / 8, NIT = BM * CPR / NT;       // 8 chunks of 8 channels per row and half, 2 per thread
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the bf16 set
+    const uint32_t smask = p.relu ? 0xffffffffu : 0x7fff7fffu;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();                                     // ring reads (h = 0) / previous half's stage reads (h = 1) are done
@@ -153,17 +180,17 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
                 const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
-                const int mm = bm * BM + px, ch = bn * BN + h * HALF + cc * 8;
-                const bool ok = mm < p.M && ch < p.Cout;
+                const int rl = sub * BM + px, mm = row0 + rl, ch = bn * BN + h * HALF + cc * 8;
+                const bool ok = mm < p.M && ch < p.Cout && (!POOL || rl < POOL_ROWS);
                 rv[it] = *(const u32x4*)(ok ? rg + (size_t)mm * p.ldr + ch : (const T*)p.zero);
             }
         }
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
-            const int mm = bm * BM + px, ch = bn * BN + h * HALF + cc * 8;
-            if (mm >= p.M || ch >= p.Cout) continue;
-            const float* sp = ct + px * CLD + cc * 8;
+            const int rl = sub * BM + px, mm = row0 + rl, ch = bn * BN + h * HALF + cc * 8;
+            if (!POOL && (mm >= p.M || ch >= p.Cout)) continue;
+            float* sp = ct + px * CLD + cc * 8;
             float4 a = *(const float4*)sp, b = *(const float4*)(sp + 4);
             if (rg) {
                 float lo, hi;
@@ -173,15 +200,61 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
                 unpack_bf16x2(rv[it][3], lo, hi); b.z += lo; b.w += hi;
             }
             if (p.relu) {
-                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-                b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+                a.x = ap_relu(a.x); a.y = ap_relu(a.y); a.z = ap_relu(a.z); a.w = ap_relu(a.w);
+                b.x = ap_relu(b.x); b.y = ap_relu(b.y); b.z = ap_relu(b.z); b.w = ap_relu(b.w);
             }
             u32x4 o;
             o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
             o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
-            *(u32x4*)(yg + (size_t)mm * p.ldy + ch) = o;
+            ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
+            if constexpr (!POOL) {
+                *(u32x4*)(yg + (size_t)mm * p.ldy + ch) = o;
+            } else {
+                // the values the stand-alone path would have stored (rounded to the 16-bit type), back into this thread's own
+                // chunk of the stage: the pooling pass below reads them per channel
+                unpack_bf16x2(o[0], a.x, a.y); unpack_bf16x2(o[1], a.z, a.w);
+                unpack_bf16x2(o[2], b.x, b.y); unpack_bf16x2(o[3], b.z, b.w);
+                *(float4*)sp = a; *(float4*)(sp + 4) = b;
+            }
+        }
+        if constexpr (POOL) {
+            // ---- pooling of this half: thread = (partition k, channel c); the sub-tile's image segments in turn.
+            // super-tile rows: image i = rows 49 i .. 49 i + 48.  sub 0 holds images 0, 1 and pixels 0..29 of image 2;
+            // sub 1 holds pixels 30..48 of image 2 (local rows 0..18), image 3 (19..67), image 4 (68..116)
+            __syncthreads();
+            float* psum = (float*)(smem + PSUM_OFF);                     // [seg][k][c]
+            float* carry = (float*)(smem + LDS_BYTES) + h * 8 * HALF;    // [k][c]: image 2's partials, sub 0 -> sub 1
+            const int k = tid >> 6, c = tid & 63;
+#pragma unroll
+            for (int seg = 0; seg < 3; ++seg) {
+                // local row of the segment's first pixel, first / last pixel of the image it holds
+                const int r0 = sub == 0 ? seg * POOL_PIX : (seg == 0 ? 0 : 19 + (seg - 1) * POOL_PIX);
+                const int p0 = (sub == 1 && seg == 0) ? 30 : 0;
+                const int p1 = (sub == 0 && seg == 2) ? 30 : POOL_PIX;
+                float sacc = (sub == 1 && seg == 0) ? carry[k * HALF + c] : 0.f;
+                // pixels k, k + 8, ... of the image, ascending: the order of avgpool_kernel's partition k
+                int px0 = k + ((p0 - k + 7) & ~7);                       // first pixel >= p0 congruent to k (p0 = 0: k itself)
+                if (p0 == 0) px0 = k;
+                for (int px = px0; px < p1; px += 8) sacc += ct[(r0 + px - p0) * CLD + c];
+                if (sub == 0 && seg == 2) carry[k * HALF + c] = sacc;
+                else psum[(seg * 8 + k) * HALF + c] = sacc;
+            }
+            __syncthreads();
+            if (tid < 3 * HALF) {
+                const int seg = tid >> 6;
+                const int img_l = sub == 0 ? seg : seg + 2;              // sub 0: images 0, 1 (seg 2 is carried); sub 1: 2, 3, 4
+                const int img = bm * POOL_IMGS + img_l, ch = bn * BN + h * HALF + c;
+                if (!(sub == 0 && seg == 2) && img < p.N && ch < p.Cout) {
+                    float t = psum[(seg * 8) * HALF + c];
+#pragma unroll
+                    for (int kk = 1; kk < 8; ++kk) t += psum[(seg * 8 + kk) * HALF + c];
+                    p.pool_out[(size_t)img * p.Cout + ch] = t / 49.0f;
+                }
+            }
         }
     }
+    ap_rng_flush(p.range_flag, rng);
+    }   // sub-tile
 }
 
 }  // namespace
@@ -194,9 +267,25 @@ bool ap_conv_lean_supported(const ConvArgs& a, int kind) {
 
 hipError_t ap_launch_conv_lean(ConvArgs a, hipStream_t st) {
     if (!a.zero || !ap_conv_lean_supported(a, K_BF16)) return hipErrorInvalidValue;
-    a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL(conv_lean_kernel, dim3(a.mtiles * a.ntiles), dim3(NT), LDS_BYTES, st, a);
+    if (a.pool_out) {
+        // conv + BatchNorm + identity + ReLU + AvgPool2d(7) + view: 7 x 7 images, every pixel of an image in one super-tile
+        if (a.Ho * a.Wo != POOL_PIX || a.M != a.N * POOL_PIX || !a.res || !a.relu) return hipErrorInvalidValue;
+        static bool attr_set[AP_MAX_DEVICES] = {};
+        int dev = 0;
+        hipError_t e = ap_current_device(&dev);
+        if (e != hipSuccess) return e;
+        if (!attr_set[dev]) {
+            e = hipFuncSetAttribute((const void*)conv_lean_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES + CARRY_BYTES);
+            if (e != hipSuccess) return e;
+            attr_set[dev] = true;
+        }
+        a.mtiles = (a.N + POOL_IMGS - 1) / POOL_IMGS;
+        hipLaunchKernelGGL(conv_lean_kernel<true>, dim3(a.mtiles * a.ntiles), dim3(NT), LDS_BYTES + CARRY_BYTES, st, a);
+        return hipGetLastError();
+    }
+    a.mtiles = (a.M + BM - 1) / BM;
+    hipLaunchKernelGGL(conv_lean_kernel<false>, dim3(a.mtiles * a.ntiles), dim3(NT), LDS_BYTES, st, a);
     return hipGetLastError();
 }
 

@@ -132,8 +132,12 @@ __global__ void __launch_bounds__(256) pair_pack_kernel(const bf16_t* __restrict
 // P: channels of t2 (first K segment); P2: channels of the second K segment (the folded downsample branch of a stage's first
 // block, model_copenet.py:41-42,97-102: x of the block sampled at the strided pixel, 1x1; 0 = identity block); C3: conv3
 // output channels; N1: conv1 width of the next block (0 = none: conv3 alone); RES: the block input is added before the ReLU
-template <int P, int P2, int C3, int N1, bool RES, int NW, int S, int D, bool IDB>
-__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2, 2))) conv_pair_kernel(const PairArgs p) {
+// PG: pixel groups of 16 per wave.  PG = 1: two workgroups per CU (<= 256 registers).  PG = 2 (layer3, where one LDS fragment read
+// per MFMA and 16 MFMAs per barrier step left the matrix pipe at a quarter of its rate): every weight fragment read from LDS feeds
+// TWO MFMAs (pixels 0-15 and 16-31 of the wave: independent accumulators), a barrier step carries 32 MFMAs per wave, the wave
+// takes a whole SIMD's register file (accumulators in the upper half), one workgroup per CU.  Same arithmetic per pixel.
+template <int P, int P2, int C3, int N1, bool RES, int NW, int S, int D, bool IDB, int PG>
+__global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 - PG, 3 - PG))) conv_pair_kernel(const PairArgs p) {
     constexpr int KA = P + P2, KP = KA / 64, HN = N1 / 128, KG = 2 * HN, NB = C3 / 128, SPC = KP + KG;
     constexpr int NXF = KA / 32, NXF1 = P / 32, NT = 64 * NW, LPW = 16 / NW, RING = S * PR_TILE;
     static_assert(!(IDB && !RES) && (RES || P2 > 0) && P % 64 == 0 && P2 % 64 == 0, "identity look-ahead needs an identity");
@@ -145,20 +149,27 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g4 = lane >> 4;
-    const int m = blockIdx.x * (16 * NW) + wave * 16 + lr;
-    const bool mok = m < p.M;
-    const size_t mc = mok ? (size_t)m : (size_t)(p.M - 1);      // ragged tail: loads clamped, stores masked
-
+    static_assert(PG == 1 || PG == 2, "one or two groups of 16 pixels per wave");
+    bool mok[PG];
+    size_t mc[PG];
+    const unsigned char *t2p[PG], *resp[PG], *x2p[PG];
+    unsigned char *outp[PG], *t1p[PG];
     const unsigned char* wnext = (const unsigned char*)p.wstream + (size_t)(wave * LPW) * 1024 + lane * 16;   // next tile to issue
-    const unsigned char* t2p = (const unsigned char*)p.t2 + (mc * P + g4 * 8) * 2;
-    const unsigned char* resp = (const unsigned char*)p.res + (mc * C3 + g4 * 8) * 2;
-    const unsigned char* x2p = t2p;                          // second K segment: pixel (ho*stride2, wo*stride2) of image n in x2
-    if constexpr (P2 > 0) {
-        const int hw = p.Ho * p.Wo, n = (int)mc / hw, rem = (int)mc - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
-        x2p = (const unsigned char*)p.x2 + ((((size_t)n * p.H2 + (size_t)ho * p.stride2) * p.W2 + (size_t)wo * p.stride2) * P2 + g4 * 8) * 2;
+#pragma unroll
+    for (int pg = 0; pg < PG; ++pg) {
+        const int m = blockIdx.x * (16 * NW * PG) + (wave * PG + pg) * 16 + lr;
+        mok[pg] = m < p.M;
+        mc[pg] = mok[pg] ? (size_t)m : (size_t)(p.M - 1);   // ragged tail: loads clamped, stores masked
+        t2p[pg] = (const unsigned char*)p.t2 + (mc[pg] * P + g4 * 8) * 2;
+        resp[pg] = (const unsigned char*)p.res + (mc[pg] * C3 + g4 * 8) * 2;
+        x2p[pg] = t2p[pg];                                   // second K segment: pixel (ho*stride2, wo*stride2) of image n in x2
+        if constexpr (P2 > 0) {
+            const int hw = p.Ho * p.Wo, n = (int)mc[pg] / hw, rem = (int)mc[pg] - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
+            x2p[pg] = (const unsigned char*)p.x2 + ((((size_t)n * p.H2 + (size_t)ho * p.stride2) * p.W2 + (size_t)wo * p.stride2) * P2 + g4 * 8) * 2;
+        }
+        outp[pg] = (unsigned char*)p.out + ((size_t)m * C3 + g4 * 8) * 2;
+        t1p[pg] = (unsigned char*)p.t1n + ((size_t)m * N1 + g4 * 8) * 2;
     }
-    unsigned char* outp = (unsigned char*)p.out + ((size_t)m * C3 + g4 * 8) * 2;
-    unsigned char* t1p = (unsigned char*)p.t1n + ((size_t)m * N1 + g4 * 8) * 2;
     // every kernel-argument load completes here: a scalar load the compiler believes pending inside the loop costs an
     // s_waitcnt lgkmcnt(0) in front of each DMA instruction, which also drains the fragment reads in flight
     asm volatile("" ::"s"(p.wstream), "s"(p.t2), "s"(p.res), "s"(p.out), "s"(p.t1n), "s"(p.M), "s"(p.x2));
@@ -190,16 +201,19 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         wf[(4 * g) % D] = lds_read_b128<o>(b); wf[(4 * g + 1) % D] = lds_read_b128<o + 2048>(b);
         wf[(4 * g + 2) % D] = lds_read_b128<o + 4096>(b); wf[(4 * g + 3) % D] = lds_read_b128<o + 6144>(b);
     };
-    // one weight tile: 16 MFMAs (8 row fragments x 2 K halves) on the 16 pixels of this wave; the wave's LPW DMA pieces go
-    // out between the MFMA groups (a piece costs its wave ~100 cycles of issue: under the matrix pipe, not in front of it).
+    // one weight tile: 16 MFMAs (8 row fragments x 2 K halves) on each 16-pixel group of this wave (acc[pg]: its 8 accumulators,
+    // bb[pg][0 / 1]: its B fragments of the two K halves); the wave's LPW DMA pieces go out between the MFMA groups (a piece costs
+    // its wave ~100 cycles of issue: under the matrix pipe, not in front of it).
     // pre: the next tile exists (its fragments are requested as this tile's are consumed)
-    auto step = [&](f32x4* acc, const u32x4& b0, const u32x4& b1, bool issue, bool pre) {
+    auto step = [&](f32x4* const (&acc)[PG], const u32x4* const (&bb)[PG], bool issue, bool pre) {
         const uint32_t a0 = fb0 + so, an = fb0 + ((so + PR_TILE) & (RING - 1));
         sfor<0, 4>([&](auto G) {
             constexpr int g = G;
             if (pre) wait_lgkmcnt<D - 4>(); else wait_lgkmcnt<0>();     // (last tile: nothing younger follows its fragments)
 #pragma unroll
-            for (int f = 0; f < 4; ++f) mm(acc[(4 * g + f) & 7], wf[(4 * g + f) % D], g < 2 ? b0 : b1);
+            for (int f = 0; f < 4; ++f)
+#pragma unroll
+                for (int pg = 0; pg < PG; ++pg) mm(acc[pg][(4 * g + f) & 7], wf[(4 * g + f) % D], bb[pg][g < 2 ? 0 : 1]);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (LPW == 4) piece(g, issue);
             else if constexpr (g & 1) piece(g >> 1, issue);
@@ -214,6 +228,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         so = (so + PR_TILE) & (RING - 1);
         si = (si + PR_TILE) & (RING - 1);
     };
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the bf16 set
     // BN + (identity) + ReLU + bf16 of the 8 consecutive channels a lane holds in fragments (2q, 2q+1); sc / sh: their tables
     auto bn8 = [&](const f32x4& lo, const f32x4& hi, const f32x4& s0, const f32x4& s1, const f32x4& h0, const f32x4& h1,
                    const u32x4* res) -> u32x4 {
@@ -236,36 +251,41 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         u32x4 o;
         o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));
         o.z = relu_pk_bf16(cvt_pk_bf16(v2.x, v2.y)); o.w = relu_pk_bf16(cvt_pk_bf16(v3.x, v3.y));
+        ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);   // fp16 range sentinel
         return o;
     };
-    auto load_identity = [&](int nb, u32x4 (&r)[4]) {        // 4 x 16 B per lane: channels nb*128 + q*32 + g4*8 .. + 7
+    auto load_identity = [&](int nb, u32x4 (&r)[PG][4]) {    // 4 x 16 B per lane and pixel group: channels nb*128 + q*32 + g4*8 .. + 7
         if constexpr (!RES) return;
-        if (PR_ABLATE & 1) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) r[q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
-            return;
+        for (int pg = 0; pg < PG; ++pg) {
+            if (PR_ABLATE & 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r[pg][q] = u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+                continue;
+            }
+            if (PR_ABLATE & 64) {                            // same 4 KiB of the group's 16 pixels, full 128-byte lines per row
+                const unsigned char* rq = (const unsigned char*)p.res + ((size_t)(mc[pg] - lr + (lane >> 3)) * C3 + nb * 128) * 2 + (lane & 7) * 16;
+                r[pg][0] = gload_b128<0>(rq); r[pg][1] = gload_b128<128>(rq);
+                rq += (size_t)8 * C3 * 2;
+                r[pg][2] = gload_b128<0>(rq); r[pg][3] = gload_b128<128>(rq);
+                continue;
+            }
+            const unsigned char* rp = resp[pg] + nb * 256;
+            r[pg][0] = gload_b128<0>(rp); r[pg][1] = gload_b128<64>(rp); r[pg][2] = gload_b128<128>(rp); r[pg][3] = gload_b128<192>(rp);
         }
-        if (PR_ABLATE & 64) {                                // same 4 KiB of the wave's 16 pixels, full 128-byte lines per row
-            const unsigned char* rq = (const unsigned char*)p.res + ((size_t)(mc - lr + (lane >> 3)) * C3 + nb * 128) * 2 + (lane & 7) * 16;
-            r[0] = gload_b128<0>(rq); r[1] = gload_b128<128>(rq);
-            rq += (size_t)8 * C3 * 2;
-            r[2] = gload_b128<0>(rq); r[3] = gload_b128<128>(rq);
-            return;
-        }
-        const unsigned char* rp = resp + nb * 256;
-        r[0] = gload_b128<0>(rp); r[1] = gload_b128<64>(rp); r[2] = gload_b128<128>(rp); r[3] = gload_b128<192>(rp);
     };
 
     // ---------------------------------------------------------------- prologue: t2 fragments, (identity of chunk 0,)
     // tiles 0 .. S-2, the first D fragments of tile 0
-    u32x4 xf[NXF];
-    sfor<0, NXF>([&](auto I) {
-        if constexpr (I < NXF1) xf[I] = gload_b128<I * 64>(t2p);
-        else xf[I] = gload_b128<(I - NXF1) * 64>(x2p);
+    u32x4 xf[PG][NXF];
+    sfor<0, PG * NXF>([&](auto II) {
+        constexpr int pg = II / NXF, I = II % NXF;
+        if constexpr (I < NXF1) xf[pg][I] = gload_b128<I * 64>(t2p[pg]);
+        else xf[pg][I] = gload_b128<(I - NXF1) * 64>(x2p[pg]);
     });
     // identity pieces of a chunk, then its packed result (= conv1 operand).  IDB: two sets, the next chunk's identity is
     // requested a whole chunk ahead; otherwise one set, requested at the chunk's first step
-    u32x4 ra[4], rb[IDB ? 4 : 1];
+    u32x4 ra[PG][4], rb[PG][4];                              // (rb is used with IDB only)
     if constexpr (IDB) load_identity(0, ra);
 #pragma unroll
     for (int t = 0; t < S - 1; ++t) {
@@ -275,9 +295,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         wnext += PR_TILE;
     }
     si = (S - 1) * PR_TILE;
-    f32x4 acc1[HN > 0 ? HN * 8 : 1];
+    f32x4 acc1[PG][HN > 0 ? HN * 8 : 1];
 #pragma unroll
-    for (int i = 0; i < HN * 8; ++i) acc1[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+        for (int i = 0; i < HN * 8; ++i) acc1[pg][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     // BatchNorm tables into LDS while those requests fly (read in the epilogues by inline-asm ds_read: a load the compiler
     // counts would be fenced against the LDS-DMA writes of the ring with vmcnt(0)).  The compiler waits for its table loads
     // with vmcnt(0), which covers the t2 fragments, the identity and the first tiles as well
@@ -289,7 +311,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
     }
     wait_vmcnt<0>();
 #pragma unroll
-    for (int i = 0; i < NXF; ++i) asm volatile("" : "+v"(xf[i]));
+    for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+        for (int i = 0; i < NXF; ++i) asm volatile("" : "+v"(xf[pg][i]));
     __syncthreads();
     rd4(std::integral_constant<int, 0>{}, fb0);
     rd4(std::integral_constant<int, 1>{}, fb0);
@@ -297,7 +321,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
 
     if (PR_ABLATE & 32) {                                    // timing build: the prologue alone
         wait_lgkmcnt<0>();
-        asm volatile("" ::"v"(wf[0]), "v"(wf[D - 1]), "v"(xf[0]), "v"(xf[NXF - 1]), "v"(ra[0]), "v"(outp), "v"(t1p), "v"(resp));
+        asm volatile("" ::"v"(wf[0]), "v"(wf[D - 1]), "v"(xf[0][0]), "v"(xf[PG - 1][NXF - 1]), "v"(ra[0][0]), "v"(outp[0]), "v"(t1p[0]), "v"(resp[0]));
         return;
     }
     // one 128-channel chunk of conv3 + its share of conv1; cur: this chunk's identity / result, nxt: the next chunk's identity
@@ -308,11 +332,13 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
 #else
 #define PRSTAMP(i) do { } while (0)
 #endif
-    auto chunk = [&](int nb, u32x4 (&cur)[4], u32x4 (&nxt)[IDB ? 4 : 1]) {
+    auto chunk = [&](int nb, u32x4 (&cur)[PG][4], u32x4 (&nxt)[PG][4]) {
         const bool lastc = nb == NB - 1;
-        f32x4 acc3[8];
+        f32x4 acc3[PG][8];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) acc3[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int pg = 0; pg < PG; ++pg)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc3[pg][i] = f32x4{0.f, 0.f, 0.f, 0.f};
         sfor<0, SPC>([&](auto J) {
             constexpr int j = J;
             // own pieces of the NEXT step's tile have landed (its fragments are requested during this step): S-3 younger
@@ -331,10 +357,18 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
             const bool issue = !(PR_ABLATE & 4) && !(lastc && rem < S - 1);
             const bool pre = !(lastc && rem == 0);
             if constexpr (j < KP) {
-                step(acc3, xf[2 * j], xf[2 * j + 1], issue, pre);
+                f32x4* accs[PG];
+                const u32x4* bbs[PG];
+#pragma unroll
+                for (int pg = 0; pg < PG; ++pg) { accs[pg] = acc3[pg]; bbs[pg] = &xf[pg][2 * j]; }
+                step(accs, bbs, issue, pre);
             } else {
                 constexpr int g = j - KP, kh = g / (HN > 0 ? HN : 1), hn = g % (HN > 0 ? HN : 1);
-                step(&acc1[hn * 8], cur[2 * kh], cur[2 * kh + 1], issue, pre);
+                f32x4* accs[PG];
+                const u32x4* bbs[PG];
+#pragma unroll
+                for (int pg = 0; pg < PG; ++pg) { accs[pg] = &acc1[pg][hn * 8]; bbs[pg] = &cur[pg][2 * kh]; }
+                step(accs, bbs, issue, pre);
             }
             if constexpr (j == 0) {                          // behind this step's DMA pieces
                 if constexpr (IDB) { if (!lastc) load_identity(nb + 1, nxt); }
@@ -354,7 +388,8 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
                         constexpr int ys = LPW * (KP - 1) < 60 ? LPW * (KP - 1) : 60;
                         if (lastc) wait_vmcnt<(LPW * nl < 60 ? LPW * nl : 60)>(); else wait_vmcnt<ys>();
                     }
-                    asm volatile("" : "+v"(cur[0]), "+v"(cur[1]), "+v"(cur[2]), "+v"(cur[3]));
+#pragma unroll
+                    for (int pg = 0; pg < PG; ++pg) asm volatile("" : "+v"(cur[pg][0]), "+v"(cur[pg][1]), "+v"(cur[pg][2]), "+v"(cur[pg][3]));
                 }
                 const uint32_t ta = tb3 + nb * 512;
                 sfor<0, 4>([&](auto Q) {
@@ -362,12 +397,15 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
                     const f32x4 s0 = lds_read_f32x4<q * 128>(ta), s1 = lds_read_f32x4<q * 128 + 16>(ta);
                     const f32x4 h0 = lds_read_f32x4<C3 * 4 + q * 128>(ta), h1 = lds_read_f32x4<C3 * 4 + q * 128 + 16>(ta);
                     wait_lgkmcnt<0>();
-                    cur[q] = bn8(acc3[2 * q], acc3[2 * q + 1], s0, s1, h0, h1, RES ? &cur[q] : nullptr);
-                    if (PR_ABLATE & 2) asm volatile("" ::"v"(cur[q]), "v"(outp));   // (timing build: keep the value live)
-                    else if (PR_ABLATE & 128) {
-                        unsigned char* oq = (unsigned char*)p.out + ((size_t)(mc - lr + (lane >> 3) + (q >> 1) * 8) * C3 + nb * 128) * 2 + (lane & 7) * 16 + (q & 1) * 128;
-                        *(u32x4*)oq = cur[q];
-                    } else if (mok) *(u32x4*)(outp + nb * 256 + q * 64) = cur[q];
+#pragma unroll
+                    for (int pg = 0; pg < PG; ++pg) {
+                        cur[pg][q] = bn8(acc3[pg][2 * q], acc3[pg][2 * q + 1], s0, s1, h0, h1, RES ? &cur[pg][q] : nullptr);
+                        if (PR_ABLATE & 2) asm volatile("" ::"v"(cur[pg][q]), "v"(outp[pg]));   // (timing build: keep the value live)
+                        else if (PR_ABLATE & 128) {
+                            unsigned char* oq = (unsigned char*)p.out + ((size_t)(mc[pg] - lr + (lane >> 3) + (q >> 1) * 8) * C3 + nb * 128) * 2 + (lane & 7) * 16 + (q & 1) * 128;
+                            *(u32x4*)oq = cur[pg][q];
+                        } else if (mok[pg]) *(u32x4*)(outp[pg] + nb * 256 + q * 64) = cur[pg][q];
+                    }
                 });
                 PRSTAMP(29);
             }
@@ -384,18 +422,22 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(2,
         const uint32_t ta = tb1 + (hn * 128 + q * 32) * 4;
         const f32x4 s0 = lds_read_f32x4<0>(ta), s1 = lds_read_f32x4<16>(ta), h0 = lds_read_f32x4<N1 * 4>(ta), h1 = lds_read_f32x4<N1 * 4 + 16>(ta);
         wait_lgkmcnt<0>();
-        const u32x4 o = bn8(acc1[hn * 8 + 2 * q], acc1[hn * 8 + 2 * q + 1], s0, s1, h0, h1, nullptr);
-        if (PR_ABLATE & 2) asm volatile("" ::"v"(o), "v"(t1p));
-        else if (mok) *(u32x4*)(t1p + (hn * 128 + q * 32) * 2) = o;
+#pragma unroll
+        for (int pg = 0; pg < PG; ++pg) {
+            const u32x4 o = bn8(acc1[pg][hn * 8 + 2 * q], acc1[pg][hn * 8 + 2 * q + 1], s0, s1, h0, h1, nullptr);
+            if (PR_ABLATE & 2) asm volatile("" ::"v"(o), "v"(t1p[pg]));
+            else if (mok[pg]) *(u32x4*)(t1p[pg] + (hn * 128 + q * 32) * 2) = o;
+        }
     });
+    ap_rng_flush(p.range_flag, rng);
 }
 
-template <int P, int P2, int C3, int N1, bool RES, int NW, int S, int D, bool IDB>
+template <int P, int P2, int C3, int N1, bool RES, int NW, int S, int D, bool IDB, int PG = 1>
 hipError_t launch_pair(const PairArgs& a, hipStream_t st) {
     static bool attr_set[AP_MAX_DEVICES] = {};
-    auto kern = conv_pair_kernel<P, P2, C3, N1, RES, NW, S, D, IDB>;
+    auto kern = conv_pair_kernel<P, P2, C3, N1, RES, NW, S, D, IDB, PG>;
     constexpr int lds = S * PR_TILE + (2 * C3 + 2 * N1) * 4;
-    static_assert(NW == 8 || lds <= 81920, "two workgroups per CU");
+    static_assert(NW == 8 || PG == 2 || lds <= 81920, "two workgroups per CU");
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
@@ -404,7 +446,7 @@ hipError_t launch_pair(const PairArgs& a, hipStream_t st) {
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
-    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW - 1) / (16 * NW)), dim3(64 * NW), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((a.M + 16 * NW * PG - 1) / (16 * NW * PG)), dim3(64 * NW), lds, st, a);
     return hipGetLastError();
 }
 
@@ -432,6 +474,11 @@ hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P,
 hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int P2, int C3, int N1, hipStream_t st) {
     if (a.M <= 0 || !a.t2 || !a.wstream || !a.out || (N1 > 0 && !a.t1n) || (P2 == 0 && !a.res) || (P2 > 0 && !a.x2))
         return hipErrorInvalidValue;
+    // a.groups: 16-pixel groups per wave: 2 = 32 pixels per wave, one workgroup per CU (layer3 shapes only); 0 / 1 = 16 pixels
+    if (a.groups == 2) {
+        if (P2 == 0 && P == 256 && N1 == 256) return launch_pair<256, 0, 1024, 256, true, 4, 4, 8, false, 2>(a, st);
+        if (P == 256 && P2 == 512 && C3 == 1024 && N1 == 0) return launch_pair<256, 512, 1024, 0, false, 4, 4, 8, false, 2>(a, st);
+    }
     // four waves per workgroup, two workgroups per CU, 4-slot ring, half a tile of fragment look-ahead.  Measured and not
     // kept (tools/pair_bench.py, 256 images): eight waves x one workgroup per CU (half the weight DMA per MFMA) is 4-10 %
     // slower; a whole tile of fragment look-ahead (64 registers) times the same

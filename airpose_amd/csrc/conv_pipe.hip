@@ -404,6 +404,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
         AP_STAMP(9);
     }
 #undef AP_STAMP
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the other kinds
+    const uint32_t smask = p.relu ? 0xffffffffu : 0x7fff7fffu;
     if constexpr (DIRECT) {
         // ------------------------------------------------------------ epilogue straight from the accumulators:
         // lane = (pixel lr, channels g4*4..+3) per fragment; 8-byte (bf16) / 16-byte (fp32) stores, the four
@@ -431,11 +433,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                         v3 += __builtin_bit_cast(float, rpre[(fm * FN + fn) * 4 + 3]);
                     }
                 }
-                if (p.relu) { v0 = fmaxf(v0, 0.f); v1 = fmaxf(v1, 0.f); v2 = fmaxf(v2, 0.f); v3 = fmaxf(v3, 0.f); }
+                if (p.relu) { v0 = ap_relu(v0); v1 = ap_relu(v1); v2 = ap_relu(v2); v3 = ap_relu(v3); }
                 if (m < p.M && ch < p.Cout) {
                     if constexpr (sizeof(T) == 2) {
                         uint2 o;
                         o.x = pack_bf16x2(v0, v1); o.y = pack_bf16x2(v2, v3);
+                        ap_rng_note(rng, o.x & smask); ap_rng_note(rng, o.y & smask);
                         *(uint2*)(yg + (size_t)m * p.ldy + ch) = o;
                     } else {
                         *(float4*)(yg + (size_t)m * p.ldy + ch) = make_float4(v0, v1, v2, v3);
@@ -510,7 +513,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             }
             if (p.relu) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
+                for (int e = 0; e < 8; ++e) v[e] = ap_relu(v[e]);
             }
             if (p.out_f32) {
                 float* yp = (float*)yg + (size_t)m * p.ldy + ch;
@@ -553,12 +556,13 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                 unpack_bf16x2(rv[it][3], lo, hi); b.z += lo; b.w += hi;
             }
             if (p.relu) {
-                a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-                b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+                a.x = ap_relu(a.x); a.y = ap_relu(a.y); a.z = ap_relu(a.z); a.w = ap_relu(a.w);
+                b.x = ap_relu(b.x); b.y = ap_relu(b.y); b.z = ap_relu(b.z); b.w = ap_relu(b.w);
             }
             u32x4 o;
             o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
             o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
+            ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
             *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
         } else {
             float4 a = *(const float4*)sp;
@@ -568,11 +572,12 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
                 a.x += __builtin_bit_cast(float, r0); a.y += __builtin_bit_cast(float, r1);
                 a.z += __builtin_bit_cast(float, r2); a.w += __builtin_bit_cast(float, r3);
             }
-            if (p.relu) { a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f); }
+            if (p.relu) { a.x = ap_relu(a.x); a.y = ap_relu(a.y); a.z = ap_relu(a.z); a.w = ap_relu(a.w); }
             *(float4*)(yg + (size_t)m * p.ldy + ch) = a;
         }
     }
     }
+    if constexpr (Elem2<T>::KIND == K_BF16) ap_rng_flush(p.range_flag, rng);
     AP_BSTAMP(7);
 }
 

@@ -346,6 +346,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     constexpr int CPR = BN / 8, NIT = BM * CPR / NT;
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the bf16 set
+    const uint32_t smask = p.relu ? 0xffffffffu : 0x7fff7fffu;
     u32x4 rv[NIT];
     if (rg) {
 #pragma unroll
@@ -371,14 +373,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
             unpack_bf16x2(rv[it][3], lo, hi); b.z += lo; b.w += hi;
         }
         if (p.relu) {
-            a.x = fmaxf(a.x, 0.f); a.y = fmaxf(a.y, 0.f); a.z = fmaxf(a.z, 0.f); a.w = fmaxf(a.w, 0.f);
-            b.x = fmaxf(b.x, 0.f); b.y = fmaxf(b.y, 0.f); b.z = fmaxf(b.z, 0.f); b.w = fmaxf(b.w, 0.f);
+            a.x = ap_relu(a.x); a.y = ap_relu(a.y); a.z = ap_relu(a.z); a.w = ap_relu(a.w);
+            b.x = ap_relu(b.x); b.y = ap_relu(b.y); b.z = ap_relu(b.z); b.w = ap_relu(b.w);
         }
         u32x4 o;
         o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
         o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
+        ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
         *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
     }
+    ap_rng_flush(p.range_flag, rng);
 }
 
 }  // namespace

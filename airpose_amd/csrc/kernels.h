@@ -25,6 +25,10 @@ struct ConvArgs {
     int relu;
     int mtiles, ntiles;   // filled by the launcher
     int out_f32;          // split-bf16 kind only: y (and res) are plain fp32 [M][ldy] instead of split pairs
+    // conv_lean.hip POOL variant (last convolution of the trunk): when set, y is NOT written; the 7 x 7 pixels of every image are
+    // averaged per channel instead (AvgPool2d(7) + view) into pool_out [N][Cout] fp32, bit-identical to conv + avgpool_kernel
+    float* pool_out;
+    int* range_flag;      // fp16 storage, or NULL: host-mapped word set to 1 when a stored value leaves the fp16 range (ap_common.h)
 };
 
 // (launchers of the 16-bit-flavoured kernel sources: kernels_h16.inc, included at the end of this file)
@@ -42,7 +46,9 @@ struct PairArgs {
     // stage-first block: second K segment = the block input x2 [N][H2][W2][P2] sampled at (ho*stride2, wo*stride2)
     const void* x2;
     int Ho, Wo, H2, W2, stride2;
+    int groups;                   // 16-pixel groups per wave: 0 / 1 (two workgroups per CU) or 2 (layer3 shapes: one workgroup per CU)
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
+    int* range_flag;              // fp16 storage, or NULL: host-mapped word set when a stored value leaves the fp16 range
 };
 
 // ---- fused layer1 bottleneck (bottleneck.hip); bf16 only
@@ -53,6 +59,7 @@ struct BneckArgs {
     const float *s1, *h1, *s2, *h2, *s3, *h3;   // BatchNorm scale / shift per conv
     const void* zero;             // >= 16 bytes of zeros
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
+    int* range_flag;              // fp16 storage, or NULL: host-mapped word set when a stored value leaves the fp16 range
     int N, H, W;                  // H, W multiples of 14
     int tiles_x, tiles_per_img, total;   // filled by the launcher
 };
@@ -165,7 +172,8 @@ hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a,
 // blend-shape contraction + skinning in one kernel (K = 4 bones per vertex, body-only pose feature, split-bf16 coefficients)
 bool ap_smplx_lbs_fused_supported(const SmplxModelDev& m);
 size_t ap_smplx_dirs_frag_bytes(int V);
-hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, hipStream_t st);
+// cut: 2 = second cut (smplx_lbs_tail_kernel, default), 1 = first cut (kept for A/B)
+hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, int cut, hipStream_t st);
 
 // ---- stand-alone geometry helpers (smplx.hip)
 hipError_t ap_launch_rot6d(const float* x6, int n, float* R, hipStream_t st);

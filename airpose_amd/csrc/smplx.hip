@@ -518,6 +518,143 @@ smplx_lbs_fused_kernel(const SmplxModelDev m, const SmplxFwdArgs a, int n_vr, in
     lf_sfor<0, 8>([&](auto PP) { skin_pair(std::integral_constant<int, (PP >> 1)>{}, std::integral_constant<int, (PP & 1)>{}, accp, gp); });
 }
 
+// ------------------------------------------------------------------------------------------------
+// Second cut of the fused contraction + skinning kernel (round 4; the default).  What the first cut's profile said
+// (profiles/r03_lbs_fused_ablation.txt, PMC): every unit at a quarter of its rate, WRITE_SIZE twice the vertex bytes, and an
+// intermittent wrong vertex in one build of it (hand-counted asm loads with loop-carried destinations).  Changes:
+//   * ORIENTATION: rows = bodies, columns = vertices (A = coefficient rows from LDS, B = direction fragments from L2 -- the same
+//     dirs_frag buffer: A and B fragments of v_mfma_f32_16x16x32 share their (16 x 8-k) lane layout).  A lane then holds (x, y, z)
+//     of ONE vertex (lr) for 8 bodies, so (i) its skinning operands (bone ids, weights, template) are loaded once per group and
+//     reused for the 8 bodies, and (ii) a store instruction writes, per body, the 16 consecutive vertices of the group: 192
+//     contiguous bytes per 16-lane group instead of 12-byte pieces to 32 different bodies -- lines complete within one or two
+//     back-to-back instructions instead of being evicted half-written;
+//   * K = 224 (7 steps): the eighth step (jaw / eye features: identically zero without face poses) is not multiplied;
+//   * SIXTEEN waves per workgroup (128 registers each) instead of eight: latency is covered by occupancy, not by a hand-counted
+//     register ring -- every load is a plain load the compiler counts (no inline-asm destinations, nothing loop-carried in
+//     flight), the next K step's fragments are requested before the current step's MFMAs.
+// Same arithmetic per product as the first cut and the two-kernel path (hi.hi + lo.hi + hi.lo on the bf16 pipe, fp32 skinning).
+constexpr int T_BB = 32, T_KS = 7, T_NW = 16, T_CROW = T_KS * 128 + 16, T_MAXJ = 55;
+
+__global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxModelDev m, const SmplxFwdArgs a, int n_vr, int groups_per_vr) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
+    float* bones = (float*)lf_smem;                                               // [T_BB][J][12]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, g4 = lane >> 4;
+    const int vr = blockIdx.x % n_vr, bg = blockIdx.x / n_vr;
+    const int b0 = bg * T_BB, J12 = m.J * 12;
+    unsigned char* coefs = lf_smem + T_BB * J12 * 4;                              // [T_BB][T_CROW]: 7 K steps x (4 x [8 hi | 8 lo])
+    float* Ps = (float*)(coefs + T_BB * T_CROW);                                  // [T_BB][16]: post transform [12] | translation [3]
+    {   // bone transforms, coefficient rows, post transforms of the 32 bodies (rows past the last body: clamped duplicates, never
+        // stored); every load of a thread is issued before its first LDS write
+        constexpr int NT = 64 * T_NW, BIT = (T_BB * T_MAXJ * 3 + NT - 1) / NT, CCH = T_KS * 8, CIT = (T_BB * CCH + NT - 1) / NT;
+        const int nb = min(T_BB, a.n - b0), n4 = nb * m.J * 3, tot = T_BB * m.J * 3;
+        const float4* src = (const float4*)(a.A + (size_t)b0 * J12);
+        float4 tb[BIT];
+        u32x4 tc[CIT];
+#pragma unroll
+        for (int k = 0; k < BIT; ++k) { const int i = tid + k * NT; tb[k] = src[i < n4 ? i : i % n4]; }
+#pragma unroll
+        for (int k = 0; k < CIT; ++k) {
+            const int i = min(tid + k * NT, T_BB * CCH - 1), bb = i / CCH, c16 = i - bb * CCH, bsrc = min(b0 + bb, a.n - 1);
+            tc[k] = *(const u32x4*)((const unsigned char*)(a.coef + (size_t)bsrc * m.ncoef) + c16 * 16);
+        }
+        float pv = 0.f;
+        if (tid < T_BB * 16) {
+            const int bb = tid >> 4, e = tid & 15, bsrc = min(b0 + bb, a.n - 1);
+            if (e < 12) pv = a.post ? a.post[(size_t)bsrc * 12 + e] : ((e == 0 || e == 5 || e == 10) ? 1.f : 0.f);
+            else if (e < 15) pv = a.transl ? a.transl[(size_t)bsrc * 3 + (e - 12)] : 0.f;
+        }
+#pragma unroll
+        for (int k = 0; k < BIT; ++k) { const int i = tid + k * NT; if (i < tot) ((float4*)bones)[i] = tb[k]; }
+#pragma unroll
+        for (int k = 0; k < CIT; ++k) {
+            const int i = tid + k * NT;
+            if (i < T_BB * CCH) { const int bb = i / CCH, c16 = i - bb * CCH; *(u32x4*)(coefs + bb * T_CROW + c16 * 16) = tc[k]; }
+        }
+        if (tid < T_BB * 16) Ps[tid] = pv;
+    }
+    __syncthreads();
+    const int ngroups = (m.V + 15) >> 4;
+    const int gend = min(ngroups, (vr + 1) * groups_per_vr);
+    const unsigned char* dbase = (const unsigned char*)m.dirs_frag + (size_t)lane * 16;
+    // fragment block of (group, K step, component c, plane): ((g * 8 + ks) * 3 + c) * 2 + plane, 1 KiB each (K = 256 layout)
+    auto frag = [&](int g, int ks, int i) { return *(const u32x4*)(dbase + ((size_t)g * 8 + ks) * 6144 + i * 1024); };
+    const unsigned char* ca = coefs + lr * T_CROW + g4 * 32;                       // this lane's A rows: bodies lr and 16 + lr
+    for (int g = vr * groups_per_vr + wave; g < gend; g += T_NW) {
+        // ------------------------------------------------ contraction: acc[c][s][r] = v_posed component c of vertex 16 g + lr
+        // for body s * 16 + 4 g4 + r
+        f32x4 acc[3][2];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { acc[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+        u32x4 cur[6];
+        // this lane's vertex: bone ids (6 bits each, + joint-vertex slot), weights, template (requested under the contraction)
+        const int v = g * 16 + lr;
+        const uint32_t id = m.skin_idx8[v];
+        const float4 w4 = *(const float4*)(m.skin_w4 + (size_t)v * 4);
+        const float tx = m.v_template[(size_t)v * 3], ty = m.v_template[(size_t)v * 3 + 1], tz = m.v_template[(size_t)v * 3 + 2];
+#pragma unroll
+        for (int ks = 0; ks < T_KS; ++ks) {
+            // (one fragment set: with four waves per SIMD the other waves' MFMAs run under this wave's L2 round trip; a second
+            //  set for explicit double-buffering does not fit 128 registers beside the skinning)
+#pragma unroll
+            for (int i = 0; i < 6; ++i) cur[i] = frag(g, ks, i);
+            const bf16x8 ah0 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + ks * 128)), al0 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + ks * 128 + 16));
+            const bf16x8 ah1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + 16 * T_CROW + ks * 128));
+            const bf16x8 al1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + 16 * T_CROW + ks * 128 + 16));
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const bf16x8 dh = __builtin_bit_cast(bf16x8, cur[2 * c]), dl = __builtin_bit_cast(bf16x8, cur[2 * c + 1]);
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, dh, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, dh, acc[c][1], 0, 0, 0);
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, dh, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al1, dh, acc[c][1], 0, 0, 0);
+                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, dl, acc[c][0], 0, 0, 0);
+                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, dl, acc[c][1], 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);               // keep the K steps in order: a hoisted load of step ks + 1 would need a second set
+        }
+        // ------------------------------------------------ skinning of the lane's vertex for its 8 bodies
+        const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
+        const bool vok = v < m.V;
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int bl = s * 16 + g4 * 4 + r;
+                const bool bok = b0 + bl < a.n;
+                const float x = acc[0][s][r] + tx, y = acc[1][s][r] + ty, z = acc[2][s][r] + tz;
+                if (a.vp_side && bok && (id >> 24)) {        // joint vertex: slot + 1 in the top byte (0 = none, padding rows too)
+                    float* q = a.vp_side + ((size_t)(b0 + bl) * m.n_jv + ((id >> 24) - 1)) * 3;
+                    q[0] = x; q[1] = y; q[2] = z;
+                }
+                const float* Ab = bones + bl * J12;
+                float T[12];
+#pragma unroll
+                for (int e = 0; e < 12; ++e) T[e] = 0.f;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const float4* Ak = (const float4*)(Ab + ((id >> (6 * k)) & 0x3fu) * 12);
+                    const float4 r0 = Ak[0], r1 = Ak[1], r2 = Ak[2];
+                    T[0] = fmaf(wv[k], r0.x, T[0]); T[1] = fmaf(wv[k], r0.y, T[1]); T[2] = fmaf(wv[k], r0.z, T[2]); T[3] = fmaf(wv[k], r0.w, T[3]);
+                    T[4] = fmaf(wv[k], r1.x, T[4]); T[5] = fmaf(wv[k], r1.y, T[5]); T[6] = fmaf(wv[k], r1.z, T[6]); T[7] = fmaf(wv[k], r1.w, T[7]);
+                    T[8] = fmaf(wv[k], r2.x, T[8]); T[9] = fmaf(wv[k], r2.y, T[9]); T[10] = fmaf(wv[k], r2.z, T[10]); T[11] = fmaf(wv[k], r2.w, T[11]);
+                }
+                const float* Pb = Ps + bl * 16;
+                float q[3];
+                q[0] = T[0] * x + T[1] * y + T[2] * z + T[3] + Pb[12];
+                q[1] = T[4] * x + T[5] * y + T[6] * z + T[7] + Pb[13];
+                q[2] = T[8] * x + T[9] * y + T[10] * z + T[11] + Pb[14];
+                if (a.post) apply_post(Pb, q);
+                if (bok && vok) {
+                    float* dst = a.vertices + ((size_t)(b0 + bl) * m.V + v) * 3;
+                    dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2];
+                }
+                __builtin_amdgcn_sched_barrier(0);           // one body at a time: the 8 bodies' bone rows all in flight spill
+            }
+    }
+}
+
 // one block per body: 55 chain joints, 21 vertex picks, 51 barycentric landmarks, projection
 __global__ void __launch_bounds__(128) smplx_joints_kernel(const SmplxModelDev m, const SmplxFwdArgs a) {
     __shared__ float As[SKIN_MAXJ * 12];
@@ -684,33 +821,39 @@ hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, h
 }
 
 bool ap_smplx_lbs_fused_supported(const SmplxModelDev& m) {
+    static_assert(T_BB == LF_BB && T_MAXJ == LF_MAXJ, "both cuts share the body-group size");
     return m.K == 4 && m.J <= LF_MAXJ && m.dirs_frag != nullptr && m.skin_idx8 != nullptr && m.coef_split && m.ncoef * 4 >= LF_KS * 128;
 }
 
 size_t ap_smplx_dirs_frag_bytes(int V) { return (size_t)((V + 15) / 16) * LF_KS * 6 * 1024; }
 
-hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, hipStream_t st) {
-    static bool attr_set[AP_MAX_DEVICES] = {};
+hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, int cut, hipStream_t st) {
+    static bool attr_set[AP_MAX_DEVICES][2] = {};
     if (!ap_smplx_lbs_fused_supported(m)) return hipErrorInvalidValue;
-    const int lds = LF_BB * m.J * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64;
+    const bool second = cut != 1;                            // 2 (default): smplx_lbs_tail_kernel; 1: the first cut (kept for A/B)
+    const int nw = second ? T_NW : LF_NW;
+    const int lds = second ? T_BB * m.J * 12 * 4 + T_BB * T_CROW + T_BB * 64 : LF_BB * m.J * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64;
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
-    if (!attr_set[dev]) {
-        e = hipFuncSetAttribute((const void*)smplx_lbs_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LF_BB * LF_MAXJ * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64);
+    if (!attr_set[dev][second]) {
+        e = second ? hipFuncSetAttribute((const void*)smplx_lbs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         T_BB * T_MAXJ * 12 * 4 + T_BB * T_CROW + T_BB * 64)
+                   : hipFuncSetAttribute((const void*)smplx_lbs_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                         LF_BB * LF_MAXJ * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64);
         if (e != hipSuccess) return e;
-        attr_set[dev] = true;
+        attr_set[dev][second] = true;
     }
-    // body groups x vertex ranges ~ one workgroup per CU; a vertex range is a whole number of rounds of the eight waves;
-    // 8 | n_vr keeps the blocks of one range on one XCD (block b runs on XCD b % 8)
+    // body groups x vertex ranges ~ one workgroup per CU; 8 | n_vr keeps the blocks of one range on one XCD (block b runs on XCD
+    // b % 8), so its direction rows are fetched from HBM once and served to the other body groups from that XCD's L2
     const int bgs = (a.n + LF_BB - 1) / LF_BB, ngroups = (m.V + 15) / 16;
     int n_vr = (n_cu + bgs - 1) / bgs;
     n_vr = n_vr >= 8 ? (n_vr / 8) * 8 : n_vr;
-    n_vr = n_vr < 1 ? 1 : (n_vr > (ngroups + LF_NW - 1) / LF_NW ? (ngroups + LF_NW - 1) / LF_NW : n_vr);
+    n_vr = n_vr < 1 ? 1 : (n_vr > (ngroups + nw - 1) / nw ? (ngroups + nw - 1) / nw : n_vr);
     const int gpv = (ngroups + n_vr - 1) / n_vr;
     n_vr = (ngroups + gpv - 1) / gpv;
-    hipLaunchKernelGGL(smplx_lbs_fused_kernel, dim3(bgs * n_vr), dim3(64 * LF_NW), lds, st, m, a, n_vr, gpv);
+    if (second) hipLaunchKernelGGL(smplx_lbs_tail_kernel, dim3(bgs * n_vr), dim3(64 * T_NW), lds, st, m, a, n_vr, gpv);
+    else hipLaunchKernelGGL(smplx_lbs_fused_kernel, dim3(bgs * n_vr), dim3(64 * LF_NW), lds, st, m, a, n_vr, gpv);
     return hipGetLastError();
 }
 

@@ -285,7 +285,7 @@ constexpr int FROWS = 15;                                  // input rows of a st
 __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                         int n_split, const bf16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
-                                                        const float* __restrict__ shift, bf16_t* __restrict__ y) {
+                                                        const float* __restrict__ shift, bf16_t* __restrict__ y, int* range_flag) {
     constexpr int WBYTES = 64 * SWLD * 2, PBYTES = (FROWS * FPW * 4 + 32) * 2;
     constexpr int VBYTES = 2 * SO * SC * 2;
     constexpr int PVBYTES = PBYTES > VBYTES ? PBYTES : VBYTES;
@@ -415,6 +415,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         }
     }
     __syncthreads();
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h): the pooled maxima carry an overflow
     for (int i = tid; i < 2 * PO * 8; i += 448) {           // (pr, px, 8-channel chunk)
         if (STEM_ABLATE & 16) break;
         const int c8 = i & 7, t = i >> 3, px = t % PO, pr = t / PO;
@@ -435,9 +436,11 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         u32x4 o;
         o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
         o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
+        ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);
         if (STEM_ABLATE & 8) asm volatile("" ::"v"(o)); else
         *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
     }
+    ap_rng_flush(range_flag, rng);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -600,7 +603,7 @@ __global__ void __launch_bounds__(448) stem_pool_split_kernel(const float* __res
 
 // ------------------------------------------------------------------------------------------------
 template <typename T>
-__global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int total) {
+__global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T* __restrict__ y, int total, int* range_flag) {
     constexpr int EPC = 16 / sizeof(T), CPP = SC / EPC;          // chunks per pixel
     const int idx = blockIdx.x * 256 + threadIdx.x;
     if (idx >= total) return;
@@ -634,6 +637,9 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T
     if constexpr (sizeof(T) == 2) {
         o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
         o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
+        uint32_t rng = 0u;                                   // fp16 range sentinel (ap_common.h): the maxima carry the stem's overflow
+        ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);
+        ap_rng_flush(range_flag, rng);
     } else {
         o.x = __builtin_bit_cast(uint32_t, m[0]); o.y = __builtin_bit_cast(uint32_t, m[1]);
         o.z = __builtin_bit_cast(uint32_t, m[2]); o.w = __builtin_bit_cast(uint32_t, m[3]);
@@ -845,9 +851,9 @@ hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int 
 #endif
 
 hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
-                                const float* shift, void* y_pooled, int n_img, hipStream_t st) {
+                                const float* shift, void* y_pooled, int n_img, int* range_flag, hipStream_t st) {
     hipLaunchKernelGGL(stem_pool_kernel, dim3(PO / 2, n_img), dim3(448), 0, st, x0, x1, n_split,
-                       (const bf16_t*)w_packed, scale, shift, (bf16_t*)y_pooled);
+                       (const bf16_t*)w_packed, scale, shift, (bf16_t*)y_pooled, range_flag);
     return hipGetLastError();
 }
 
@@ -871,11 +877,11 @@ hipError_t ap_launch_stem_pool_split(const float* x0, const float* x1, int n_spl
 }
 #endif
 
-hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStream_t st) {
+hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, int* range_flag, hipStream_t st) {
     if (kind == K_BF16) {
         const int total = n_img * PO * PO * (SC / 8);
         hipLaunchKernelGGL(maxpool_kernel<bf16_t>, dim3((total + 255) / 256), dim3(256), 0, st, (const bf16_t*)x,
-                           (bf16_t*)y, total);
+                           (bf16_t*)y, total, range_flag);
     }
 #ifndef AP_F16                                               // (the fp16 set carries the 16-bit kind only)
     else if (kind == K_SPLIT) {
@@ -885,7 +891,7 @@ hipError_t ap_launch_maxpool(const void* x, void* y, int n_img, int kind, hipStr
     } else if (kind == K_F32) {
         const int total = n_img * PO * PO * (SC / 4);
         hipLaunchKernelGGL(maxpool_kernel<float>, dim3((total + 255) / 256), dim3(256), 0, st, (const float*)x,
-                           (float*)y, total);
+                           (float*)y, total, range_flag);
     }
 #endif
     else return hipErrorInvalidValue;

@@ -200,6 +200,10 @@ int ap_conv_pair_ds_nhwc(int precision, const void* t2, const void* x, const voi
  * Results are identical (bitwise) for every setting except 14 / the automatic choice on those layers: the slab kernel sums
  * the K range channel-chunk-outer, tap-inner instead of tap-outer, i.e. it agrees to fp32 re-association. */
 int ap_set_conv_config(int cfg);
+/* Tuning/testing knob (process-wide, one atomic word) of the fused pair kernel on the layer3 shapes (P = 256): 16-pixel groups
+ * per wave -- 1: 16 pixels per wave, two workgroups per CU; 2: 32 pixels per wave (every weight fragment read from LDS feeds two
+ * MFMAs, 32 MFMAs per barrier step), one workgroup per CU; -1: the library's choice.  Results are bit-identical. */
+int ap_set_pair_groups(int groups);
 /* Profiling aid: device buffer of 160 uint64 receiving per-phase cycle stamps of workgroup 0 of the pipelined
  * convolution kernel (2 waves x 8 K steps x 10 stamps); NULL (default) disables it. */
 int ap_debug_set_trace(void* device_buf_160_u64);
@@ -237,6 +241,11 @@ int ap_net_set_fuse_ds(ap_net* h, int on);
 /* bf16 and bf16x2 modes: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool
  * kernels (bit-identical results; kept for A/B measurement). */
 int ap_net_set_fuse_stem(ap_net* h, int on);
+/* 16-bit modes: on = 1 computes AvgPool2d(7) + view (model_copenet.py:173-175) in the epilogue of the last convolution
+ * (layer4.2 conv3 + bn3 + identity + ReLU, :38-47): the 7 x 7 x 2048 block output is never written and no pooling kernel runs;
+ * on = 0 (default: measured neutral to slightly slower inside the two-stream trunk) writes it and runs the pooling kernel.
+ * Bit-identical features (same summands, same summation order). */
+int ap_net_set_fuse_pool(ap_net* h, int on);
 /* 16-bit modes: on = 1 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
  * intermediates never leave the CU; bottleneck2.hip: weights resident in LDS, x in registers), on = 0 as its three
  * (two + folded-downsample) convolutions.  Both give the same bits (parity-tested). */
