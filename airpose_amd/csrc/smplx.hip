@@ -534,6 +534,11 @@ smplx_lbs_fused_kernel(const SmplxModelDev m, const SmplxFwdArgs a, int n_vr, in
 //     flight), the next K step's fragments are requested before the current step's MFMAs.
 // Same arithmetic per product as the first cut and the two-kernel path (hi.hi + lo.hi + hi.lo on the bf16 pipe, fp32 skinning).
 constexpr int T_BB = 32, T_KS = 7, T_NW = 16, T_CROW = T_KS * 128 + 16, T_MAXJ = 55;
+// Timing-only builds (results WRONG, times valid): -DT_ABLATE=<bits>: 1 no vertex stores | 2 no bone gathers / blend | 4 direction
+// fragments loaded once per group instead of once per K step | 8 no MFMAs | 16 no prologue copies
+#ifndef T_ABLATE
+#define T_ABLATE 0
+#endif
 
 __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxModelDev m, const SmplxFwdArgs a, int n_vr, int groups_per_vr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
@@ -597,14 +602,17 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
         for (int ks = 0; ks < T_KS; ++ks) {
             // (one fragment set: with four waves per SIMD the other waves' MFMAs run under this wave's L2 round trip; a second
             //  set for explicit double-buffering does not fit 128 registers beside the skinning)
+            if (!(T_ABLATE & 4) || ks == 0) {
 #pragma unroll
-            for (int i = 0; i < 6; ++i) cur[i] = frag(g, ks, i);
+                for (int i = 0; i < 6; ++i) cur[i] = frag(g, ks, i);
+            }
             const bf16x8 ah0 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + ks * 128)), al0 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + ks * 128 + 16));
             const bf16x8 ah1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + 16 * T_CROW + ks * 128));
             const bf16x8 al1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + 16 * T_CROW + ks * 128 + 16));
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const bf16x8 dh = __builtin_bit_cast(bf16x8, cur[2 * c]), dl = __builtin_bit_cast(bf16x8, cur[2 * c + 1]);
+                if (T_ABLATE & 8) { asm volatile("" : "+v"(acc[c][0]), "+v"(acc[c][1]) : "v"(dh), "v"(dl), "v"(ah0), "v"(al0), "v"(ah1), "v"(al1)); continue; }
                 acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, dh, acc[c][0], 0, 0, 0);
                 acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, dh, acc[c][1], 0, 0, 0);
                 acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al0, dh, acc[c][0], 0, 0, 0);
@@ -631,9 +639,9 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 const float* Ab = bones + bl * J12;
                 float T[12];
 #pragma unroll
-                for (int e = 0; e < 12; ++e) T[e] = 0.f;
+                for (int e = 0; e < 12; ++e) T[e] = (T_ABLATE & 2) ? wv[e & 3] : 0.f;
 #pragma unroll
-                for (int k = 0; k < 4; ++k) {
+                for (int k = 0; k < ((T_ABLATE & 2) ? 0 : 4); ++k) {
                     const float4* Ak = (const float4*)(Ab + ((id >> (6 * k)) & 0x3fu) * 12);
                     const float4 r0 = Ak[0], r1 = Ak[1], r2 = Ak[2];
                     T[0] = fmaf(wv[k], r0.x, T[0]); T[1] = fmaf(wv[k], r0.y, T[1]); T[2] = fmaf(wv[k], r0.z, T[2]); T[3] = fmaf(wv[k], r0.w, T[3]);
@@ -646,7 +654,8 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 q[1] = T[4] * x + T[5] * y + T[6] * z + T[7] + Pb[13];
                 q[2] = T[8] * x + T[9] * y + T[10] * z + T[11] + Pb[14];
                 if (a.post) apply_post(Pb, q);
-                if (bok && vok) {
+                if (T_ABLATE & 1) asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]));
+                else if (bok && vok) {
                     float* dst = a.vertices + ((size_t)(b0 + bl) * m.V + v) * 3;
                     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2];
                 }

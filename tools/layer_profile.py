@@ -77,6 +77,8 @@ for si, (nm, M, N, K, inel, res) in enumerate(shapes):
             nm = nm + "+" + shapes[nx][0].split(".", 2)[0][1:] + "." + shapes[nx][0].split(".")[1] + ".c1"
     else:
         cfg = r[0].split("<")[1].split(">")[0].replace("unsigned short", "bf16") if "<" in r[0] else r[0].split("::")[-1].split("(")[0]
+        if "conv_lean_kernel" in r[0]:
+            cfg = "conv_lean_kernel" + ("<pool>" if "<true>" in r[0] else "")
     tot += dur
     bylayer[nm[:2]] = bylayer.get(nm[:2], 0) + dur
     print("%-16s M=%7d N=%4d K=%4d %-22s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
