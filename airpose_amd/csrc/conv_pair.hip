@@ -239,6 +239,21 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
         }
         // two values per instruction (v_pk_fma_f32 / v_pk_add_f32: the same IEEE fma / add per component as the scalar
         // epilogue of the stand-alone kernels), one v_cvt_pk + one packed integer max per pair
+#ifdef PR_SCALAR_EPI                                         // A/B build: one v_fma_f32 / v_add_f32 per value instead of the packed forms
+        f32x2 v0, v1, v2, v3;
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v0.x) : "v"(lo.x), "v"(s0.x), "v"(h0.x)); asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v0.y) : "v"(lo.y), "v"(s0.y), "v"(h0.y));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v1.x) : "v"(lo.z), "v"(s0.z), "v"(h0.z)); asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v1.y) : "v"(lo.w), "v"(s0.w), "v"(h0.w));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v2.x) : "v"(hi.x), "v"(s1.x), "v"(h1.x)); asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v2.y) : "v"(hi.y), "v"(s1.y), "v"(h1.y));
+        asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v3.x) : "v"(hi.z), "v"(s1.z), "v"(h1.z)); asm("v_fma_f32 %0, %1, %2, %3" : "=v"(v3.y) : "v"(hi.w), "v"(s1.w), "v"(h1.w));
+        if (res) {
+            const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
+            float a_, b_;
+            unpack_bf16x2(r0, a_, b_); asm("v_add_f32 %0, %0, %1" : "+v"(v0.x) : "v"(a_)); asm("v_add_f32 %0, %0, %1" : "+v"(v0.y) : "v"(b_));
+            unpack_bf16x2(r1, a_, b_); asm("v_add_f32 %0, %0, %1" : "+v"(v1.x) : "v"(a_)); asm("v_add_f32 %0, %0, %1" : "+v"(v1.y) : "v"(b_));
+            unpack_bf16x2(r2, a_, b_); asm("v_add_f32 %0, %0, %1" : "+v"(v2.x) : "v"(a_)); asm("v_add_f32 %0, %0, %1" : "+v"(v2.y) : "v"(b_));
+            unpack_bf16x2(r3, a_, b_); asm("v_add_f32 %0, %0, %1" : "+v"(v3.x) : "v"(a_)); asm("v_add_f32 %0, %0, %1" : "+v"(v3.y) : "v"(b_));
+        }
+#else
         f32x2 v0 = __builtin_elementwise_fma(lo.xy, s0.xy, h0.xy), v1 = __builtin_elementwise_fma(lo.zw, s0.zw, h0.zw);
         f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
         if (res) {
@@ -248,6 +263,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
             { float a_, b_; unpack_bf16x2(r2, a_, b_); v2 += f32x2{a_, b_}; }
             { float a_, b_; unpack_bf16x2(r3, a_, b_); v3 += f32x2{a_, b_}; }
         }
+#endif
         u32x4 o;
         o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));
         o.z = relu_pk_bf16(cvt_pk_bf16(v2.x, v2.y)); o.w = relu_pk_bf16(cvt_pk_bf16(v3.x, v3.y));

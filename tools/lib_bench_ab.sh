@@ -1,4 +1,5 @@
 #!/bin/bash
-# whole-bench A/B of two library builds on one box, interleaved: tools/lib_bench_ab.sh <suffix of the alternative build> [reps]
+# whole-bench A/B of library builds, interleaved on one box: tools/lib_bench_ab.sh "<suffixes, '-' = product>" [reps] [extra bench args]
 cd ${GRAFT_REPO_ROOT:-/root/repo}
-for rep in $(seq 1 ${2:-3}); do for suf in "$1" ""; do L=$PWD/airpose_amd/libairpose_hip$suf.so; echo -n "lib${suf:-(product)} r$rep: "; AIRPOSE_HIP_LIB=$L python bench.py --steps 20 --warmup 5 --cpu-sample 0 --parity-steps 0 --repeat-blocks 2 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stage_ms_per_step']; print('%.0f pairs/s  %.3f ms/step  conv %.3f ms  frac %.4f  stem %.3f  tail %.3f' % (d['value'], d['ms_per_step'], s['conv_stack'], d['roofline']['frac'], s['stem_maxpool'], s['smplx_prep']+s['smplx_blend_gemm']+s['smplx_skin']+s['smplx_joints']))"; done; done
+SUFS=$1; REPS=${2:-3}; shift 2
+for rep in $(seq 1 $REPS); do for suf in $SUFS; do s=$suf; [ "$suf" = "-" ] && s=""; echo -n "lib${s:-(product)} r$rep: "; AIRPOSE_HIP_LIB=$PWD/airpose_amd/libairpose_hip$s.so python bench.py --steps 20 --warmup 5 --cpu-sample 0 --parity-steps 0 --b64 0 --repeat-blocks 2 "$@" 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['stage_ms_per_step']; print('%.0f pairs/s  %.3f ms/step  conv %.3f ms  frac %.4f' % (d['repeat_blocks']['median'], d['ms_per_step'], s['conv_stack'], d['roofline']['frac']))"; done; done
