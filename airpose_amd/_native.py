@@ -66,6 +66,7 @@ SIGNATURES = {
     "ap_net_set_fuse_ief": (_i, [_vp, _i]),
     "ap_net_set_fuse_stem": (_i, [_vp, _i]),
     "ap_net_set_fuse_pool": (_i, [_vp, _i]),
+    "ap_net_set_tiled": (_i, [_vp, _i]),
     "ap_net_set_fuse_ds": (_i, [_vp, _i]),
     "ap_net_set_fuse_block": (_i, [_vp, _i]),
     "ap_net_set_fuse_pair": (_i, [_vp, _i]),

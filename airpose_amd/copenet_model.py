@@ -331,6 +331,10 @@ class copenet(nn.Module):
         """bf16 / f16: AvgPool2d(7) in the epilogue of the last convolution (default) or as its own kernel."""
         self._set_knob("ap_net_set_fuse_pool", on)
 
+    def set_tiled(self, on):
+        """bf16 / f16: pair-kernel-only intermediates in the pair kernel's fragment order (default) or NHWC; same bits."""
+        self._set_knob("ap_net_set_tiled", on)
+
     def set_fuse_stem(self, on):
         self._set_knob("ap_net_set_fuse_stem", on)
 

@@ -85,6 +85,20 @@ __device__ __forceinline__ void ap_rng_note_signed(uint32_t&, uint32_t) {}
 __device__ __forceinline__ void ap_rng_flush(int*, uint32_t) {}
 #endif
 
+// Fragment-tiled activation layout [M/16][C/8][16 pixels][8 channels] of 16-bit elements (the t2 / identity / block-output tensors
+// between a convolution and the fused pair kernel, conv_pair.hip): offset, in elements, of the 8-channel group ch..ch+7 of pixel m.
+// The pair kernel's lane (pixel lr, channel group g4) pieces of a wave instruction then form one contiguous KiB.
+__device__ __forceinline__ size_t ap_tiled_off(size_t m, int ch, int C) {
+    return ((m >> 4) * (size_t)(C >> 3) + (size_t)(ch >> 3)) * 128 + (m & 15) * 8;
+}
+// item q of an LDS-staged epilogue (CPR 8-channel chunks per tile row) -> (pixel row px, chunk cc).  NHWC output: consecutive
+// threads walk the chunks of a row (contiguous 16-byte pieces); tiled output: consecutive threads walk 16 pixels of one chunk
+// (contiguous 16-byte pieces of a 256-byte micro-tile)
+__device__ __forceinline__ void ap_epi_item(int q, int cpr, bool tiled, int& px, int& cc) {
+    if (tiled) { px = (q & 15) | ((q / (16 * cpr)) << 4); cc = (q >> 4) % cpr; }
+    else { px = q / cpr; cc = q - px * cpr; }
+}
+
 // two fp32 -> one dword of two bf16, round to nearest even.  One v_cvt_pk_bf16_f32 for the PAIR: written as two (__bf16) casts
 // and an or, hipcc emits the same instruction once per VALUE (second source a dummy) plus a shift / or to merge them -- three
 // VALU instructions per pair in every epilogue of the trunk instead of one (identical results: it is the same conversion).

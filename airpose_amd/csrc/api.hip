@@ -208,6 +208,8 @@ hipError_t dispatch_conv(ConvArgs& a, int prec /* AP_PREC_* */, hipStream_t st) 
         else if (mt128 * nt64 >= 128) cfg = a.x2 ? (mt128 * nt128 >= 64 ? 11 : 100) : 12;
         else cfg = 100;
     }
+    // the fragment-tiled output exists in the LDS-staged 16-bit epilogues only (trunk_chunk asks for it in the automatic modes)
+    if (a.y_tiled && (is_bf16 != 1 || cfg == 17 || (cfg >= 4 && cfg <= 7) || (a.Cout & 7))) return hipErrorInvalidValue;
     if (cfg == 100) return H16(prec, ap_launch_conv)(a, is_bf16, st);
     hipError_t e = zero_line(&a.zero);
     if (e != hipSuccess) return e;
@@ -247,6 +249,7 @@ struct ap_net {
     double fold_bar = 1e-5;        // (ap_net_set_fold_bar: test aid)
     bool fuse_ds = true;           // first block of a stage: downsample conv folded into conv3 as a second K segment
     bool fuse_block = true;        // 16-bit modes: each layer1 bottleneck as one kernel (bottleneck2.hip); off: separate convs
+    bool tiled = true;             // 16-bit modes: tensors only the fused pair kernel reads (t2, identity) in its fragment-tiled layout
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     bool fuse_pool = false;        // 16-bit modes: AvgPool2d(7) in the epilogue of layer4.2 conv3 (conv_lean.hip POOL variant; bit-identical).
@@ -427,9 +430,10 @@ int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const
 }
 
 int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int prec,
-             hipStream_t st, int* rflag = nullptr) {
+             hipStream_t st, int* rflag = nullptr, int y_tiled = 0) {
     ConvArgs a{};
     a.range_flag = rflag;
+    a.y_tiled = y_tiled;
     a.x = x; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = res; a.y = y;
     a.N = N; a.H = H; a.W = W; a.Cin = L.cin;
     a.Ho = (H + 2 * L.pad - L.k) / L.stride + 1;
@@ -839,6 +843,15 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     int blk = 0;
     bool t1_ready = false;                                   // ws_t1 already holds this block's conv1 output (fused pair)
     bool pooled = false;                                     // the last convolution wrote the pooled features itself
+    // Fragment-tiled intermediates (ap_common.h: ap_tiled_off): a tensor whose ONLY reader is the fused pair kernel is stored
+    // as [M/16][C/8][16 pixels][8 channels], the order the pair kernel's lanes fetch it in -- t2 of every pair block, and a
+    // pair block's output when the next block is an identity pair block that also got its conv1 from this kernel.  Same
+    // values, same arithmetic: the features are bit-identical with the layout off (ap_net_set_tiled).
+    const bool tiling = bf && h->tiled && g_conv_mode.load(std::memory_order_relaxed) < 0;
+    auto is_pair = [&](const ap_net::Block& X) {
+        return bf && h->fuse_pair && X.pair_p && &X != &h->blocks.back() && (!X.has_down || h->fuse_ds);
+    };
+    bool cur_tiled = false;                                  // layout of `cur`
     for (auto& B : h->blocks) {
         if (signal_at >= 2 && blk++ == signal_at - 2) HIP_TRY(hipEventRecord(h->ev_skew, st));
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
@@ -851,8 +864,10 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         }
         if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, h->range_flag))) return rc;
         t1_ready = false;
-        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, h->range_flag))) return rc;
-        if (bf && h->fuse_pair && B.pair_p && &B != &h->blocks.back() && (!B.has_down || h->fuse_ds)) {
+        const bool pair = is_pair(B);
+        const int t2_tiled = pair && tiling;
+        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, h->range_flag, t2_tiled))) return rc;
+        if (pair) {
             // conv3 (+ identity | + folded downsample, ReLU) AND -- where the pair carries it -- the next block's conv1 in one
             // kernel: the block output is written once and not read back for conv1 (model_copenet.py:38-45 of this block,
             // :29-31 of the next)
@@ -864,6 +879,9 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.s1 = Nx.c1.scale.as<float>(); a.h1 = Nx.c1.shift.as<float>();
             a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg; a.range_flag = h->range_flag;
             a.groups = pair_groups(B.pair_p);
+            a.t2_tiled = t2_tiled; a.res_tiled = cur_tiled;
+            a.out_tiled = t2_tiled && B.pair_n1 > 0 && is_pair(Nx) && !Nx.has_down;
+            cur_tiled = a.out_tiled != 0;
             if (B.has_down) { a.x2 = cur; a.Ho = a.Wo = Ho; a.H2 = a.W2 = H; a.stride2 = L3.stride2; }
             else a.res = cur;
             HIP_TRY(H16(prec, ap_launch_conv_pair)(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
@@ -1467,6 +1485,12 @@ int ap_net_set_fuse_ief(ap_net* h, int on) {
 int ap_net_set_fuse_pool(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_pool = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_tiled(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->tiled = on != 0;
     return AP_OK;
 }
 

@@ -238,7 +238,8 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
     uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the other kinds
     const uint32_t smask = p.relu ? 0xffffffffu : 0x7fff7fffu;
     for (int q = tid; q < BM * CPR; q += 256) {
-        const int px = q / CPR, cc = q - px * CPR;
+        int px, cc;
+        ap_epi_item(q, CPR, KIND == K_BF16 && p.y_tiled != 0, px, cc);
         const int m = bm * BM + px, ch = bn * BN + cc * EPO;
         if (m >= p.M || ch >= p.Cout) continue;
         const float* src = ct + px * CLD + cc * EPO;
@@ -260,7 +261,7 @@ __global__ void __launch_bounds__(256) conv_igemm_kernel(const ConvArgs p) {
             o.x = pack_bf16x2(a.x, a.y); o.y = pack_bf16x2(a.z, a.w);
             o.z = pack_bf16x2(b.x, b.y); o.w = pack_bf16x2(b.z, b.w);
             ap_rng_note(rng, o.x & smask); ap_rng_note(rng, o.y & smask); ap_rng_note(rng, o.z & smask); ap_rng_note(rng, o.w & smask);
-            *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
+            *(u32x4*)(yg + (p.y_tiled ? ap_tiled_off((size_t)m, ch, p.Cout) : (size_t)m * p.ldy + ch)) = o;
         } else if constexpr (KIND == K_SPLIT) {
             float v[8];
 #pragma unroll

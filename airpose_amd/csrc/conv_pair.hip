@@ -160,19 +160,29 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
         const int m = blockIdx.x * (16 * NW * PG) + (wave * PG + pg) * 16 + lr;
         mok[pg] = m < p.M;
         mc[pg] = mok[pg] ? (size_t)m : (size_t)(p.M - 1);   // ragged tail: loads clamped, stores masked
-        t2p[pg] = (const unsigned char*)p.t2 + (mc[pg] * P + g4 * 8) * 2;
-        resp[pg] = (const unsigned char*)p.res + (mc[pg] * C3 + g4 * 8) * 2;
+        // NHWC rows, or (p.*_tiled) the fragment-tiled layout [M/16][C/8][16 pixels][8 channels]: the 16-byte piece of pixel m,
+        // channel group c8 sits at ((m >> 4) * (C / 8) + c8) * 256 + (m & 15) * 16 -- a wave instruction (16 pixels x the 4
+        // channel groups of its lane groups) then touches ONE contiguous KiB instead of 16 rows x 64 B
+        t2p[pg] = p.t2_tiled ? (const unsigned char*)p.t2 + (((mc[pg] >> 4) * (P / 8) + g4) * 256 + (mc[pg] & 15) * 16)
+                             : (const unsigned char*)p.t2 + (mc[pg] * P + g4 * 8) * 2;
+        resp[pg] = p.res_tiled ? (const unsigned char*)p.res + (((mc[pg] >> 4) * (C3 / 8) + g4) * 256 + (mc[pg] & 15) * 16)
+                               : (const unsigned char*)p.res + (mc[pg] * C3 + g4 * 8) * 2;
         x2p[pg] = t2p[pg];                                   // second K segment: pixel (ho*stride2, wo*stride2) of image n in x2
         if constexpr (P2 > 0) {
             const int hw = p.Ho * p.Wo, n = (int)mc[pg] / hw, rem = (int)mc[pg] - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
             x2p[pg] = (const unsigned char*)p.x2 + ((((size_t)n * p.H2 + (size_t)ho * p.stride2) * p.W2 + (size_t)wo * p.stride2) * P2 + g4 * 8) * 2;
         }
-        outp[pg] = (unsigned char*)p.out + ((size_t)m * C3 + g4 * 8) * 2;
+        outp[pg] = p.out_tiled ? (unsigned char*)p.out + ((((size_t)m >> 4) * (C3 / 8) + g4) * 256 + ((size_t)m & 15) * 16)
+                               : (unsigned char*)p.out + ((size_t)m * C3 + g4 * 8) * 2;
         t1p[pg] = (unsigned char*)p.t1n + ((size_t)m * N1 + g4 * 8) * 2;
     }
     // every kernel-argument load completes here: a scalar load the compiler believes pending inside the loop costs an
     // s_waitcnt lgkmcnt(0) in front of each DMA instruction, which also drains the fragment reads in flight
     asm volatile("" ::"s"(p.wstream), "s"(p.t2), "s"(p.res), "s"(p.out), "s"(p.t1n), "s"(p.M), "s"(p.x2));
+    // byte strides of a 32-channel step (one B fragment) and of a 128-channel chunk in the two layouts
+    const int t2_fs = p.t2_tiled ? 1024 : 64;
+    const int res_fs = p.res_tiled ? 1024 : 64, res_cs = p.res_tiled ? 4096 : 256;
+    const int out_fs = p.out_tiled ? 1024 : 64, out_cs = p.out_tiled ? 4096 : 256;
 
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     // A fragment of tile row f*16 + lr, K half s: chunk s*4 + g4 at position (s*4 + g4) ^ (lr & 7): byte ^ 64 for s = 1
@@ -286,8 +296,9 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
                 r[pg][2] = gload_b128<0>(rq); r[pg][3] = gload_b128<128>(rq);
                 continue;
             }
-            const unsigned char* rp = resp[pg] + nb * 256;
-            r[pg][0] = gload_b128<0>(rp); r[pg][1] = gload_b128<64>(rp); r[pg][2] = gload_b128<128>(rp); r[pg][3] = gload_b128<192>(rp);
+            const unsigned char* rp = resp[pg] + nb * res_cs;
+            r[pg][0] = gload_b128<0>(rp); r[pg][1] = gload_b128<0>(rp + res_fs); r[pg][2] = gload_b128<0>(rp + 2 * res_fs);
+            r[pg][3] = gload_b128<0>(rp + 3 * res_fs);
         }
     };
 
@@ -296,7 +307,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
     u32x4 xf[PG][NXF];
     sfor<0, PG * NXF>([&](auto II) {
         constexpr int pg = II / NXF, I = II % NXF;
-        if constexpr (I < NXF1) xf[pg][I] = gload_b128<I * 64>(t2p[pg]);
+        if constexpr (I < NXF1) xf[pg][I] = gload_b128<0>(t2p[pg] + I * t2_fs);
         else xf[pg][I] = gload_b128<(I - NXF1) * 64>(x2p[pg]);
     });
     // identity pieces of a chunk, then its packed result (= conv1 operand).  IDB: two sets, the next chunk's identity is
@@ -420,7 +431,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
                         else if (PR_ABLATE & 128) {
                             unsigned char* oq = (unsigned char*)p.out + ((size_t)(mc[pg] - lr + (lane >> 3) + (q >> 1) * 8) * C3 + nb * 128) * 2 + (lane & 7) * 16 + (q & 1) * 128;
                             *(u32x4*)oq = cur[pg][q];
-                        } else if (mok[pg]) *(u32x4*)(outp[pg] + nb * 256 + q * 64) = cur[pg][q];
+                        } else if (mok[pg]) *(u32x4*)(outp[pg] + nb * out_cs + q * out_fs) = cur[pg][q];
                     }
                 });
                 PRSTAMP(29);

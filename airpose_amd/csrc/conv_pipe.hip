@@ -531,7 +531,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
         if (rg) {
 #pragma unroll
             for (int it = 0; it < NIT; ++it) {
-                const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
+                int px, cc;
+                ap_epi_item(tid + it * NT, CPR, sizeof(T) == 2 && p.y_tiled != 0, px, cc);
                 const int m = bm * BM + px, ch = bn * BN + cc * EPC;
                 const bool ok = m < p.M && ch < p.Cout;
                 rv[it] = *(const u32x4*)(ok ? rg + (size_t)m * p.ldr + ch : (const T*)p.zero);
@@ -542,7 +543,8 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
 
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
+        int px, cc;
+        ap_epi_item(tid + it * NT, CPR, sizeof(T) == 2 && p.y_tiled != 0, px, cc);
         const int m = bm * BM + px, ch = bn * BN + cc * EPC;
         if (m >= p.M || ch >= p.Cout) continue;
         const float* sp = ct + px * CLD + cc * EPC;
@@ -563,7 +565,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
             o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
             ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
-            *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
+            *(u32x4*)(yg + (p.y_tiled ? ap_tiled_off((size_t)m, ch, p.Cout) : (size_t)m * p.ldy + ch)) = o;
         } else {
             float4 a = *(const float4*)sp;
             if (rg) {

@@ -352,7 +352,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     if (rg) {
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
-            const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
+            int px, cc;
+            ap_epi_item(tid + it * NT, CPR, p.y_tiled != 0, px, cc);
             const int m = bm * BM + px, ch = bn * BN + cc * 8;
             const bool ok = m < p.M && ch < p.Cout;
             rv[it] = *(const u32x4*)(ok ? rg + (size_t)m * p.ldr + ch : (const T*)p.zero);
@@ -360,7 +361,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
-        const int q = tid + it * NT, px = q / CPR, cc = q - px * CPR;
+        int px, cc;
+        ap_epi_item(tid + it * NT, CPR, p.y_tiled != 0, px, cc);
         const int m = bm * BM + px, ch = bn * BN + cc * 8;
         if (m >= p.M || ch >= p.Cout) continue;
         const float* sp = ct + px * CLD + cc * 8;
@@ -380,7 +382,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
         o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
         ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
-        *(u32x4*)(yg + (size_t)m * p.ldy + ch) = o;
+        *(u32x4*)(yg + (p.y_tiled ? ap_tiled_off((size_t)m, ch, p.Cout) : (size_t)m * p.ldy + ch)) = o;
     }
     ap_rng_flush(p.range_flag, rng);
 }

@@ -27,6 +27,8 @@ struct ConvArgs {
     int out_f32;          // split-bf16 kind only: y (and res) are plain fp32 [M][ldy] instead of split pairs
     // conv_lean.hip POOL variant (last convolution of the trunk): when set, y is NOT written; the 7 x 7 pixels of every image are
     // averaged per channel instead (AvgPool2d(7) + view) into pool_out [N][Cout] fp32, bit-identical to conv + avgpool_kernel
+    int y_tiled;          // 16-bit kinds, LDS-staged epilogues: y in the fragment-tiled layout [M/16][Cout/8][16 pixels][8 channels]
+                          // (the t2 operand of the fused pair kernel) instead of NHWC rows; Cout % 8 == 0, y sized for M rounded up to 16
     float* pool_out;
     int* range_flag;      // fp16 storage, or NULL: host-mapped word set to 1 when a stored value leaves the fp16 range (ap_common.h)
 };
@@ -46,6 +48,7 @@ struct PairArgs {
     // stage-first block: second K segment = the block input x2 [N][H2][W2][P2] sampled at (ho*stride2, wo*stride2)
     const void* x2;
     int Ho, Wo, H2, W2, stride2;
+    int t2_tiled, res_tiled, out_tiled;   // t2 / res / out in the fragment-tiled layout [M/16][C/8][16][8] instead of NHWC rows
     int groups;                   // 16-pixel groups per wave: 0 / 1 (two workgroups per CU) or 2 (layer3 shapes: one workgroup per CU)
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
     int* range_flag;              // fp16 storage, or NULL: host-mapped word set when a stored value leaves the fp16 range

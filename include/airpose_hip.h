@@ -246,6 +246,11 @@ int ap_net_set_fuse_stem(ap_net* h, int on);
  * on = 0 (default: measured neutral to slightly slower inside the two-stream trunk) writes it and runs the pooling kernel.
  * Bit-identical features (same summands, same summation order). */
 int ap_net_set_fuse_pool(ap_net* h, int on);
+/* 16-bit modes: on = 1 (default) stores the tensors whose only reader is the fused pair kernel (conv2's output of a pair
+ * block; a pair block's output when the next block is an identity pair block) in that kernel's fragment order
+ * [M/16][C/8][16 pixels][8 channels] instead of NHWC rows, so each of its wave-wide 16-byte accesses covers one contiguous KiB;
+ * on = 0 keeps NHWC everywhere.  The layout is internal to the trunk workspaces; features are bit-identical either way. */
+int ap_net_set_tiled(ap_net* h, int on);
 /* 16-bit modes: on = 1 (default) runs each layer1 bottleneck as ONE kernel (ap_bottleneck64_nhwc: the 64-channel
  * intermediates never leave the CU; bottleneck2.hip: weights resident in LDS, x in registers), on = 0 as its three
  * (two + folded-downsample) convolutions.  Both give the same bits (parity-tested). */

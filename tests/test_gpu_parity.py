@@ -672,6 +672,24 @@ def test_fused_pool_is_bit_identical(net16, dev, n):
         net16.set_fuse_pool(0)
 
 
+@pytest.mark.parametrize("n", [1, 3, 4, 64])
+def test_tiled_intermediates_are_bit_identical(net16, dev, n):
+    """Fragment-tiled storage of the pair-kernel-only tensors (default; ap_common.h ap_tiled_off: conv2's output of a pair block,
+    identity/output between consecutive identity pair blocks) against NHWC everywhere: a pure relayout, so the features carry
+    the same bits -- at 1 and 3 images (layer3 M = 196 / 588: a partly filled last micro-tile of 16 pixels), 4 and 64."""
+    gen = torch.Generator(device="cpu").manual_seed(300 + n)
+    x = torch.randn(n, 3, 224, 224, generator=gen).to(dev)
+    got = net16.forward_feat_ext(x).clone()
+    try:
+        net16.set_tiled(0)
+        ref = net16.forward_feat_ext(x).clone()
+    finally:
+        net16.set_tiled(1)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref)
+    assert torch.equal(net16.forward_feat_ext(x), ref)       # and back on
+
+
 def test_fused_layer1_matches_separate_convs(net16, golden, copenet_inputs, dev):
     """Whole-bottleneck fusion of layer1 (default, bottleneck2.hip) vs its separate convolutions, through the trunk."""
     x = copenet_inputs["im0"].to(dev)
