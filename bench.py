@@ -362,6 +362,8 @@ def main():
         net.set_fuse_pair(int(os.environ["AIRPOSE_FUSE_PAIR"]))
     if os.environ.get("AIRPOSE_TILED"):                     # A/B aid: fragment-tiled pair-kernel intermediates (default) / NHWC
         net.set_tiled(int(os.environ["AIRPOSE_TILED"]))
+    if os.environ.get("AIRPOSE_FUSE_STEM"):                 # A/B aid: 1 persistent stem + pool kernel (default), 2 its first cut, 0 two kernels
+        net.set_fuse_stem(int(os.environ["AIRPOSE_FUSE_STEM"]))
     if os.environ.get("AIRPOSE_FUSE_POOL"):                 # A/B aid: AvgPool2d(7) in the last convolution's epilogue (default) / own kernel
         net.set_fuse_pool(int(os.environ["AIRPOSE_FUSE_POOL"]))
     if os.environ.get("AIRPOSE_FUSE_BLOCK"):                # A/B aid: layer1 blocks: 1 fused kernel each (default), 0 separate convs

@@ -238,7 +238,7 @@ int ap_net_set_fuse_ief(ap_net* h, int on);
  * fp64, no downsample tensor written or re-read); on = 0 runs the two convolutions of Bottleneck.forward
  * (model_copenet.py:38-45) separately.  Both are parity-tested. */
 int ap_net_set_fuse_ds(ap_net* h, int on);
-/* bf16 and bf16x2 modes: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool
+/* 16-bit and bf16x2 modes: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool
  * kernels (bit-identical results; kept for A/B measurement). */
 int ap_net_set_fuse_stem(ap_net* h, int on);
 /* 16-bit modes: on = 1 computes AvgPool2d(7) + view (model_copenet.py:173-175) in the epilogue of the last convolution

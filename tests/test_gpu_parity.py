@@ -917,16 +917,20 @@ def test_trunk_bf16_close_to_golden(golden, netbf, copenet_inputs, dev):
     assert e0 < TOLBF
 
 
-def test_fused_stem_pool_is_bit_identical(netbf, dev):
-    """conv1+bn1+relu+maxpool fused kernel == stem kernel followed by the max-pool kernel, bit for bit."""
-    from airpose_amd import weights as W
-    x = torch.from_numpy(W.synthetic_inputs(5, 3)["im1"]).to(dev)
-    netbf.set_fuse_stem(1)
-    a = netbf.forward_feat_ext(x)
-    netbf.set_fuse_stem(0)
-    b = netbf.forward_feat_ext(x)
-    netbf.set_fuse_stem(1)
-    assert torch.equal(a, b)
+@pytest.mark.parametrize("n", [1, 5, 64])
+def test_fused_stem_pool_is_bit_identical(net16, dev, n):
+    """conv1+bn1+relu+maxpool fused kernel == stem kernel followed by the max-pool kernel, bit for bit, in both 16-bit types."""
+    gen = torch.Generator(device="cpu").manual_seed(500 + n)
+    x = torch.randn(n, 3, 224, 224, generator=gen).to(dev)
+    x[0, :, :9, :] = 3.0                                      # a flat top edge: the first strip's missing conv row must not win a maximum
+    try:
+        net16.set_fuse_stem(0)
+        ref = net16.forward_feat_ext(x).clone()
+    finally:
+        net16.set_fuse_stem(1)
+    got = net16.forward_feat_ext(x)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref)
 
 
 def test_fused_split_stem_pool_is_bit_identical(netx2, dev):
