@@ -513,7 +513,7 @@ def main():
         srt = sorted(blocks)
         res["repeat_blocks"] = {"n": len(blocks), "steps_each": args.steps, "median": srt[len(srt) // 2], "min": srt[0],
                                 "max": srt[-1], "unit": "pairs/s", "note": "block 0 is `value`"}
-        if tb is not None:
+        if tb is not None and tb["passes"] > 0:              # (--stage-steps 0: no instrumented tail passes)
             p = max(tb["passes"], 1)
             # default: blend-shape contraction + skinning are ONE kernel (smplx_lbs_fused_kernel), timed in the blend slot; the
             # skin slot is then empty (two-kernel path: AIRPOSE_SMPLX_FUSED=0)
