@@ -862,6 +862,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             std::swap(cur, nxt);
             continue;
         }
+        if (!t1_ready && cur_tiled) return fail(AP_ESTATE, "trunk: conv1 of a block would read a tiled block output");
         if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, h->range_flag))) return rc;
         t1_ready = false;
         const bool pair = is_pair(B);
@@ -886,6 +887,8 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             else a.res = cur;
             HIP_TRY(H16(prec, ap_launch_conv_pair)(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
             t1_ready = B.pair_n1 > 0;
+        } else if (cur_tiled) {                               // (cannot happen: out_tiled is only set when the next block is a pair block)
+            return fail(AP_ESTATE, "trunk: a tiled block output reached a kernel that reads NHWC");
         } else if (B.has_down && h->fuse_ds) {
             if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st, h->range_flag))) return rc;
         } else if (bf && h->fuse_pool && &B == &h->blocks.back() && !B.has_down && Ho == 7 &&
