@@ -344,6 +344,8 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     }
     __syncthreads();
     constexpr int CPR = BN / 8, NIT = BM * CPR / NT;
+    int et = tid;                                            // opaque copy: the item maps below are computed HERE, not hoisted above
+    asm volatile("" : "+v"(et));                             // the K loop (one more live register there spills)
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
     uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the bf16 set
@@ -353,7 +355,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
         for (int it = 0; it < NIT; ++it) {
             int px, cc;
-            ap_epi_item(tid + it * NT, CPR, p.y_tiled != 0, px, cc);
+            ap_epi_item(et + it * NT, CPR, p.y_tiled != 0, px, cc);
             const int m = bm * BM + px, ch = bn * BN + cc * 8;
             const bool ok = m < p.M && ch < p.Cout;
             rv[it] = *(const u32x4*)(ok ? rg + (size_t)m * p.ldr + ch : (const T*)p.zero);
@@ -362,7 +364,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
         int px, cc;
-        ap_epi_item(tid + it * NT, CPR, p.y_tiled != 0, px, cc);
+        ap_epi_item(et + it * NT, CPR, p.y_tiled != 0, px, cc);
         const int m = bm * BM + px, ch = bn * BN + cc * 8;
         if (m >= p.M || ch >= p.Cout) continue;
         const float* sp = ct + px * CLD + cc * 8;
