@@ -64,10 +64,20 @@ template <int OFF> __device__ __forceinline__ f32x4 lds_read_f32x4(uint32_t addr
 }
 // register load the compiler does not count (a load it counts is answered with vmcnt(0) beside LDS-DMA and would drain the
 // weight ring): the destination is valid only behind the hand-placed wait that names it
+// cache policy of the activation traffic: bit 0 = streaming (nt) loads of t2 / identity / x2 (each byte is read once; measured
+// +0.3 % on the whole bench, 5 interleaved pairs, profiles/r04_pair_nt_ab.txt), bit 1 = nt stores (measured -0.5 %: off)
+#ifndef PR_NT
+#define PR_NT 1
+#endif
 template <int OFF> __device__ __forceinline__ u32x4 gload_b128(const unsigned char* p) {
     u32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+    if (PR_NT & 1) asm volatile("global_load_dwordx4 %0, %1, off offset:%2 nt" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off offset:%2" : "=v"(r) : "v"(p), "n"(OFF) : "memory");
     return r;
+}
+__device__ __forceinline__ void gstore_b128(unsigned char* p, const u32x4& v) {
+    if (PR_NT & 2) __builtin_nontemporal_store(v, (u32x4*)p);
+    else *(u32x4*)p = v;
 }
 template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
     if constexpr (I < N) {
@@ -431,7 +441,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
                         else if (PR_ABLATE & 128) {
                             unsigned char* oq = (unsigned char*)p.out + ((size_t)(mc[pg] - lr + (lane >> 3) + (q >> 1) * 8) * C3 + nb * 128) * 2 + (lane & 7) * 16 + (q & 1) * 128;
                             *(u32x4*)oq = cur[pg][q];
-                        } else if (mok[pg]) *(u32x4*)(outp[pg] + nb * out_cs + q * out_fs) = cur[pg][q];
+                        } else if (mok[pg]) gstore_b128(outp[pg] + nb * out_cs + q * out_fs, cur[pg][q]);
                     }
                 });
                 PRSTAMP(29);
@@ -453,7 +463,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
         for (int pg = 0; pg < PG; ++pg) {
             const u32x4 o = bn8(acc1[pg][hn * 8 + 2 * q], acc1[pg][hn * 8 + 2 * q + 1], s0, s1, h0, h1, nullptr);
             if (PR_ABLATE & 2) asm volatile("" ::"v"(o), "v"(t1p[pg]));
-            else if (mok[pg]) *(u32x4*)(t1p[pg] + (hn * 128 + q * 32) * 2) = o;
+            else if (mok[pg]) gstore_b128(t1p[pg] + (hn * 128 + q * 32) * 2, o);
         }
     });
     ap_rng_flush(p.range_flag, rng);
