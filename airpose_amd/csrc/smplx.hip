@@ -548,8 +548,24 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
     const int lr = lane & 15, g4 = lane >> 4;
     const int vr = blockIdx.x % n_vr, bg = blockIdx.x / n_vr;
     const int b0 = bg * T_BB, J12 = m.J * 12;
-    unsigned char* coefs = lf_smem + T_BB * J12 * 4;                              // [T_BB][T_CROW]: 7 K steps x (4 x [8 hi | 8 lo])
+    // bone tables at the compile-time stride [T_BB][T_MAXJ][12]: a body's table is then an immediate offset from ONE per-lane base
+    // (with the runtime stride J * 12 hipcc kept eight per-body addresses in registers across the group loop)
+    constexpr int J12C = T_MAXJ * 12;
+    unsigned char* coefs = lf_smem + T_BB * J12C * 4;                             // [T_BB][T_CROW]: 7 K steps x (4 x [8 hi | 8 lo])
     float* Ps = (float*)(coefs + T_BB * T_CROW);                                  // [T_BB][16]: post transform [12] | translation [3]
+    const int ngroups = (m.V + 15) >> 4;
+    const int gend = min(ngroups, (vr + 1) * groups_per_vr);
+    const unsigned char* dbase = (const unsigned char*)m.dirs_frag + (size_t)lane * 16;
+    // fragment block of (group, K step, component c, plane): ((g * 8 + ks) * 3 + c) * 2 + plane, 1 KiB each (K = 256 layout)
+    auto frag = [&](int g, int ks, int i) { return *(const u32x4*)(dbase + ((size_t)g * 8 + ks) * 6144 + i * 1024); };
+    // The direction fragments of a K step are requested ONE STEP AHEAD into the other of two register sets (the step after a
+    // group's last one is the next group's first: its loads fly under the skinning), all six of a step back to back: with one set
+    // hipcc serialised load -> s_waitcnt vmcnt(0) -> MFMA pairs inside a step (three to four dependent L2 round trips per K step).
+    // Plain loads, counted by the compiler; the address of a prefetch past the last group is clamped to the group itself.
+    int g = vr * groups_per_vr + wave;
+    u32x4 fa[6], fb[6];
+#pragma unroll
+    for (int i = 0; i < 6; ++i) fa[i] = frag(min(g, ngroups - 1), 0, i);           // (issued ahead of the prologue's own loads)
     {   // bone transforms, coefficient rows, post transforms of the 32 bodies (rows past the last body: clamped duplicates, never
         // stored); every load of a thread is issued before its first LDS write
         constexpr int NT = 64 * T_NW, BIT = (T_BB * T_MAXJ * 3 + NT - 1) / NT, CCH = T_KS * 8, CIT = (T_BB * CCH + NT - 1) / NT;
@@ -571,7 +587,10 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
             else if (e < 15) pv = a.transl ? a.transl[(size_t)bsrc * 3 + (e - 12)] : 0.f;
         }
 #pragma unroll
-        for (int k = 0; k < BIT; ++k) { const int i = tid + k * NT; if (i < tot) ((float4*)bones)[i] = tb[k]; }
+        for (int k = 0; k < BIT; ++k) {
+            const int i = tid + k * NT, J3 = m.J * 3, bb = i / J3;
+            if (i < tot) ((float4*)bones)[bb * (T_MAXJ * 3) + (i - bb * J3)] = tb[k];
+        }
 #pragma unroll
         for (int k = 0; k < CIT; ++k) {
             const int i = tid + k * NT;
@@ -580,32 +599,30 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
         if (tid < T_BB * 16) Ps[tid] = pv;
     }
     __syncthreads();
-    const int ngroups = (m.V + 15) >> 4;
-    const int gend = min(ngroups, (vr + 1) * groups_per_vr);
-    const unsigned char* dbase = (const unsigned char*)m.dirs_frag + (size_t)lane * 16;
-    // fragment block of (group, K step, component c, plane): ((g * 8 + ks) * 3 + c) * 2 + plane, 1 KiB each (K = 256 layout)
-    auto frag = [&](int g, int ks, int i) { return *(const u32x4*)(dbase + ((size_t)g * 8 + ks) * 6144 + i * 1024); };
     const unsigned char* ca = coefs + lr * T_CROW + g4 * 32;                       // this lane's A rows: bodies lr and 16 + lr
-    for (int g = vr * groups_per_vr + wave; g < gend; g += T_NW) {
+    const float* const bones_l = bones + g4 * 4 * J12C;                            // this lane's skinning bodies: 4 g4 + r (+ 16)
+    const float* const Ps_l = Ps + g4 * 4 * 16;
+    for (; g < gend; g += T_NW) {
         // ------------------------------------------------ contraction: acc[c][s][r] = v_posed component c of vertex 16 g + lr
         // for body s * 16 + 4 g4 + r
         f32x4 acc[3][2];
 #pragma unroll
         for (int c = 0; c < 3; ++c) { acc[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        u32x4 cur[6];
         // this lane's vertex: bone ids (6 bits each, + joint-vertex slot), weights, template (requested under the contraction)
         const int v = g * 16 + lr;
         const uint32_t id = m.skin_idx8[v];
         const float4 w4 = *(const float4*)(m.skin_w4 + (size_t)v * 4);
         const float tx = m.v_template[(size_t)v * 3], ty = m.v_template[(size_t)v * 3 + 1], tz = m.v_template[(size_t)v * 3 + 2];
+        const int gn = g + T_NW < gend ? g + T_NW : g;
+        lf_sfor<0, T_KS>([&](auto KS) {
+            constexpr int ks = decltype(KS)::value;
+            u32x4 (&cur)[6] = (ks & 1) ? fb : fa;
+            u32x4 (&nxt)[6] = (ks & 1) ? fa : fb;
+            if (!(T_ABLATE & 4)) {
 #pragma unroll
-        for (int ks = 0; ks < T_KS; ++ks) {
-            // (one fragment set: with four waves per SIMD the other waves' MFMAs run under this wave's L2 round trip; a second
-            //  set for explicit double-buffering does not fit 128 registers beside the skinning)
-            if (!(T_ABLATE & 4) || ks == 0) {
-#pragma unroll
-                for (int i = 0; i < 6; ++i) cur[i] = frag(g, ks, i);
+                for (int i = 0; i < 6; ++i) nxt[i] = ks + 1 < T_KS ? frag(g, ks + 1, i) : frag(gn, 0, i);
             }
+            __builtin_amdgcn_sched_barrier(0);               // requests first: hipcc otherwise sinks them behind the step's MFMAs
             const bf16x8 ah0 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + ks * 128)), al0 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + ks * 128 + 16));
             const bf16x8 ah1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + 16 * T_CROW + ks * 128));
             const bf16x8 al1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(ca + 16 * T_CROW + ks * 128 + 16));
@@ -620,23 +637,34 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah0, dl, acc[c][0], 0, 0, 0);
                 acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, dl, acc[c][1], 0, 0, 0);
             }
-            __builtin_amdgcn_sched_barrier(0);               // keep the K steps in order: a hoisted load of step ks + 1 would need a second set
-        }
+            __builtin_amdgcn_sched_barrier(0);               // keep the K steps in order: nothing of step ks + 2 before step ks is done
+        });
         // ------------------------------------------------ skinning of the lane's vertex for its 8 bodies
         const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
         const bool vok = v < m.V;
+        // store addresses: one uniform base per workgroup + a 32-bit lane offset that walks the lane's 8 bodies (the eight
+        // 64-bit per-body pointers hipcc otherwise keeps across the whole group loop were spilled once the second fragment
+        // set took their registers, and a scratch reload sits behind every earlier store of the wave)
+        char* const vbase = (char*)(a.vertices + (size_t)b0 * m.V * 3);
+        const uint32_t vstep = (uint32_t)m.V * 12u;
+        uint32_t voff = ((uint32_t)(g4 * 4) * (uint32_t)m.V + (uint32_t)v) * 12u;
+        char* const sbase = (char*)(a.vp_side + (size_t)b0 * m.n_jv * 3);          // joint-vertex side buffer, same scheme
+        const uint32_t sstep = (uint32_t)m.n_jv * 12u;
+        uint32_t soff = ((uint32_t)(g4 * 4) * (uint32_t)m.n_jv + ((id >> 24) - 1u)) * 12u;   // (only used when id >> 24 != 0)
+        asm volatile("" : "+v"(voff), "+v"(soff));           // opaque: hipcc otherwise hoists eight per-body offsets out of the group loop (and spills them)
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 const int bl = s * 16 + g4 * 4 + r;
                 const bool bok = b0 + bl < a.n;
                 const float x = acc[0][s][r] + tx, y = acc[1][s][r] + ty, z = acc[2][s][r] + tz;
                 if (a.vp_side && bok && (id >> 24)) {        // joint vertex: slot + 1 in the top byte (0 = none, padding rows too)
-                    float* q = a.vp_side + ((size_t)(b0 + bl) * m.n_jv + ((id >> 24) - 1)) * 3;
+                    float* q = (float*)(sbase + soff);
                     q[0] = x; q[1] = y; q[2] = z;
                 }
-                const float* Ab = bones + bl * J12;
+                soff += sstep;
+                const float* Ab = bones_l + (s * 16 + r) * J12C;
                 float T[12];
 #pragma unroll
                 for (int e = 0; e < 12; ++e) T[e] = (T_ABLATE & 2) ? wv[e & 3] : 0.f;
@@ -648,7 +676,7 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                     T[4] = fmaf(wv[k], r1.x, T[4]); T[5] = fmaf(wv[k], r1.y, T[5]); T[6] = fmaf(wv[k], r1.z, T[6]); T[7] = fmaf(wv[k], r1.w, T[7]);
                     T[8] = fmaf(wv[k], r2.x, T[8]); T[9] = fmaf(wv[k], r2.y, T[9]); T[10] = fmaf(wv[k], r2.z, T[10]); T[11] = fmaf(wv[k], r2.w, T[11]);
                 }
-                const float* Pb = Ps + bl * 16;
+                const float* Pb = Ps_l + (s * 16 + r) * 16;
                 float q[3];
                 q[0] = T[0] * x + T[1] * y + T[2] * z + T[3] + Pb[12];
                 q[1] = T[4] * x + T[5] * y + T[6] * z + T[7] + Pb[13];
@@ -656,11 +684,18 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 if (a.post) apply_post(Pb, q);
                 if (T_ABLATE & 1) asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]));
                 else if (bok && vok) {
-                    float* dst = a.vertices + ((size_t)(b0 + bl) * m.V + v) * 3;
+                    float* dst = (float*)(vbase + voff);
                     dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2];
                 }
+                voff += vstep;
                 __builtin_amdgcn_sched_barrier(0);           // one body at a time: the 8 bodies' bone rows all in flight spill
             }
+            voff += 12u * vstep;                             // bodies 16 + 4 g4 ...
+            soff += 12u * sstep;
+        }
+        static_assert(T_KS & 1, "an odd number of K steps leaves the next group's first fragments in the second set");
+#pragma unroll
+        for (int i = 0; i < 6; ++i) fa[i] = fb[i];           // the next group's first step (requested before the skinning)
     }
 }
 
@@ -841,7 +876,7 @@ hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs&
     if (!ap_smplx_lbs_fused_supported(m)) return hipErrorInvalidValue;
     const bool second = cut != 1;                            // 2 (default): smplx_lbs_tail_kernel; 1: the first cut (kept for A/B)
     const int nw = second ? T_NW : LF_NW;
-    const int lds = second ? T_BB * m.J * 12 * 4 + T_BB * T_CROW + T_BB * 64 : LF_BB * m.J * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64;
+    const int lds = second ? T_BB * T_MAXJ * 12 * 4 + T_BB * T_CROW + T_BB * 64 : LF_BB * m.J * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64;
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
