@@ -60,9 +60,47 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
             coef[i] = v;
         }
     };
+    // ---- every global load of the wave is requested here, before the first result is used (as written top-down the kernel
+    // was six dependent memory round trips: coefficients -> pose -> translation -> parents -> joint shape directions -> ...).
+    // Pointers are selected, loads unconditional (a load inside a branch is waited for at the branch's end); lanes without a
+    // value of their own read betas[sb][0..9], which every call supplies.
+    const float* safe = a.betas + (size_t)sb * 10;
+    const int jc = j < m.J ? j : m.J - 1;
+    const float c_in = *(j < 10 ? safe + j : (a.expression && j < 20) ? a.expression + (size_t)sb * 10 + (j - 10) : safe);
+    float x9[9];                                             // pose6d: six numbers of joint j (lanes 0..21); else: its 3x3 rotation
+    const float* src9 = safe;
+    bool has9 = false;
+    if (a.pose6d) {
+        if (j < 22) src9 = a.pose6d + (size_t)sb * a.pose6d_ld + 6 * j;
+    } else {
+        if (j == 0) { if (a.global_orient) { src9 = a.global_orient + (size_t)b * 9; has9 = true; } }
+        else if (j < 22) { src9 = a.body_pose + ((size_t)b * 21 + (j - 1)) * 9; has9 = true; }
+        else if (j < m.J && a.extra_pose) { src9 = a.extra_pose + ((size_t)b * (m.J - 22) + (j - 22)) * 9; has9 = true; }
+    }
+#pragma unroll
+    for (int e = 0; e < 9; ++e) x9[e] = (e < 6 || !a.pose6d) ? src9[e] : 0.f;
+    // root lane: translation of the post transform, camera centre (copenet_twoview.py:237-243, :311,317)
+    const float* tsrc = !a.pose6d ? nullptr : inmesh ? a.in_trans + (size_t)sb * 3 : a.post_t ? a.post_t + (size_t)b * a.post_t_ld : nullptr;
+    const float* tp = tsrc ? tsrc : safe;
+    const float l0 = tp[0], l1 = tp[1], l2 = tp[2];
+    const bool cc = a.pose6d && a.cc_ws && !inmesh;
+    const int half = a.n_main / 2;
+    const float* Kc = !cc ? safe : (b < half ? a.intr0 + (size_t)b * 9 : a.intr1 + (size_t)(b - half) * 9);
+    const float ccx = Kc[2], ccy = Kc[5];
+    float prt[12];                                           // caller-supplied post transform (SMPLX.forward path)
+#pragma unroll
+    for (int e = 0; e < 12; ++e) prt[e] = (!a.pose6d && a.post && a.post_rt) ? a.post_rt[(size_t)b * 12 + e] : ((e == 0 || e == 5 || e == 10) ? 1.f : 0.f);
+    const int par_in = m.parents[jc], dep_in = m.depth[jc];
+    float jt_in[3], sd_in[3][20];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        jt_in[c] = m.j_template[jc * 3 + c];
+#pragma unroll
+        for (int l = 0; l < 20; ++l) sd_in[c][l] = m.j_shapedirs[((size_t)jc * 3 + c) * 20 + l];
+    }
+
     if (j < 20) {
-        float c = j < 10 ? a.betas[(size_t)sb * 10 + j] : (a.expression ? a.expression[(size_t)sb * 10 + j - 10] : 0.f);
-        if (inmesh) c = 0.f;
+        const float c = (inmesh || (j >= 10 && !a.expression)) ? 0.f : c_in;
         cf[j] = c;
         put(j, c);
     }
@@ -74,49 +112,42 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
     if (a.pose6d) {
         if (j < 22) {
             float Rj[9];
-            rot6d_dev(a.pose6d + (size_t)sb * a.pose6d_ld + 6 * j, Rj);
-            if (a.rotmat_out && !inmesh)
-                for (int e = 0; e < 9; ++e) a.rotmat_out[((size_t)b * 22 + j) * 9 + e] = Rj[e];
+            rot6d_dev(x9, Rj);
             if (j == 0) {
                 // root 6D is the transform_smpl rotation; the chain root stays identity (copenet_twoview.py:237-243)
                 float* P = a.post + (size_t)b * 12;
+                float t3[3] = {0.f, 0.f, 0.f};
+                if (tsrc) { t3[0] = l0; t3[1] = l1; t3[2] = l2; }
+                const bool rw = !inmesh && a.post_t && a.pose_rw;
+                if (rw) {                                   // pred_smpltrans /= trans_scale, in place on pred_pose (:214-218)
+#pragma unroll
+                    for (int rr = 0; rr < 3; ++rr) t3[rr] = t3[rr] / a.trans_scale;
+                }
+#pragma unroll
                 for (int rr = 0; rr < 3; ++rr) {
-                    float t = 0.f;
-                    if (inmesh) {
-                        t = a.in_trans[(size_t)sb * 3 + rr];
-                    } else if (a.post_t) {
-                        t = a.post_t[(size_t)b * a.post_t_ld + rr];
-                        if (a.pose_rw) {                    // pred_smpltrans /= trans_scale, in place on pred_pose (:214-218)
-                            t = t / a.trans_scale;
-                            a.pose_rw[(size_t)b * a.post_t_ld + rr] = t;
-                        }
-                    }
+                    if (rw) a.pose_rw[(size_t)b * a.post_t_ld + rr] = t3[rr];
                     P[rr * 4 + 0] = inmesh ? (rr == 0 ? 1.f : 0.f) : Rj[rr * 3 + 0];
                     P[rr * 4 + 1] = inmesh ? (rr == 1 ? 1.f : 0.f) : Rj[rr * 3 + 1];
                     P[rr * 4 + 2] = inmesh ? (rr == 2 ? 1.f : 0.f) : Rj[rr * 3 + 2];
-                    P[rr * 4 + 3] = t;
+                    P[rr * 4 + 3] = t3[rr];
                 }
-                if (a.cc_ws && !inmesh) {                   // camera_center = intr[:, :2, 2] of this body's view (:311,317)
-                    const int half = a.n_main / 2;
-                    const float* K = (b < half ? a.intr0 + (size_t)b * 9 : a.intr1 + (size_t)(b - half) * 9);
-                    a.cc_ws[(size_t)b * 2 + 0] = K[2];
-                    a.cc_ws[(size_t)b * 2 + 1] = K[5];
+                if (cc) {
+                    a.cc_ws[(size_t)b * 2 + 0] = ccx;
+                    a.cc_ws[(size_t)b * 2 + 1] = ccy;
                 }
             } else {
                 for (int e = 0; e < 9; ++e) R[e] = Rj[e];
             }
+            if (a.rotmat_out && !inmesh)
+                for (int e = 0; e < 9; ++e) a.rotmat_out[((size_t)b * 22 + j) * 9 + e] = Rj[e];
         }
     } else {
-        const float* src = nullptr;
-        if (j == 0) src = a.global_orient ? a.global_orient + (size_t)b * 9 : nullptr;
-        else if (j < 22) src = a.body_pose + ((size_t)b * 21 + (j - 1)) * 9;
-        else if (j < m.J && a.extra_pose) src = a.extra_pose + ((size_t)b * (m.J - 22) + (j - 22)) * 9;
-        if (src)
-            for (int e = 0; e < 9; ++e) R[e] = src[e];
+        if (has9)
+            for (int e = 0; e < 9; ++e) R[e] = x9[e];
         if (j == 0 && a.post) {
             float* P = a.post + (size_t)b * 12;
-            for (int e = 0; e < 12; ++e)
-                P[e] = a.post_rt ? a.post_rt[(size_t)b * 12 + e] : ((e == 0 || e == 5 || e == 10) ? 1.f : 0.f);
+#pragma unroll
+            for (int e = 0; e < 12; ++e) P[e] = prt[e];
         }
     }
     if (j >= 1 && j < m.J) {
@@ -124,16 +155,17 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
     }
     __syncthreads();
     if (j < m.J) {
+#pragma unroll
         for (int c = 0; c < 3; ++c) {
-            const float* sd = m.j_shapedirs + ((size_t)j * 3 + c) * 20;
             float acc = 0.f;
-            for (int l = 0; l < 20; ++l) acc = fmaf(sd[l], cf[l], acc);
-            Jr[j][c] = m.j_template[j * 3 + c] + acc;
+#pragma unroll
+            for (int l = 0; l < 20; ++l) acc = fmaf(sd_in[c][l], cf[l], acc);
+            Jr[j][c] = jt_in[c] + acc;
         }
     }
     __syncthreads();
-    const int par = (j < m.J && j > 0) ? m.parents[j] : 0;
-    const int dep = j < m.J ? m.depth[j] : -1;
+    const int par = (j < m.J && j > 0) ? par_in : 0;
+    const int dep = j < m.J ? dep_in : -1;
     float rel[3] = {0.f, 0.f, 0.f};
     if (j < m.J) {
         for (int c = 0; c < 3; ++c) rel[c] = j == 0 ? Jr[0][c] : Jr[j][c] - Jr[par][c];
@@ -725,6 +757,50 @@ __global__ void __launch_bounds__(128) smplx_joints_kernel(const SmplxModelDev m
     const float* vp = a.vposed + (size_t)b * m.ldv;
     const float* vs = a.vp_side ? a.vp_side + (size_t)b * m.n_jv * 3 : nullptr;    // fused path: [slot][3], slot = m.jv_slot[v]
     float o[3];
+    if (vs && m.K == 4 && m.skin_idx8 && t >= m.J) {
+        // fused path, four bones per vertex: the thread's 1 (vertex pick) or 3 (landmark corners) vertices in three batches of
+        // loads -- vertex ids and barycentric weights | slot, packed bone ids, weights | v_posed -- instead of a dependent chain
+        // per corner and per bone (~10 L2 round trips); same blend order and arithmetic as skin_point_dyn with K = 4
+        const bool lm = t >= m.J + m.n_extra;
+        const int l = lm ? t - m.J - m.n_extra : 0;
+        int vid[3];
+        float bw[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            vid[f] = lm ? m.lmk_tri[l * 3 + f] : m.extra_verts[t - m.J];
+            bw[f] = lm ? m.lmk_bary[l * 3 + f] : 0.f;
+        }
+        int slot[3];
+        uint32_t id8[3];
+        float4 w4[3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            slot[f] = m.jv_slot[vid[f]];
+            id8[f] = m.skin_idx8[vid[f]];
+            w4[f] = *(const float4*)(m.skin_w4 + (size_t)vid[f] * 4);
+        }
+        float q[3][3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            q[f][0] = vs[3 * slot[f]]; q[f][1] = vs[3 * slot[f] + 1]; q[f][2] = vs[3 * slot[f] + 2];
+        }
+        float pf[3][3];
+#pragma unroll
+        for (int f = 0; f < 3; ++f) {
+            const int idx[4] = {(int)(id8[f] & 0x3fu), (int)((id8[f] >> 6) & 0x3fu), (int)((id8[f] >> 12) & 0x3fu), (int)((id8[f] >> 18) & 0x3fu)};
+            const float w[4] = {w4[f].x, w4[f].y, w4[f].z, w4[f].w};
+            skin_point<4>(As, idx, w, q[f][0], q[f][1], q[f][2], pf[f]);
+        }
+        if (lm) {
+            o[0] = o[1] = o[2] = 0.f;
+#pragma unroll
+            for (int f = 0; f < 3; ++f) {
+                o[0] = fmaf(pf[f][0], bw[f], o[0]); o[1] = fmaf(pf[f][1], bw[f], o[1]); o[2] = fmaf(pf[f][2], bw[f], o[2]);
+            }
+        } else {
+            o[0] = pf[0][0]; o[1] = pf[0][1]; o[2] = pf[0][2];
+        }
+    } else {
     auto skin = [&](int v, float* out) {
         const float* q = vs ? vs + 3 * m.jv_slot[v] : vp + 3 * v;
         skin_point_dyn(As, m.skin_idx + (size_t)v * m.K, m.skin_w + (size_t)v * m.K, m.K, q[0], q[1], q[2], out);
@@ -742,6 +818,7 @@ __global__ void __launch_bounds__(128) smplx_joints_kernel(const SmplxModelDev m
             const float bw = m.lmk_bary[l * 3 + f];
             o[0] = fmaf(p[0], bw, o[0]); o[1] = fmaf(p[1], bw, o[1]); o[2] = fmaf(p[2], bw, o[2]);
         }
+    }
     }
     o[0] += Ps[12]; o[1] += Ps[13]; o[2] += Ps[14];
     if (a.post) apply_post(Ps, o);
