@@ -218,55 +218,67 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
     __shared__ float Sd[NJ * 3][10], PT[3][2][9], CAM[32];
     // ---- every global input of the frame is requested up front (one memory latency instead of one per use: the
     //      kernel is a chain of short dependent phases, and it runs 300 times back to back)
-    const bool rob = a.robust[f] != 0;
-    const bool pair_prev = a.n_pairs > 0 && f > 0 && a.robust[f - 1] && rob;
-    const bool pair_next = a.n_pairs > 0 && f + 1 < L && rob && a.robust[f + 1];
-    {
-        constexpr int SIT = (NJ * 3 * 10 + 63) / 64;         // 12 loads per lane, all issued before the first LDS write
-        float sv[SIT];
+    //      Pointers are clamped / selected and the loads unconditional: hipcc waits for a load at the end of the branch it sits
+    //      in, and with one branch per input (lane < 54, lane < 32, lane < NJ, pair_prev ...) the "up front" block was ten
+    //      dependent round trips in the ISA (24 x s_waitcnt vmcnt(0)) of a kernel that is nothing but latency.
+    const int fp = f > 0 ? f - 1 : f, fn = f + 1 < L ? f + 1 : f;
+    // (the lane's depth and parent once, in registers: read inside the level loops they were a memory round trip per level)
+    const int my_depth = c_depth[min(lane, NJ - 1)], my_parent = c_parent[min(lane, NJ - 1)];
+    const int rob_i = a.robust[f], robp_i = a.robust[fp], robn_i = a.robust[fn];
+    constexpr int SIT = (NJ * 3 * 10 + 63) / 64;             // 12 loads per lane, all issued before the first LDS write
+    float sv[SIT];
 #pragma unroll
-        for (int k = 0; k < SIT; ++k) {
-            const int i = min(lane + k * 64, NJ * 3 * 10 - 1);
-            sv[k] = a.j_shapedirs[(i / 10) * a.jsd_ld + i % 10];
-        }
-#pragma unroll
-        for (int k = 0; k < SIT; ++k) {
-            const int i = lane + k * 64;
-            if (i < NJ * 3 * 10) Sd[i / 10][i % 10] = sv[k];
-        }
+    for (int k = 0; k < SIT; ++k) {
+        const int i = min(lane + k * 64, NJ * 3 * 10 - 1);
+        sv[k] = a.j_shapedirs[(i / 10) * a.jsd_ld + i % 10];
     }
-    if (lane < 54) {                                         // phi | tau of this frame and of its neighbours, both views
-        const int which = lane / 18, v = (lane % 18) / 9, e = lane % 9;
-        const int ff = which == 0 ? f : which == 1 ? (f > 0 ? f - 1 : f) : (f + 1 < L ? f + 1 : f);
-        PT[which][v][e] = e < 6 ? a.phi[((size_t)v * L + ff) * 6 + e] : a.tau[((size_t)v * L + ff) * 3 + e - 6];
+    float ptv;
+    {                                                        // phi | tau of this frame and of its neighbours, both views (lanes 0..53)
+        const int l54 = min(lane, 53), which = l54 / 18, v = (l54 % 18) / 9, e = l54 % 9;
+        const int ff = which == 0 ? f : which == 1 ? fp : fn;
+        ptv = *(e < 6 ? a.phi + ((size_t)v * L + ff) * 6 + e : a.tau + ((size_t)v * L + ff) * 3 + (e - 6));
     }
-    if (lane < 32) CAM[lane] = lane < 24 ? a.extr[lane] : a.intr[lane - 24];
-    float gtv[2][2][3] = {}, tmpl[3] = {0.f, 0.f, 0.f}, aprev[3] = {0.f, 0.f, 0.f}, anext[3] = {0.f, 0.f, 0.f}, betav[10];
+    const float camv = *(lane < 24 ? a.extr + lane : a.intr + (min(lane, 31) - 24));
+    float gtv[2][2][3], tmpl[3], aprev[3], anext[3], betav[10], ov[6];
 #pragma unroll
     for (int k = 0; k < 10; ++k) betav[k] = a.beta[k];
-    if (lane < NJ) {
+    {
+        const int lj = min(lane, NJ - 1), lb = min(lane, NB - 1);
 #pragma unroll
-        for (int c = 0; c < 3; ++c) tmpl[c] = a.j_template[lane * 3 + c];
+        for (int c = 0; c < 3; ++c) tmpl[c] = a.j_template[lj * 3 + c];
 #pragma unroll
         for (int v = 0; v < 2; ++v)
 #pragma unroll
             for (int det = 0; det < 2; ++det) {
-                const float* gt = a.j2d + ((((size_t)v * L + f) * 2 + det) * NJ + lane) * 3;
+                const float* gt = a.j2d + ((((size_t)v * L + f) * 2 + det) * NJ + lj) * 3;
                 gtv[v][det][0] = gt[0]; gtv[v][det][1] = gt[1]; gtv[v][det][2] = gt[2];
             }
+        const float* Ap = a.aa_all + ((size_t)fp * NB + lb) * 3;
+        const float* An = a.aa_all + ((size_t)fn * NB + lb) * 3;
+        const float* o = a.O + (size_t)f * a.ldo + 6 * lb;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { aprev[c] = Ap[c]; anext[c] = An[c]; }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) ov[c] = o[c];
     }
-    if (lane < NB) {
-        const float* A = a.aa_all + ((size_t)f * NB + lane) * 3;
-        if (pair_prev) { aprev[0] = A[-NB * 3]; aprev[1] = A[-NB * 3 + 1]; aprev[2] = A[-NB * 3 + 2]; }
-        if (pair_next) { anext[0] = A[NB * 3]; anext[1] = A[NB * 3 + 1]; anext[2] = A[NB * 3 + 2]; }
+    const bool rob = rob_i != 0;
+    const bool pair_prev = a.n_pairs > 0 && f > 0 && robp_i && rob;
+    const bool pair_next = a.n_pairs > 0 && f + 1 < L && rob && robn_i;
+#pragma unroll
+    for (int k = 0; k < SIT; ++k) {
+        const int i = lane + k * 64;
+        if (i < NJ * 3 * 10) Sd[i / 10][i % 10] = sv[k];
     }
+    if (lane < 54) PT[lane / 18][(lane % 18) / 9][lane % 9] = ptv;
+    if (lane < 32) CAM[lane] = camv;
+    if (!pair_prev) { aprev[0] = aprev[1] = aprev[2] = 0.f; }
+    if (!pair_next) { anext[0] = anext[1] = anext[2] = 0.f; }
     // ---- decoder tail: 6-D -> R -> axis-angle -> R' (lbs.batch_rodrigues), body joints 1..21
     GS g; AA q; RD rd;
     V3 a2 = v3(0, 0, 0), aav = v3(0, 0, 0);
     if (lane < NB) {
-        const float* o = a.O + (size_t)f * a.ldo + 6 * lane;
-        a2 = v3(o[1], o[3], o[5]);
-        g = gs_fwd(v3(o[0], o[2], o[4]), a2);
+        a2 = v3(ov[1], ov[3], ov[5]);
+        g = gs_fwd(v3(ov[0], ov[2], ov[4]), a2);
         const float R[9] = {g.b1.x, g.b2.x, g.b3.x, g.b1.y, g.b2.y, g.b3.y, g.b1.z, g.b2.z, g.b3.z};
         q = aa_fwd(R);
         aav = q.aa;
@@ -295,8 +307,8 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
     __syncthreads();
     // ---- kinematic chain (batch_rigid_transform), level by level
     for (int d = 0; d <= 7; ++d) {
-        if (lane < NJ && c_depth[lane] == d) {
-            const int p = c_parent[lane];
+        if (lane < NJ && my_depth == d) {
+            const int p = my_parent;
             if (p < 0) {
 #pragma unroll
                 for (int e = 0; e < 9; ++e) G[lane][e] = Rl[lane][e];
@@ -376,8 +388,8 @@ __global__ void __launch_bounds__(64) fit_frame_kernel(const FitArgs a, int it) 
     __syncthreads();
     // ---- chain backward, deepest level first: G_i = G_p [R_i | rel_i]
     for (int d = 7; d >= 1; --d) {
-        if (lane < NJ && c_depth[lane] == d) {
-            const int p = c_parent[lane];
+        if (lane < NJ && my_depth == d) {
+            const int p = my_parent;
             const float rel[3] = {Jr[lane][0] - Jr[p][0], Jr[lane][1] - Jr[p][1], Jr[lane][2] - Jr[p][2]};
             float drel[3];
 #pragma unroll
