@@ -4,6 +4,8 @@
 //   avg    AvgPool2d(7, stride 1) + view(B, -1)             model_copenet.py:66, 173-174
 // The stem reads the caller's NCHW fp32 crop directly (input contract) and
 // writes NHWC in the trunk's storage type, so no separate layout-conversion pass exists.
+#include <type_traits>
+
 #include "ap_common.h"
 #include "kernels.h"
 
@@ -86,6 +88,18 @@ __global__ void __launch_bounds__(256) stem_direct_kernel(const float* __restric
     }
 }
 
+// Kernel rows in the order 0, 2, 4, 6, 1, 3, 5 (both MFMA stems of the 16-bit kinds, fused and unfused: same fp32 summation order,
+// so they stay bit-identical).  Conv row fm at kernel row kb reads input row 2 fm + kb: within one parity the rows of step kb + 2
+// are the rows of step kb moved up by one conv row, so the fused strip kernel keeps its five fragments in registers and reads
+// ONE new input-row fragment per step instead of five (15 instead of 35 per strip; its K loop is bound by LDS reads).
+__device__ constexpr int stem_kb_of(int step) { return step < 4 ? 2 * step : 2 * (step - 4) + 1; }
+template <int I, int N, typename F> __device__ __forceinline__ void stem_sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        stem_sfor<I + 1, N>(f);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // MFMA stem (bf16 throughput path).  One workgroup = 16x16 conv outputs x 64 channels.
 // GEMM view: M = pixels, N = 64, K' = 7 kernel rows x 32 (7 taps x 4 channel slots, the 4th slot and an 8th tap are
@@ -131,7 +145,8 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int kb = 0; kb < SKB; ++kb) {                      // k-block = kernel row; lane group g = taps 2g, 2g+1
+    for (int step = 0; step < SKB; ++step) {                // k-block = kernel row; lane group g = taps 2g, 2g+1
+        const int kb = stem_kb_of(step);
         u32x4 wf[4], xf[4];
 #pragma unroll
         for (int fn = 0; fn < 4; ++fn) wf[fn] = *(const u32x4*)(wsm + (fn * 16 + lr) * SWLD + kb * 32 + g * 8);
@@ -365,28 +380,41 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         for (int fm = 0; fm < 5; ++fm)
 #pragma unroll
             for (int fn = 0; fn < FNH; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll 1
-        for (int kb = 0; kb < SKB; ++kb) {                  // k-block = kernel row; lane group g = taps 2g, 2g+1
-            u32x4 wf[FNH], xf[5];
+        // k-block = kernel row (order: stem_kb_of); lane group g = taps 2g, 2g+1.  xf[(fm + rot) % 5] holds input row 2 fm + kb
+        u32x4 xf[5];
+        const bf16_t* xbase = patch + (2 * xo + 2 * g) * 4;
+        const bf16_t* wbase = wsm + (half * FNH * 16 + lr) * SWLD + g * 8;
+        stem_sfor<0, SKB>([&](auto ST) {
+            constexpr int step = decltype(ST)::value, kb = stem_kb_of(step);
+            constexpr bool first = step == 0 || step == 4;   // first step of a parity: all five rows; then one new row per step
+            constexpr int rot = first ? 0 : (step < 4 ? step : step - 4);
+            u32x4 wf[FNH];
 #pragma unroll
             for (int fn = 0; fn < FNH; ++fn) {
                 if (STEM_ABLATE & 128) wf[fn] = u32x4{0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-                else wf[fn] = *(const u32x4*)(wsm + ((half * FNH + fn) * 16 + lr) * SWLD + kb * 32 + g * 8);
+                else wf[fn] = *(const u32x4*)(wbase + fn * 16 * SWLD + kb * 32);
             }
+            if constexpr (first) {
 #pragma unroll
-            for (int fm = 0; fm < 5; ++fm) {
-                if (STEM_ABLATE & 128) xf[fm] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
-                else xf[fm] = *(const u32x4*)(patch + ((2 * fm + kb) * FPW + 2 * xo + 2 * g) * 4);
+                for (int fm = 0; fm < 5; ++fm) {
+                    if (STEM_ABLATE & 128) xf[fm] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
+                    else xf[fm] = *(const u32x4*)(xbase + (2 * fm + kb) * FPW * 4);
+                }
+            } else {
+                // rows 2 fm + kb for fm = 0..3 are the previous step's rows of fm + 1; the slot the previous fm = 0 left takes row 8 + kb
+                if (STEM_ABLATE & 128) xf[(4 + rot) % 5] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
+                else xf[(4 + rot) % 5] = *(const u32x4*)(xbase + (8 + kb) * FPW * 4);
             }
 #pragma unroll
             for (int fm = 0; fm < 5; ++fm)
 #pragma unroll
                 for (int fn = 0; fn < FNH; ++fn) {
-                    if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[fm]));
+                    if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[(fm + rot) % 5]));
                     else acc[fm][fn] = ap_mfma16(
-                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[fm]), acc[fm][fn]);
+                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[(fm + rot) % 5]), acc[fm][fn]);
                 }
-        }
+            __builtin_amdgcn_sched_barrier(0);               // one kernel row at a time (hoisted reads of later rows spill the accumulators)
+        });
         __syncthreads();                                     // every wave is done with the patch: vm may overwrite it
 #pragma unroll
         for (int fn = 0; fn < FNH; ++fn) {
