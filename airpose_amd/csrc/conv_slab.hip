@@ -164,6 +164,27 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
                                          16, 0, 0);
     };
 
+    // ---------------------------------------------------------------- prologue DMA FIRST: slab 0 (+ the zero piece of slab 1, which
+    // the K loop skips when the slab is short), weight tiles 0 and 1
+    if (srole) {
+        if (wave == 7) {
+            issue_zero_row(0);
+            issue_zero_row(1);
+            wait_vmcnt<0>();                                 // (the same wave overwrites rows of that piece below)
+        }
+        for (int j = wave - 6; j < need; j += 2) issue_slab(0, 0, j);   // wave 7: the odd pieces, among them the last one
+    } else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            issue_weights(t, 0, false);
+            issue_weights(t, 1, false);
+            if (wave < 4) issue_weights(t, 2, false);
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    // (requested before the per-lane tap table below: its 8 integer divisions and 36 validity tests are ~800 instructions, 2 us,
+    //  that used to run BEFORE the first operand request -- the request's own 1.5-us round trip then came on top, a third of a
+    //  layer2 tile's lifetime.  Measured: neutral on its own -- the other workgroup of the CU covers it -- kept as the saner order)
     // ---------------------------------------------------------------- MFMA state
     const int lr = lane & 15, g4 = lane >> 4;
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
@@ -176,7 +197,17 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     for (int fm = 0; fm < FM; ++fm) {
         const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
         const int m = bm * BM + px;
-        const int rem = m % HW, ho = rem / W, wo = rem - ho * W;
+        // pixel -> (row, column) of its image by multiplication with the launcher's reciprocals (exact for (M + tile) H W < 2^32:
+        // __umulhi(m, ceil(2^32 / d)) = m / d there); hipcc's 32-bit division is ~25 instructions, eight of them per lane here
+        int rem, ho;
+        if (p.magic_hw) {
+            rem = m - (int)__umulhi((unsigned)m, p.magic_hw) * HW;
+            ho = (int)__umulhi((unsigned)rem, p.magic_w);
+        } else {
+            rem = m % HW;
+            ho = rem / W;
+        }
+        const int wo = rem - ho * W;
 #pragma unroll
         for (int t = 0; t < 9; ++t) {
             const int r = t / 3, sx = t % 3;
@@ -229,23 +260,6 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         for (int part = 0; part < FM; ++part) tap_addr_part(part, f, tap, sbase, xa);
     };
 
-    // ---------------------------------------------------------------- prologue: slab 0 (+ the zero piece of slab 1, which
-    // the K loop skips when the slab is short), weight tiles 0 and 1
-    if (srole) {
-        if (wave == 7) {
-            issue_zero_row(0);
-            issue_zero_row(1);
-            wait_vmcnt<0>();                                 // (the same wave overwrites rows of that piece below)
-        }
-        for (int j = wave - 6; j < need; j += 2) issue_slab(0, 0, j);   // wave 7: the odd pieces, among them the last one
-    } else {
-#pragma unroll
-        for (int t = 0; t < 2; ++t) {
-            issue_weights(t, 0, false);
-            issue_weights(t, 1, false);
-            if (wave < 4) issue_weights(t, 2, false);
-        }
-    }
     uint32_t xa[FM];                                         // fragment addresses of the tile whose first half is read next
     tap_addr(pk[0], 0, lds0, xa);
     wait_vmcnt<0>();
@@ -411,6 +425,12 @@ hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st) {
     }
     a.mtiles = (a.M + BM - 1) / BM;
     a.ntiles = (a.Cout + BN - 1) / BN;
+    {
+        const unsigned long long hw = (unsigned long long)a.H * a.W, lim = 1ull << 32;
+        const bool fits = ((unsigned long long)a.M + BM) * hw < lim;
+        a.magic_hw = fits ? (unsigned)((lim + hw - 1) / hw) : 0u;
+        a.magic_w = fits ? (unsigned)((lim + a.W - 1) / a.W) : 0u;
+    }
     hipLaunchKernelGGL(conv_slab_kernel, dim3(a.mtiles * a.ntiles), dim3(NT), LDS_BYTES, st, a);
     return hipGetLastError();
 }
