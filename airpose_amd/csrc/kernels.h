@@ -24,7 +24,7 @@ struct ConvArgs {
     int ldx, ldy, ldr, wld;
     int relu;
     int mtiles, ntiles;   // filled by the launcher
-    unsigned magic_hw, magic_w;   // filled by the launcher: ceil(2^32 / (H W)), ceil(2^32 / W) when (M + tile) * H * W < 2^32 (0 = divide)
+    unsigned magic_hw, magic_w;   // conv_slab, filled by its launcher: ceil(2^32 / (H W)), ceil(2^32 / W) when (M + tile) * H * W < 2^32 (0 = divide)
     int out_f32;          // split-bf16 kind only: y (and res) are plain fp32 [M][ldy] instead of split pairs
     // conv_lean.hip POOL variant (last convolution of the trunk): when set, y is NOT written; the 7 x 7 pixels of every image are
     // averaged per channel instead (AvgPool2d(7) + view) into pool_out [N][Cout] fp32, bit-identical to conv + avgpool_kernel
