@@ -194,10 +194,16 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
             float4 a = *(const float4*)sp, b = *(const float4*)(sp + 4);
             if (rg) {
                 float lo, hi;
+#ifdef AP_F16
+                (void)lo; (void)hi;
+                ap_res_add2(a.x, a.y, rv[it][0]); ap_res_add2(a.z, a.w, rv[it][1]);
+                ap_res_add2(b.x, b.y, rv[it][2]); ap_res_add2(b.z, b.w, rv[it][3]);
+#else
                 unpack_bf16x2(rv[it][0], lo, hi); a.x += lo; a.y += hi;
                 unpack_bf16x2(rv[it][1], lo, hi); a.z += lo; a.w += hi;
                 unpack_bf16x2(rv[it][2], lo, hi); b.x += lo; b.y += hi;
                 unpack_bf16x2(rv[it][3], lo, hi); b.z += lo; b.w += hi;
+#endif
             }
             if (p.relu) {
                 a.x = ap_relu(a.x); a.y = ap_relu(a.y); a.z = ap_relu(a.z); a.w = ap_relu(a.w);

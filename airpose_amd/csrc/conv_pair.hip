@@ -278,10 +278,17 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
         f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
         if (res) {
             const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
+#ifdef AP_F16
+            { float a_ = v0.x, b_ = v0.y; ap_res_add2(a_, b_, r0); v0 = f32x2{a_, b_}; }
+            { float a_ = v1.x, b_ = v1.y; ap_res_add2(a_, b_, r1); v1 = f32x2{a_, b_}; }
+            { float a_ = v2.x, b_ = v2.y; ap_res_add2(a_, b_, r2); v2 = f32x2{a_, b_}; }
+            { float a_ = v3.x, b_ = v3.y; ap_res_add2(a_, b_, r3); v3 = f32x2{a_, b_}; }
+#else
             { float a_, b_; unpack_bf16x2(r0, a_, b_); v0 += f32x2{a_, b_}; }
             { float a_, b_; unpack_bf16x2(r1, a_, b_); v1 += f32x2{a_, b_}; }
             { float a_, b_; unpack_bf16x2(r2, a_, b_); v2 += f32x2{a_, b_}; }
             { float a_, b_; unpack_bf16x2(r3, a_, b_); v3 += f32x2{a_, b_}; }
+#endif
         }
 #endif
         u32x4 o;
