@@ -444,26 +444,24 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
     }
     __syncthreads();
     uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h): the pooled maxima carry an overflow
+    // horizontal 3-maximum on the PACKED 16-bit values: every pooled candidate is a post-ReLU value (>= +0), and for non-negative
+    // bf16 / fp16 the integer order of the bit patterns is the order of the values, so one v_pk_max_i16 per two channels and
+    // neighbour replaces the unpack (conversion), two fp32 maxima and the re-packing (52 -> 8 VALU per 8-channel item)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    auto pkmax = [](uint32_t a, uint32_t b) -> uint32_t {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+    };
     for (int i = tid; i < 2 * PO * 8; i += 448) {           // (pr, px, 8-channel chunk)
         if (STEM_ABLATE & 16) break;
         const int c8 = i & 7, t = i >> 3, px = t % PO, pr = t / PO;
-        float m[8];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) m[e] = 0.f;
+        u32x4 o = u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int dx = -1; dx <= 1; ++dx) {
             const int cx = 2 * px + dx;
             if (cx < 0) continue;
             const u32x4 q = *(const u32x4*)(vm + ((pr * SO + cx) * SC + ((c8 ^ (cx & 7)) << 3)));
-            float lo, hi;
-            unpack_bf16x2(q.x, lo, hi); m[0] = fmaxf(m[0], lo); m[1] = fmaxf(m[1], hi);
-            unpack_bf16x2(q.y, lo, hi); m[2] = fmaxf(m[2], lo); m[3] = fmaxf(m[3], hi);
-            unpack_bf16x2(q.z, lo, hi); m[4] = fmaxf(m[4], lo); m[5] = fmaxf(m[5], hi);
-            unpack_bf16x2(q.w, lo, hi); m[6] = fmaxf(m[6], lo); m[7] = fmaxf(m[7], hi);
+            o.x = pkmax(o.x, q.x); o.y = pkmax(o.y, q.y); o.z = pkmax(o.z, q.z); o.w = pkmax(o.w, q.w);
         }
-        u32x4 o;
-        o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
-        o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
         ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);
         if (STEM_ABLATE & 8) asm volatile("" ::"v"(o)); else
         *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
