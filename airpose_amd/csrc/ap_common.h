@@ -75,6 +75,16 @@ __device__ __forceinline__ void ap_rng_note(uint32_t& m, uint32_t packed) {
 }
 // epilogues WITHOUT a ReLU (stand-alone operator, unfused downsample branch) can also overflow to -inf: sign bits masked first
 __device__ __forceinline__ void ap_rng_note_signed(uint32_t& m, uint32_t packed) { ap_rng_note(m, packed & 0x7fff7fffu); }
+// two packed dwords of NON-NEGATIVE values (post-ReLU) per instruction: gfx950's three-input packed fp16 maximum (for values >= +0
+// the same order as the integer maximum above; a NaN propagates and is >= 0x7c00 as well)
+__device__ __forceinline__ void ap_rng_note2(uint32_t& m, uint32_t a, uint32_t b) {
+    asm("v_pk_maximum3_f16 %0, %0, %1, %2" : "+v"(m) : "v"(a), "v"(b));
+}
+// the four dwords of a 16-byte store; relu: wave-uniform
+__device__ __forceinline__ void ap_rng_note4(uint32_t& m, uint32_t a, uint32_t b, uint32_t c, uint32_t d, bool relu) {
+    if (relu) { ap_rng_note2(m, a, b); ap_rng_note2(m, c, d); }
+    else { ap_rng_note_signed(m, a); ap_rng_note_signed(m, b); ap_rng_note_signed(m, c); ap_rng_note_signed(m, d); }
+}
 __device__ __forceinline__ void ap_rng_flush(int* flag, uint32_t m) {
     if (flag && ((m & 0xffffu) >= 0x7c00u || (m >> 16) >= 0x7c00u))
         __hip_atomic_store(flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -82,6 +92,8 @@ __device__ __forceinline__ void ap_rng_flush(int* flag, uint32_t m) {
 #else
 __device__ __forceinline__ void ap_rng_note(uint32_t&, uint32_t) {}
 __device__ __forceinline__ void ap_rng_note_signed(uint32_t&, uint32_t) {}
+__device__ __forceinline__ void ap_rng_note2(uint32_t&, uint32_t, uint32_t) {}
+__device__ __forceinline__ void ap_rng_note4(uint32_t&, uint32_t, uint32_t, uint32_t, uint32_t, bool) {}
 __device__ __forceinline__ void ap_rng_flush(int*, uint32_t) {}
 #endif
 

@@ -154,7 +154,7 @@ __device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32
     u32x4 o;
     o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));
     o.z = relu_pk_bf16(cvt_pk_bf16(v2.x, v2.y)); o.w = relu_pk_bf16(cvt_pk_bf16(v3.x, v3.y));
-    ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);   // fp16 range sentinel (ap_common.h)
+    ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);   // fp16 range sentinel (ap_common.h)
     return o;
 }
 

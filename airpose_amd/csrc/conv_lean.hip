@@ -151,7 +151,6 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
     const T* __restrict__ rg = (const T*)p.res;
     constexpr int CPR = HALF / 8, NIT = BM * CPR / NT;       // 8 chunks of 8 channels per row and half, 2 per thread
     uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the bf16 set
-    const uint32_t smask = p.relu ? 0xffffffffu : 0x7fff7fffu;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
         __syncthreads();                                     // ring reads (h = 0) / previous half's stage reads (h = 1) are done
@@ -212,7 +211,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(6, 6)))
             u32x4 o;
             o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
             o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
-            ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
+            ap_rng_note4(rng, o[0], o[1], o[2], o[3], p.relu != 0);
             if constexpr (!POOL) {
                 *(u32x4*)(yg + (size_t)mm * p.ldy + ch) = o;
             } else {

@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
         u32x4 o;
         o.x = relu_pk_bf16(cvt_pk_bf16(v0.x, v0.y)); o.y = relu_pk_bf16(cvt_pk_bf16(v1.x, v1.y));
         o.z = relu_pk_bf16(cvt_pk_bf16(v2.x, v2.y)); o.w = relu_pk_bf16(cvt_pk_bf16(v3.x, v3.y));
-        ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);   // fp16 range sentinel
+        ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);   // fp16 range sentinel
         return o;
     };
     auto load_identity = [&](int nb, u32x4 (&r)[PG][4]) {    // 4 x 16 B per lane and pixel group: channels nb*128 + q*32 + g4*8 .. + 7

@@ -564,7 +564,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
             u32x4 o;
             o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
             o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
-            ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
+            ap_rng_note4(rng, o[0], o[1], o[2], o[3], p.relu != 0);
             *(u32x4*)(yg + (p.y_tiled ? ap_tiled_off((size_t)m, ch, p.Cout) : (size_t)m * p.ldy + ch)) = o;
         } else {
             float4 a = *(const float4*)sp;

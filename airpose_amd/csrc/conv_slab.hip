@@ -363,7 +363,6 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     T* __restrict__ yg = (T*)p.y;
     const T* __restrict__ rg = (const T*)p.res;
     uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h); nothing in the bf16 set
-    const uint32_t smask = p.relu ? 0xffffffffu : 0x7fff7fffu;
     u32x4 rv[NIT];
     if (rg) {
 #pragma unroll
@@ -397,7 +396,7 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         u32x4 o;
         o[0] = pack_bf16x2(a.x, a.y); o[1] = pack_bf16x2(a.z, a.w);
         o[2] = pack_bf16x2(b.x, b.y); o[3] = pack_bf16x2(b.z, b.w);
-        ap_rng_note(rng, o[0] & smask); ap_rng_note(rng, o[1] & smask); ap_rng_note(rng, o[2] & smask); ap_rng_note(rng, o[3] & smask);
+        ap_rng_note4(rng, o[0], o[1], o[2], o[3], p.relu != 0);
         *(u32x4*)(yg + (p.y_tiled ? ap_tiled_off((size_t)m, ch, p.Cout) : (size_t)m * p.ldy + ch)) = o;
     }
     ap_rng_flush(p.range_flag, rng);

@@ -462,7 +462,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
             const u32x4 q = *(const u32x4*)(vm + ((pr * SO + cx) * SC + ((c8 ^ (cx & 7)) << 3)));
             o.x = pkmax(o.x, q.x); o.y = pkmax(o.y, q.y); o.z = pkmax(o.z, q.z); o.w = pkmax(o.w, q.w);
         }
-        ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);
+        ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);
         if (STEM_ABLATE & 8) asm volatile("" ::"v"(o)); else
         *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
     }
@@ -664,7 +664,7 @@ __global__ void __launch_bounds__(256) maxpool_kernel(const T* __restrict__ x, T
         o.x = pack_bf16x2(m[0], m[1]); o.y = pack_bf16x2(m[2], m[3]);
         o.z = pack_bf16x2(m[4], m[5]); o.w = pack_bf16x2(m[6], m[7]);
         uint32_t rng = 0u;                                   // fp16 range sentinel (ap_common.h): the maxima carry the stem's overflow
-        ap_rng_note(rng, o.x); ap_rng_note(rng, o.y); ap_rng_note(rng, o.z); ap_rng_note(rng, o.w);
+        ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);
         ap_rng_flush(range_flag, rng);
     } else {
         o.x = __builtin_bit_cast(uint32_t, m[0]); o.y = __builtin_bit_cast(uint32_t, m[1]);
