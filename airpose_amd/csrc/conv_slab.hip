@@ -338,6 +338,48 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
 
     // ---------------------------------------------------------------- epilogue (as conv_pipe.hip: fp32 stage in LDS,
     // BatchNorm + residual + ReLU, 16-byte coalesced stores)
+    if (!p.res && p.relu) {
+        // conv2 of a bottleneck (no residual, ReLU): BatchNorm, rounding and ReLU BEFORE the stage, on packed pairs -- the stage holds
+        // 16-bit values (34 KB instead of 68, half the LDS traffic of the epilogue) and the second half is a 16-byte copy.  Same
+        // result: rounding is monotonic and keeps the sign, so relu(round(v)) = round(relu(v)).
+        constexpr int CLD16 = BN + 8;                        // 272-byte rows: 4 dwords of bank shift per row (tiled and NHWC item maps)
+        T* c16 = (T*)smem;
+        uint32_t rng = 0u;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int chl = wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
+            const int ch = bn * BN + chl;
+            const float4 sc = *(const float4*)(p.scale + ch);
+            const float4 sh = *(const float4*)(p.shift + ch);
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
+                uint2 o;
+                o.x = pack_bf16x2(acc[fm][fn][0] * sc.x + sh.x, acc[fm][fn][1] * sc.y + sh.y);
+                o.y = pack_bf16x2(acc[fm][fn][2] * sc.z + sh.z, acc[fm][fn][3] * sc.w + sh.w);
+                asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.x));
+                asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.y));
+                ap_rng_note2(rng, o.x, o.y);
+                *(uint2*)(c16 + px * CLD16 + chl) = o;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8, NIT = BM * CPR / NT;
+        int et = tid;
+        asm volatile("" : "+v"(et));
+        T* __restrict__ yg = (T*)p.y;
+#pragma unroll
+        for (int it = 0; it < NIT; ++it) {
+            int px, cc;
+            ap_epi_item(et + it * NT, CPR, p.y_tiled != 0, px, cc);
+            const int m = bm * BM + px, ch = bn * BN + cc * 8;
+            if (m >= p.M || ch >= p.Cout) continue;
+            const u32x4 o = *(const u32x4*)(c16 + px * CLD16 + cc * 8);
+            *(u32x4*)(yg + (p.y_tiled ? ap_tiled_off((size_t)m, ch, p.Cout) : (size_t)m * p.ldy + ch)) = o;
+        }
+        ap_rng_flush(p.range_flag, rng);
+        return;
+    }
     float* ct = (float*)smem;
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
