@@ -451,6 +451,46 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
     AP_BSTAMP(4);
     __syncthreads();                                         // all MFMA reads done before the ring is reused
 
+    if constexpr (!SPLIT && sizeof(T) == 2) {
+        if (!rg && p.relu) {
+            // no residual, ReLU (conv1 / conv2 of a bottleneck, the folded-downsample conv3): BatchNorm, rounding and the packed ReLU
+            // BEFORE the stage, which then holds 16-bit values -- half the LDS traffic of the epilogue, and its second half is a
+            // 16-byte copy (conv_slab.hip).  Same result: relu(round(v)) = round(relu(v)).
+            constexpr int CLD16 = BN + 8;                    // row stride in 16-bit elements: 4 dwords of bank shift per row
+            T* c16 = (T*)smem;
+#pragma unroll
+            for (int fn = 0; fn < FN; ++fn) {
+                const int chl = wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
+                const int ch = bn * BN + chl;
+                const float4 sc = *(const float4*)(p.scale + ch);
+                const float4 sh = *(const float4*)(p.shift + ch);
+#pragma unroll
+                for (int fm = 0; fm < FM; ++fm) {
+                    const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
+                    uint2 o;
+                    o.x = pack_bf16x2(acc[fm][fn][0] * sc.x + sh.x, acc[fm][fn][1] * sc.y + sh.y);
+                    o.y = pack_bf16x2(acc[fm][fn][2] * sc.z + sh.z, acc[fm][fn][3] * sc.w + sh.w);
+                    asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.x));
+                    asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.y));
+                    ap_rng_note2(rng, o.x, o.y);
+                    *(uint2*)(c16 + px * CLD16 + chl) = o;
+                }
+            }
+            __syncthreads();
+            T* __restrict__ yq = (T*)p.y;
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                int px, cc;
+                ap_epi_item(tid + it * NT, CPR, p.y_tiled != 0, px, cc);
+                const int m = bm * BM + px, ch = bn * BN + cc * EPC;
+                if (m >= p.M || ch >= p.Cout) continue;
+                const u32x4 o = *(const u32x4*)(c16 + px * CLD16 + cc * EPC);
+                *(u32x4*)(yq + (p.y_tiled ? ap_tiled_off((size_t)m, ch, p.Cout) : (size_t)m * p.ldy + ch)) = o;
+            }
+            ap_rng_flush(p.range_flag, rng);
+            return;
+        }
+    }
     // ---------------------------------------------------------------- epilogue (as conv_igemm.hip)
     float* ct = (float*)smem;
 #pragma unroll
