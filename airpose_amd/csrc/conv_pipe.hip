@@ -449,6 +449,14 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
         return;
     }
     AP_BSTAMP(4);
+    // BatchNorm rows of the wave's channels, requested ahead of the barrier (conv_slab.hip)
+    float4 scv[FN], shv[FN];
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int ch = bn * BN + wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
+        scv[fn] = *(const float4*)(p.scale + ch);
+        shv[fn] = *(const float4*)(p.shift + ch);
+    }
     __syncthreads();                                         // all MFMA reads done before the ring is reused
 
     if constexpr (!SPLIT && sizeof(T) == 2) {
@@ -461,9 +469,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
 #pragma unroll
             for (int fn = 0; fn < FN; ++fn) {
                 const int chl = wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
-                const int ch = bn * BN + chl;
-                const float4 sc = *(const float4*)(p.scale + ch);
-                const float4 sh = *(const float4*)(p.shift + ch);
+                const float4 sc = scv[fn], sh = shv[fn];
 #pragma unroll
                 for (int fm = 0; fm < FM; ++fm) {
                     const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
@@ -496,9 +502,7 @@ __global__ void __launch_bounds__(64 * WAVES_M * WAVES_N) conv_pipe_kernel(const
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
         const int chl = wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
-        const int ch = bn * BN + chl;
-        const float4 sc = *(const float4*)(p.scale + ch);
-        const float4 sh = *(const float4*)(p.shift + ch);
+        const float4 sc = scv[fn], sh = shv[fn];
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
             const int px = wm * (BM / WAVES_M) + fm * 16 + lr;

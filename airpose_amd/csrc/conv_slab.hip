@@ -333,6 +333,19 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
             ws ^= 1;
         }
     }
+    // BatchNorm rows of the wave's channels: requested HERE, ahead of the settle / barrier below (requested where they are used
+    // they were two dependent L2 round trips at the head of every tile's epilogue; the fragment registers are dead by now)
+    __builtin_amdgcn_sched_barrier(0);                       // (not into the K loop: no register to spare there)
+    float4 scv[FN], shv[FN];
+    int tq = threadIdx.x;                                    // (the lane's channel offset from an opaque copy of the thread id: kept alive across
+    asm volatile("" : "+v"(tq));                             //  the K loop it was the one register too many and spilled)
+    const int lre = tq & 15, g4e = (tq & 63) >> 4;           // the epilogue's own copies of lr / g4
+#pragma unroll
+    for (int fn = 0; fn < FN; ++fn) {
+        const int ch = bn * BN + wn * (BN / WAVES_N) + fn * 16 + g4e * 4;
+        scv[fn] = *(const float4*)(p.scale + ch);
+        shv[fn] = *(const float4*)(p.shift + ch);
+    }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results settle before the epilogue's VALU reads them
     __syncthreads();                                         // all MFMA reads done before the buffers are reused
 
@@ -347,13 +360,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         uint32_t rng = 0u;
 #pragma unroll
         for (int fn = 0; fn < FN; ++fn) {
-            const int chl = wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
-            const int ch = bn * BN + chl;
-            const float4 sc = *(const float4*)(p.scale + ch);
-            const float4 sh = *(const float4*)(p.shift + ch);
+            const int chl = wn * (BN / WAVES_N) + fn * 16 + g4e * 4;
+            const float4 sc = scv[fn], sh = shv[fn];
 #pragma unroll
             for (int fm = 0; fm < FM; ++fm) {
-                const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
+                const int px = wm * (BM / WAVES_M) + fm * 16 + lre;
                 uint2 o;
                 o.x = pack_bf16x2(acc[fm][fn][0] * sc.x + sh.x, acc[fm][fn][1] * sc.y + sh.y);
                 o.y = pack_bf16x2(acc[fm][fn][2] * sc.z + sh.z, acc[fm][fn][3] * sc.w + sh.w);
@@ -383,13 +394,11 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
     float* ct = (float*)smem;
 #pragma unroll
     for (int fn = 0; fn < FN; ++fn) {
-        const int chl = wn * (BN / WAVES_N) + fn * 16 + g4 * 4;
-        const int ch = bn * BN + chl;
-        const float4 sc = *(const float4*)(p.scale + ch);
-        const float4 sh = *(const float4*)(p.shift + ch);
+        const int chl = wn * (BN / WAVES_N) + fn * 16 + g4e * 4;
+        const float4 sc = scv[fn], sh = shv[fn];
 #pragma unroll
         for (int fm = 0; fm < FM; ++fm) {
-            const int px = wm * (BM / WAVES_M) + fm * 16 + lr;
+            const int px = wm * (BM / WAVES_M) + fm * 16 + lre;
             float4 v;
             v.x = acc[fm][fn][0] * sc.x + sh.x;
             v.y = acc[fm][fn][1] * sc.y + sh.y;
