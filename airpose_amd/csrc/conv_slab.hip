@@ -347,6 +347,32 @@ __global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(4, 4)))
         shv[fn] = *(const float4*)(p.shift + ch);
     }
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");          // last MFMA results settle before the epilogue's VALU reads them
+    if (!p.res && p.relu && p.y_tiled) {
+        // Fragment-tiled output (t2 of a pair block: [M/16][C/8][16 pixels][8 channels]) straight from the accumulators: a lane holds
+        // 4 consecutive channels of pixel lr per fragment, lanes g4 = 2k, 2k+1 the two halves of channel group k, so a wave's 8-byte
+        // stores of one (fm, fn) fill two ADJACENT 256-byte micro-tiles completely -- 512 contiguous bytes per instruction.  No LDS
+        // stage, no barrier: the epilogue of these layers is BatchNorm, rounding, packed ReLU and eight stores.
+        T* __restrict__ yt = (T*)p.y;
+        uint32_t rng = 0u;
+#pragma unroll
+        for (int fn = 0; fn < FN; ++fn) {
+            const int ch = bn * BN + wn * (BN / WAVES_N) + fn * 16 + g4e * 4;
+            const float4 sc = scv[fn], sh = shv[fn];
+#pragma unroll
+            for (int fm = 0; fm < FM; ++fm) {
+                const int m = bm * BM + wm * (BM / WAVES_M) + fm * 16 + lre;
+                uint2 o;
+                o.x = pack_bf16x2(acc[fm][fn][0] * sc.x + sh.x, acc[fm][fn][1] * sc.y + sh.y);
+                o.y = pack_bf16x2(acc[fm][fn][2] * sc.z + sh.z, acc[fm][fn][3] * sc.w + sh.w);
+                asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.x));
+                asm("v_pk_max_i16 %0, %0, 0" : "+v"(o.y));
+                ap_rng_note2(rng, o.x, o.y);
+                if (m < p.M && ch < p.Cout) *(uint2*)(yt + ap_tiled_off((size_t)m, ch, p.Cout) + (ch & 7)) = o;
+            }
+        }
+        ap_rng_flush(p.range_flag, rng);
+        return;
+    }
     __syncthreads();                                         // all MFMA reads done before the buffers are reused
 
     // ---------------------------------------------------------------- epilogue (as conv_pipe.hip: fp32 stage in LDS,
