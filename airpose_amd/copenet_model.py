@@ -181,6 +181,25 @@ class copenet(nn.Module):
             N.check(self._L().ap_trunk_fwd(h, N.dptr(x, "x"), x.shape[0], N.dptr(out), N.stream_ptr(dev)), "ap_trunk_fwd")
         return out
 
+    def forward_feat_ext_twoview(self, x0, x1, out=None):
+        """xf0, xf1 of forward() (model_copenet.py:140-141) in one native call: two (B,3,224,224) -> (2,B,2048); the two views run
+        as two concurrent trunk passes exactly as inside forward().  ``out``: a caller-owned (2,B,2048) fp32 buffer."""
+        self._check_eval()
+        dev = self._dev(x0)
+        B = x0.shape[0]
+        if x0.dim() != 4 or x0.shape[1:] != (3, 224, 224) or x1.shape != x0.shape:
+            raise RuntimeError("forward_feat_ext_twoview expects two (B, 3, 224, 224) NCHW crops")
+        x0, x1 = N.f32c(x0), N.f32c(x1, dev)
+        if out is None:
+            out = torch.empty(2, B, 2048, device=dev, dtype=torch.float32)
+        elif tuple(out.shape) != (2, B, 2048) or out.dtype != torch.float32 or not out.is_contiguous() or out.device != dev:
+            raise RuntimeError("out must be a contiguous (2, %d, 2048) fp32 tensor on %s" % (B, dev))
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(self._L().ap_trunk_fwd_twoview(h, N.dptr(x0, "x0"), N.dptr(x1, "x1"), B, N.dptr(out), N.stream_ptr(dev)),
+                    "ap_trunk_fwd_twoview")
+        return out
+
     @staticmethod
     def _bs(t, B, width, name):
         """(tensor, batch stride) for an optional (1|B, >=width) initial-state tensor."""

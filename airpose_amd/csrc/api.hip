@@ -1201,6 +1201,12 @@ int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* s
     return trunk_fwd(h, x_nchw, n_img, nullptr, 0, feat, (hipStream_t)stream);
 }
 
+int ap_trunk_fwd_twoview(ap_net* h, const float* x0, const float* x1, int B, float* feat, void* stream) {
+    if (!h || !x0 || !x1 || !feat) return fail(AP_EINVAL, "ap_trunk_fwd_twoview: null argument");
+    if (B <= 0) return fail(AP_EINVAL, "ap_trunk_fwd_twoview: bad batch");
+    return trunk_fwd(h, x0, B, x1, B, feat, (hipStream_t)stream);
+}
+
 int ap_regressor_fwd(ap_net* h, const float* xf0, const float* xf1, const float* bb0, const float* bb1,
                      const float* pos0, const float* pos1, const float* init_theta0, int theta0_bs,
                      const float* init_theta1, int theta1_bs, const float* init_shape0, int shape0_bs,

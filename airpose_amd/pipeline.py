@@ -3,7 +3,12 @@
 test-mode output dict out.  Python only orchestrates: TWO C-ABI calls per forward -- ap_copenet_fwd and
 ap_smplx_fwd_twoview (translation un-scale in place on pred_pose, rot6d, SMPL-X for both views, root transform,
 projection with the camera centres read from the intrinsics, optionally the test-mode input meshes) -- and no
-torch kernel in between."""
+torch kernel in between.
+
+``submit`` is the serving form of the same forward: the trunk of batch i+1 is issued on the caller's stream while the IEF
+loop and the SMPL-X stage of batch i (0.12 ms of latency-bound and HBM-bound kernels behind a 5.5 ms MFMA-heavy trunk, plus the
+two cross-queue hops around them) run on a second stream.  Same kernels, same results; what changes is when the outputs are
+ready (``Pending.wait``)."""
 import torch
 
 from . import _native as N
@@ -12,10 +17,28 @@ TRANS_SCALE = 0.05               # copenet_twoview.py:199
 FOCAL_LENGTH = (1475.0, 1475.0)  # copenet/src/copenet/constants.py:7
 
 
+class Pending(object):
+    """Result of ``TwoViewInference.submit``: ``out`` (the dict ``__call__`` returns) is being produced on the pipeline's second
+    stream.  ``wait()`` makes a stream (default: the current one) wait for it, ``synchronize()`` blocks the host; reading ``out``
+    before either is a race, exactly as with any tensor produced on another stream."""
+
+    def __init__(self, out, done, stream):
+        self.out, self._done, self._stream = out, done, stream
+
+    def wait(self, stream=None):
+        (stream if stream is not None else torch.cuda.current_stream(self._stream.device)).wait_event(self._done)
+        return self.out
+
+    def synchronize(self):
+        self._done.synchronize()
+        return self.out
+
+
 class TwoViewInference(object):
     def __init__(self, model, smplx, iters=3, focal_length=FOCAL_LENGTH):
         self.model, self.smplx, self.iters, self.focal_length = model, smplx, iters, focal_length
         self._pos = {}
+        self._pl = {}            # submit(): per (B, device) the second stream, two feature slots and their events
 
     def init_position(self, B, device):
         """[0,0,10] * 0.05 (copenet_twoview.py:184-185,201-203), cached per (B, device)."""
@@ -31,8 +54,50 @@ class TwoViewInference(object):
 
     def __call__(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False):
         im0, im1 = batch["im0"], batch["im1"]
-        B, dev = im0.shape[0], im0.device
         p0, b0, p1, b1 = self.forward_net(im0, im1, batch["bb0"], batch["bb1"])
+        return self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
+
+    def submit(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False):
+        """The forward of ``__call__`` with its two halves on two streams: trunk (both views, model_copenet.py:140-141) on the
+        CURRENT stream, IEF loop (:144-157) + SMPL-X stage (copenet_twoview.py:222-257,307-317) on the pipeline's own stream, which
+        waits for the features.  Returns at once with a ``Pending``; the next ``submit`` starts its trunk without waiting for this
+        one's tail.  The features are double-buffered (a slot is rewritten by the trunk two submits later, after the IEF loop that
+        read it).  ``batch['bb*']`` / ``['intr*']`` are read on the second stream: do not overwrite them in place before
+        ``Pending.wait`` / ``synchronize`` (the images are consumed on the current stream, as usual)."""
+        im0, im1 = batch["im0"], batch["im1"]
+        B, dev = im0.shape[0], im0.device
+        main = torch.cuda.current_stream(dev)
+        key = (B, dev)
+        st = self._pl.get(key)
+        if st is None:
+            # default priority: a high-priority second stream was measured SLOWER than no overlap at all (42.1k against 43.2k
+            # pairs/s at B = 256: the tail's workgroups displace the next trunk's stems); HIP offers no lower priority than 0
+            st = self._pl[key] = {"side": torch.cuda.Stream(device=dev), "n": 0,
+                                  "feat": [torch.empty(2, B, 2048, device=dev, dtype=torch.float32) for _ in range(2)],
+                                  "ready": [torch.cuda.Event() for _ in range(2)], "read": [None, None],
+                                  "done": [torch.cuda.Event() for _ in range(2)]}
+        side, slot = st["side"], st["n"] & 1
+        st["n"] += 1
+        pos = self.init_position(B, dev)
+        if st["read"][slot] is not None:                     # the IEF loop of two submits ago has read this slot
+            main.wait_event(st["read"][slot])
+        feat = self.model.forward_feat_ext_twoview(im0, im1, out=st["feat"][slot])
+        st["ready"][slot].record(main)
+        side.wait_event(st["ready"][slot])
+        with torch.cuda.stream(side):
+            for k in ("bb0", "bb1", "intr0", "intr1"):       # the caching allocator must not recycle them under the second stream
+                if torch.is_tensor(batch.get(k)) and batch[k].is_cuda:
+                    batch[k].record_stream(side)
+            p0, b0, p1, b1 = self.model.forward_ief(feat[0], feat[1], batch["bb0"], batch["bb1"], pos, pos, iters=self.iters)
+            if st["read"][slot] is None:
+                st["read"][slot] = torch.cuda.Event()
+            st["read"][slot].record(side)
+            out = self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
+            st["done"][slot].record(side)
+        return Pending(out, st["done"][slot], side)
+
+    def _tail(self, p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh):
+        B, dev = p0.shape[0], p0.device
         # pred_pose0/1 and betas0/1 are the two halves of one (2,B,.) buffer: both views run as 2B bodies
         pose = p0._base if p0._base is not None and p0._base.shape == (2, B, 135) else torch.stack([p0, p1])
         betas = b0._base if b0._base is not None and b0._base.shape == (2, B, 10) else torch.stack([b0, b1])

@@ -310,6 +310,8 @@ def main():
     ap.add_argument("--repeat-blocks", type=int, default=4, help="extra K-step blocks after the contract's one (spread)")
     ap.add_argument("--parity-steps", type=int, default=3, help="steps of the parity-grade mode after the main loop (0 = skip)")
     ap.add_argument("--parity-pairs", type=int, default=128, help="pairs (two input seeds) on which the TIMED mode is checked against the CPU oracle (0 = skip)")
+    ap.add_argument("--overlap-tail", type=int, default=0,
+                    help="1: TwoViewInference.submit -- IEF loop + SMPL-X stage of step i on a second stream under the trunk of step i+1")
     ap.add_argument("--b64", type=int, default=1, help="also time BASELINE config 1 (batch 64, network only, bf16 and f16): 0 = skip")
     args = ap.parse_args()
 
@@ -378,7 +380,11 @@ def main():
     def step():
         if args.no_tail:
             return pipe.forward_net(batch["im0"], batch["im1"], batch["bb0"], batch["bb1"])
+        if args.overlap_tail and not instrumented[0]:
+            return pipe.submit(batch, want_rotmat=True)
         return pipe(batch, want_rotmat=True)
+
+    instrumented = [False]                                   # the per-stage steps after the timed region run serially
 
     def fence():
         torch.cuda.synchronize()
@@ -419,9 +425,31 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         blocks.append(world * B * args.steps / dt)
+    # serving form of the same forward (TwoViewInference.submit): one more block of K steps with the IEF loop + SMPL-X stage of
+    # step i on a second stream under the trunk of step i+1 -- same kernels, bit-identical outputs, reported beside the headline
+    overlap = None
+    if not args.no_tail and not args.overlap_tail:
+        for _ in range(2):
+            pend = pipe.submit(batch, want_rotmat=True)
+        fence()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            pend = pipe.submit(batch, want_rotmat=True)
+        fence()
+        dt = time.perf_counter() - t1
+        del pend
+        if use_dist:
+            t = torch.tensor([dt], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        overlap = {"pairs_per_s": world * B * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+                   "what": "TwoViewInference.submit: IEF loop + SMPL-X stage of step i on a second stream under the trunk of step "
+                           "i+1 (serving form; outputs bit-identical, ready at Pending.wait); the headline above is the "
+                           "stream-ordered forward of the reference boundary"}
     net.timing(reset=True)
     # stage breakdown: a few more steps, fully instrumented, outside the timed region
     net.enable_timing(1)
+    instrumented[0] = True
     if not args.no_tail:
         body.enable_timing(True)
         body.timing(reset=True)
@@ -564,6 +592,8 @@ def main():
                                                              "read after the timed and instrumented steps)"}
         if b64 is not None:
             res["b64"] = b64
+        if overlap is not None:
+            res["overlap_tail"] = overlap
         if vs is not None:
             res["view_split"] = vs
         if cpu is not None:

@@ -83,6 +83,13 @@ int ap_net_range_status(ap_net* h, void* stream, int reset);
  * x: [n_img][3][224][224] NCHW fp32 (the reference input contract); feat: [n_img][2048] fp32. */
 int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* stream);
 
+/* The two forward_feat_ext calls of copenet.forward (model_copenet.py:140-141: xf0 = forward_feat_ext(x0), xf1 = ...(x1)) as ONE
+ * call: x0, x1: [B][3][224][224] NCHW fp32; feat: [2][B][2048] fp32 (view 0 rows, then view 1 rows).  Same kernels and the same
+ * two concurrent passes as inside ap_copenet_fwd, which is this call followed by ap_regressor_fwd on the handle's own feature
+ * buffer; a caller that keeps the features (or runs the IEF loop / the SMPL-X stage of batch i on another stream while the trunk of
+ * batch i+1 runs on this one: airpose_amd.pipeline.TwoViewInference.submit) uses the two halves. */
+int ap_trunk_fwd_twoview(ap_net* h, const float* x0, const float* x1, int B, float* feat, void* stream);
+
 /* IEF loop of copenet.forward (model_copenet.py:119-159) starting from trunk features.
  * xf*: [B][2048]; bb*, pos*: [B][3]; init_theta*: [tb][>=132] with batch stride theta*_bs floats
  * (0 broadcasts one row; NULL = model mean pose); init_shape*: [sb][10] likewise (NULL = mean shape).

@@ -766,6 +766,35 @@ def test_f16_whole_pipeline_matches_oracle(netf16, body, copenet_sd, copenet_inp
             assert e < 1e-4, "%s %s rel err %.3e" % (k, nm, e)
 
 
+@pytest.mark.parametrize("B", [3, 64])
+def test_pipelined_submit_is_bit_identical_to_call(netf16, body, dev, B):
+    """TwoViewInference.submit (trunk of batch i+1 on the caller's stream under the IEF loop + SMPL-X stage of batch i on a second
+    stream; ap_trunk_fwd_twoview + ap_regressor_fwd + ap_smplx_fwd_twoview) against __call__ (ap_copenet_fwd +
+    ap_smplx_fwd_twoview on one stream): the same kernels on the same data, so every output equal to the bit -- over six
+    back-to-back submits of three different batches (the double-buffered features and the reused events go round three times;
+    B = 64 takes the two-stream trunk)."""
+    from airpose_amd import pipeline, weights as W
+    pipe = pipeline.TwoViewInference(netf16, body)
+    batches = [{k: torch.from_numpy(v).to(dev) for k, v in W.synthetic_inputs(500 + i, B).items()} for i in range(3)]
+    want = [{k: v.clone() for k, v in pipe(b, want_angles=True).items()} for b in batches]
+    torch.cuda.synchronize()
+    pend = [pipe.submit(batches[i % 3], want_angles=True) for i in range(6)]
+    for i in (5, 0, 3, 1, 4, 2):                             # collected out of order
+        got = pend[i].synchronize()
+        assert set(got) == set(want[i % 3])
+        for k, v in want[i % 3].items():
+            assert torch.equal(got[k], v), (i, k)
+    # wait(): the current stream is ordered behind the tail
+    p = pipe.submit(batches[1])
+    v = p.wait()["pred_vertices_cam0"] + 0.0
+    assert torch.equal(v, want[1]["pred_vertices_cam0"])
+    f = netf16.forward_feat_ext_twoview(batches[0]["im0"], batches[0]["im1"])
+    assert torch.equal(f[0], netf16.forward_feat_ext(batches[0]["im0"])) or B >= 64    # (one pass vs two: same kernels per image)
+    assert torch.equal(f[1], netf16.forward_feat_ext(batches[0]["im1"])) or B >= 64
+    with pytest.raises(RuntimeError):
+        netf16.forward_feat_ext_twoview(batches[0]["im0"], batches[0]["im1"], out=torch.empty(2, B, 2047, device=dev))
+
+
 def test_f16_refuses_weights_outside_the_fp16_range(copenet_sd, dev):
     """A (BatchNorm-folded) weight above 65 504 would be inf in fp16 storage: AP_PREC_F16 refuses the checkpoint when it
     packs it, AP_PREC_BF16 (fp32's exponent range) takes it."""
