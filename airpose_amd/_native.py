@@ -45,6 +45,7 @@ SIGNATURES = {
     "ap_net_range_status": (_i, [_vp, _vp, _i]),
     "ap_trunk_fwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "ap_trunk_fwd_twoview": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
+    "ap_trunk_fwd_twoview_async": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "ap_regressor_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_regressor_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ap_copenet_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),

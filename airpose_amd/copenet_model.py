@@ -181,9 +181,11 @@ class copenet(nn.Module):
             N.check(self._L().ap_trunk_fwd(h, N.dptr(x, "x"), x.shape[0], N.dptr(out), N.stream_ptr(dev)), "ap_trunk_fwd")
         return out
 
-    def forward_feat_ext_twoview(self, x0, x1, out=None):
+    def forward_feat_ext_twoview(self, x0, x1, out=None, out_stream=None):
         """xf0, xf1 of forward() (model_copenet.py:140-141) in one native call: two (B,3,224,224) -> (2,B,2048); the two views run
-        as two concurrent trunk passes exactly as inside forward().  ``out``: a caller-owned (2,B,2048) fp32 buffer."""
+        as two concurrent trunk passes exactly as inside forward().  ``out``: a caller-owned (2,B,2048) fp32 buffer.
+        ``out_stream``: a torch stream on which the features become ready INSTEAD of the current one (the inputs are still taken
+        in the order of the current stream, which is then not made to wait for the trunk: ap_trunk_fwd_twoview_async)."""
         self._check_eval()
         dev = self._dev(x0)
         B = x0.shape[0]
@@ -196,8 +198,12 @@ class copenet(nn.Module):
             raise RuntimeError("out must be a contiguous (2, %d, 2048) fp32 tensor on %s" % (B, dev))
         with self._lock, torch.cuda.device(dev):
             h = self._native(dev)
-            N.check(self._L().ap_trunk_fwd_twoview(h, N.dptr(x0, "x0"), N.dptr(x1, "x1"), B, N.dptr(out), N.stream_ptr(dev)),
-                    "ap_trunk_fwd_twoview")
+            if out_stream is None:
+                N.check(self._L().ap_trunk_fwd_twoview(h, N.dptr(x0, "x0"), N.dptr(x1, "x1"), B, N.dptr(out), N.stream_ptr(dev)),
+                        "ap_trunk_fwd_twoview")
+            else:
+                N.check(self._L().ap_trunk_fwd_twoview_async(h, N.dptr(x0, "x0"), N.dptr(x1, "x1"), B, N.dptr(out), N.stream_ptr(dev),
+                                                             ctypes.c_void_p(out_stream.cuda_stream)), "ap_trunk_fwd_twoview_async")
         return out
 
     @staticmethod

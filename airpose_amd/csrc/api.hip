@@ -266,7 +266,8 @@ struct ap_net {
     int dual_skew = 0;             // experiment: the second pass starts after the first has finished its stem (1) / its block k-2 (k >= 2)
     hipEvent_t ev_skew = nullptr;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool unjoined = false;         // ap_trunk_fwd_twoview_async: the last two-pass call joined into another stream than its inputs'
+    hipEvent_t ev_fork = nullptr, ev_in = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     int passes_per_view = 1;       // experiment: 2 = each view as two concurrent half passes (four streams)
     DevBuf ws_H, ws_S, ws_T1, ws_T2, ws_D, ws_state;
     Timing tm;
@@ -933,17 +934,21 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
 }
 
 // trunk over the concatenation [x0 (n0 images) | x1 (n1 images)]; feat rows follow the same order
-int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st);
-int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
+int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st, hipStream_t st_out);
+// st: the stream the inputs are ordered on; st_out (default: st): the stream the features are ordered on.  With two streams
+// (ap_trunk_fwd_twoview_async) st is never made to wait for the passes: the next call's passes queue behind this call's on the
+// internal streams and the caller's stream stays free
+int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st, hipStream_t st_out = nullptr) {
+    if (!st_out) st_out = st;
     if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
     if (n0 <= 0 || n1 < 0 || !x0 || (n1 && !x1) || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
     if (h->range_flag && h->range_mode && __atomic_load_n(h->range_flag, __ATOMIC_RELAXED))
         return fail(AP_ERANGE, "AP_PREC_F16: an earlier trunk pass of this handle produced non-finite features (a stored activation left "
                                "the fp16 range); clear with ap_net_range_status(h, stream, 1) and use AP_PREC_BF16 for this checkpoint");
-    int rc_pass = trunk_passes(h, x0, n0, x1, n1, feat, st);
+    int rc_pass = trunk_passes(h, x0, n0, x1, n1, feat, st, st_out);
     if (rc_pass) return rc_pass;
     if (h->range_flag && h->range_mode == 2) {
-        HIP_TRY(hipStreamSynchronize(st));
+        HIP_TRY(hipStreamSynchronize(st_out));
         if (__atomic_load_n(h->range_flag, __ATOMIC_RELAXED))
             return fail(AP_ERANGE, "AP_PREC_F16: non-finite trunk features (a stored activation left the fp16 range); use AP_PREC_BF16 "
                                    "for this checkpoint");
@@ -951,7 +956,7 @@ int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float
     return AP_OK;
 }
 
-int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st) {
+int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st, hipStream_t st_out) {
     const int n_img = n0 + n1;
     const int chunk = h->chunk > 0 ? h->chunk : 512;
     const size_t IMG_ELEMS = (size_t)3 * 224 * 224;
@@ -990,7 +995,8 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
         // join every stream that forked, also after a failed launch: later calls reuse tw[q] on the caller's stream order
         for (int q = 0; q < forked; ++q) {
             HIP_TRY(hipEventRecord(h->ev_join[q], h->aux[q]));
-            HIP_TRY(hipStreamWaitEvent(st, h->ev_join[q], 0));
+            HIP_TRY(hipStreamWaitEvent(st_out, h->ev_join[q], 0));
+            if (st_out != st) h->unjoined = true;            // st itself is not behind these passes
         }
         if (rc) return rc;
         if (h->tm.on) {
@@ -1002,6 +1008,16 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
             h->tm.passes++;
         }
         return AP_OK;
+    }
+    if (h->unjoined) {                                       // an asynchronous two-pass call came before: its passes may still use tw[0]
+        for (int q = 0; q < 4; ++q) HIP_TRY(hipStreamWaitEvent(st_out, h->ev_join[q], 0));
+        h->unjoined = false;
+    }
+    if (st_out != st) {                                      // one pass: it runs on st_out, behind the inputs
+        if (!h->ev_in) HIP_TRY(hipEventCreateWithFlags(&h->ev_in, hipEventDisableTiming));
+        HIP_TRY(hipEventRecord(h->ev_in, st));
+        HIP_TRY(hipStreamWaitEvent(st_out, h->ev_in, 0));
+        st = st_out;
     }
     for (int i0 = 0; i0 < n_img; i0 += chunk) {
         const int i1 = std::min(n_img, i0 + chunk);
@@ -1142,6 +1158,7 @@ void ap_net_destroy(ap_net* h) {
         if (h->ev_join[i]) (void)hipEventDestroy(h->ev_join[i]);
     }
     if (h->ev_fork) (void)hipEventDestroy(h->ev_fork);
+    if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_skew) (void)hipEventDestroy(h->ev_skew);
     if (h->range_flag) (void)hipHostFree(h->range_flag);
     delete h;
@@ -1205,6 +1222,12 @@ int ap_trunk_fwd_twoview(ap_net* h, const float* x0, const float* x1, int B, flo
     if (!h || !x0 || !x1 || !feat) return fail(AP_EINVAL, "ap_trunk_fwd_twoview: null argument");
     if (B <= 0) return fail(AP_EINVAL, "ap_trunk_fwd_twoview: bad batch");
     return trunk_fwd(h, x0, B, x1, B, feat, (hipStream_t)stream);
+}
+
+int ap_trunk_fwd_twoview_async(ap_net* h, const float* x0, const float* x1, int B, float* feat, void* in_stream, void* out_stream) {
+    if (!h || !x0 || !x1 || !feat) return fail(AP_EINVAL, "ap_trunk_fwd_twoview_async: null argument");
+    if (B <= 0) return fail(AP_EINVAL, "ap_trunk_fwd_twoview_async: bad batch");
+    return trunk_fwd(h, x0, B, x1, B, feat, (hipStream_t)in_stream, (hipStream_t)out_stream);
 }
 
 int ap_regressor_fwd(ap_net* h, const float* xf0, const float* xf1, const float* bb0, const float* bb1,

@@ -5,9 +5,9 @@ ap_smplx_fwd_twoview (translation un-scale in place on pred_pose, rot6d, SMPL-X 
 projection with the camera centres read from the intrinsics, optionally the test-mode input meshes) -- and no
 torch kernel in between.
 
-``submit`` is the serving form of the same forward: the trunk of batch i+1 is issued on the caller's stream while the IEF
-loop and the SMPL-X stage of batch i (0.12 ms of latency-bound and HBM-bound kernels behind a 5.5 ms MFMA-heavy trunk, plus the
-two cross-queue hops around them) run on a second stream.  Same kernels, same results; what changes is when the outputs are
+``submit`` is the serving form of the same forward: the trunk passes of batch i+1 queue directly behind those of batch i while
+the IEF loop and the SMPL-X stage of batch i (0.12 ms of latency-bound and HBM-bound kernels behind a 5.5 ms MFMA-heavy trunk, plus
+the cross-queue hops around them) run on a second stream.  Same kernels, same results; what changes is when the outputs are
 ready (``Pending.wait``)."""
 import torch
 
@@ -58,15 +58,16 @@ class TwoViewInference(object):
         return self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
 
     def submit(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False):
-        """The forward of ``__call__`` with its two halves on two streams: trunk (both views, model_copenet.py:140-141) on the
-        CURRENT stream, IEF loop (:144-157) + SMPL-X stage (copenet_twoview.py:222-257,307-317) on the pipeline's own stream, which
-        waits for the features.  Returns at once with a ``Pending``; the next ``submit`` starts its trunk without waiting for this
-        one's tail.  The features are double-buffered (a slot is rewritten by the trunk two submits later, after the IEF loop that
-        read it).  ``batch['bb*']`` / ``['intr*']`` are read on the second stream: do not overwrite them in place before
-        ``Pending.wait`` / ``synchronize`` (the images are consumed on the current stream, as usual)."""
+        """The forward of ``__call__`` for a serving loop: the inputs are taken in the order of the CURRENT stream; trunk (both
+        views, model_copenet.py:140-141) on the model's two pass streams, IEF loop (:144-157) + SMPL-X stage
+        (copenet_twoview.py:222-257,307-317) on the pipeline's own stream, which is the one the passes join into
+        (ap_trunk_fwd_twoview_async).  Returns at once with a ``Pending``; the current stream is not made to wait for anything, so
+        the passes of the next ``submit`` queue directly behind this one's and its tail runs under them.  At most two batches are in
+        flight (the third ``submit`` blocks the host until the first has finished); the features are double-buffered.  The inputs of
+        a batch are referenced until its slot comes round again; do not overwrite them in place before ``Pending.wait`` /
+        ``synchronize``."""
         im0, im1 = batch["im0"], batch["im1"]
         B, dev = im0.shape[0], im0.device
-        main = torch.cuda.current_stream(dev)
         key = (B, dev)
         st = self._pl.get(key)
         if st is None:
@@ -74,26 +75,19 @@ class TwoViewInference(object):
             # pairs/s at B = 256: the tail's workgroups displace the next trunk's stems); HIP offers no lower priority than 0
             st = self._pl[key] = {"side": torch.cuda.Stream(device=dev), "n": 0,
                                   "feat": [torch.empty(2, B, 2048, device=dev, dtype=torch.float32) for _ in range(2)],
-                                  "ready": [torch.cuda.Event() for _ in range(2)], "read": [None, None],
-                                  "done": [torch.cuda.Event() for _ in range(2)]}
+                                  "done": [torch.cuda.Event() for _ in range(2)], "busy": [False, False], "keep": [None, None]}
         side, slot = st["side"], st["n"] & 1
         st["n"] += 1
+        if st["busy"][slot]:                                 # two submits ago: its tail has read the slot's features and inputs
+            st["done"][slot].synchronize()
         pos = self.init_position(B, dev)
-        if st["read"][slot] is not None:                     # the IEF loop of two submits ago has read this slot
-            main.wait_event(st["read"][slot])
-        feat = self.model.forward_feat_ext_twoview(im0, im1, out=st["feat"][slot])
-        st["ready"][slot].record(main)
-        side.wait_event(st["ready"][slot])
+        st["keep"][slot] = batch
+        feat = self.model.forward_feat_ext_twoview(im0, im1, out=st["feat"][slot], out_stream=side)
         with torch.cuda.stream(side):
-            for k in ("bb0", "bb1", "intr0", "intr1"):       # the caching allocator must not recycle them under the second stream
-                if torch.is_tensor(batch.get(k)) and batch[k].is_cuda:
-                    batch[k].record_stream(side)
             p0, b0, p1, b1 = self.model.forward_ief(feat[0], feat[1], batch["bb0"], batch["bb1"], pos, pos, iters=self.iters)
-            if st["read"][slot] is None:
-                st["read"][slot] = torch.cuda.Event()
-            st["read"][slot].record(side)
             out = self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
             st["done"][slot].record(side)
+        st["busy"][slot] = True
         return Pending(out, st["done"][slot], side)
 
     def _tail(self, p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh):

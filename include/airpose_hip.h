@@ -90,6 +90,13 @@ int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* s
  * batch i+1 runs on this one: airpose_amd.pipeline.TwoViewInference.submit) uses the two halves. */
 int ap_trunk_fwd_twoview(ap_net* h, const float* x0, const float* x1, int B, float* feat, void* stream);
 
+/* ap_trunk_fwd_twoview with the inputs ordered on one stream and the features on another: x0 / x1 are read after the work queued
+ * on in_stream so far; feat is complete in the order of out_stream; in_stream is NOT made to wait for the trunk.  Back-to-back calls
+ * queue their passes behind each other on the handle's internal streams, so the stem of batch i+1 starts while the last layers
+ * of batch i still run (the serving loop of airpose_amd.pipeline.TwoViewInference.submit).  The caller keeps x0 / x1 unchanged
+ * until work queued on out_stream after this call has run.  in_stream == out_stream: ap_trunk_fwd_twoview. */
+int ap_trunk_fwd_twoview_async(ap_net* h, const float* x0, const float* x1, int B, float* feat, void* in_stream, void* out_stream);
+
 /* IEF loop of copenet.forward (model_copenet.py:119-159) starting from trunk features.
  * xf*: [B][2048]; bb*, pos*: [B][3]; init_theta*: [tb][>=132] with batch stride theta*_bs floats
  * (0 broadcasts one row; NULL = model mean pose); init_shape*: [sb][10] likewise (NULL = mean shape).
