@@ -15,6 +15,7 @@ from . import _native as N
 
 TRANS_SCALE = 0.05               # copenet_twoview.py:199
 FOCAL_LENGTH = (1475.0, 1475.0)  # copenet/src/copenet/constants.py:7
+DEPTH = 3                        # submit(): batches in flight (feature slots); the host blocks on the oldest when all are taken
 
 
 class Pending(object):
@@ -57,13 +58,18 @@ class TwoViewInference(object):
         p0, b0, p1, b1 = self.forward_net(im0, im1, batch["bb0"], batch["bb1"])
         return self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
 
-    def submit(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False):
+    def submit_net(self, im0, im1, bb0, bb1):
+        """``forward_net`` issued as ``submit`` issues the whole forward: Pending.out = (pred_pose0, pred_betas0, pred_pose1,
+        pred_betas1)."""
+        return self.submit({"im0": im0, "im1": im1, "bb0": bb0, "bb1": bb1}, net_only=True)
+
+    def submit(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False, net_only=False):
         """The forward of ``__call__`` for a serving loop: the inputs are taken in the order of the CURRENT stream; trunk (both
         views, model_copenet.py:140-141) on the model's two pass streams, IEF loop (:144-157) + SMPL-X stage
         (copenet_twoview.py:222-257,307-317) on the pipeline's own stream, which is the one the passes join into
         (ap_trunk_fwd_twoview_async).  Returns at once with a ``Pending``; the current stream is not made to wait for anything, so
-        the passes of the next ``submit`` queue directly behind this one's and its tail runs under them.  At most two batches are in
-        flight (the third ``submit`` blocks the host until the first has finished); the features are double-buffered.  The inputs of
+        the passes of the next ``submit`` queue directly behind this one's and its tail runs under them.  At most DEPTH = 3 batches are
+        in flight (the next ``submit`` blocks the host until the oldest has finished); one feature buffer per batch in flight.  The inputs of
         a batch are referenced until its slot comes round again; do not overwrite them in place before ``Pending.wait`` /
         ``synchronize``."""
         im0, im1 = batch["im0"], batch["im1"]
@@ -74,18 +80,19 @@ class TwoViewInference(object):
             # default priority: a high-priority second stream was measured SLOWER than no overlap at all (42.1k against 43.2k
             # pairs/s at B = 256: the tail's workgroups displace the next trunk's stems); HIP offers no lower priority than 0
             st = self._pl[key] = {"side": torch.cuda.Stream(device=dev), "n": 0,
-                                  "feat": [torch.empty(2, B, 2048, device=dev, dtype=torch.float32) for _ in range(2)],
-                                  "done": [torch.cuda.Event() for _ in range(2)], "busy": [False, False], "keep": [None, None]}
-        side, slot = st["side"], st["n"] & 1
+                                  "feat": [torch.empty(2, B, 2048, device=dev, dtype=torch.float32) for _ in range(DEPTH)],
+                                  "done": [torch.cuda.Event() for _ in range(DEPTH)], "busy": [False] * DEPTH, "keep": [None] * DEPTH}
+        side, slot = st["side"], st["n"] % DEPTH
         st["n"] += 1
-        if st["busy"][slot]:                                 # two submits ago: its tail has read the slot's features and inputs
+        if st["busy"][slot]:                                 # DEPTH submits ago: its tail has read the slot's features and inputs
             st["done"][slot].synchronize()
         pos = self.init_position(B, dev)
         st["keep"][slot] = batch
         feat = self.model.forward_feat_ext_twoview(im0, im1, out=st["feat"][slot], out_stream=side)
         with torch.cuda.stream(side):
-            p0, b0, p1, b1 = self.model.forward_ief(feat[0], feat[1], batch["bb0"], batch["bb1"], pos, pos, iters=self.iters)
-            out = self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
+            out = self.model.forward_ief(feat[0], feat[1], batch["bb0"], batch["bb1"], pos, pos, iters=self.iters)
+            if not net_only:
+                out = self._tail(*out, batch, want_rotmat, want_angles, want_input_mesh)
             st["done"][slot].record(side)
         st["busy"][slot] = True
         return Pending(out, st["done"][slot], side)

@@ -771,7 +771,7 @@ def test_pipelined_submit_is_bit_identical_to_call(netf16, body, dev, B):
     """TwoViewInference.submit (trunk of batch i+1 on the caller's stream under the IEF loop + SMPL-X stage of batch i on a second
     stream; ap_trunk_fwd_twoview + ap_regressor_fwd + ap_smplx_fwd_twoview) against __call__ (ap_copenet_fwd +
     ap_smplx_fwd_twoview on one stream): the same kernels on the same data, so every output equal to the bit -- over six
-    back-to-back submits of three different batches (the double-buffered features and the reused events go round three times;
+    back-to-back submits of three different batches (the feature slots and their reused events go round twice;
     B = 64 takes the two-stream trunk)."""
     from airpose_amd import pipeline, weights as W
     pipe = pipeline.TwoViewInference(netf16, body)
@@ -788,6 +788,8 @@ def test_pipelined_submit_is_bit_identical_to_call(netf16, body, dev, B):
     p = pipe.submit(batches[1])
     v = p.wait()["pred_vertices_cam0"] + 0.0
     assert torch.equal(v, want[1]["pred_vertices_cam0"])
+    q = pipe.submit_net(*(batches[2][k] for k in ("im0", "im1", "bb0", "bb1"))).synchronize()
+    assert torch.equal(q[0][:, 3:], want[2]["pred_pose0"][:, 3:]) and torch.equal(q[3], want[2]["pred_betas1"])
     f = netf16.forward_feat_ext_twoview(batches[0]["im0"], batches[0]["im1"])
     assert torch.equal(f[0], netf16.forward_feat_ext(batches[0]["im0"])) or B >= 64    # (one pass vs two: same kernels per image)
     assert torch.equal(f[1], netf16.forward_feat_ext(batches[0]["im1"])) or B >= 64
