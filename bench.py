@@ -326,6 +326,7 @@ def main():
                     help="1 (default): steps issued through TwoViewInference.submit (serving form: the passes of step i+1 queue behind "
                          "those of step i, IEF loop + SMPL-X stage of step i on a second stream under them); 0: the stream-ordered "
                          "forward.  The other form is timed for one more block and reported beside the headline")
+    ap.add_argument("--other-form", type=int, default=1, help="0: skip the extra block that times the other step-issue form (profiling runs)")
     ap.add_argument("--b64", type=int, default=1, help="also time BASELINE config 1 (batch 64, network only, bf16 and f16): 0 = skip")
     args = ap.parse_args()
 
@@ -393,6 +394,8 @@ def main():
 
     def step():
         if args.no_tail:
+            if args.overlap_tail and not instrumented[0]:
+                return pipe.submit_net(batch["im0"], batch["im1"], batch["bb0"], batch["bb1"])
             return pipe.forward_net(batch["im0"], batch["im1"], batch["bb0"], batch["bb1"])
         if args.overlap_tail and not instrumented[0]:
             return pipe.submit(batch, want_rotmat=True)
@@ -442,7 +445,7 @@ def main():
     # the other form of the same forward, one more block of K steps: stream-ordered __call__ when the headline is the serving form
     # (TwoViewInference.submit) and the other way round -- same kernels, bit-identical outputs
     other = None
-    if not args.no_tail:
+    if not args.no_tail and args.other_form:
         other_step = (lambda: pipe(batch, want_rotmat=True)) if args.overlap_tail else (lambda: pipe.submit(batch, want_rotmat=True))
         for _ in range(2):
             pend = other_step()
@@ -536,8 +539,8 @@ def main():
                        "trunk_chunk_images": chunk,
                        "trunk_passes": "2 concurrent passes (one per view) on 2 HIP streams" if dual else "1 pass per chunk",
                        "step_issue": ("TwoViewInference.submit: the trunk passes of step i+1 queue behind those of step i, IEF loop + "
-                                      "SMPL-X stage of step i on a second stream under them (at most 2 steps in flight); all K steps "
-                                      "complete inside the timed region") if (args.overlap_tail and not args.no_tail) else
+                                      "SMPL-X stage of step i on a second stream under them (at most 3 steps in flight); all K steps "
+                                      "complete inside the timed region") if args.overlap_tail else
                                      "stream-ordered: every step complete on the caller's stream before the next starts",
                        "sharding": "whole pairs per GPU, no data-path collective"},
             "roofline": {"bound": "mfma",
