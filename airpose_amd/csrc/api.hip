@@ -961,8 +961,10 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
     const int chunk = h->chunk > 0 ? h->chunk : 512;
     const size_t IMG_ELEMS = (size_t)3 * 224 * 224;
     // (measured: +4..5 % at 64 images per view, -4 % at 32, where the launches no longer fill the chip)
-    if (h->dual_stream && n0 >= 64 && n1 >= 64 && n_img <= chunk) {
-        // two views = two concurrent passes: fork from the caller's stream, one pass per internal stream, join
+    if (h->dual_stream && n0 >= 64 && n1 >= 64 && chunk >= 128) {
+        // two views = two concurrent passes: fork from the caller's stream, one pass per internal stream, join.  A view of more
+        // than chunk / 2 images goes through its stream in slices of chunk / 2 (same workspace, stream order), so 2 x 256 images
+        // are in flight whatever the batch
         if (!h->aux[0]) {
             for (int i = 0; i < 4; ++i) {
                 HIP_TRY(hipStreamCreateWithFlags(&h->aux[i], hipStreamNonBlocking));
@@ -972,25 +974,39 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
             HIP_TRY(hipEventCreateWithFlags(&h->ev_skew, hipEventDisableTiming));
         }
         const int ppv = h->passes_per_view == 2 ? 2 : 1, np = 2 * ppv;
+        const int per = chunk / 2 / ppv;                     // images of one slice of one pass
+        auto part_of = [&](int q, int* lo, int* cnt) {       // pass q's share of its view
+            const int v = q / ppv, part = q % ppv, nv = v ? n1 : n0;
+            *lo = part * (nv / ppv);
+            *cnt = part == ppv - 1 ? nv - *lo : nv / ppv;
+        };
         // every pass's workspace is sized BEFORE the fork: a grow inside a pass would synchronise the device and free
         // buffers while the sibling pass is in flight
+        int rounds = 1;
         for (int q = 0; q < np; ++q) {
-            const int v = q / ppv, part = q % ppv, nv = v ? n1 : n0, lo = part * (nv / ppv);
-            int rc = reserve_trunk_ws(h, h->tw[q], part == ppv - 1 ? nv - lo : nv / ppv);
+            int lo, cnt;
+            part_of(q, &lo, &cnt);
+            int rc = reserve_trunk_ws(h, h->tw[q], std::min(cnt, per));
             if (rc) return rc;
+            rounds = std::max(rounds, (cnt + per - 1) / per);
         }
         HIP_TRY(hipEventRecord(h->ev_fork, st));
-        size_t ev[4][4] = {};
+        std::vector<size_t> ev((size_t)np * rounds * 4, 0);
         int rc = AP_OK, forked = 0;
         for (int q = 0; q < np && !rc; ++q) {
-            const int v = q / ppv, part = q % ppv;
-            const int nv = v ? n1 : n0, lo = part * (nv / ppv), cnt = part == ppv - 1 ? nv - lo : nv / ppv;
-            const float* xv = (v ? x1 : x0) + (size_t)lo * IMG_ELEMS;
+            const int v = q / ppv;
+            int lo, cnt;
+            part_of(q, &lo, &cnt);
             HIP_TRY(hipStreamWaitEvent(h->aux[q], h->ev_fork, 0));
             forked = q + 1;
             if (q == 1 && np == 2 && h->dual_skew) HIP_TRY(hipStreamWaitEvent(h->aux[1], h->ev_skew, 0));
-            rc = trunk_chunk(h, h->tw[q], xv, cnt, nullptr, 0, feat + ((v ? (size_t)n0 : 0) + lo) * 2048, h->aux[q], ev[q],
-                             (q == 0 && np == 2) ? h->dual_skew : 0);
+            const int nr = (cnt + per - 1) / per;            // slices of equal size (+-1): 261 images = 131 + 130, not 256 + 5
+            for (int r = 0, s0 = 0, c = 0; r < nr && !rc; ++r, s0 += c) {
+                c = cnt / nr + (r < cnt % nr ? 1 : 0);
+                const float* xv = (v ? x1 : x0) + (size_t)(lo + s0) * IMG_ELEMS;
+                rc = trunk_chunk(h, h->tw[q], xv, c, nullptr, 0, feat + ((v ? (size_t)n0 : 0) + lo + s0) * 2048, h->aux[q],
+                                 &ev[((size_t)q * rounds + r) * 4], (q == 0 && np == 2 && r == 0) ? h->dual_skew : 0);
+            }
         }
         // join every stream that forked, also after a failed launch: later calls reuse tw[q] on the caller's stream order
         for (int q = 0; q < forked; ++q) {
@@ -1000,8 +1016,16 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
         }
         if (rc) return rc;
         if (h->tm.on) {
-            auto quad = [&](int stage, int a, int b) {       // span over the first and the last pass issued (two streams: exact)
-                for (int q : {0, np - 1}) { h->tm.quads[stage].push_back(ev[q][a]); h->tm.quads[stage].push_back(ev[q][b]); }
+            // per slice round: span over the first and the last pass issued (two streams: exact); a pass without a slice in this
+            // round (views of different sizes) lends the other pass's events
+            auto quad = [&](int stage, int a, int b) {
+                for (int r = 0; r < rounds; ++r)
+                    for (int q : {0, np - 1}) {
+                        const size_t* e = &ev[((size_t)q * rounds + r) * 4];
+                        if (!e[b]) e = &ev[((size_t)(np - 1 - q) * rounds + r) * 4];
+                        h->tm.quads[stage].push_back(e[a]);
+                        h->tm.quads[stage].push_back(e[b]);
+                    }
             };
             quad(1, 1, 2);
             if (h->tm.on == 1) { quad(0, 0, 1); quad(2, 2, 3); }

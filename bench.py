@@ -511,7 +511,7 @@ def main():
         # 52 convs: 4 downsample convs folded into conv3, layer1's 3 bottlenecks are one fused kernel each (bf16)
         # two-view forwards of >= 64 pairs run the two views as two concurrent trunk passes (two internal streams):
         # twice the launches at half the images each; conv_ms is then the span over both passes
-        dual = bool(args.dual_stream) and B >= 64 and 2 * B <= chunk
+        dual = bool(args.dual_stream) and B >= 64 and chunk >= 128    # (views above chunk / 2 images: slices of chunk / 2 per pass stream)
         # bf16: 3 fused layer1 bottlenecks + 13 blocks x 3 convs = 42 launches per pass, minus the 8 conv1 layers that ride in a
         # fused conv3 -> conv1 pair (layer2.0-2.3, layer3.1-3.4 as producers): 34
         half = args.precision in ("bf16", "f16")               # the throughput kernels (either 16-bit storage type)

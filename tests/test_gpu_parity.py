@@ -797,6 +797,28 @@ def test_pipelined_submit_is_bit_identical_to_call(netf16, body, dev, B):
         netf16.forward_feat_ext_twoview(batches[0]["im0"], batches[0]["im1"], out=torch.empty(2, B, 2047, device=dev))
 
 
+def test_two_stream_trunk_in_slices_above_one_chunk(netf16, dev):
+    """A two-view batch above one chunk keeps the two concurrent passes: each view goes through its stream in slices of chunk / 2
+    images (here chunk = 128: 96 images per view = two slices of 48).  Features equal to the bit to the one-view calls (a
+    feature row does not depend on the batch it arrives in)."""
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x0 = torch.randn(96, 3, 224, 224, generator=g).to(dev)
+    x1 = torch.randn(96, 3, 224, 224, generator=g).to(dev)
+    want0, want1 = netf16.forward_feat_ext(x0).clone(), netf16.forward_feat_ext(x1).clone()
+    try:
+        netf16.set_chunk(128)
+        for _ in range(2):
+            f = netf16.forward_feat_ext_twoview(x0, x1)
+            assert torch.equal(f[0], want0) and torch.equal(f[1], want1)
+        side = torch.cuda.Stream(device=dev)
+        f = netf16.forward_feat_ext_twoview(x0, x1, out_stream=side)
+        side.synchronize()
+        assert torch.equal(f[0], want0) and torch.equal(f[1], want1)
+    finally:
+        netf16.set_chunk(0)
+    assert torch.equal(netf16.forward_feat_ext_twoview(x0, x1)[1], want1)
+
+
 def test_f16_refuses_weights_outside_the_fp16_range(copenet_sd, dev):
     """A (BatchNorm-folded) weight above 65 504 would be inf in fp16 storage: AP_PREC_F16 refuses the checkpoint when it
     packs it, AP_PREC_BF16 (fp32's exponent range) takes it."""
