@@ -960,6 +960,11 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
     const int n_img = n0 + n1;
     const int chunk = h->chunk > 0 ? h->chunk : 512;
     const size_t IMG_ELEMS = (size_t)3 * 224 * 224;
+    if (h->dual_stream && !n1 && n0 >= 128) {                // one list of images (forward_feat_ext, the single-view heads): its two
+        n1 = n0 - n0 / 2;                                    // halves as the two concurrent passes (feature rows stay in list order)
+        n0 = n0 / 2;
+        x1 = x0 + (size_t)n0 * IMG_ELEMS;
+    }
     // (measured: +4..5 % at 64 images per view, -4 % at 32, where the launches no longer fill the chip)
     if (h->dual_stream && n0 >= 64 && n1 >= 64 && chunk >= 128) {
         // two views = two concurrent passes: fork from the caller's stream, one pass per internal stream, join.  A view of more
