@@ -48,8 +48,16 @@ class TwoViewInference(object):
             self._pos[key] = (torch.tensor([0.0, 0.0, 10.0], device=device).expand(B, -1).clone() * TRANS_SCALE)
         return self._pos[key]
 
+    def _behind_submits(self, dev):
+        """The stream-ordered calls share the handles' workspaces (regressor, SMPL-X) with the tails of earlier ``submit`` calls,
+        which run on the pipeline's own stream: order the current stream behind the youngest of them."""
+        for (_, d), st in self._pl.items():
+            if d == dev and st["n"] and st["busy"][(st["n"] - 1) % DEPTH]:
+                torch.cuda.current_stream(dev).wait_event(st["done"][(st["n"] - 1) % DEPTH])
+
     def forward_net(self, im0, im1, bb0, bb1):
         B, dev = im0.shape[0], im0.device
+        self._behind_submits(dev)
         pos = self.init_position(B, dev)
         return self.model(x0=im0, x1=im1, bb0=bb0, bb1=bb1, init_position0=pos, init_position1=pos, iters=self.iters)
 
@@ -71,10 +79,15 @@ class TwoViewInference(object):
         the passes of the next ``submit`` queue directly behind this one's and its tail runs under them.  At most DEPTH = 3 batches are
         in flight (the next ``submit`` blocks the host until the oldest has finished); one feature buffer per batch in flight.  The inputs of
         a batch are referenced until its slot comes round again; do not overwrite them in place before ``Pending.wait`` /
-        ``synchronize``."""
+        ``synchronize``.  ``model`` and ``smplx`` are used on the pipeline's stream while a batch is in flight: other callers of the
+        same two objects go through this pipeline (``__call__`` / ``forward_net`` order themselves behind the submits) or wait for the
+        last ``Pending`` first."""
         im0, im1 = batch["im0"], batch["im1"]
         B, dev = im0.shape[0], im0.device
         key = (B, dev)
+        for (b2, d2), o in self._pl.items():                 # a batch of another size in flight: same handles, another stream
+            if d2 == dev and b2 != B and o["n"] and o["busy"][(o["n"] - 1) % DEPTH]:
+                o["done"][(o["n"] - 1) % DEPTH].synchronize()
         st = self._pl.get(key)
         if st is None:
             # default priority: a high-priority second stream was measured SLOWER than no overlap at all (42.1k against 43.2k

@@ -788,6 +788,19 @@ def test_pipelined_submit_is_bit_identical_to_call(netf16, body, dev, B):
     p = pipe.submit(batches[1])
     v = p.wait()["pred_vertices_cam0"] + 0.0
     assert torch.equal(v, want[1]["pred_vertices_cam0"])
+    # soak: 45 submits without a host wait in between (the host only blocks when all DEPTH slots are taken), every result checked
+    pend = [pipe.submit(batches[i % 3], want_rotmat=False) for i in range(45)]
+    for i, p in enumerate(pend):
+        got = p.synchronize()
+        for k in ("pred_pose0", "pred_betas1", "pred_vertices_cam1", "pred_j2d_cam0"):
+            assert torch.equal(got[k], want[i % 3][k]), (i, k)
+    del pend
+    # a stream-ordered call right behind submits (shared regressor / SMPL-X workspaces): ordered behind them by the pipeline
+    pend = [pipe.submit(batches[i]) for i in range(3)]
+    got = pipe(batches[0], want_angles=True)
+    for k, v in want[0].items():
+        assert torch.equal(got[k], v), k
+    assert torch.equal(pend[2].synchronize()["pred_j2d_cam1"], want[2]["pred_j2d_cam1"])
     q = pipe.submit_net(*(batches[2][k] for k in ("im0", "im1", "bb0", "bb1"))).synchronize()
     assert torch.equal(q[0][:, 3:], want[2]["pred_pose0"][:, 3:]) and torch.equal(q[3], want[2]["pred_betas1"])
     f = netf16.forward_feat_ext_twoview(batches[0]["im0"], batches[0]["im1"])
