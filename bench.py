@@ -552,9 +552,13 @@ def main():
                          "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of the trunk in %d launches per step: conv_pipe_kernel "
                                    "(dominant instance <T,128,128,2,4,2>; stride-1 3x3 layers in the 16-bit modes: conv_slab_kernel; conv3 of layer2-3 blocks together with the next block's conv1: conv_pair_kernel; "
                                    "conv3 of the layer4 identity blocks: conv_lean_kernel) + the fused layer1 bottlenecks in the 16-bit modes "
-                                   "(bneck2_kernel<ds> / <identity>); time = HIP-event span of the conv stack "
-                                   "(over both concurrent passes when the two views run on two streams)" % launches,
+                                   "(bneck2_kernel<ds> / <identity>); time = HIP events around the conv stack on the streams that run "
+                                   "it: stream-ordered steps: the span over both concurrent passes; steps issued through submit (the "
+                                   "passes of consecutive steps run free of each other and drift apart): the mean of the two passes' "
+                                   "own durations, each of which shares the chip with the other stream throughout (equal to the "
+                                   "span in lock step); frac_of_step_time = the same flops over the whole step time" % launches,
                          "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "frac_of_step_time": conv_flops_step / (elapsed / args.steps) / 1e12 / peak,
                          "traffic": pmc_traffic(),
                          "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,
                          "avg_launch_ms": conv_ms_step / launches},
