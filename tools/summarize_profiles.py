@@ -25,7 +25,7 @@ if db:
     c = sqlite3.connect(db[0])
     rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     with open(os.path.join(O, tag + "_kernel_stats.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 --dual-stream 0  (%s)\n" % tag)
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 --b64 0 --other-form 0 --dual-stream 0  (%s)\n" % tag)
         f.write("name,calls,total_us,avg_us,pct\n")
         for n, calls, tot, avg, pct in rows:
             f.write('"%s",%d,%.3f,%.3f,%.2f\n' % (n[:110], calls, tot, avg, pct))
@@ -37,7 +37,7 @@ if db2:
     c = sqlite3.connect(db2[0])
     rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
     with open(os.path.join(O, tag + "_kernel_stats_two_streams.csv"), "w") as f:
-        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0  (%s; default = two concurrent trunk passes: kernel durations overlap)\n" % tag)
+        f.write("# rocprofv3 --kernel-trace --stats -- python bench.py --steps 5 --warmup 2 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 --b64 0 --other-form 0  (%s; default = two concurrent trunk passes: kernel durations overlap)\n" % tag)
         f.write("name,calls,total_us,avg_us,pct\n")
         for n, calls, tot, avg, pct in rows:
             f.write('"%s",%d,%.3f,%.3f,%.2f\n' % (n[:110], calls, tot, avg, pct))
@@ -56,7 +56,7 @@ for ctr, col in (("FETCH_SIZE", 1), ("WRITE_SIZE", 2)):
 if acc:
     fetch = write = launches = 0
     with open(os.path.join(O, tag + "_pmc_hbm_traffic.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0  (%d passes of the hot path; %s)\n" % (steps, tag))
+        f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 --b64 0 --other-form 0  (%d passes of the hot path; %s)\n" % (steps, tag))
         f.write("# units: KB as reported; MI355X_MICROARCH.md: hbm_bytes = (FETCH_SIZE + WRITE_SIZE) * 1024, and on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x\n")
         f.write("kernel,launches,fetch_KB_total,write_KB_total,fetch_MB_per_launch_raw,fetch_MB_per_launch_x2,write_MB_per_launch\n")
         for k, (n, fe, wr) in sorted(acc.items(), key=lambda kv: -kv[1][1]):
@@ -85,7 +85,7 @@ for p in glob.glob(os.path.join(O, tag + "_pmc_MFMA", "**", "*counter_collection
 if macc:
     tb = tg = 0.0
     with open(os.path.join(O, tag + "_pmc_mfma_busy.csv"), "w") as f:
-        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --dual-stream 0  (%s)\n" % tag)
+        f.write("# rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE -- python bench.py --steps 2 --warmup 1 --stage-steps 0 --cpu-sample 0 --parity-steps 0 --repeat-blocks 0 --b64 0 --other-form 0 --dual-stream 0  (%s)\n" % tag)
         f.write("# mfma_busy_pct = 100 * SQ_VALU_MFMA_BUSY_CYCLES / (GRBM_GUI_ACTIVE / 8 XCDs * 1024 SIMDs); 100 %% = every SIMD's matrix pipe busy for the whole dispatch\n")
         f.write("kernel,launches,mfma_busy_cycles,insts_mfma,gui_active_cycles_per_xcd,mfma_busy_pct\n")
         for k, d in sorted(macc.items(), key=lambda kv: -kv[1].get("GRBM_GUI_ACTIVE", 0)):
