@@ -27,7 +27,13 @@ class Pending(object):
         self.out, self._done, self._stream = out, done, stream
 
     def wait(self, stream=None):
-        (stream if stream is not None else torch.cuda.current_stream(self._stream.device)).wait_event(self._done)
+        stream = stream if stream is not None else torch.cuda.current_stream(self._stream.device)
+        stream.wait_event(self._done)
+        # the outputs were allocated on the pipeline's stream: tell the caching allocator that ``stream`` uses them too, or a block
+        # freed by the consumer could be handed to the next tail while kernels of ``stream`` still read it
+        for t in (self.out.values() if isinstance(self.out, dict) else self.out):
+            if torch.is_tensor(t):
+                t.record_stream(stream)
         return self.out
 
     def synchronize(self):
