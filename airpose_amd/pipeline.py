@@ -38,7 +38,7 @@ class Pending(object):
 
     def synchronize(self):
         self._done.synchronize()
-        return self.out
+        return self.wait()                                   # (the event is complete: only the allocator bookkeeping of wait() remains)
 
 
 class TwoViewInference(object):
