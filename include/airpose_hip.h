@@ -80,7 +80,9 @@ int ap_net_set_range_check(ap_net* h, int mode);
 int ap_net_range_status(ap_net* h, void* stream, int reset);
 
 /* copenet.forward_feat_ext (model_copenet.py:161-176).
- * x: [n_img][3][224][224] NCHW fp32 (the reference input contract); feat: [n_img][2048] fp32. */
+ * x: [n_img][3][224][224] NCHW fp32 (the reference input contract); feat: [n_img][2048] fp32.
+ * A list of >= 128 images runs as two concurrent passes over its halves on the handle's internal streams (forked from and joined
+ * back into `stream`; ap_net_set_dual_stream(h, 0): one pass on `stream` itself); a feature row does not depend on the split. */
 int ap_trunk_fwd(ap_net* h, const float* x_nchw, int n_img, float* feat, void* stream);
 
 /* The two forward_feat_ext calls of copenet.forward (model_copenet.py:140-141: xf0 = forward_feat_ext(x0), xf1 = ...(x1)) as ONE
