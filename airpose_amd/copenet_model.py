@@ -352,6 +352,14 @@ class copenet(nn.Module):
         """bf16 / f16: conv3 of an identity block and conv1 of the next block as one pixel-local kernel (default) or two."""
         self._set_knob("ap_net_set_fuse_pair", on)
 
+    def set_fuse_tail(self, on):
+        """bf16 / f16: conv1 of layer2.0 inside the kernel of layer1's last bottleneck (default) or as its own convolution."""
+        self._set_knob("ap_net_set_fuse_tail", on)
+
+    def set_even_out(self, on):
+        """bf16 / f16: block outputs only a stride-2 downsample reads are stored at the even pixels only (default) or in full."""
+        self._set_knob("ap_net_set_even_out", on)
+
     def set_fuse_pool(self, on):
         """bf16 / f16: AvgPool2d(7) in the epilogue of the last convolution (default) or as its own kernel."""
         self._set_knob("ap_net_set_fuse_pool", on)

@@ -270,6 +270,9 @@ struct ap_net {
     bool fuse_block = true;        // 16-bit modes: each layer1 bottleneck as one kernel (bottleneck2.hip); off: separate convs
     bool tiled = true;             // 16-bit modes: tensors only the fused pair kernel reads (t2, identity) in its fragment-tiled layout
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
+    bool fuse_tail = true;         // 16-bit modes: conv1 of layer2.0 inside the kernel of layer1's last block (bottleneck2.hip, tail variant);
+                                   // the block output is then stored at the even pixels only (layer2.0's stride-2 downsample reads nothing else)
+    bool even_out = true;          // 16-bit modes: a pair block whose output is read by a stride-2 downsample branch ONLY stores the even pixels
     bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     bool fuse_pool = false;        // 16-bit modes: AvgPool2d(7) in the epilogue of layer4.2 conv3 (conv_lean.hip POOL variant; bit-identical).
                                    // Off by default: measured neutral (fp16) to -0.5 % (bf16) in the two-stream trunk, profiles/r04_fuse_pool_ab.txt
@@ -484,10 +487,17 @@ int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int H
 }
 
 // fused layer1 bottleneck (bf16): x [N][H][H][c1.cin] -> y [N][H][H][256]
+// c1n (or NULL): conv1 of the NEXT block computed on the block output in the same kernel -> t1n [N][H][H][128]; y_even: the block
+// output is stored at the even pixels only (its one remaining reader is a stride-2 downsample branch)
 int run_bneck64(const Layer& c1, const Layer& c2, const Layer& c3, bool ds, const void* x, int N, int H, void* y,
-                int prec, hipStream_t st, int* rflag = nullptr) {
+                int prec, hipStream_t st, int* rflag = nullptr, const Layer* c1n = nullptr, void* t1n = nullptr, int y_even = 0) {
     BneckArgs a{};
     a.range_flag = rflag;
+    if (c1n) {
+        if (ds || c1n->cin != 256 || c1n->cout != 128 || c1n->k != 1 || c1n->stride != 1 || !t1n)
+            return fail(AP_ESHAPE, "fused layer1 bottleneck + next conv1: identity block, 1x1, 256 -> 128");
+        a.w1n = c1n->w.p; a.s1n = c1n->scale.as<float>(); a.h1n = c1n->shift.as<float>(); a.t1n = t1n; a.y_even = y_even;
+    }
     a.x = x; a.y = y;
     a.w1 = c1.w.p; a.w2 = c2.w.p; a.w3 = c3.w.p;
     a.s1 = c1.scale.as<float>(); a.h1 = c1.shift.as<float>();
@@ -878,7 +888,15 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         if (bf && h->fuse_block && B.c2.cout == 64 && B.c2.stride == 1 && H % 14 == 0 && (!B.has_down || B.c1.cin == 64)) {
             // layer1: conv1 -> conv2 -> conv3 (+identity | folded downsample) in one kernel, intermediates in LDS
             const Layer& L3 = B.has_down ? B.c3ds : B.c3;
-            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, prec, st, h->range_flag))) return rc;
+            // last block of layer1: conv1 of layer2.0 (model_copenet.py:29-31) on the block output while it is in registers; what
+            // is left to read of that output is layer2.0's stride-2 downsample branch (:41-42, :97-102) -> even pixels only
+            const ap_net::Block* Nx = &B != &h->blocks.back() ? &B + 1 : nullptr;
+            const bool tail = h->fuse_tail && !B.has_down && Nx && Nx->has_down && Nx->c1.cin == 256 && Nx->c1.cout == 128 &&
+                              Nx->c2.stride == 2 && Nx->down.stride == 2 && g_conv_mode.load(std::memory_order_relaxed) < 0;
+            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, prec, st, h->range_flag, tail ? &Nx->c1 : nullptr,
+                                  w.ws_t1.p, tail && h->even_out)))
+                return rc;
+            t1_ready = tail;
             std::swap(cur, nxt);
             continue;
         }
@@ -903,8 +921,12 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.t2_tiled = t2_tiled; a.res_tiled = cur_tiled;
             a.out_tiled = t2_tiled && B.pair_n1 > 0 && is_pair(Nx) && !Nx.has_down;
             cur_tiled = a.out_tiled != 0;
-            if (B.has_down) { a.x2 = cur; a.Ho = a.Wo = Ho; a.H2 = a.W2 = H; a.stride2 = L3.stride2; }
+            a.Ho = a.Wo = Ho;
+            if (B.has_down) { a.x2 = cur; a.H2 = a.W2 = H; a.stride2 = L3.stride2; }
             else a.res = cur;
+            // the next block is a stage's first one and got its conv1 from this kernel: all that is read of `out` is that block's
+            // stride-2 downsample branch (model_copenet.py:41-42, :97-102) -- the even pixels
+            a.out_even = h->even_out && !a.out_tiled && B.pair_n1 > 0 && Nx.has_down && Nx.down.stride == 2 && Nx.c2.stride == 2;
             HIP_TRY(H16(prec, ap_launch_conv_pair)(a, B.pair_p, B.pair_p2, B.pair_c3, B.pair_n1, st));
             t1_ready = B.pair_n1 > 0;
         } else if (cur_tiled) {                               // (cannot happen: out_tiled is only set when the next block is a pair block)
@@ -1407,6 +1429,25 @@ int ap_bottleneck64_nhwc(int precision, const void* x, const void* w1, const flo
     return AP_OK;
 }
 
+int ap_bottleneck64_tail_nhwc(int precision, const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
+                              const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
+                              const void* w1n, const float* s1n, const float* h1n, void* t1n, int y_even, int N, int H, int W,
+                              void* stream) {
+    if (!prec_half(precision) || !x || !w1 || !s1 || !h1 || !w2 || !s2 || !h2 || !w3 || !s3 || !h3 || !y || !w1n || !s1n || !h1n ||
+        !t1n || N <= 0)
+        return fail(AP_EINVAL, "ap_bottleneck64_tail_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
+    if (H <= 0 || W <= 0 || H % 14 || W % 14) return fail(AP_ESHAPE, "ap_bottleneck64_tail_nhwc: H, W multiples of 14");
+    BneckArgs a{};
+    a.x = x; a.y = y; a.w1 = w1; a.w2 = w2; a.w3 = w3;
+    a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3;
+    a.w1n = w1n; a.s1n = s1n; a.h1n = h1n; a.t1n = t1n; a.y_even = y_even != 0;
+    a.N = N; a.H = H; a.W = W;
+    HIP_TRY(zero_line(&a.zero));
+    a.dbg = g_conv_dbg;
+    HIP_TRY(H16(precision, ap_launch_bneck2)(a, 0, (hipStream_t)stream));
+    return AP_OK;
+}
+
 // The fused pair kernel consumes its two weight matrices as ONE stream of 16-KiB tiles in consumption order.  The stream is
 // CALLER-OWNED: packed once by ap_conv_pair_pack into a buffer of ap_conv_pair_stream_bytes, handed to every launch -- the
 // library keeps no hidden copy keyed by weight addresses (an allocator may reuse an address for new contents).
@@ -1554,6 +1595,18 @@ int ap_net_set_fuse_block(ap_net* h, int on) {
 int ap_net_set_fuse_pair(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_pair = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_fuse_tail(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->fuse_tail = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_even_out(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->even_out = on != 0;
     return AP_OK;
 }
 

@@ -48,7 +48,7 @@ namespace {
 constexpr int B2_TS = 14;
 // LDS map (bytes), per variant.  DS = first block of layer1: cin = 64, conv3 carries the folded downsample branch as a second
 // K segment of 64 (W3 rows of 128), no identity
-template <bool DS> struct B2Map {
+template <bool DS, bool TAIL = false> struct B2Map {
     static constexpr int CIN = DS ? 64 : 256;
     static constexpr int NK1 = CIN / 32;                     // K groups of conv1 = x fragments per pixel row
     static constexpr int CH3 = DS ? 16384 : 8192;            // one W3 chunk (64 channels x K3): [K3 / 64 halves][64 rows][128 B]
@@ -58,11 +58,14 @@ template <bool DS> struct B2Map {
     static constexpr int T1 = W2 + 73728;                    // [16 x 16 halo pixels][128 B]; W3 chunks 2, 3 during conv3
     static constexpr int W3 = T1 + 32768;                    // W3 chunks 0, 1
     static constexpr int TAB = W3 + 2 * CH3;                 // s1 h1 s2 h2 (64 floats each), s3 h3 (256 each)
-    static constexpr int TOTAL = TAB + 3072;
-    static constexpr int Q = 2 * NK1 + 4 * NP3 + 16;         // vector-memory operations of a wave per tile: NX loads, 16 stores, 4 NP3 DMA pieces
-    static_assert(2 * CH3 <= 32768 && TOTAL <= 160 * 1024, "chunks 2, 3 fit the t1 buffer; LDS per CU");
+    static constexpr int TOTAL = TAB + 3072 + (TAIL ? 1024 : 0);   // tail variant: + s1n h1n (128 floats each)
+    // vector-memory operations of a wave per tile: NX loads, 16 stores, 4 NP3 DMA pieces; tail variant: + 8 DMA pieces (the next
+    // block's conv1 weights in eight 8-KB units) and 8 stores (its output)
+    static constexpr int Q = 2 * NK1 + 4 * NP3 + 16 + (TAIL ? 16 : 0);
+    static_assert(!(DS && TAIL), "the tail variant is the identity block");
+    static_assert(2 * CH3 <= 32768 && TOTAL <= 160 * 1024 && Q - 2 <= 63, "chunks 2, 3 fit the t1 buffer; LDS per CU; vmcnt is 6 bits");
 };
-constexpr int T_S1 = 0, T_H1 = 256, T_S2 = 512, T_H2 = 768, T_S3 = 1024, T_H3 = 2048;
+constexpr int T_S1 = 0, T_H1 = 256, T_S2 = 512, T_H2 = 768, T_S3 = 1024, T_H3 = 2048, T_S1N = 3072, T_H1N = 3584;
 
 template <int N> __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(B2_SAFE ? 0 : N) : "memory");
@@ -158,10 +161,10 @@ __device__ __forceinline__ u32x4 bn8(const f32x4& lo, const f32x4& hi, const f32
     return o;
 }
 
-template <bool DS>
+template <bool DS, bool TAIL>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 bneck2_kernel(const BneckArgs a) {
-    using M = B2Map<DS>;
+    using M = B2Map<DS, TAIL>;
     constexpr int L_W1 = M::W1, L_W2 = M::W2, L_T1 = M::T1, L_W3 = M::W3, L_TAB = M::TAB, CIN = M::CIN, NK1 = M::NK1, NX = 2 * M::NK1;
     constexpr int CH3 = M::CH3, K3 = DS ? 128 : 64, Q = M::Q;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
@@ -190,6 +193,7 @@ bneck2_kernel(const BneckArgs a) {
             tb[T_S2 / 4 + tid] = a.s2[tid]; tb[T_H2 / 4 + tid] = a.h2[tid];
         }
         if (tid < 256) { tb[T_S3 / 4 + tid] = a.s3[tid]; tb[T_H3 / 4 + tid] = a.h3[tid]; }
+        if constexpr (TAIL) { if (tid < 128) { tb[T_S1N / 4 + tid] = a.s1n[tid]; tb[T_H1N / 4 + tid] = a.h1n[tid]; } }
     }
     // W3 by LDS-DMA: chunk cc = channels cc*64 .. +63 (rows permuted); per 64-wide K half one 1-KB piece (8 rows) per wave
     const int prow = lane >> 3;
@@ -204,7 +208,20 @@ bneck2_kernel(const BneckArgs a) {
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(w3src + cc * (64 * K3 * 2) + kh * 128),
                                              (__attribute__((address_space(3))) void*)(smem + off + kh * 8192 + wave * 1024), 16, 0, 0);
     };
+    // tail variant: conv1 of the next block, W1' [128][256], in eight 8-KB units of the W3 chunk shape: unit u = output channels
+    // (u / 4) * 64 .. + 63 (rows permuted like every tile here), K columns (u % 4) * 64 .. + 63; one 1-KB piece per wave and unit.
+    // Units pass through the six 8-KB slots S0, S1 (the W3 slots) and T0 .. T3 (the t1 buffer) behind the W3 chunks
+    const uint32_t w1noff = (uint32_t)((b2_row_channel(wave * 8 + prow) * 256 + (((lane & 7) ^ prow) * 8)) * 2);
+    auto dmaU = [&](auto UU, auto SL) {                      // SL: 0, 1 = S0, S1; 2 .. 5 = T0 .. T3
+        constexpr int u = UU, sl = SL;
+        if (B2_ABLATE & 4) return;
+        constexpr int off = sl < 2 ? L_W3 + sl * 8192 : L_T1 + (sl - 2) * 8192;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((const unsigned char*)a.w1n + w1noff + (u / 4) * (64 * 256 * 2) + (u % 4) * 128),
+                                         (__attribute__((address_space(3))) void*)(smem + off + wave * 1024), 16, 0, 0);
+    };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I4 = std::integral_constant<int, 4>; using I5 = std::integral_constant<int, 5>;
+    using I6 = std::integral_constant<int, 6>; using I7 = std::integral_constant<int, 7>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
     // ---------------------------------------------------------------- lane constants: derived per tile from the lane id
@@ -239,7 +256,9 @@ bneck2_kernel(const BneckArgs a) {
     // fragment reads, and scalar loads return out of order)
     const int tpi = a.tiles_per_img, tlx = a.tiles_x, total = a.total;
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc(yg, 0, (int)((uint32_t)a.N * H * W * 512u), 0x00020000);   // (< 0xffff0000: launcher)
-    asm volatile("" ::"s"(tpi), "s"(tlx), "s"(total), "s"(H), "s"(W), "s"(xg), "s"(yg), "s"(a.w3));
+    const int yeven = TAIL ? a.y_even : 0;
+    const auto t1rsrc = __builtin_amdgcn_make_buffer_rsrc(TAIL ? (unsigned char*)a.t1n : yg, 0, (int)((uint32_t)a.N * H * W * 256u), 0x00020000);
+    asm volatile("" ::"s"(tpi), "s"(tlx), "s"(total), "s"(H), "s"(W), "s"(xg), "s"(yg), "s"(a.w3), "s"(a.w1n), "s"(yeven));
 
     // x of the wave's two halo rows of tile T as B fragments: xs[g*NK1 + k] = channels k*32 + g4*8 .. + 7 of pixel (row g, col lr).
     // xptr: the two row pointers; xone<i>: one 16-byte piece per lane (fragment i/2 of row i%2; fragments 2m, 2m+1 of a pixel share a 128-byte line)
@@ -263,7 +282,7 @@ bneck2_kernel(const BneckArgs a) {
     // nothing to store -- junk columns (lane 0 / 15), junk rows (halo row 0 / 15) -- carry an offset behind
     // the end of the buffer and the hardware drops them, so every wave ISSUES the same 16 stores per tile whatever it holds
     // (the hand-counted vmcnt waits depend on that) without a branch or a dump line
-    struct OutRows { uint32_t off[2]; };
+    struct OutRows { uint32_t off[2], off1[2]; };            // off1: the pixel's row of t1n (tail variant)
     constexpr uint32_t OOB = 0xffff0000u;
     auto optr = [&](int T, OutRows& o, int lr, int g4) {
         const int n = T / tpi, r = T - n * tpi, ty = r / tlx, tx = r - ty * tlx;
@@ -272,7 +291,9 @@ bneck2_kernel(const BneckArgs a) {
         for (int g = 0; g < 2; ++g) {
             const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R;
             const bool ok = R >= 1 && R <= 14 && lr >= 1 && lr <= 14 && !(B2_ABLATE & 32);
-            o.off[g] = ok ? ((((uint32_t)n * H + hy) * W + hx) * 256 + g4 * 8) * 2 : OOB;
+            // y_even: only the pixels a stride-2 reader of y samples
+            o.off[g] = ok && !(yeven && ((hy | hx) & 1)) ? ((((uint32_t)n * H + hy) * W + hx) * 256 + g4 * 8) * 2 : OOB;
+            if constexpr (TAIL) o.off1[g] = ok ? ((((uint32_t)n * H + hy) * W + hx) * 128 + g4 * 8) * 2 : OOB;
         }
     };
     auto rdA = [&](u32x4 (&w)[4], uint32_t addr) {
@@ -412,19 +433,21 @@ bneck2_kernel(const BneckArgs a) {
         // own pieces of W3 chunks 0, 1 (requested in the last tile, behind them: 8 stores, NX x loads); the barrier also says
         // every wave is done reading t1
         B2STAMP(6);
-        wait_vmcnt<8 + NX>();
+        wait_vmcnt<(TAIL ? 4 : 8) + NX>();                  // (tail variant: behind them the 4 stores of the last conv1' chunk)
         __builtin_amdgcn_s_barrier();
         B2STAMP(7);
         dma3(I2{}); dma3(I3{});
+        if constexpr (TAIL) { dmaU(I0{}, I4{}); dmaU(I1{}, I5{}); }      // units 0, 1 -> T2, T3
         sfor<0, 4>([&](auto CC) {
             constexpr int cc = CC;
             if constexpr (cc == 1) B2STAMP(8);
             if constexpr (cc == 3) B2STAMP(11);
             if constexpr (cc == 2) {
                 B2STAMP(9);
-                wait_vmcnt<8>();                             // own pieces of chunks 2, 3; behind them the stores of chunks 0, 1
+                wait_vmcnt<TAIL ? 10 : 8>();                 // own pieces of chunks 2, 3; behind them the stores of chunks 0, 1 (+ units 0, 1)
                 __builtin_amdgcn_s_barrier();                // ... everybody's; and the slots of chunks 0, 1 are free
-                dma3(I0{}); dma3(I1{});                      // for the next tile
+                if constexpr (TAIL) { dmaU(I2{}, I0{}); dmaU(I3{}, I1{}); }   // units 2, 3 -> S0, S1
+                else { dma3(I0{}); dma3(I1{}); }             // for the next tile
                 B2STAMP(10);
             }
             const uint32_t base = cc < 2 ? aW3 + cc * CH3 : aW3b + (cc - 2) * CH3;
@@ -458,6 +481,7 @@ bneck2_kernel(const BneckArgs a) {
                     constexpr int g = GG;
                     const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3],
                                         DS ? nullptr : &xc[DS ? 0 : g * 8 + cc * 2 + q], rng);
+                    if constexpr (TAIL) xc[g * 8 + cc * 2 + q] = o;      // the block output replaces x: conv1' operand (same fragment)
                     if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(opp.off[g]));
                     else if (B2_ABLATE & 64) {               // shape experiment (data of the wrong pixels): 8 CONSECUTIVE lanes = one 128-byte line
                         const int R = 2 * wave + g, hy = ty * B2_TS - 1 + R, p = (ll >> 3) + 8 * q;
@@ -469,6 +493,61 @@ bneck2_kernel(const BneckArgs a) {
                 if constexpr (cc == 1 && q == 0) B2STAMP(15);
             });
         });
+        // ------------------------------------------------------------ tail variant: conv1 of the next block (256 -> 128) on the
+        // block output held in xc, two chunks of 64 channels x two halves of K (four K groups of 32 = two units each).
+        // Queue of the wave since chunks 2, 3 were requested:  c2 c3 u0 u1 | 8 st | u2 u3 | 8 st | u4 u5 | u6 u7 | 4 st | c0' c1' | 4 st
+        if constexpr (TAIL) {
+            auto grp = [&](uint32_t b, auto G) -> uint32_t { constexpr int g = decltype(G)::value; return (b + (g >> 1) * 8192) ^ ((g & 1) ? 64u : 0u); };
+            auto sub = [&](auto KB, uint32_t base) {         // K groups kb .. kb + 3: units at base, base + 8192
+                constexpr int kb = decltype(KB)::value;
+                rdA(wf[0], base);
+                rdA(wf[1], base ^ 64u);
+                sfor<0, 4>([&](auto S) {
+                    constexpr int sg = S;
+                    if constexpr (sg + 1 < 4) wait_lgkmcnt<4>(); else wait_lgkmcnt<0>();
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) { mm(acc[f], wf[sg & 1][f], xc[kb + sg]); mm(acc[4 + f], wf[sg & 1][f], xc[NK1 + kb + sg]); }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if constexpr (sg + 2 < 4) rdA(wf[sg & 1], grp(base, std::integral_constant<int, sg + 2>{}));
+                });
+            };
+            auto epi = [&](auto CB) {                        // BN + ReLU + 16-bit of chunk cb, 16-byte stores to t1n
+                constexpr int cb = decltype(CB)::value;
+                sfor<0, 2>([&](auto Q) {
+                    constexpr int q = Q;
+                    constexpr int to = cb * 256 + q * 128;
+                    rdT(tq, tab, std::integral_constant<int, T_S1N + to>{}, std::integral_constant<int, T_H1N + to>{});
+                    wait_lgkmcnt<0>();
+                    sfor<0, 2>([&](auto GG) {
+                        constexpr int g = GG;
+                        const u32x4 o = bn8(acc[g * 4 + 2 * q], acc[g * 4 + 2 * q + 1], tq[0], tq[1], tq[2], tq[3], nullptr, rng);
+                        if (B2_ABLATE & 2) asm volatile("" ::"v"(o), "v"(opp.off1[g]));
+                        else __builtin_amdgcn_raw_buffer_store_b128(o, t1rsrc, opp.off1[g] + cb * 128 + q * 64, 0, 0);
+                    });
+                });
+            };
+            wait_vmcnt<18>();                                // own pieces of units 0, 1
+            __builtin_amdgcn_s_barrier();                    // ... everybody's; T0, T1 (W3 chunks 2, 3) are free
+            dmaU(I4{}, I2{}); dmaU(I5{}, I3{});              // units 4, 5 -> T0, T1
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sub(I0{}, aW3b + 16384);                         // chunk A, K groups 0-3 (T2, T3)
+            wait_vmcnt<10>();                                // units 2, 3
+            __builtin_amdgcn_s_barrier();                    // T2, T3 free
+            dmaU(I6{}, I4{}); dmaU(I7{}, I5{});              // units 6, 7 -> T2, T3
+            sub(I4{}, aW3);                                  // chunk A, K groups 4-7 (S0, S1)
+            epi(I0{});
+            wait_vmcnt<6>();                                 // units 4, 5
+            __builtin_amdgcn_s_barrier();                    // S0, S1 free
+            dma3(I0{}); dma3(I1{});                          // W3 chunks 0, 1 of the next tile
+#pragma unroll
+            for (int i = 0; i < 8; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+            sub(I0{}, aW3b);                                 // chunk B, K groups 0-3 (T0, T1)
+            wait_vmcnt<6>();                                 // units 6, 7
+            __builtin_amdgcn_s_barrier();
+            sub(I4{}, aW3b + 16384);                         // chunk B, K groups 4-7 (T2, T3)
+            epi(I1{});
+        }
 #ifdef AP_TRACE
         B2STAMP(12);
         if (a.dbg && blockIdx.x == 0 && tile_no == 5 && (wave & 3) == 0 && lane == 0)
@@ -525,9 +604,12 @@ hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st) {
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)bneck2_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2Map<false>::TOTAL);
+        e = hipFuncSetAttribute((const void*)bneck2_kernel<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2Map<false>::TOTAL);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)bneck2_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, B2Map<true>::TOTAL);
+        e = hipFuncSetAttribute((const void*)bneck2_kernel<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, B2Map<true>::TOTAL);
+        if (e != hipSuccess) return e;
+        constexpr int lds_t = B2Map<false, true>::TOTAL;
+        e = hipFuncSetAttribute((const void*)bneck2_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_t);
         if (e != hipSuccess) return e;
         n_cu_dev[dev] = n;
     }
@@ -535,8 +617,12 @@ hipError_t ap_launch_bneck2(BneckArgs a, int ds, hipStream_t st) {
     a.tiles_per_img = a.tiles_x * (a.H / B2_TS);
     a.total = a.N * a.tiles_per_img;
     const int grid = a.total < n_cu_dev[dev] ? a.total : n_cu_dev[dev];
-    if (ds) hipLaunchKernelGGL(bneck2_kernel<true>, dim3(grid), dim3(512), B2Map<true>::TOTAL, st, a);
-    else hipLaunchKernelGGL(bneck2_kernel<false>, dim3(grid), dim3(512), B2Map<false>::TOTAL, st, a);
+    if (a.w1n && (ds || !a.s1n || !a.h1n || !a.t1n)) return hipErrorInvalidValue;
+    if ((size_t)a.N * a.H * a.W * 256 >= 0xffff0000ull) return hipErrorInvalidValue;
+    constexpr int lds_ds = B2Map<true>::TOTAL, lds_id = B2Map<false>::TOTAL, lds_tail = B2Map<false, true>::TOTAL;
+    if (ds) hipLaunchKernelGGL((bneck2_kernel<true, false>), dim3(grid), dim3(512), lds_ds, st, a);
+    else if (a.w1n) hipLaunchKernelGGL((bneck2_kernel<false, true>), dim3(grid), dim3(512), lds_tail, st, a);
+    else hipLaunchKernelGGL((bneck2_kernel<false, false>), dim3(grid), dim3(512), lds_id, st, a);
     return hipGetLastError();
 }
 

@@ -160,7 +160,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g4 = lane >> 4;
     static_assert(PG == 1 || PG == 2, "one or two groups of 16 pixels per wave");
-    bool mok[PG];
+    bool mok[PG], sok[PG];                                   // sok: the pixel's row of `out` is stored
     size_t mc[PG];
     const unsigned char *t2p[PG], *resp[PG], *x2p[PG];
     unsigned char *outp[PG], *t1p[PG];
@@ -177,6 +177,11 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
                              : (const unsigned char*)p.t2 + (mc[pg] * P + g4 * 8) * 2;
         resp[pg] = p.res_tiled ? (const unsigned char*)p.res + (((mc[pg] >> 4) * (C3 / 8) + g4) * 256 + (mc[pg] & 15) * 16)
                                : (const unsigned char*)p.res + (mc[pg] * C3 + g4 * 8) * 2;
+        sok[pg] = mok[pg];
+        if (p.out_even) {                                    // `out` is read by a stride-2 1x1 only (the next block's downsample branch,
+            const int hw = p.Ho * p.Wo, rem = (int)mc[pg] % hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;   // model_copenet.py:97-102)
+            sok[pg] = mok[pg] && !((ho | wo) & 1);
+        }
         x2p[pg] = t2p[pg];                                   // second K segment: pixel (ho*stride2, wo*stride2) of image n in x2
         if constexpr (P2 > 0) {
             const int hw = p.Ho * p.Wo, n = (int)mc[pg] / hw, rem = (int)mc[pg] - n * hw, ho = rem / p.Wo, wo = rem - ho * p.Wo;
@@ -448,7 +453,7 @@ __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 
                         else if (PR_ABLATE & 128) {
                             unsigned char* oq = (unsigned char*)p.out + ((size_t)(mc[pg] - lr + (lane >> 3) + (q >> 1) * 8) * C3 + nb * 128) * 2 + (lane & 7) * 16 + (q & 1) * 128;
                             *(u32x4*)oq = cur[pg][q];
-                        } else if (mok[pg]) gstore_b128(outp[pg] + nb * out_cs + q * out_fs, cur[pg][q]);
+                        } else if (sok[pg]) gstore_b128(outp[pg] + nb * out_cs + q * out_fs, cur[pg][q]);
                     }
                 });
                 PRSTAMP(29);

@@ -50,6 +50,7 @@ struct PairArgs {
     const void* x2;
     int Ho, Wo, H2, W2, stride2;
     int t2_tiled, res_tiled, out_tiled;   // t2 / res / out in the fragment-tiled layout [M/16][C/8][16][8] instead of NHWC rows
+    int out_even;                 // `out` (NHWC only) is stored at the even (ho, wo) pixels only: its one reader is a stride-2 1x1; needs Ho, Wo
     int groups;                   // 16-pixel groups per wave: 0 / 1 (two workgroups per CU) or 2 (layer3 shapes: one workgroup per CU)
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
     int* range_flag;              // fp16 storage, or NULL: host-mapped word set when a stored value leaves the fp16 range
@@ -66,6 +67,13 @@ struct BneckArgs {
     int* range_flag;              // fp16 storage, or NULL: host-mapped word set when a stored value leaves the fp16 range
     int N, H, W;                  // H, W multiples of 14
     int tiles_x, tiles_per_img, total;   // filled by the launcher
+    // identity block only (tail variant): conv1 of the NEXT block (256 -> 128, 1x1, model_copenet.py:29-31 of layer2.0) on the
+    // block output while it is still in registers -- t1n [N][H][W][128]; with y_even the block output itself is stored at the
+    // even (row, column) pixels only: all a stride-2 downsample branch (model_copenet.py:97-102) ever reads of it
+    const void* w1n;              // packed rows [128][256], or NULL: plain block
+    const float *s1n, *h1n;       // BatchNorm scale / shift of that conv1 [128]
+    void* t1n;
+    int y_even;
 };
 
 // ---- stem / pooling (stem.hip)

@@ -387,6 +387,10 @@ def main():
         net.set_fuse_stem(int(os.environ["AIRPOSE_FUSE_STEM"]))
     if os.environ.get("AIRPOSE_FUSE_POOL"):                 # A/B aid: AvgPool2d(7) in the last convolution's epilogue (default) / own kernel
         net.set_fuse_pool(int(os.environ["AIRPOSE_FUSE_POOL"]))
+    if os.environ.get("AIRPOSE_FUSE_TAIL"):                 # A/B aid: conv1 of layer2.0 inside layer1's last kernel (default) / own convolution
+        net.set_fuse_tail(int(os.environ["AIRPOSE_FUSE_TAIL"]))
+    if os.environ.get("AIRPOSE_EVEN_OUT"):                  # A/B aid: block outputs only a stride-2 downsample reads: even pixels (default) / in full
+        net.set_even_out(int(os.environ["AIRPOSE_EVEN_OUT"]))
     if os.environ.get("AIRPOSE_FUSE_BLOCK"):                # A/B aid: layer1 blocks: 1 fused kernel each (default), 0 separate convs
         net.set_fuse_block(int(os.environ["AIRPOSE_FUSE_BLOCK"]))
     if os.environ.get("AIRPOSE_PAIR_GROUPS"):                # A/B aid: 16-pixel groups per wave of the layer3 pair kernel (ap_set_pair_groups)

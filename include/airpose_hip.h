@@ -184,6 +184,17 @@ int ap_bottleneck64_nhwc(int precision, const void* x, const void* w1, const flo
                          const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
                          int N, int H, int W, int Cin, int downsample, void* stream);
 
+/* The identity form of ap_bottleneck64_nhwc (Cin = 256) with conv1 of the NEXT bottleneck (1x1, 256 -> 128, + BN + ReLU:
+ * model_copenet.py:29-31 of layer2.0) computed on the block output while it is still in registers (bottleneck2.hip, tail
+ * variant): t1n [N][H][W][128] = relu(bn1n(conv1n(y))).  w1n [128][256] K-contiguous rows, s1n / h1n [128].  y_even = 1: y is
+ * stored at the even (row, column) pixels only -- all that layer2.0's stride-2 downsample branch (model_copenet.py:41-42,
+ * :97-102) reads of it; the other pixels of y are left untouched.  y and t1n carry the same bits as ap_bottleneck64_nhwc
+ * followed by ap_conv2d_nhwc. */
+int ap_bottleneck64_tail_nhwc(int precision, const void* x, const void* w1, const float* s1, const float* h1, const void* w2,
+                              const float* s2, const float* h2, const void* w3, const float* s3, const float* h3, void* y,
+                              const void* w1n, const float* s1n, const float* h1n, void* t1n, int y_even, int N, int H, int W,
+                              void* stream);
+
 /* Fused pair kernel on NHWC 16-bit tensors (precision = AP_PREC_BF16 or AP_PREC_F16): conv3 (+ identity | + folded downsample,
  * ReLU) of a bottleneck and conv1 (+ ReLU) of the NEXT bottleneck as one pixel-local kernel (conv_pair.hip; replaces
  * model_copenet.py:38-45 of one block and :29-31 of the next per launch).  The two weight matrices are consumed as ONE stream of
@@ -276,6 +287,14 @@ int ap_net_set_fuse_block(ap_net* h, int on);
  * downsample branch as a second K segment): the block output makes one HBM trip less per block boundary.  Bit-identical to the two stand-alone kernels.  Default on; replaces model_copenet.py:38-45 (+ :29-31 of the
  * next block) per launch. */
 int ap_net_set_fuse_pair(ap_net* h, int on);
+/* 16-bit modes: on = 1 (default) computes conv1 of layer2.0 inside the kernel of layer1's last bottleneck
+ * (ap_bottleneck64_tail_nhwc): the 56 x 56 x 256 block output is not read back for it (model_copenet.py:29-31 at :64).
+ * Bit-identical to the stand-alone convolution. */
+int ap_net_set_fuse_tail(ap_net* h, int on);
+/* 16-bit modes: on = 1 (default): a block output whose only remaining reader is the next block's stride-2 downsample branch
+ * (model_copenet.py:41-42, :97-102; its conv1 having been computed by the producing kernel) is stored at the even pixels only.
+ * Features are bit-identical either way. */
+int ap_net_set_even_out(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);
 /* Two-view forwards (>= 64 images per view, both views within one chunk) run the two views as two concurrent trunk

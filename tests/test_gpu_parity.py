@@ -653,6 +653,68 @@ def test_fused_bottleneck_full_size_is_deterministic(dev, prec):
         assert torch.equal(o.view(torch.int16), outs[0].view(torch.int16))
 
 
+@pytest.mark.parametrize("y_even", [0, 1])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_fused_bottleneck_tail_equals_block_then_conv1(dev, prec, y_even):
+    """bottleneck2.hip tail variant (layer1's last block + conv1 of layer2.0, model_copenet.py:27-47 then :29-31 of the next
+    block): t1n must carry the bits of ap_bottleneck64_nhwc followed by the stand-alone 1x1 convolution, y the bits of the plain
+    block -- everywhere (y_even = 0) or at the even pixels with the others untouched (y_even = 1).  37 images = 592 tiles on 256
+    workgroups: every hand-counted wait of the persistent loop is met in its steady state and in a partial last round."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    bf = H16[prec]
+    g = torch.Generator().manual_seed(177 + y_even)
+    N, H = 37, 56
+    x = torch.randn(N, H, H, 256, generator=g).to(bf).to(dev)
+    w1 = (torch.randn(128, 256, generator=g) * (2.0 / 256) ** 0.5).to(bf).to(dev)
+    w2 = (torch.randn(128, 576, generator=g) * (2.0 / 576) ** 0.5).to(bf).to(dev)
+    w3 = (torch.randn(256, 64, generator=g) * (2.0 / 64) ** 0.5).to(bf).to(dev)
+    w1n = (torch.randn(128, 256, generator=g) * (2.0 / 256) ** 0.5).to(bf).to(dev)
+    sc = [(torch.rand(c, generator=g) + 0.5).to(dev) for c in (128, 128, 256, 128)]
+    sh = [(torch.randn(c, generator=g) * 0.1).to(dev) for c in (128, 128, 256, 128)]
+    y = torch.full((N, H, H, 256), float("nan"), dtype=bf, device=dev)
+    t1n = torch.full((N, H, H, 128), float("nan"), dtype=bf, device=dev)
+    y_ref = torch.empty_like(y)
+    t1n_ref = torch.empty_like(t1n)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    B = Nn.PRECISIONS[prec]
+    Nn.check(L.ap_bottleneck64_tail_nhwc(B, p(x), p(w1), p(sc[0]), p(sh[0]), p(w2), p(sc[1]), p(sh[1]), p(w3), p(sc[2]), p(sh[2]),
+                                         p(y), p(w1n), p(sc[3]), p(sh[3]), p(t1n), y_even, N, H, H, st), "ap_bottleneck64_tail_nhwc")
+    Nn.check(L.ap_bottleneck64_nhwc(B, p(x), p(w1), p(sc[0]), p(sh[0]), p(w2), p(sc[1]), p(sh[1]), p(w3), p(sc[2]), p(sh[2]),
+                                    p(y_ref), N, H, H, 256, 0, st), "ap_bottleneck64_nhwc")
+    Nn.check(L.ap_conv2d_nhwc(B, p(y_ref), p(w1n), p(sc[3]), p(sh[3]), None, p(t1n_ref), N, H, H, 256, 128, 1, 1, 0, 1, st), "c1n")
+    torch.cuda.synchronize()
+    assert torch.isfinite(t1n.float()).all()
+    assert torch.equal(t1n.view(torch.int16), t1n_ref.view(torch.int16))
+    yi, ri = y.view(torch.int16), y_ref.view(torch.int16)
+    if y_even:
+        assert torch.equal(yi[:, ::2, ::2], ri[:, ::2, ::2])
+        assert torch.isnan(y[:, 1::2].float()).all() and torch.isnan(y[:, :, 1::2].float()).all()   # untouched
+    else:
+        assert torch.equal(yi, ri)
+
+
+@pytest.mark.parametrize("n", [1, 3, 64])
+def test_fused_tail_and_even_outputs_are_bit_identical(net16, dev, n):
+    """conv1 of layer2.0 inside layer1's last kernel (ap_net_set_fuse_tail) and even-pixel-only stores of the block outputs whose
+    one remaining reader is a stride-2 downsample branch (layer1.2, layer2.3: ap_net_set_even_out): same features, bit for bit,
+    in every combination of the two knobs."""
+    gen = torch.Generator(device="cpu").manual_seed(400 + n)
+    x = torch.randn(n, 3, 224, 224, generator=gen).to(dev)
+    got = net16.forward_feat_ext(x).clone()
+    assert torch.isfinite(got).all()
+    try:
+        for tail, even in ((0, 0), (1, 0), (0, 1)):
+            net16.set_fuse_tail(tail)
+            net16.set_even_out(even)
+            assert torch.equal(net16.forward_feat_ext(x), got), (tail, even)
+    finally:
+        net16.set_fuse_tail(1)
+        net16.set_even_out(1)
+    assert torch.equal(net16.forward_feat_ext(x), got)
+
+
 @pytest.mark.parametrize("n", [1, 2, 5, 6, 13, 64])
 def test_fused_pool_is_bit_identical(net16, dev, n):
     """AvgPool2d(7) in the epilogue of layer4.2 conv3 (conv_lean.hip POOL variant: super-tiles of 5 images, the third one split

@@ -47,9 +47,16 @@ if "bneck" in rows[k][0]:        # layer1 as three fused bottleneck kernels: fol
         dur = r[3] / 1e3
         tot += dur
         bylayer["l1"] = bylayer.get("l1", 0) + dur
-        print("l1.%d.fused M=%7d (conv1+conv2+conv3%s) %-22s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
-            bi, M, "+ds" if bi == 0 else "+id", r[0].split("::")[-1].split("(")[0], r[4] // 512, dur, fl / dur / 1e6,
-            by / 1e6, by / dur / 1e3))
+        tail = "<false, true>" in r[0]              # tail variant: + conv1 of layer2.0; the block output at the even pixels only
+        if tail:
+            _, M1, N1, K1, _, _ = rest[0]
+            assert rest[0][0] == "l2.0.c1"
+            fl += 2.0 * M1 * N1 * K1
+            by = (M * blk[0][3] + M * 256 // 4 + M1 * N1) * 2
+            rest = rest[1:]
+        print("l1.%d.fused M=%7d (conv1+conv2+conv3%s%s) %-22s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
+            bi, M, "+ds" if bi == 0 else "+id", "+l2.0.c1" if tail else "", r[0].split("::")[-1].split("(")[0], r[4] // 512, dur,
+            fl / dur / 1e6, by / 1e6, by / dur / 1e3))
     shapes = rest
 import re
 skip = set()
