@@ -57,6 +57,7 @@ SIGNATURES = {
     "ap_conv2d_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 9 + [_vp]),
     "ap_set_conv_config": (_i, [_i]),
     "ap_set_pair_groups": (_i, [_i]),
+    "ap_abi_version": (_i, []),
     "ap_debug_set_trace": (_i, [_vp]),
     "ap_net_enable_timing": (_i, [_vp, _i]),
     "ap_net_timing": (_i, [_vp, _c.POINTER(_c.c_double), _i64p, _i]),
@@ -102,6 +103,7 @@ SIGNATURES = {
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }
 
+ABI_VERSION = 5          # include/airpose_hip.h: AP_ABI_VERSION
 _lib = None
 _lib_lock = threading.Lock()
 
@@ -117,6 +119,10 @@ def lib():
                         "airpose_amd: %s is missing -- build it with `python -c 'import __graft_entry__ as g; "
                         "g.build()'` (hipcc, gfx950).  There is no CPU fallback." % LIB_PATH)
                 L = ctypes.CDLL(LIB_PATH)
+                abi = getattr(L, "ap_abi_version", None)
+                if abi is None or abi() != ABI_VERSION:      # signatures differ: calling through them would pass pointers as ints
+                    raise RuntimeError("airpose_amd: %s exports ABI %s, this binding is written against ABI %d (include/airpose_hip.h: "
+                                       "AP_ABI_VERSION) -- rebuild the library" % (LIB_PATH, "?" if abi is None else abi(), ABI_VERSION))
                 for name, (res, args) in SIGNATURES.items():
                     fn = getattr(L, name)
                     fn.restype, fn.argtypes = res, args

@@ -191,6 +191,7 @@ class copenet(nn.Module):
         B = x0.shape[0]
         if x0.dim() != 4 or x0.shape[1:] != (3, 224, 224) or x1.shape != x0.shape:
             raise RuntimeError("forward_feat_ext_twoview expects two (B, 3, 224, 224) NCHW crops")
+        x0_in, x1_in = x0, x1
         x0, x1 = N.f32c(x0), N.f32c(x1, dev)
         if out is None:
             out = torch.empty(2, B, 2048, device=dev, dtype=torch.float32)
@@ -204,6 +205,12 @@ class copenet(nn.Module):
             else:
                 N.check(self._L().ap_trunk_fwd_twoview_async(h, N.dptr(x0, "x0"), N.dptr(x1, "x1"), B, N.dptr(out), N.stream_ptr(dev),
                                                              ctypes.c_void_p(out_stream.cuda_stream)), "ap_trunk_fwd_twoview_async")
+                # The current stream is NOT behind the passes: an fp32 / contiguous COPY made above (half, uint8, strided crops) would
+                # go back to the caching allocator when this function returns and could be handed out again on the current stream
+                # while the passes still read it.  out_stream is behind the passes (the joins are queued): tie the copies to it.
+                for conv, orig in ((x0, x0_in), (x1, x1_in)):
+                    if conv is not orig:
+                        conv.record_stream(out_stream)
         return out
 
     @staticmethod

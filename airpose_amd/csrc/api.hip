@@ -1190,7 +1190,8 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
 // ================================================================================== C ABI
 extern "C" {
 
-const char* ap_version(void) { return "airpose_hip 0.1 (gfx950)"; }
+const char* ap_version(void) { return "airpose_hip 0.5 (gfx950; abi 5)"; }
+int ap_abi_version(void) { return AP_ABI_VERSION; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
 int ap_net_create(ap_net** out, int device, int precision, int variant) {
@@ -1636,8 +1637,13 @@ int ap_net_set_fuse_stem(ap_net* h, int on) {
 
 int ap_net_set_fold(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    if (on && h->fold_rejected)
-        return fail(AP_ESTATE, "ap_net_set_fold: the fold was rejected for this checkpoint by ap_net_finalize (ap_net_fold_status)");
+    if (on && h->fold_rejected) {
+        // a remembered knob re-applied to a checkpoint the probe rejects (copenet._set_knob) must not turn every later call
+        // into an error: the literal chain stays, ap_net_fold_status says why
+        fprintf(stderr, "airpose_hip: ap_net_set_fold(1) ignored -- ap_net_finalize rejected the fold for this checkpoint "
+                        "(ap_net_fold_status); the handle keeps evaluating the literal fc1 -> fc2 -> dec chain\n");
+        return AP_OK;
+    }
     h->fold = on != 0;
     return AP_OK;
 }
@@ -1645,7 +1651,9 @@ int ap_net_set_fold(ap_net* h, int on) {
 int ap_net_set_fold_bar(ap_net* h, double bar) {
     if (!h || !(bar >= 0.0)) return fail(AP_EINVAL, "ap_net_set_fold_bar: handle, bar >= 0");
     h->fold_bar = bar;
-    h->finalized = false;                                    // takes effect at the next ap_net_finalize
+    // the bar is applied by ap_net_finalize: re-run it here when the handle holds a packed checkpoint, so the handle never
+    // sits in a silently un-finalized state (a forward would fail with "ap_net_finalize has not been called")
+    if (h->finalized) return ap_net_finalize(h);
     return AP_OK;
 }
 

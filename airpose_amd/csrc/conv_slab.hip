@@ -503,7 +503,8 @@ hipError_t ap_launch_conv_slab(ConvArgs a, hipStream_t st) {
     a.ntiles = (a.Cout + BN - 1) / BN;
     {
         const unsigned long long hw = (unsigned long long)a.H * a.W, lim = 1ull << 32;
-        const bool fits = ((unsigned long long)a.M + BM) * hw < lim;
+        // (W == 1 or H W == 1: ceil(2^32 / 1) does not fit 32 bits and would truncate to 0 -> wrong rows; those shapes divide)
+        const bool fits = ((unsigned long long)a.M + BM) * hw < lim && a.W > 1 && hw > 1;
         a.magic_hw = fits ? (unsigned)((lim + hw - 1) / hw) : 0u;
         a.magic_w = fits ? (unsigned)((lim + a.W - 1) / a.W) : 0u;
     }

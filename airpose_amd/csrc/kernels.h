@@ -26,10 +26,10 @@ struct ConvArgs {
     int mtiles, ntiles;   // filled by the launcher
     unsigned magic_hw, magic_w;   // conv_slab, filled by its launcher: ceil(2^32 / (H W)), ceil(2^32 / W) when (M + tile) * H * W < 2^32 (0 = divide)
     int out_f32;          // split-bf16 kind only: y (and res) are plain fp32 [M][ldy] instead of split pairs
-    // conv_lean.hip POOL variant (last convolution of the trunk): when set, y is NOT written; the 7 x 7 pixels of every image are
-    // averaged per channel instead (AvgPool2d(7) + view) into pool_out [N][Cout] fp32, bit-identical to conv + avgpool_kernel
     int y_tiled;          // 16-bit kinds, LDS-staged epilogues: y in the fragment-tiled layout [M/16][Cout/8][16 pixels][8 channels]
                           // (the t2 operand of the fused pair kernel) instead of NHWC rows; Cout % 8 == 0, y sized for M rounded up to 16
+    // conv_lean.hip POOL variant (last convolution of the trunk): when set, y is NOT written; the 7 x 7 pixels of every image are
+    // averaged per channel instead (AvgPool2d(7) + view) into pool_out [N][Cout] fp32, bit-identical to conv + avgpool_kernel
     float* pool_out;
     int* range_flag;      // fp16 storage, or NULL: host-mapped word set to 1 when a stored value leaves the fp16 range (ap_common.h)
 };

@@ -23,8 +23,8 @@ class Pending(object):
     stream.  ``wait()`` makes a stream (default: the current one) wait for it, ``synchronize()`` blocks the host; reading ``out``
     before either is a race, exactly as with any tensor produced on another stream."""
 
-    def __init__(self, out, done, stream):
-        self.out, self._done, self._stream = out, done, stream
+    def __init__(self, out, done, stream, model=None):
+        self.out, self._done, self._stream, self._model = out, done, stream, model
 
     def wait(self, stream=None):
         stream = stream if stream is not None else torch.cuda.current_stream(self._stream.device)
@@ -37,7 +37,13 @@ class Pending(object):
         return self.out
 
     def synchronize(self):
+        """Block the host until the batch is done.  precision="f16": raises RangeError if a stored activation of THIS or an earlier
+        pass of the handle left the fp16 range (the deferred sentinel of ap_net_set_range_check would otherwise only speak up
+        at the next forward -- never, for the last batch of a run)."""
         self._done.synchronize()
+        if self._model is not None and getattr(self._model, "precision", None) == "f16":
+            with torch.cuda.stream(self._stream):
+                self._model.range_status()
         return self.wait()                                   # (the event is complete: only the allocator bookkeeping of wait() remains)
 
 
@@ -114,7 +120,7 @@ class TwoViewInference(object):
                 out = self._tail(*out, batch, want_rotmat, want_angles, want_input_mesh)
             st["done"][slot].record(side)
         st["busy"][slot] = True
-        return Pending(out, st["done"][slot], side)
+        return Pending(out, st["done"][slot], side, self.model)
 
     def _tail(self, p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh):
         B, dev = p0.shape[0], p0.device

@@ -47,7 +47,12 @@ extern "C" {
 typedef struct ap_net ap_net;     /* ResNet-50 trunk + IEF regressor */
 typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
 
+/* ABI number of this header: bumped whenever an exported signature changes or an entry point is removed (5: round 5 --
+ * ap_conv_pair_* / ap_bottleneck64_nhwc take a leading `precision` and a caller-packed weight stream since 4).  A binding built
+ * against another number must refuse to load the library (airpose_amd/_native.py does). */
+#define AP_ABI_VERSION 5
 const char* ap_version(void);
+int ap_abi_version(void);
 const char* ap_last_error(void);
 
 /* ---------------------------------------------------------------------------------------------
@@ -72,10 +77,14 @@ int ap_net_precision(const ap_net* h);
  *                           mode 2: synchronous -- every trunk-running call (ap_trunk_fwd, ap_copenet_fwd, ap_hmr_fwd, ...)
  *                           synchronises its stream after the trunk and returns AP_ERANGE for its OWN pass; mode 0: off
  *   ap_net_range_status     synchronises `stream` and returns AP_OK or AP_ERANGE; reset != 0 clears the flag
- * What the sentinel sees: inf / NaN that reach the last layer.  An overflowed (+inf) activation propagates through the following
- * convolutions as +-inf / NaN; ReLU clears -inf and, in the kernels that clamp with v_max_f32, NaN -- so the sentinel is a strong
- * indicator, not a proof (an overflow all of whose descendants are clamped goes unseen).  The weight check of ap_net_finalize is
- * exact. */
+ * What the sentinel sees: EVERY stored activation.  An overflow can only be born where an fp32 result is converted for storage,
+ * and every stored activation of the trunk is post-ReLU, i.e. it is born as +inf = 0x7c00: each epilogue of the fp16 kernel set
+ * folds the packed dwords it stores into a running 16-bit maximum (one v_pk_max_i16 / v_pk_maximum3_f16 per two or four values)
+ * and sets the flag once per thread at the end of the kernel (ap_common.h: ap_rng_note / ap_rng_flush); the pooling stage checks
+ * the features as well.  (A check of the pooled features alone is NOT enough: measured, the NaNs an inf turns into downstream
+ * carry a set sign bit and every ReLU clears them.)  The weight check of ap_net_finalize is exact.
+ * In the deferred mode the forward that overflows itself returns AP_OK: a one-shot caller, or the last batch of a run, asks
+ * ap_net_range_status once its stream is done (airpose_amd: Pending.synchronize() and copenet.range_status() do). */
 int ap_net_set_range_check(ap_net* h, int mode);
 int ap_net_range_status(ap_net* h, void* stream, int reset);
 

@@ -2,6 +2,7 @@
 include/airpose_hip.h declares (no compute calls: there is no GPU here), the host mirrors keep the
 reference's contracts, and the product refuses to run without the GPU instead of falling back."""
 import os
+import ctypes
 import re
 
 import numpy as np
@@ -30,6 +31,20 @@ def test_library_exports_every_declared_symbol():
         assert n in _native.SIGNATURES, "ctypes signature missing for " + n
     assert sorted(_native.SIGNATURES) == names
     assert b"gfx950" in L.ap_version()
+
+
+def test_abi_version_matches_header_and_binding():
+    """An out-of-tree caller built against another header must be able to tell: the library exports the ABI number of the header
+    it was built from, and the ctypes binding refuses any other."""
+    import re
+    from airpose_amd import _native
+    hdr = open(os.path.join(REPO, "include", "airpose_hip.h")).read()
+    want = int(re.search(r"#define\s+AP_ABI_VERSION\s+(\d+)", hdr).group(1))
+    L = ctypes.CDLL(_native.LIB_PATH)
+    L.ap_abi_version.restype = ctypes.c_int
+    assert L.ap_abi_version() == want == _native.ABI_VERSION
+    L.ap_version.restype = ctypes.c_char_p
+    assert ("abi %d" % want).encode() in L.ap_version()
 
 
 def test_state_dict_contract_matches_reference(golden, copenet_sd):

@@ -695,6 +695,47 @@ def test_fused_bottleneck_tail_equals_block_then_conv1(dev, prec, y_even):
         assert torch.equal(yi, ri)
 
 
+def test_submit_keeps_converted_inputs_alive(netf16, body, dev):
+    """submit() with crops that are NOT fp32-contiguous (half precision, a strided view): forward_feat_ext_twoview makes fp32
+    copies, and in the asynchronous form the caller's stream is not behind the trunk passes -- the copies must outlive the call
+    (record_stream on the pipeline's stream), or the caching allocator hands their blocks to the next allocation on the caller's
+    stream while the passes still read them.  Allocations + fills of the same size right behind every submit try to provoke that."""
+    from airpose_amd import pipeline, weights as W
+    B = 64
+    pipe = pipeline.TwoViewInference(netf16, body)
+    base = {k: torch.from_numpy(v).to(dev) for k, v in W.synthetic_inputs(640, B).items()}
+    half = dict(base)
+    half["im0"], half["im1"] = base["im0"].half(), base["im1"].half()
+    ref_in = dict(base)
+    ref_in["im0"], ref_in["im1"] = half["im0"].float(), half["im1"].float()
+    want = {k: v.clone() for k, v in pipe(ref_in).items()}
+    torch.cuda.synchronize()
+    pend = []
+    for i in range(6):
+        pend.append(pipe.submit(half))
+        junk = [torch.full((B, 3, 224, 224), float(i + 1), device=dev) for _ in range(2)]   # same size as the converted crops
+        del junk
+    for p in pend:
+        got = p.synchronize()
+        for k in ("pred_pose0", "pred_betas1", "pred_vertices_cam1"):
+            assert torch.equal(got[k], want[k]), k
+    big = torch.cat([base["im0"], base["im0"]], 0)           # strided view: every second image
+    sv = dict(base)
+    sv["im0"] = big[::2]
+    assert not sv["im0"].is_contiguous() or B == 1
+    ref2 = dict(base)
+    ref2["im0"] = big[::2].contiguous()
+    want2 = {k: v.clone() for k, v in pipe(ref2).items()}
+    torch.cuda.synchronize()
+    pend = []
+    for i in range(4):
+        pend.append(pipe.submit(sv))
+        junk = torch.full((B, 3, 224, 224), -1.0, device=dev)
+        del junk
+    for p in pend:
+        assert torch.equal(p.synchronize()["pred_vertices_cam0"], want2["pred_vertices_cam0"])
+
+
 @pytest.mark.parametrize("n", [1, 3, 64])
 def test_fused_tail_and_even_outputs_are_bit_identical(net16, dev, n):
     """conv1 of layer2.0 inside layer1's last kernel (ap_net_set_fuse_tail) and even-pixel-only stores of the block outputs whose
