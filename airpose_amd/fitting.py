@@ -77,3 +77,40 @@ class AirPosePlusFitter:
                  "beta": grad[nz + nphi + L * 6:]}
             res.append(g)
         return res[0] if len(res) == 1 else tuple(res)
+
+
+def synthetic_fit_problem(frames, seed, device):
+    """Seeded stand-in for the gated inputs of the fitting loop (VPoser V02_05 weights, OpenPose / AlphaPose detections), for
+    LATENCY measurements: a random-initialised decoder (nn.Linear init), an initial state around the upright pose and 2-D
+    detections scattered around the projection of a body 8 m in front of each camera.  The loop runs a fixed number of
+    iterations whatever the data; tests that need observations consistent with a ground-truth motion build them with the
+    oracle's generator instead.  Returns (vposer, state, data) with data = j2d (2,L,2,24,3), robust (L,), intr (2,4), extr (2,3,4)."""
+    g = torch.Generator().manual_seed(seed)
+    rnd = lambda *s: torch.randn(*s, generator=g)
+    uni = lambda *s: torch.rand(*s, generator=g)
+    L = frames
+
+    def lin(o, i):
+        b = 1.0 / i ** 0.5
+        return (uni(o, i) * 2 - 1) * b, (uni(o) * 2 - 1) * b
+    vp = {}
+    vp["w1"], vp["b1"] = lin(512, 32)
+    vp["w2"], vp["b2"] = lin(512, 512)
+    vp["w3"], vp["b3"] = lin(126, 512)
+    t = torch.linspace(0, 1, L).unsqueeze(1)
+    st = {"z": 0.8 * rnd(1, 32) + 0.3 * rnd(L, 32), "beta": torch.zeros(10)}
+    for v in (0, 1):
+        st["phi%d" % v] = torch.tensor([[1.0, 0, 0, 0, -1.0, 0]]) + 0.15 * rnd(1, 6) + 0.05 * t * rnd(1, 6) + 0.05 * rnd(L, 6)
+        st["tau%d" % v] = torch.tensor([[0.0, 0.2, 8.0]]) + 0.3 * rnd(1, 3) + 0.4 * t * rnd(1, 3) + 0.2 * rnd(L, 3)
+    intr = torch.tensor([[1475.0, 1475.0, 960.0, 540.0], [1470.0, 1480.0, 950.0, 545.0]])
+    extr = torch.eye(4)[:3].unsqueeze(0).repeat(2, 1, 1).contiguous()
+    j2d = torch.zeros(2, L, 2, 24, 3)
+    for v in (0, 1):
+        centre = torch.stack([intr[v, 2] + 40.0 * rnd(L, 1), intr[v, 3] + 40.0 * rnd(L, 1)], -1)      # (L,1,2): the body's image
+        limbs = 90.0 * rnd(1, 24, 2)                                                               # a fixed 24-joint layout around it
+        for det in (0, 1):
+            j2d[v, :, det, :, :2] = centre + limbs + 3.0 * rnd(L, 24, 2)
+            j2d[v, :, det, :, 2] = uni(L, 24)
+    data = {"j2d": j2d, "robust": uni(L) > 0.1, "intr": intr, "extr": extr}
+    dev = torch.device(device)
+    return vp, {k: v.to(dev) for k, v in st.items()}, {k: (v.to(dev) if v.is_floating_point() else v) for k, v in data.items()}

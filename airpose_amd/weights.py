@@ -34,12 +34,15 @@ def _conv(rs, cout, cin, k):
     return rs.normal(0.0, std, size=(cout, cin, k, k)).astype(np.float32)
 
 
-def _bn(rs, sd, prefix, c, last=False):
-    lo, hi = (0.25, 0.75) if last else (0.5, 1.5)
+def _bn(rs, sd, prefix, c, last=False, wide=False):
+    # wide: the second statistics range of the parity sweeps (gamma, var ~ U(.25, 2): scales from 0.18 to 4 per channel instead of
+    # 0.4 to 2.1; the last BN of a block keeps half the gamma range so that 16 residual blocks do not blow the activations up)
+    lo, hi = ((0.125, 1.0) if last else (0.25, 2.0)) if wide else ((0.25, 0.75) if last else (0.5, 1.5))
     sd[prefix + ".weight"] = rs.uniform(lo, hi, size=c).astype(np.float32)
     sd[prefix + ".bias"] = rs.normal(0.0, 0.1, size=c).astype(np.float32)
     sd[prefix + ".running_mean"] = rs.normal(0.0, 0.1, size=c).astype(np.float32)
-    sd[prefix + ".running_var"] = rs.uniform(0.5, 1.5, size=c).astype(np.float32)
+    vlo, vhi = (0.25, 2.0) if wide else (0.5, 1.5)
+    sd[prefix + ".running_var"] = rs.uniform(vlo, vhi, size=c).astype(np.float32)
     sd[prefix + ".num_batches_tracked"] = np.zeros((), dtype=np.int64)
 
 
@@ -53,24 +56,24 @@ def _linear(rs, sd, prefix, cout, cin, xavier_gain=None):
     sd[prefix + ".bias"] = rs.uniform(-bb, bb, size=cout).astype(np.float32)
 
 
-def trunk_state_dict(rs):
+def trunk_state_dict(rs, wide_bn=False):
     """ResNet-50 v1.5 trunk entries (conv1/bn1/layer1..4), reference order."""
     sd = OrderedDict()
     sd["conv1.weight"] = _conv(rs, 64, 3, 7)
-    _bn(rs, sd, "bn1", 64)
+    _bn(rs, sd, "bn1", 64, wide=wide_bn)
     inplanes = 64
     for li, (planes, nblocks) in enumerate(zip(PLANES, LAYERS), start=1):
         for bi in range(nblocks):
             p = "layer%d.%d" % (li, bi)
             sd[p + ".conv1.weight"] = _conv(rs, planes, inplanes, 1)
-            _bn(rs, sd, p + ".bn1", planes)
+            _bn(rs, sd, p + ".bn1", planes, wide=wide_bn)
             sd[p + ".conv2.weight"] = _conv(rs, planes, planes, 3)
-            _bn(rs, sd, p + ".bn2", planes)
+            _bn(rs, sd, p + ".bn2", planes, wide=wide_bn)
             sd[p + ".conv3.weight"] = _conv(rs, planes * EXPANSION, planes, 1)
-            _bn(rs, sd, p + ".bn3", planes * EXPANSION, last=True)
+            _bn(rs, sd, p + ".bn3", planes * EXPANSION, last=True, wide=wide_bn)
             if bi == 0:
                 sd[p + ".downsample.0.weight"] = _conv(rs, planes * EXPANSION, inplanes, 1)
-                _bn(rs, sd, p + ".downsample.1", planes * EXPANSION, last=True)
+                _bn(rs, sd, p + ".downsample.1", planes * EXPANSION, last=True, wide=wide_bn)
             inplanes = planes * EXPANSION
     return sd
 
@@ -81,10 +84,11 @@ def load_mean_params(path):
             d["cam"].astype(np.float32)[None])
 
 
-def copenet_state_dict(seed, mean_params_path, variant="copenet"):
-    """Full state_dict (numpy arrays) for the two-view ``copenet`` (or ``hmr`` / ``copenet_singleview``) module."""
+def copenet_state_dict(seed, mean_params_path, variant="copenet", wide_bn=False):
+    """Full state_dict (numpy arrays) for the two-view ``copenet`` (or ``hmr`` / ``copenet_singleview``) module.
+    wide_bn: BatchNorm gamma / running_var from U(.25, 2) instead of U(.5, 1.5) (same random stream positions)."""
     rs = np.random.RandomState(seed)
-    sd = trunk_state_dict(rs)
+    sd = trunk_state_dict(rs, wide_bn)
     if variant not in ("copenet", "hmr", "singleview", "muhmr"):
         raise ValueError(variant)
     fc1_in = {"copenet": FC1_IN, "hmr": HMR_FC1_IN, "singleview": 2048 + 3 + 135 + 10, "muhmr": 2048 + 3 + 132 + 10 + 136}[variant]

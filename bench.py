@@ -161,6 +161,93 @@ def timed_mode_parity(sd, md, pipe, dev, n_threads, seeds=(4321, 777), pairs_per
             "oracle_seconds": time.perf_counter() - t0}
 
 
+def parity_sweep(args, md, body, dev, n_threads, pairs_per_cell=16):
+    """the parity claim as a property, not a sample.  EVERY mode (the two 16-bit storage types and the two
+    parity-grade modes) against the fp32 CPU oracle over 3 weight seeds x 2 input seeds plus a second BatchNorm-statistics range
+    (gamma, running_var ~ U(.25, 2)): worst slice-max error and worst element-wise error per mode and per checkpoint."""
+    import torch
+    from airpose_amd import copenet_model, pipeline
+    from airpose_amd import weights as W
+    from oracle import pipeline_ref
+    ckpts = [("seed20240901", 20240901, False), ("seed7", 7, False), ("seed99", 99, False), ("seed20240901_widebn", 20240901, True)]
+    in_seeds = (4321, 777)
+    modes = ("f16", "bf16", "bf16x2", "fp32")
+    n_all = torch.get_num_threads()
+    res = {m: {"max_rel_err": 0.0, "max_elementwise_err": 0.0, "by_checkpoint": {}, "worst_slice": None} for m in modes}
+    t0 = time.perf_counter()
+    nets = {}
+    try:
+        for name, wseed, wide in ckpts:
+            sdw = W.to_torch(W.copenet_state_dict(wseed, MEAN, wide_bn=wide))
+            cells = []
+            torch.set_num_threads(n_threads)
+            for s in in_seeds:
+                inp = {k: torch.from_numpy(v) for k, v in W.synthetic_inputs(s, pairs_per_cell).items()}
+                with torch.no_grad():
+                    want = pipeline_ref.infer(sdw, md, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], inp["intr0"], inp["intr1"])
+                cells.append((inp, want))
+            torch.set_num_threads(n_all)
+            for m in modes:
+                if m not in nets:
+                    nets[m] = copenet_model.getcopenet(MEAN, precision=m).eval()
+                net = nets[m]
+                net.load_state_dict(sdw)
+                pipe = pipeline.TwoViewInference(net, body, iters=3)
+                worst, worst_el, wslice = 0.0, 0.0, None
+                for inp, want in cells:
+                    got = {k: v.float().cpu() for k, v in pipe({k: v.to(dev) for k, v in inp.items()}, want_rotmat=True).items()}
+                    e, el = slice_errs(got, want), slice_errs(got, want, elementwise_atol=1e-2)
+                    ks = max(e, key=e.get)
+                    if e[ks] > worst:
+                        worst, wslice = e[ks], ks
+                    worst_el = max(worst_el, max(el.values()))
+                if m == "f16":
+                    net.range_status()
+                res[m]["by_checkpoint"][name] = {"max_rel_err": worst, "max_elementwise_err": worst_el}
+                if worst > res[m]["max_rel_err"]:
+                    res[m]["max_rel_err"], res[m]["worst_slice"] = worst, "%s @ %s" % (wslice, name)
+                res[m]["max_elementwise_err"] = max(res[m]["max_elementwise_err"], worst_el)
+                del pipe
+    finally:
+        torch.set_num_threads(n_all)
+    del nets
+    torch.cuda.empty_cache()
+    for m in modes:
+        res[m]["meets_bar"] = res[m]["max_rel_err"] < 1e-4
+    return {"modes": res, "bar": 1e-4, "checkpoints": [c[0] for c in ckpts], "input_seeds": list(in_seeds),
+            "pairs_per_checkpoint": len(in_seeds) * pairs_per_cell, "checked_pairs_per_mode": len(ckpts) * len(in_seeds) * pairs_per_cell,
+            "error_measure": "max|a-b| / max|b| per semantic slice; elementwise: max |a-b| / (1e-2 + |b|)",
+            "checkpoints_note": "copenet_state_dict(seed) of airpose_amd/weights.py; widebn: BatchNorm gamma / running_var ~ U(.25, 2) "
+                                "(last BN of a block: gamma ~ U(.125, 1)) instead of U(.5, 1.5)",
+            "seconds": time.perf_counter() - t0}
+
+
+def airpose_plus_block(body_md, dev, frames=64, iters=300):
+    """BASELINE config 4 (AirPose+: copenet_twoview + SMPLify-X-style fitting loop, batch 64, end-to-end latency): the fitting loop
+    of bundle_adj.py:262-401 (300 Adam steps over a sequence of 64 frames, 2 views x 2 detectors x 24 joints) through ap_fit_run
+    on a seeded synthetic problem; the network forward of the same 64 pairs is the b64 block of this line."""
+    import torch
+    from airpose_amd import smplx as smplx_mod
+    from airpose_amd.fitting import AirPosePlusFitter, synthetic_fit_problem
+    body = smplx_mod.SMPLX(model_data=body_md, batch_size=frames, create_transl=False).to(dev)
+    vp, st, dd = synthetic_fit_problem(frames, 77, dev)
+    fitter = AirPosePlusFitter(vp, body, dev)
+    run = lambda n: fitter.run(st, dd["j2d"], dd["robust"], dd["intr"], dd["extr"], n_iters=n, want_loss=True)
+    run(5)
+    torch.cuda.synchronize()
+    best = None
+    for _ in range(3):
+        t0 = time.perf_counter()
+        _, hist = run(iters)
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) * 1e3
+        best = ms if best is None or ms < best else best
+    return {"frames": frames, "iters": iters, "ms": best, "ms_per_iteration": best / iters, "unit": "ms", "higher_is_better": False,
+            "what": "ap_fit_run: %d Adam steps (VPoser latent, per-view root 6D + translation, shared betas), inputs resident on the "
+                    "device, best of 3; loss %.4g -> %.4g" % (iters, float(hist[0, :3].sum()), float(hist[-1, :3].sum())),
+            "reference": "copenet_real_data/scripts/bundle_adj.py:262-401"}
+
+
 def b64_block(args, sd, body, dev):
     """BASELINE config 1 (copenet_twoview forward, batch 64 two-view, 3 IEF iterations, network only) in both 16-bit storage
     types: pairs/s and the conv-stack fraction of the MFMA peak from HIP events inside its own timed steps."""
@@ -323,7 +410,10 @@ def main():
     ap.add_argument("--stage-steps", type=int, default=5, help="extra untimed steps with per-stage HIP events")
     ap.add_argument("--force-dist", action="store_true", help="initialise the RCCL process group even with one rank (test aid)")
     ap.add_argument("--dual-stream", type=int, default=1, help="two-view trunk as two concurrent passes (default) or one pass (0)")
-    ap.add_argument("--repeat-blocks", type=int, default=4, help="extra K-step blocks after the contract's one (spread)")
+    ap.add_argument("--repeat-blocks", type=int, default=6, help="extra blocks after the contract's K-step one (spread; GPU busy >= 3 s)")
+    ap.add_argument("--repeat-steps", type=int, default=100, help="steps of each extra block")
+    ap.add_argument("--parity-sweep", type=int, default=1, help="every mode vs the CPU oracle over 3 weight seeds x 2 input seeds + a second BN range (0 = skip)")
+    ap.add_argument("--airpose-plus", type=int, default=1, help="BASELINE config 4: 300-iteration fit of 64 frames (0 = skip)")
     ap.add_argument("--parity-steps", type=int, default=3, help="steps of the parity-grade mode after the main loop (0 = skip)")
     ap.add_argument("--parity-pairs", type=int, default=128, help="pairs (two input seeds) on which the TIMED mode is checked against the CPU oracle (0 = skip)")
     ap.add_argument("--overlap-tail", type=int, default=1,
@@ -438,10 +528,11 @@ def main():
     # the same block again, a few times: spread of the headline inside one process (the contract's `value` stays the
     # first block; the timed region of 20 steps is only ~0.14 s)
     blocks = [world * B * args.steps / elapsed]
+    rsteps = max(args.repeat_steps, 1)
     for _ in range(max(args.repeat_blocks, 0)):
         fence()
         t1 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(rsteps):
             out = step()
         fence()
         dt = time.perf_counter() - t1
@@ -449,7 +540,7 @@ def main():
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        blocks.append(world * B * args.steps / dt)
+        blocks.append(world * B * rsteps / dt)
     # the other form of the same forward, one more block of K steps: stream-ordered __call__ when the headline is the serving form
     # (TwoViewInference.submit) and the other way round -- same kernels, bit-identical outputs
     other = None
@@ -458,17 +549,20 @@ def main():
         for _ in range(2):
             pend = other_step()
         fence()
+        net.timing(reset=True)
         t1 = time.perf_counter()
         for _ in range(args.steps):
             pend = other_step()
         fence()
         dt = time.perf_counter() - t1
+        tm_other = net.timing(reset=True)
         del pend
         if use_dist:
             t = torch.tensor([dt], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         other = {"pairs_per_s": world * B * args.steps / dt, "ms_per_step": 1e3 * dt / args.steps,
+                 "conv_stack_ms": tm_other["conv_ms"] / max(tm_other["passes"], 1),
                  "what": ("TwoViewInference.__call__: every step complete in the order of the caller's stream before the next one "
                           "starts (the reference boundary's semantics)") if args.overlap_tail else
                          ("TwoViewInference.submit: the passes of step i+1 queue behind those of step i, IEF loop + SMPL-X stage "
@@ -503,6 +597,15 @@ def main():
     b64 = None
     if rank == 0 and world == 1 and args.b64 and args.precision in ("bf16", "f16") and B != 64:
         b64 = b64_block(args, sd, body, dev)
+    sweep = None
+    if rank == 0 and world == 1 and not args.no_tail and cpu is not None and args.parity_sweep:
+        sweep = parity_sweep(args, md, body, dev, cpu["cores"])
+    fitres = None
+    if rank == 0 and world == 1 and args.airpose_plus and not args.no_tail:
+        try:
+            fitres = airpose_plus_block(md, dev)
+        except Exception as e:                               # noqa: BLE001 (reported, not swallowed)
+            fitres = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
     # the secondary measurement must never cost the primary one: an exception in the view-split block (it needs the pair
     # communicators of a multi-GPU node, which no box of this round offered) is reported in the line instead of ending the run
     vs = None
@@ -525,13 +628,23 @@ def main():
         # fused conv3 -> conv1 pair (layer2.0-2.3, layer3.1-3.4 as producers): 34
         half = args.precision in ("bf16", "f16")               # the throughput kernels (either 16-bit storage type)
         pairs_on = half and os.environ.get("AIRPOSE_FUSE_PAIR", "1") != "0"
-        launches = ((34 if pairs_on else 42) if half else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
+        tail_on = half and os.environ.get("AIRPOSE_FUSE_TAIL", "1") != "0"      # conv1 of layer2.0 rides in layer1's last kernel
+        launches = (((34 if pairs_on else 42) - (1 if tail_on else 0)) if half else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
         # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
+        # roofline.achieved of the trunk + regressor line = pairs/s x 16.3916 GFLOP (trunk 2 x 8.174 incl. the stem +
+        # regressor 0.043) against the dense bf16 / fp16 MFMA peak -- the WHOLE step time in the denominator
+        path_flops_pair = (conv_stack_flops_per_image() + STEM_FLOPS_PER_IMAGE) * 2 + REG_FLOPS_PER_PAIR
+        value = world * B * args.steps / elapsed
+        path_tf = value / world * path_flops_pair / 1e12
+        # the conv stack alone, as a span: the stream-ordered block (the two passes of a step run in lock step and the HIP events
+        # bracket both) when it was timed; in the serving form the passes of consecutive steps drift apart and only each pass's own
+        # duration exists (reported as conv_stack_own_ms: it shares the chip with the other pass's stem / pooling part of the time)
+        span_ms = other.get("conv_stack_ms") if (other is not None and args.overlap_tail) else (conv_ms_step if not args.overlap_tail else None)
         res = {
             "metric": "two-view frames/sec at batch %d (224x224)" % B,
-            "value": world * B * args.steps / elapsed,
+            "value": value,
             "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
@@ -547,10 +660,12 @@ def main():
                        "pairs_per_gpu": B, "global_pairs": world * B, "image": "224x224", "ief_iters": 3,
                        "trunk_chunk_images": chunk,
                        "trunk_passes": "2 concurrent passes (one per view) on 2 HIP streams" if dual else "1 pass per chunk",
-                       "step_issue": ("TwoViewInference.submit: the trunk passes of step i+1 queue behind those of step i, IEF loop + "
+                       "step_issue": ("TwoViewInference.submit (serving form): the trunk passes of step i+1 queue behind those of step i, IEF loop + "
                                       "SMPL-X stage of step i on a second stream under them (at most 3 steps in flight); all K steps "
-                                      "complete inside the timed region") if args.overlap_tail else
-                                     "stream-ordered: every step complete on the caller's stream before the next starts",
+                                      "complete inside the timed region; outputs bit-identical to forward().  The figure with the "
+                                      "REFERENCE's forward() semantics (every step complete in stream order before the next starts) is "
+                                      "`stream_ordered.pairs_per_s` of this line -- use that one to compare across rounds") if args.overlap_tail else
+                                     "stream-ordered: every step complete on the caller's stream before the next starts (the reference's forward() semantics)",
                        "sharding": "whole pairs per GPU, no data-path collective"},
             "roofline": {"bound": "mfma",
                          "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of the trunk in %d launches per step: conv_pipe_kernel "
@@ -561,22 +676,29 @@ def main():
                                    "passes of consecutive steps run free of each other and drift apart): the mean of the two passes' "
                                    "own durations, each of which shares the chip with the other stream throughout (equal to the "
                                    "span in lock step); frac_of_step_time = the same flops over the whole step time" % launches,
-                         "achieved": achieved, "peak": peak, "unit": "TFLOP/s", "frac": achieved / peak,
+                         "achieved": path_tf, "peak": peak, "unit": "TFLOP/s", "frac": path_tf / peak,
+                         "formula": "SURVEY 8(d): pairs/s per GPU x %.4f GFLOP per pair (trunk incl. stem x 2 views + 3 IEF iterations) / peak; "
+                                    "whole step time in the denominator" % (path_flops_pair / 1e9),
+                         "conv_stack_span_ms": span_ms,
+                         "conv_stack_achieved": None if span_ms is None else conv_flops_step / (span_ms * 1e-3) / 1e12,
+                         "conv_stack_frac": None if span_ms is None else conv_flops_step / (span_ms * 1e-3) / 1e12 / peak,
+                         "conv_stack_span_of": "the stream-ordered block of this run (HIP events bracket both lock-step passes of a step)",
+                         "conv_stack_own_ms": conv_ms_step, "conv_stack_own_frac": achieved / peak,
                          "frac_of_step_time": conv_flops_step / (elapsed / args.steps) / 1e12 / peak,
                          "traffic": pmc_traffic(),
+                         "traffic_source": "latest committed rocprofv3 PMC pass (profiles/r*_pmc_traffic.json): counters cannot be collected inside the timed run",
                          "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,
-                         "avg_launch_ms": conv_ms_step / launches},
+                         "avg_launch_ms": (span_ms if span_ms is not None else conv_ms_step) / launches},
             "stage_ms_per_step": {"stem_maxpool": ts["stem_ms"] / max(ts["passes"], 1), "conv_stack": conv_ms_step,
                                   "avgpool": ts["avgpool_ms"] / max(ts["passes"], 1),
                                   "regressor": ts["regressor_ms"] / max(ts["passes"], 1),
                                   "source": "conv_stack: HIP events inside the timed region; other stages: %d extra "
                                             "instrumented steps after it" % args.stage_steps},
-            "path_tflops": (conv_flops_step + STEM_FLOPS_PER_IMAGE * n_img + REG_FLOPS_PER_PAIR * B) * args.steps
-                           / elapsed / 1e12,
+            "path_tflops": path_tf,
         }
         srt = sorted(blocks)
-        res["repeat_blocks"] = {"n": len(blocks), "steps_each": args.steps, "median": srt[len(srt) // 2], "min": srt[0],
-                                "max": srt[-1], "unit": "pairs/s", "note": "block 0 is `value`"}
+        res["repeat_blocks"] = {"n": len(blocks), "steps_each": rsteps, "median": srt[len(srt) // 2], "min": srt[0],
+                                "max": srt[-1], "unit": "pairs/s", "note": "block 0 is `value` (K = %d steps); the others run %d steps each" % (args.steps, rsteps)}
         if tb is not None and tb["passes"] > 0:              # (--stage-steps 0: no instrumented tail passes)
             p = max(tb["passes"], 1)
             # default: blend-shape contraction + skinning are ONE kernel (smplx_lbs_fused_kernel), timed in the blend slot; the
@@ -628,6 +750,18 @@ def main():
                                                              "read after the timed and instrumented steps)"}
         if b64 is not None:
             res["b64"] = b64
+        if sweep is not None:
+            res["parity_sweep"] = sweep
+            if "parity_of_timed_mode" in res and args.precision in sweep["modes"]:
+                sm = sweep["modes"][args.precision]
+                res["parity_of_timed_mode"].update({
+                    "holds_on_every_checkpoint_of_the_sweep": sm["meets_bar"], "sweep_max_rel_err": sm["max_rel_err"],
+                    "sweep_worst": sm["worst_slice"],
+                    "modes_that_hold_the_bar_on_every_checkpoint": [m for m, v in sweep["modes"].items() if v["meets_bar"]],
+                    "note": "meets_bar refers to the benchmark checkpoint (128 pairs, 2 input seeds); parity_sweep repeats the check for every "
+                            "mode over 3 weight seeds and a second BatchNorm-statistics range"})
+        if fitres is not None:
+            res["airpose_plus"] = fitres
         if other is not None:
             res["stream_ordered" if args.overlap_tail else "overlap_tail"] = other
         if vs is not None:

@@ -50,7 +50,8 @@ def _worker(rank, world, port, out_dir):
     from airpose_amd import weights as W
     from oracle import copenet_ref
     sd = W.to_torch(W.copenet_state_dict(20240901, MEAN_PARAMS))
-    g = torch.Generator().manual_seed(17)                      # same data on both ranks
+    grp, v = rank // 2, rank % 2                               # pair group and this rank's view
+    g = torch.Generator().manual_seed(17 + grp)                # same data on both ranks of a pair group, other data per group
     B = 3
     xf = [torch.randn(B, 2048, generator=g), torch.randn(B, 2048, generator=g)]
     bb = [torch.rand(B, 3, generator=g), torch.rand(B, 3, generator=g)]
@@ -65,13 +66,13 @@ def _worker(rank, world, port, out_dir):
     groups = D.make_pair_groups(world)
     ief = D.ViewSplitIEF(step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
     with torch.no_grad():
-        pose, betas = ief.run(xf[rank], bb[rank], pos[rank], sd["init_pose"], sd["init_shape"], iters=3, shared_init=True)
+        pose, betas = ief.run(xf[v], bb[v], pos[v], sd["init_pose"], sd["init_shape"], iters=3, shared_init=True)
         assert ief.n_exchanges == 2            # both views start from the model's mean state: none before iteration 1
         want = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], iters=3)
         # caller-supplied per-view initial state (model_copenet.py:121-136): the first exchange is needed
         th = [torch.randn(B, 132, generator=g) * 0.3, torch.randn(B, 132, generator=g) * 0.3]
         sh = [torch.randn(B, 10, generator=g) * 0.3, torch.randn(B, 10, generator=g) * 0.3]
-        pose_c, betas_c = ief.run(xf[rank], bb[rank], pos[rank], th[rank], sh[rank], iters=2, shared_init=False)
+        pose_c, betas_c = ief.run(xf[v], bb[v], pos[v], th[v], sh[v], iters=2, shared_init=False)
         assert ief.n_exchanges == 4
         want_c = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], init_theta0=th[0], init_theta1=th[1],
                                  init_shape0=sh[0], init_shape1=sh[1], iters=2)
@@ -83,9 +84,9 @@ def _worker(rank, world, port, out_dir):
         assert torch.equal(p1, keep) and not torch.equal(p1, p2)
         assert p1.data_ptr() != p2.data_ptr()
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), pose=pose.numpy(), betas=betas.numpy(),
-             want_pose=want[2 * rank].numpy(), want_betas=want[2 * rank + 1].numpy(),
+             want_pose=want[2 * v].numpy(), want_betas=want[2 * v + 1].numpy(),
              pose_c=pose_c.numpy(), betas_c=betas_c.numpy(),
-             want_pose_c=want_c[2 * rank].numpy(), want_betas_c=want_c[2 * rank + 1].numpy())
+             want_pose_c=want_c[2 * v].numpy(), want_betas_c=want_c[2 * v + 1].numpy())
     # default sharding: no collective on the data path -- only the bench's barrier / max-reduce
     t = torch.tensor([float(rank + 1)])
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -94,12 +95,20 @@ def _worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_view_split_ief_matches_two_view_oracle(tmp_path):
-    world, port = 2, _free_port()
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])       # 4 ranks = two pair groups side by side (the first real multi-GPU run forms four)
+def test_view_split_ief_matches_two_view_oracle(tmp_path, world):
+    port = _free_port()
     mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    poses = []
     for r in range(world):
         d = np.load(str(tmp_path / ("r%d.npz" % r)))
         assert np.allclose(d["pose"], d["want_pose"], rtol=0, atol=2e-6)
         assert np.allclose(d["betas"], d["want_betas"], rtol=0, atol=2e-6)
         assert np.allclose(d["pose_c"], d["want_pose_c"], rtol=0, atol=2e-6)
         assert np.allclose(d["betas_c"], d["want_betas_c"], rtol=0, atol=2e-6)
+        poses.append(d["pose"])
+    if world == 4:                                            # the groups really carried different pairs
+        assert not np.allclose(poses[0], poses[2])

@@ -1655,6 +1655,41 @@ def test_whole_pipeline_fp32_matches_oracle(net32, body, copenet_sd, copenet_inp
             assert e < TOL32, nm
 
 
+@pytest.mark.parametrize("wseed,wide", [(7, False), (99, False), (20240901, True)])
+def test_f16_parity_on_other_checkpoints(body, smplx_model, dev, wseed, wide):
+    """The 1e-4 bar of the fp16-storage throughput mode across checkpoints, not on the one synthetic checkpoint (seed 20240901,
+    BatchNorm gamma / var ~ U(.5, 1.5)) the other parity numbers rest on: 16 pairs each, slice-max error of every output against
+    the fp32 CPU oracle.
+      * two more weight seeds of the same family: fp16 storage stays below 1e-4 (measured 2.6e-5 / 3.8e-5);
+      * a second BatchNorm-statistics range (gamma, var ~ U(.25, 2)): that checkpoint is ~30x worse conditioned -- the exact-fp32
+        mode itself lands at 4e-6 instead of 3e-7, split-bf16 at 2.4e-5 instead of 7.5e-7 -- and 11 significand bits of storage
+        do NOT hold the bar there (1.8e-3; bf16: 1e-2).  What is asserted for it: the split-bf16 parity mode holds 1e-4, fp16
+        storage stays within 5e-3 and finite (the range sentinel silent).  bench.py reports the same sweep for every mode."""
+    from airpose_amd import copenet_model, pipeline
+    from airpose_amd import weights as W
+    from oracle import pipeline_ref
+    sd = W.to_torch(W.copenet_state_dict(wseed, MEAN_PARAMS, wide_bn=wide))
+    inp = {k: torch.from_numpy(v) for k, v in W.synthetic_inputs(31 + wseed % 1000, 16).items()}
+    with torch.no_grad():
+        want = pipeline_ref.infer(sd, smplx_model, inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], inp["intr0"], inp["intr1"])
+    gin = {k: v.to(dev) for k, v in inp.items()}
+    for prec, bar in (("f16", 5e-3 if wide else 1e-4), ("bf16x2", TOL32)):
+        net = copenet_model.getcopenet(MEAN_PARAMS, precision=prec).eval()
+        net.load_state_dict(sd)
+        got = pipeline.TwoViewInference(net, body)(gin)
+        worst = 0.0
+        for k in sorted(want):
+            if k not in got:
+                continue
+            for nm, e in key_errs(k, got[k].float().cpu().numpy(), want[k].numpy()).items():
+                worst = max(worst, e)
+                assert e < bar, (prec, nm, e)
+        if prec == "f16":
+            net.range_status()
+        print("%s seed %d wide %d: worst slice %.3e" % (prec, wseed, wide, worst))
+        del net
+
+
 def test_test_mode_input_meshes_match_oracle(net32, body, copenet_sd, copenet_inputs, smplx_model, dev):
     """The rest of the reference's test-mode dict (copenet_twoview.py:258-279, 330-331, 342-343): the beta = 0 meshes
     placed at in_smpltrans, produced by the same native call as 2B more bodies; and nothing but the two C-ABI calls
