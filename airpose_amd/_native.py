@@ -79,6 +79,9 @@ SIGNATURES = {
     "ap_conv_pair_ds_nhwc": (_i, [_i] + [_vp] * 9 + [_i] * 6 + [_vp]),
     "ap_bottleneck64_nhwc": (_i, [_i] + [_vp] * 11 + [_i] * 5 + [_vp]),
     "ap_bottleneck64_tail_nhwc": (_i, [_i] + [_vp] * 15 + [_i] * 4 + [_vp]),
+    "ap_block_img_stream_bytes": (_c.c_int64, []),
+    "ap_block_img_pack": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
+    "ap_block_img_nhwc": (_i, [_i] + [_vp] * 9 + [_i, _vp]),
     "ap_net_set_fuse_tail": (_i, [_vp, _i]),
     "ap_net_set_even_out": (_i, [_vp, _i]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),

@@ -1449,6 +1449,25 @@ int ap_bottleneck64_tail_nhwc(int precision, const void* x, const void* w1, cons
     return AP_OK;
 }
 
+int64_t ap_block_img_stream_bytes(void) { return (int64_t)k_bf16::ap_block_img_stream_bytes(); }
+
+int ap_block_img_pack(int precision, const void* w1, const void* w2, const void* w3, void* wstream, void* stream) {
+    if (!prec_half(precision) || !w1 || !w2 || !w3 || !wstream)
+        return fail(AP_EINVAL, "ap_block_img_pack: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
+    HIP_TRY(H16(precision, ap_launch_block_img_pack)(w1, w2, w3, wstream, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const float* s1, const float* h1, const float* s2,
+                      const float* h2, const float* s3, const float* h3, void* y, int N, void* stream) {
+    if (!prec_half(precision) || !x || !wstream || !s1 || !h1 || !s2 || !h2 || !s3 || !h3 || !y || N <= 0)
+        return fail(AP_EINVAL, "ap_block_img_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
+    BlkImgArgs a{};
+    a.x = x; a.y = y; a.wfrag = wstream; a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3; a.N = N;
+    HIP_TRY(H16(precision, ap_launch_block_img)(a, (hipStream_t)stream));
+    return AP_OK;
+}
+
 // The fused pair kernel consumes its two weight matrices as ONE stream of 16-KiB tiles in consumption order.  The stream is
 // CALLER-OWNED: packed once by ap_conv_pair_pack into a buffer of ap_conv_pair_stream_bytes, handed to every launch -- the
 // library keeps no hidden copy keyed by weight addresses (an allocator may reuse an address for new contents).

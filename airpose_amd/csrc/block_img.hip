@@ -1,0 +1,344 @@
+// One identity bottleneck of layer3 (1024 -> 256 -> 256 -> 1024 at 14 x 14) as ONE image-resident kernel (16-bit storage, gfx950).
+//
+//   out = relu(bn3(conv3(relu(bn2(conv2_3x3(relu(bn1(conv1(x))))))) + x)          Bottleneck.forward, model_copenet.py:27-47
+//
+// What the launch-per-layer path cannot have: the 14 x 14 x 256 intermediates of a whole image (t1, then t2: 112 KB of 16-bit
+// values) live in the LDS of one CU from the first convolution to the last.  A workgroup owns an image:
+//   * four waves, one per SIMD, the whole 512-entry register file each (56 accumulators of 16 x 16 in the accumulator half);
+//     a wave computes 64 (conv1 / conv2; 32 in conv3) output channels for ALL 224 pixel slots of the image, so an LDS operand
+//     fragment feeds four MFMAs and a weight fragment fourteen: 18 operand fetches per 56 v_mfma_f32_16x16x32 (0.32 per MFMA;
+//     the 128 x 128-tile kernels of this library: 0.75, the pair kernel: 1.0);
+//   * pixels in 14 rows of 16 slots (columns 14, 15 hold zeros): a 3 x 3 tap is a constant slot shift, the zero columns are the
+//     horizontal padding, one zero row above and below the vertical one -- no per-lane masks, no halo exchange, no slab;
+//   * weights never touch the LDS: each wave streams ITS rows as MFMA A fragments straight from L2 (packed at finalize time in
+//     fragment order and in consumption order: one contiguous 4-KiB piece per wave and K step of 32; 2.2 MB per block, the same
+//     stream for every image, resident in the XCD's L2) through a four-piece register ring -- ordinary loads the compiler counts;
+//   * x (401 KB per image) passes through a two-stage LDS ring in K chunks of 64 for conv1 (register-staged, two chunks ahead)
+//     and is read a second time, as the identity, in the accumulator layout of conv3's epilogue;
+//   * conv2 and conv3 run without a single barrier (their B operand is the resident image, their A operand is private).
+// LDS: 258 slots x 512 B (16 zero slots + 1 above, 224 image slots, 16 + 1 below) = 129 KB; XOR swizzle chunk ^ (slot & 15) so the
+// 16 pixels of a ds_read_b128 lane group hit 16 different 16-byte bank slots for every tap shift.
+// K order per output element = the ring kernel's (tap-outer, channel-inner, K steps of 32 in order): same sums.
+#include <type_traits>
+
+#include "ap_common.h"
+#include "kernels.h"
+
+AP_NS_BEGIN
+
+namespace {
+
+constexpr int BI_HW = 14, BI_PIX = 196, BI_P = 256, BI_C = 1024;
+constexpr int BI_SLOTS = 258;                                // physical slots: u = 16 (row + 1) + col + 1
+constexpr int BI_T_BYTES = BI_SLOTS * 512;                   // 132 096
+constexpr int BI_XS = 17 * 512;                              // x staging ring inside the image region (rows 0 ..), two stages
+constexpr int BI_XS_STAGE = 224 * 128;                       // 28 672
+constexpr int BI_STEPS12 = 32 + 72;                          // 4-KiB pieces of conv1 + conv2 per wave
+constexpr int BI_SLOTS_TOTAL = BI_STEPS12 + 32;              // + conv3: 64 steps of 2 KiB
+constexpr size_t BI_WAVE_BYTES = (size_t)BI_SLOTS_TOTAL * 4096;   // 557 056 per wave, 2 228 224 per block
+static_assert(BI_XS + 2 * BI_XS_STAGE <= 241 * 512, "the staging ring stays clear of the zero rows");
+
+template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        sfor<I + 1, N>(f);
+    }
+}
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+
+// channel (within its tile) of row rho of a wave's weight tile: a lane's accumulator elements of a fragment PAIR are then 8
+// consecutive channels = one 16-byte piece of a B fragment / of an NHWC row (conv_pair.hip: pr_row_channel)
+__host__ __device__ __forceinline__ int bi_row_channel(int rho) {
+    const int f = rho >> 4, i = rho & 15;
+    return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3);
+}
+
+// weight stream: wave w -> [conv1: 32 steps][conv2: 72 steps (tap-major)] of 4 fragments (64 rows) + [conv3: 8 chunks x 8 steps] of
+// 2 fragments (32 rows); fragment = [lane 64][8 K values]: row lane & 15, K columns 8 (lane >> 4) .. + 7 of the step's 32
+__global__ void __launch_bounds__(256) blk_img_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
+                                                           const bf16_t* __restrict__ w3, unsigned char* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_wave = BI_WAVE_BYTES / 16;
+    if (idx >= 4 * per_wave) return;
+    const int w = (int)(idx / per_wave);
+    const int p = (int)(idx - (size_t)w * per_wave);
+    const bf16_t* src;
+    if (p < BI_STEPS12 * 256) {
+        const int step = p >> 8, f = (p >> 6) & 3, lane = p & 63;
+        const int ch = w * 64 + bi_row_channel(f * 16 + (lane & 15));
+        if (step < 32) src = w1 + (size_t)ch * BI_C + step * 32 + (lane >> 4) * 8;
+        else src = w2 + (size_t)ch * (9 * BI_P) + (step - 32) * 32 + (lane >> 4) * 8;
+    } else {
+        const int q = p - BI_STEPS12 * 256, step = q >> 7, f = (q >> 6) & 1, lane = q & 63;
+        const int chunk = step >> 3, ks = step & 7;
+        const int ch = chunk * 128 + w * 32 + bi_row_channel(f * 16 + (lane & 15));     // (f < 2: channels 0 .. 31 of the tile)
+        src = w3 + (size_t)ch * BI_P + ks * 32 + (lane >> 4) * 8;
+    }
+    *(u32x4*)(dst + idx * 16) = *(const u32x4*)src;
+}
+
+__device__ __forceinline__ uint32_t bi_cvt_pk(float a, float b) {
+    uint32_t r;
+    asm(AP_CVTPK_ASM " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ uint32_t bi_relu_pk(uint32_t u) {
+    uint32_t r;
+    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(u));
+    return r;
+}
+// BN (+ identity) + ReLU + 16-bit of the 8 consecutive channels a lane holds in a fragment pair: the expression of the stand-alone
+// kernels' epilogue (fma, add, max, round)
+__device__ __forceinline__ u32x4 bi_bn8(const f32x4& lo, const f32x4& hi, const f32x4& s0, const f32x4& s1, const f32x4& h0,
+                                        const f32x4& h1, const u32x4* res, uint32_t& rng) {
+    f32x2 v0 = __builtin_elementwise_fma(lo.xy, s0.xy, h0.xy), v1 = __builtin_elementwise_fma(lo.zw, s0.zw, h0.zw);
+    f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
+    if (res) {
+        const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
+#ifdef AP_F16
+        { float a_ = v0.x, b_ = v0.y; ap_res_add2(a_, b_, r0); v0 = f32x2{a_, b_}; }
+        { float a_ = v1.x, b_ = v1.y; ap_res_add2(a_, b_, r1); v1 = f32x2{a_, b_}; }
+        { float a_ = v2.x, b_ = v2.y; ap_res_add2(a_, b_, r2); v2 = f32x2{a_, b_}; }
+        { float a_ = v3.x, b_ = v3.y; ap_res_add2(a_, b_, r3); v3 = f32x2{a_, b_}; }
+#else
+        { float a_, b_; unpack_bf16x2(r0, a_, b_); v0 += f32x2{a_, b_}; }
+        { float a_, b_; unpack_bf16x2(r1, a_, b_); v1 += f32x2{a_, b_}; }
+        { float a_, b_; unpack_bf16x2(r2, a_, b_); v2 += f32x2{a_, b_}; }
+        { float a_, b_; unpack_bf16x2(r3, a_, b_); v3 += f32x2{a_, b_}; }
+#endif
+    }
+    u32x4 o;
+    o.x = bi_relu_pk(bi_cvt_pk(v0.x, v0.y)); o.y = bi_relu_pk(bi_cvt_pk(v1.x, v1.y));
+    o.z = bi_relu_pk(bi_cvt_pk(v2.x, v2.y)); o.w = bi_relu_pk(bi_cvt_pk(v3.x, v3.y));
+    ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);
+    return o;
+}
+__device__ __forceinline__ void bi_mm(f32x4& c, const u32x4& w, const u32x4& x) {
+    c = ap_mfma16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c);
+}
+__device__ __forceinline__ u32x4 bi_lds(const unsigned char* smem, uint32_t off) {
+    return *(const u32x4*)__builtin_assume_aligned(smem + off, 16);
+}
+__device__ __forceinline__ void bi_sts(unsigned char* smem, uint32_t off, const u32x4& v) {
+    *(u32x4*)__builtin_assume_aligned(smem + off, 16) = v;
+}
+
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) blk_img_kernel(const BlkImgArgs a) {
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    uint32_t rng = 0u;
+
+    // zero rows (slots 0 .. 16 and 241 .. 257): written once, never touched again (the staging ring lies between them)
+    for (int idx = tid; idx < 34 * 32; idx += 256) {
+        const int s = idx >> 5, c = idx & 31, u = s < 17 ? s : 241 + (s - 17);
+        bi_sts(smem, u * 512 + c * 16, u32x4{0u, 0u, 0u, 0u});
+    }
+
+    // ---- weight stream of this wave: 4-KiB pieces in consumption order, four pieces ahead in registers
+    const unsigned char* const wstart = (const unsigned char*)a.wfrag + (size_t)wave * BI_WAVE_BYTES + lane * 16;
+    const unsigned char* wp = wstart;
+    int wcnt = 0;
+    u32x4 ar[4][4];
+    auto pf = [&](auto SL) {                                 // refill ring slot SL with the next piece of the stream
+        constexpr int sl = decltype(SL)::value;
+#pragma unroll
+        for (int f = 0; f < 4; ++f) ar[sl][f] = *(const u32x4*)(wp + f * 1024);
+        wp += 4096;
+        if (++wcnt == BI_SLOTS_TOTAL) { wcnt = 0; wp = wstart; }
+    };
+    sfor<0, 4>([&](auto S) { pf(S); });
+
+    // ---- x staging (conv1): thread = (column col, 16-byte piece pc) of rows xr0 + 2 j, j = 0 .. 6
+    const int xcol = (tid >> 3) & 15, xpc = tid & 7, xr0 = tid >> 7;
+    const int xpix0 = xr0 * BI_HW + (xcol < BI_HW ? xcol : BI_HW - 1);                   // (junk columns: a valid pixel's data, finite)
+    const uint32_t xs_w = BI_XS + (uint32_t)((xr0 * 16 + xcol) * 128 + ((xpc ^ (xcol & 7)) << 4));
+    // B fragments of conv1 out of a staging buffer: slot 16 g + li, piece 4 ks + kq at position piece ^ (slot & 7)
+    const uint32_t xs_r = BI_XS + (uint32_t)(li * 128 + (((li >> 2) & 1) << 6) + ((kq ^ (li & 3)) << 4));
+    // B fragments out of the image region: physical slot u = 16 R + li + dc + 1 (R = row + 1), chunk 4 ks + kq at position
+    // chunk ^ (u & 15) of its 256-byte half: base(dc) ^ ((ks & 3) << 6) + R * 8192 + (ks >> 2) * 256
+    auto tbase = [&](int dc) -> uint32_t {
+        const int m = li + dc + 1;
+        return (uint32_t)(m * 512 + (((m >> 2) & 3) << 6) + ((kq ^ (m & 3)) << 4));
+    };
+    // where this lane's 8 channels (chunk index cidx of 32) of pixel (row g, column li) go in the image region
+    auto twr = [&](int g, int cidx) -> uint32_t {
+        const int u = 16 * (g + 1) + li + 1;
+        return (uint32_t)(u * 512 + (cidx & 16) * 16 + (((cidx ^ u) & 15) << 4));
+    };
+
+    const unsigned char* const xg = (const unsigned char*)a.x;
+    unsigned char* const yg = (unsigned char*)a.y;
+    f32x4 acc[4][14];
+
+    for (int img = blockIdx.x; img < a.N; img += gridDim.x) {
+        const unsigned char* ximg = xg + (size_t)img * (BI_PIX * BI_C * 2);
+        // ================================================================ conv1: 16 chunks of 64 input channels
+        u32x4 xa[7], xb[7];                                  // staging registers: even / odd chunks, two chunks ahead
+        auto xload = [&](u32x4 (&r)[7], int c) {
+            const unsigned char* p = ximg + ((size_t)xpix0 * BI_C + c * 64 + xpc * 8) * 2;
+#pragma unroll
+            for (int j = 0; j < 7; ++j) r[j] = *(const u32x4*)(p + (size_t)j * (2 * BI_HW * BI_C * 2));
+        };
+        auto xstore = [&](const u32x4 (&r)[7], int stage) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) bi_sts(smem, xs_w + stage * BI_XS_STAGE + j * (32 * 128), r[j]);
+        };
+        xload(xa, 0);
+        xload(xb, 1);
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int g = 0; g < 14; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();                                     // every wave is done with the image region (last image's conv3)
+        xstore(xa, 0);
+        xload(xa, 2);
+        __syncthreads();
+        auto c1_step = [&](auto SL, int stage, int ks) {     // one K step of 32: ring slot SL, staging buffer `stage`, half ks
+            constexpr int sl = decltype(SL)::value;
+            const uint32_t rb = (xs_r + stage * BI_XS_STAGE) ^ (ks ? 64u : 0u);
+#pragma unroll
+            for (int g = 0; g < 14; ++g) {
+                const u32x4 b = bi_lds(smem, rb + g * 2048);
+#pragma unroll
+                for (int f = 0; f < 4; ++f) bi_mm(acc[f][g], ar[sl][f], b);
+            }
+            pf(SL);
+        };
+        for (int c = 0; c < 16; c += 2) {
+            // chunk c from stage 0; chunk c + 1 -> stage 1 (free since the barrier that ended chunk c - 1); then chunk c + 3 requested
+            xstore(xb, 1);
+            if (c + 3 < 16) xload(xb, c + 3);
+            c1_step(std::integral_constant<int, 0>{}, 0, 0);
+            c1_step(std::integral_constant<int, 1>{}, 0, 1);
+            __syncthreads();
+            if (c + 2 < 16) { xstore(xa, 0); if (c + 4 < 16) xload(xa, c + 4); }
+            c1_step(std::integral_constant<int, 2>{}, 1, 0);
+            c1_step(std::integral_constant<int, 3>{}, 1, 1);
+            __syncthreads();
+        }
+        // t1 = relu(bn1(.)) -> image region (every wave is past the last barrier: nobody reads the staging ring any more)
+        auto to_lds = [&](const float* sc, const float* sh) {
+            sfor<0, 2>([&](auto Q) {
+                constexpr int q = Q;
+                const int ch = wave * 64 + q * 32 + kq * 8;
+                const f32x4 s0 = *(const f32x4*)(sc + ch), s1 = *(const f32x4*)(sc + ch + 4);
+                const f32x4 h0 = *(const f32x4*)(sh + ch), h1 = *(const f32x4*)(sh + ch + 4);
+#pragma unroll
+                for (int g = 0; g < 14; ++g) {
+                    u32x4 o = bi_bn8(acc[2 * q][g], acc[2 * q + 1][g], s0, s1, h0, h1, nullptr, rng);
+                    if (li >= BI_HW) o = u32x4{0u, 0u, 0u, 0u};          // the zero columns = horizontal padding of conv2
+                    bi_sts(smem, twr(g, wave * 8 + q * 4 + kq), o);
+                }
+            });
+        };
+        to_lds(a.s1, a.h1);
+        __syncthreads();
+#pragma unroll
+        for (int f = 0; f < 4; ++f)
+#pragma unroll
+            for (int g = 0; g < 14; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // ================================================================ conv2: 9 taps x 8 K steps, no barrier
+        sfor<0, 3>([&](auto DR) {
+            constexpr int dr = decltype(DR)::value - 1;
+            for (int dc = -1; dc <= 1; ++dc) {
+                const uint32_t tb = tbase(dc);
+                sfor<0, 8>([&](auto KS) {
+                    constexpr int ks = KS, sl = ks & 3;
+                    const uint32_t rb = (tb ^ ((uint32_t)(ks & 3) << 6)) + (ks >> 2) * 256;
+#pragma unroll
+                    for (int g = 0; g < 14; ++g) {
+                        if (g + dr < 0 || g + dr >= BI_HW) continue;     // the row above / below the image: zeros
+                        const u32x4 b = bi_lds(smem, rb + (g + dr + 1) * 8192);
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) bi_mm(acc[f][g], ar[sl][f], b);
+                    }
+                    pf(std::integral_constant<int, sl>{});
+                });
+            }
+        });
+        __syncthreads();                                     // every wave is done reading t1
+        to_lds(a.s2, a.h2);
+        __syncthreads();
+
+        // ================================================================ conv3: 8 chunks of 128 channels (32 per wave), no barrier
+        {
+            const uint32_t tb = tbase(0);
+            // identity / output: this lane's 8 channels of pixel (row g, column li)
+            const int pcol = li < BI_HW ? li : BI_HW - 1;
+            const size_t pix_off = ((size_t)img * BI_PIX + pcol) * (BI_C * 2) + (size_t)(wave * 32 + kq * 8) * 2;
+            u32x4 ida[14], idb[14];
+            auto idload = [&](u32x4 (&r)[14], int chunk) {
+#pragma unroll
+                for (int g = 0; g < 14; ++g) r[g] = *(const u32x4*)(xg + pix_off + (size_t)g * (BI_HW * BI_C * 2) + chunk * 256);
+            };
+            auto chunk_fn = [&](int chunk, u32x4 (&idc)[14], u32x4 (&idn)[14]) {
+                constexpr int half = 0;                      // (28 accumulators; a chunk's 8 steps of 2 KiB = the 4 ring slots)
+                if (chunk + 1 < 8) idload(idn, chunk + 1);
+#pragma unroll
+                for (int g = 0; g < 14; ++g) { acc[0][g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+                sfor<0, 8>([&](auto KS) {
+                    constexpr int ks = KS, sl = ks >> 1, fo = (ks & 1) * 2;
+                    const uint32_t rb = (tb ^ ((uint32_t)(ks & 3) << 6)) + (ks >> 2) * 256;
+#pragma unroll
+                    for (int g = 0; g < 14; ++g) {
+                        const u32x4 b = bi_lds(smem, rb + (g + 1) * 8192);
+                        bi_mm(acc[half * 2][g], ar[sl][fo], b);
+                        bi_mm(acc[half * 2 + 1][g], ar[sl][fo + 1], b);
+                    }
+                    if constexpr (ks & 1) pf(std::integral_constant<int, sl>{});
+                });
+                const int ch = chunk * 128 + wave * 32 + kq * 8;
+                const f32x4 s0 = *(const f32x4*)(a.s3 + ch), s1 = *(const f32x4*)(a.s3 + ch + 4);
+                const f32x4 h0 = *(const f32x4*)(a.h3 + ch), h1 = *(const f32x4*)(a.h3 + ch + 4);
+#pragma unroll
+                for (int g = 0; g < 14; ++g) {
+                    const u32x4 o = bi_bn8(acc[half * 2][g], acc[half * 2 + 1][g], s0, s1, h0, h1, &idc[g], rng);
+                    if (li < BI_HW) *(u32x4*)(yg + pix_off + (size_t)g * (BI_HW * BI_C * 2) + chunk * 256) = o;
+                }
+            };
+            idload(ida, 0);
+            for (int c = 0; c < 8; c += 2) {
+                chunk_fn(c, ida, idb);
+                chunk_fn(c + 1, idb, ida);
+            }
+        }
+    }
+    ap_rng_flush(a.range_flag, rng);
+}
+
+}  // namespace
+
+size_t ap_block_img_stream_bytes(void) { return 4 * BI_WAVE_BYTES; }
+
+// w1 [256][1024], w2 [256][3][3][256], w3 [1024][256]: K-contiguous 16-bit rows as packed for the stand-alone kernels
+hipError_t ap_launch_block_img_pack(const void* w1, const void* w2, const void* w3, void* dst, hipStream_t st) {
+    if (!w1 || !w2 || !w3 || !dst) return hipErrorInvalidValue;
+    const size_t pieces = 4 * BI_WAVE_BYTES / 16;
+    hipLaunchKernelGGL(blk_img_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w1,
+                       (const bf16_t*)w2, (const bf16_t*)w3, (unsigned char*)dst);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_block_img(const BlkImgArgs& a, hipStream_t st) {
+    static int n_cu_dev[AP_MAX_DEVICES] = {};
+    if (a.N <= 0 || !a.x || !a.y || !a.wfrag || !a.s1 || !a.h1 || !a.s2 || !a.h2 || !a.s3 || !a.h3) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!n_cu_dev[dev]) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)blk_img_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, BI_T_BYTES);
+        if (e != hipSuccess) return e;
+        n_cu_dev[dev] = n;
+    }
+    const int grid = a.N < n_cu_dev[dev] ? a.N : n_cu_dev[dev];
+    hipLaunchKernelGGL(blk_img_kernel, dim3(grid), dim3(256), BI_T_BYTES, st, a);
+    return hipGetLastError();
+}
+
+AP_NS_END

@@ -76,6 +76,16 @@ struct BneckArgs {
     int y_even;
 };
 
+// ---- image-resident layer3 identity bottleneck (block_img.hip); 16-bit storage
+struct BlkImgArgs {
+    const void* x;                // [N][14][14][1024] NHWC
+    void* y;                      // [N][14][14][1024]
+    const void* wfrag;            // the three weight matrices as per-wave MFMA-fragment streams (ap_launch_block_img_pack)
+    const float *s1, *h1, *s2, *h2, *s3, *h3;   // BatchNorm scale / shift per conv
+    int N;
+    int* range_flag;              // fp16 storage, or NULL
+};
+
 // ---- stem / pooling (stem.hip)
 
 // ---- regressor glue (regressor.hip); all fp32

@@ -204,6 +204,19 @@ int ap_bottleneck64_tail_nhwc(int precision, const void* x, const void* w1, cons
                               const void* w1n, const float* s1n, const float* h1n, void* t1n, int y_even, int N, int H, int W,
                               void* stream);
 
+/* One identity bottleneck of layer3 (1024 -> 256 -> 256 -> 1024 on 14 x 14 images; Bottleneck.forward, model_copenet.py:27-47
+ * as iterated by :64) as ONE image-resident kernel (block_img.hip): a workgroup owns an image, both 256-channel intermediates
+ * stay in its LDS, the weights stream from L2 as MFMA fragments.  x, y [N][14][14][1024] NHWC in the storage type of `precision`
+ * (AP_PREC_BF16 or AP_PREC_F16); s*, h* fp32 BatchNorm scale / shift ([256], [256], [1024]).  The weights are consumed as one
+ * caller-owned stream of ap_block_img_stream_bytes() bytes built by ap_block_img_pack from w1 [256][1024], w2 [256][3][3][256],
+ * w3 [1024][256] (K-contiguous rows as for ap_conv2d_nhwc); re-pack whenever the weights change.
+ * y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x) with the intermediates rounded to the storage type exactly
+ * where the three-convolution path rounds them. */
+int64_t ap_block_img_stream_bytes(void);
+int ap_block_img_pack(int precision, const void* w1, const void* w2, const void* w3, void* wstream, void* stream);
+int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const float* s1, const float* h1, const float* s2,
+                      const float* h2, const float* s3, const float* h3, void* y, int N, void* stream);
+
 /* Fused pair kernel on NHWC 16-bit tensors (precision = AP_PREC_BF16 or AP_PREC_F16): conv3 (+ identity | + folded downsample,
  * ReLU) of a bottleneck and conv1 (+ ReLU) of the NEXT bottleneck as one pixel-local kernel (conv_pair.hip; replaces
  * model_copenet.py:38-45 of one block and :29-31 of the next per launch).  The two weight matrices are consumed as ONE stream of

@@ -695,6 +695,51 @@ def test_fused_bottleneck_tail_equals_block_then_conv1(dev, prec, y_even):
         assert torch.equal(yi, ri)
 
 
+@pytest.mark.parametrize("N", [1, 3, 300])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_block_img_equals_three_convs(dev, prec, N):
+    """block_img.hip (one layer3 identity bottleneck per launch, an image per workgroup, t1 / t2 resident in LDS, weights streamed
+    from L2 as MFMA fragments; Bottleneck.forward, model_copenet.py:27-47) against conv1 -> conv2 -> conv3(+identity) through the
+    stand-alone ring kernel (ap_set_conv_config(11): same K order, same rounding points): 1 image, 3 images, and 300 images on 256
+    workgroups (the persistent loop, the weight-stream wrap and the staging ring across images)."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    bf = H16[prec]
+    g = torch.Generator().manual_seed(900 + N)
+    H = 14
+    x = torch.randn(N, H, H, 1024, generator=g).to(bf).to(dev)
+    w1 = (torch.randn(256, 1024, generator=g) * (2.0 / 1024) ** 0.5).to(bf).to(dev)
+    w2 = (torch.randn(256, 2304, generator=g) * (2.0 / 2304) ** 0.5).to(bf).to(dev)
+    w3 = (torch.randn(1024, 256, generator=g) * (2.0 / 256) ** 0.5).to(bf).to(dev)
+    sc = [(torch.rand(c, generator=g) + 0.5).to(dev) for c in (256, 256, 1024)]
+    sh = [(torch.randn(c, generator=g) * 0.1).to(dev) for c in (256, 256, 1024)]
+    sc[2] = sc[2] * 0.5
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    B = Nn.PRECISIONS[prec]
+    ws = torch.empty(L.ap_block_img_stream_bytes(), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_block_img_pack(B, p(w1), p(w2), p(w3), p(ws), st), "ap_block_img_pack")
+    y = torch.full((N, H, H, 1024), float("nan"), dtype=bf, device=dev)
+    Nn.check(L.ap_block_img_nhwc(B, p(x), p(ws), p(sc[0]), p(sh[0]), p(sc[1]), p(sh[1]), p(sc[2]), p(sh[2]), p(y), N, st), "ap_block_img_nhwc")
+    t1 = torch.empty(N, H, H, 256, dtype=bf, device=dev)
+    t2 = torch.empty_like(t1)
+    y2 = torch.empty_like(y)
+    try:
+        Nn.check(L.ap_set_conv_config(11), "cfg")
+        Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w1), p(sc[0]), p(sh[0]), None, p(t1), N, H, H, 1024, 256, 1, 1, 0, 1, st), "c1")
+        Nn.check(L.ap_conv2d_nhwc(B, p(t1), p(w2), p(sc[1]), p(sh[1]), None, p(t2), N, H, H, 256, 256, 3, 1, 1, 1, st), "c2")
+        Nn.check(L.ap_conv2d_nhwc(B, p(t2), p(w3), p(sc[2]), p(sh[2]), p(x), p(y2), N, H, H, 256, 1024, 1, 1, 0, 1, st), "c3")
+    finally:
+        L.ap_set_conv_config(-1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    e = rel_err(y.float().cpu().numpy(), y2.float().cpu().numpy())
+    nbad = int((y.view(torch.int16) != y2.view(torch.int16)).sum())
+    print("block_img vs three convs: rel err %.3e, %d of %d values differ" % (e, nbad, y.numel()))
+    assert e < (1.6e-2 if prec == "bf16" else 2e-3)          # one 16-bit step of an intermediate at most
+    assert nbad == 0                                          # same K order per output element: the same bits
+
+
 def test_submit_keeps_converted_inputs_alive(netf16, body, dev):
     """submit() with crops that are NOT fp32-contiguous (half precision, a strided view): forward_feat_ext_twoview makes fp32
     copies, and in the asynchronous form the caller's stream is not behind the trunk passes -- the copies must outlive the call
