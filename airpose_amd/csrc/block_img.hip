@@ -116,11 +116,65 @@ __device__ __forceinline__ u32x4 bi_bn8(const f32x4& lo, const f32x4& hi, const 
 __device__ __forceinline__ void bi_mm(f32x4& c, const u32x4& w, const u32x4& x) {
     c = ap_mfma16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c);
 }
-__device__ __forceinline__ u32x4 bi_lds(const unsigned char* smem, uint32_t off) {
-    return *(const u32x4*)__builtin_assume_aligned(smem + off, 16);
-}
 __device__ __forceinline__ void bi_sts(unsigned char* smem, uint32_t off, const u32x4& v) {
     *(u32x4*)__builtin_assume_aligned(smem + off, 16) = v;
+}
+
+// ---- hand-placed memory operations and MFMAs.  Left to hipcc (first cut of this file, bit-identical results, 3x slower) every
+// operand fragment was read right in front of its four MFMAs behind an s_waitcnt lgkmcnt(0), every weight prefetch was sunk to its
+// use behind vmcnt(0), and the accumulators wandered between the two register halves.  Here, as in the other kernels of this
+// library: loads are asm statements the compiler cannot move, a destination is valid only behind the counted wait that covers
+// it, and an MFMA updates its accumulator in place.  vmcnt / lgkmcnt retire in order per type, so a wait for "at most N younger
+// operations" is exact when N operations are known to follow the target and merely conservative when more do.
+#ifndef BI_SAFE
+#define BI_SAFE 0                                            // 1: every counted vmcnt becomes 0, 2: every counted lgkmcnt too (cross-checks)
+#endif
+template <int N> __device__ __forceinline__ void bi_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BI_SAFE ? 0 : N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int N> __device__ __forceinline__ void bi_wait_lgkm() {
+    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(BI_SAFE > 1 ? 0 : N) : "memory");
+    __builtin_amdgcn_sched_barrier(0);
+}
+template <int OFF> __device__ __forceinline__ void bi_ldsr(u32x4& r, uint32_t addr) {
+    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
+}
+// uniform base (SGPR pair) + 32-bit lane offset
+template <int OFF> __device__ __forceinline__ void bi_gld(u32x4& r, uint32_t voff, const unsigned char* sbase) {
+    // (the bases are uniform by construction; readfirstlane makes that provable where hipcc lost track: folded away otherwise)
+    const uint64_t u = (uint64_t)sbase;
+    const uint64_t su = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
+                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
+    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(su), "n"(OFF) : "memory");
+}
+__device__ __forceinline__ void bi_mma(f32x4& c, const u32x4& w, const u32x4& x) {
+    asm volatile(AP_MFMA16_ASM " %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
+}
+__device__ __forceinline__ void bi_mma0(f32x4& c, const u32x4& w, const u32x4& x) {      // first K step: C = 0
+    asm volatile(AP_MFMA16_ASM " %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(x));
+}
+// The last MFMAs' results must settle before a VALU instruction reads them, and hipcc pads nothing around an asm MFMA: the nops
+// name the accumulators as operands, or the compiler hoists its v_accvgpr_read above them (it did: register-only instructions
+// ignore a "memory" clobber)
+__device__ __forceinline__ void bi_settle28(f32x4 (&p)[14], f32x4 (&q)[14]) {
+    asm volatile("s_nop 15\n\ts_nop 15"
+                 : "+a"(p[0]), "+a"(p[1]), "+a"(p[2]), "+a"(p[3]), "+a"(p[4]), "+a"(p[5]), "+a"(p[6]), "+a"(p[7]), "+a"(p[8]), "+a"(p[9]),
+                   "+a"(p[10]), "+a"(p[11]), "+a"(p[12]), "+a"(p[13]), "+a"(q[0]), "+a"(q[1]), "+a"(q[2]), "+a"(q[3]), "+a"(q[4]),
+                   "+a"(q[5]), "+a"(q[6]), "+a"(q[7]), "+a"(q[8]), "+a"(q[9]), "+a"(q[10]), "+a"(q[11]), "+a"(q[12]), "+a"(q[13]));
+    __builtin_amdgcn_sched_barrier(0);
+}
+// B-fragment pipeline of one segment of NR 16-pixel groups: LA reads in flight ahead of the MFMAs, 8 fragment registers
+template <int NR, typename RD, typename USE> __device__ __forceinline__ void bi_pipe(u32x4 (&b)[8], RD&& rd, USE&& use) {
+    constexpr int LA = 7;
+    sfor<0, (NR < LA ? NR : LA)>([&](auto I) __attribute__((always_inline)) { rd(I, b[decltype(I)::value & 7]); });
+    sfor<0, NR>([&](auto I) __attribute__((always_inline)) {
+        constexpr int n = decltype(I)::value, rem = NR - 1 - n;
+        bi_wait_lgkm<(rem < LA - 1 ? rem : LA - 1)>();
+        use(I, b[n & 7]);
+        __builtin_amdgcn_sched_barrier(0);
+        if constexpr (n + LA < NR) rd(std::integral_constant<int, n + LA>{}, b[(n + LA) & 7]);
+    });
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) blk_img_kernel(const BlkImgArgs a) {
@@ -128,6 +182,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, kq = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     uint32_t rng = 0u;
 
     // zero rows (slots 0 .. 16 and 241 .. 257): written once, never touched again (the staging ring lies between them)
@@ -136,91 +191,116 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         bi_sts(smem, u * 512 + c * 16, u32x4{0u, 0u, 0u, 0u});
     }
 
+    const unsigned char* const xg = (const unsigned char*)a.x;
+    const float *bs1 = a.s1, *bh1 = a.h1, *bs2 = a.s2, *bh2 = a.h2;
+    const unsigned char* const bs3 = (const unsigned char*)a.s3 + wave * 128;
+    const unsigned char* const bh3 = (const unsigned char*)a.h3 + wave * 128;
+    const int nimg = a.N;
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)a.y, 0, (int)((uint32_t)nimg * (BI_PIX * BI_C * 2u)), 0x00020000);
     // ---- weight stream of this wave: 4-KiB pieces in consumption order, four pieces ahead in registers
-    const unsigned char* const wstart = (const unsigned char*)a.wfrag + (size_t)wave * BI_WAVE_BYTES + lane * 16;
-    const unsigned char* wp = wstart;
+    const unsigned char* const wsb = (const unsigned char*)a.wfrag + (size_t)wave * BI_WAVE_BYTES;
+    // every kernel-argument load completes here (scalar loads share lgkmcnt with the counted fragment reads)
+    asm volatile("" ::"s"(xg), "s"(bs1), "s"(bh1), "s"(bs2), "s"(bh2), "s"(bs3), "s"(bh3), "s"(nimg), "s"(wsb));
+    const uint32_t wlane = lane * 16;
+    const unsigned char* wp = wsb;
     int wcnt = 0;
     u32x4 ar[4][4];
-    auto pf = [&](auto SL) {                                 // refill ring slot SL with the next piece of the stream
+    auto refill = [&](auto SL, u32x4 (&r)[4][4]) __attribute__((always_inline)) {           // ring slot SL <- the next piece of the stream
         constexpr int sl = decltype(SL)::value;
-#pragma unroll
-        for (int f = 0; f < 4; ++f) ar[sl][f] = *(const u32x4*)(wp + f * 1024);
+        bi_gld<0>(r[sl][0], wlane, wp); bi_gld<1024>(r[sl][1], wlane, wp);
+        bi_gld<2048>(r[sl][2], wlane, wp); bi_gld<3072>(r[sl][3], wlane, wp);
         wp += 4096;
-        if (++wcnt == BI_SLOTS_TOTAL) { wcnt = 0; wp = wstart; }
+        if (++wcnt == BI_SLOTS_TOTAL) { wcnt = 0; wp = wsb; }
     };
-    sfor<0, 4>([&](auto S) { pf(S); });
+    sfor<0, 4>([&](auto S) __attribute__((always_inline)) { refill(S, ar); });
 
     // ---- x staging (conv1): thread = (column col, 16-byte piece pc) of rows xr0 + 2 j, j = 0 .. 6
     const int xcol = (tid >> 3) & 15, xpc = tid & 7, xr0 = tid >> 7;
-    const int xpix0 = xr0 * BI_HW + (xcol < BI_HW ? xcol : BI_HW - 1);                   // (junk columns: a valid pixel's data, finite)
+    const uint32_t xoff = (uint32_t)(((xr0 * BI_HW + (xcol < BI_HW ? xcol : BI_HW - 1)) * BI_C + xpc * 8) * 2);   // (junk columns: a valid pixel, finite)
     const uint32_t xs_w = BI_XS + (uint32_t)((xr0 * 16 + xcol) * 128 + ((xpc ^ (xcol & 7)) << 4));
     // B fragments of conv1 out of a staging buffer: slot 16 g + li, piece 4 ks + kq at position piece ^ (slot & 7)
-    const uint32_t xs_r = BI_XS + (uint32_t)(li * 128 + (((li >> 2) & 1) << 6) + ((kq ^ (li & 3)) << 4));
+    const uint32_t xs_r = lds0 + BI_XS + (uint32_t)(li * 128 + (((li >> 2) & 1) << 6) + ((kq ^ (li & 3)) << 4));
     // B fragments out of the image region: physical slot u = 16 R + li + dc + 1 (R = row + 1), chunk 4 ks + kq at position
-    // chunk ^ (u & 15) of its 256-byte half: base(dc) ^ ((ks & 3) << 6) + R * 8192 + (ks >> 2) * 256
-    auto tbase = [&](int dc) -> uint32_t {
+    // chunk ^ (u & 15) of its 256-byte half: (base(dc) ^ ((ks & 3) << 6)) + R * 8192 + (ks >> 2) * 256
+    auto tbase = [&](int dc) __attribute__((always_inline)) -> uint32_t {
         const int m = li + dc + 1;
-        return (uint32_t)(m * 512 + (((m >> 2) & 3) << 6) + ((kq ^ (m & 3)) << 4));
+        return lds0 + (uint32_t)(m * 512 + (((m >> 2) & 3) << 6) + ((kq ^ (m & 3)) << 4));
     };
     // where this lane's 8 channels (chunk index cidx of 32) of pixel (row g, column li) go in the image region
-    auto twr = [&](int g, int cidx) -> uint32_t {
+    auto twr = [&](int g, int cidx) __attribute__((always_inline)) -> uint32_t {
         const int u = 16 * (g + 1) + li + 1;
         return (uint32_t)(u * 512 + (cidx & 16) * 16 + (((cidx ^ u) & 15) << 4));
     };
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
-    const unsigned char* const xg = (const unsigned char*)a.x;
-    unsigned char* const yg = (unsigned char*)a.y;
     f32x4 acc[4][14];
+    u32x4 bf[8];
 
-    for (int img = blockIdx.x; img < a.N; img += gridDim.x) {
-        const unsigned char* ximg = xg + (size_t)img * (BI_PIX * BI_C * 2);
+    for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
+        const unsigned char* const ximg = xg + (size_t)img * (BI_PIX * BI_C * 2);
         // ================================================================ conv1: 16 chunks of 64 input channels
         u32x4 xa[7], xb[7];                                  // staging registers: even / odd chunks, two chunks ahead
-        auto xload = [&](u32x4 (&r)[7], int c) {
-            const unsigned char* p = ximg + ((size_t)xpix0 * BI_C + c * 64 + xpc * 8) * 2;
-#pragma unroll
-            for (int j = 0; j < 7; ++j) r[j] = *(const u32x4*)(p + (size_t)j * (2 * BI_HW * BI_C * 2));
+        auto xload = [&](u32x4 (&r)[7], int c) __attribute__((always_inline)) {             // 7 loads, always (c >= 16: the same 16 bytes for every lane)
+            const unsigned char* sp = c < 16 ? ximg + c * 128 : xg;
+            const uint32_t vo = c < 16 ? xoff : 0u;
+            const uint32_t st = c < 16 ? 2 * BI_HW * BI_C * 2 : 0;
+            bi_gld<0>(r[0], vo, sp); bi_gld<0>(r[1], vo, sp + st); bi_gld<0>(r[2], vo, sp + 2 * st); bi_gld<0>(r[3], vo, sp + 3 * st);
+            bi_gld<0>(r[4], vo, sp + 4 * st); bi_gld<0>(r[5], vo, sp + 5 * st); bi_gld<0>(r[6], vo, sp + 6 * st);
         };
-        auto xstore = [&](const u32x4 (&r)[7], int stage) {
+        auto xstore = [&](u32x4 (&r)[7], int stage) __attribute__((always_inline)) {
 #pragma unroll
-            for (int j = 0; j < 7; ++j) bi_sts(smem, xs_w + stage * BI_XS_STAGE + j * (32 * 128), r[j]);
+            for (int j = 0; j < 7; ++j) {
+                asm volatile("" : "+v"(r[j]));
+                bi_sts(smem, xs_w + stage * BI_XS_STAGE + j * (32 * 128), r[j]);
+            }
         };
         xload(xa, 0);
         xload(xb, 1);
-#pragma unroll
-        for (int f = 0; f < 4; ++f)
-#pragma unroll
-            for (int g = 0; g < 14; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        bi_wait_vm<7>();                                     // chunk 0 (and everything older: the ring, the last image's stores)
         __syncthreads();                                     // every wave is done with the image region (last image's conv3)
         xstore(xa, 0);
         xload(xa, 2);
         __syncthreads();
-        auto c1_step = [&](auto SL, int stage, int ks) {     // one K step of 32: ring slot SL, staging buffer `stage`, half ks
-            constexpr int sl = decltype(SL)::value;
-            const uint32_t rb = (xs_r + stage * BI_XS_STAGE) ^ (ks ? 64u : 0u);
+        // one K half-chunk pair = two K steps of 32 out of staging buffer STAGE on ring slots SL0, SL0 + 1
+        auto c1_pair = [&](auto STAGE, auto SL0, auto FIRST, u32x4 (&b)[8], u32x4 (&r)[4][4], f32x4 (&ac)[4][14]) __attribute__((always_inline)) {
+            constexpr int stage = decltype(STAGE)::value, sl0 = decltype(SL0)::value;
+            constexpr bool first = decltype(FIRST)::value != 0;
+            const uint32_t ra = xs_r + stage * BI_XS_STAGE, rb = ra ^ 64u;
+            bi_pipe<28>(b,
+                [&](auto I, u32x4& d) __attribute__((always_inline)) { constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14; bi_ldsr<g * 2048>(d, ks ? rb : ra); },
+                [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                    constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14, sl = sl0 + ks;
+                    if constexpr (g == 0 && !first) bi_wait_vm<26>();
 #pragma unroll
-            for (int g = 0; g < 14; ++g) {
-                const u32x4 b = bi_lds(smem, rb + g * 2048);
-#pragma unroll
-                for (int f = 0; f < 4; ++f) bi_mm(acc[f][g], ar[sl][f], b);
-            }
-            pf(SL);
+                    for (int f = 0; f < 4; ++f) {
+                        if constexpr (first && stage == 0 && ks == 0) bi_mma0(ac[f][g], r[sl][f], d);
+                        else bi_mma(ac[f][g], r[sl][f], d);
+                    }
+                    if constexpr (g == 13) refill(std::integral_constant<int, sl>{}, r);
+                });
         };
-        for (int c = 0; c < 16; c += 2) {
+        auto c1_iter = [&](int c, auto FIRST) __attribute__((always_inline)) {
+            constexpr bool first = decltype(FIRST)::value != 0;
             // chunk c from stage 0; chunk c + 1 -> stage 1 (free since the barrier that ended chunk c - 1); then chunk c + 3 requested
+            bi_wait_vm<(first ? 7 : 23)>();
             xstore(xb, 1);
-            if (c + 3 < 16) xload(xb, c + 3);
-            c1_step(std::integral_constant<int, 0>{}, 0, 0);
-            c1_step(std::integral_constant<int, 1>{}, 0, 1);
+            xload(xb, c + 3);
+            c1_pair(I0{}, I0{}, FIRST, bf, ar, acc);
             __syncthreads();
-            if (c + 2 < 16) { xstore(xa, 0); if (c + 4 < 16) xload(xa, c + 4); }
-            c1_step(std::integral_constant<int, 2>{}, 1, 0);
-            c1_step(std::integral_constant<int, 3>{}, 1, 1);
+            bi_wait_vm<(first ? 15 : 23)>();
+            if (c + 2 < 16) xstore(xa, 0);
+            xload(xa, c + 4);
+            c1_pair(I1{}, I2{}, I0{}, bf, ar, acc);
             __syncthreads();
-        }
+        };
+        c1_iter(0, I1{});
+        for (int c = 2; c < 16; c += 2) c1_iter(c, I0{});
+        bi_settle28(acc[0], acc[1]);                         // the last MFMA results settle before VALU reads them
+        bi_settle28(acc[2], acc[3]);
         // t1 = relu(bn1(.)) -> image region (every wave is past the last barrier: nobody reads the staging ring any more)
-        auto to_lds = [&](const float* sc, const float* sh) {
-            sfor<0, 2>([&](auto Q) {
+        auto to_lds = [&](const float* sc, const float* sh) __attribute__((always_inline)) {
+            sfor<0, 2>([&](auto Q) __attribute__((always_inline)) {
                 constexpr int q = Q;
                 const int ch = wave * 64 + q * 32 + kq * 8;
                 const f32x4 s0 = *(const f32x4*)(sc + ch), s1 = *(const f32x4*)(sc + ch + 4);
@@ -233,79 +313,98 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
             });
         };
-        to_lds(a.s1, a.h1);
-        __syncthreads();
+        to_lds(bs1, bh1);
 #pragma unroll
         for (int f = 0; f < 4; ++f)
 #pragma unroll
             for (int g = 0; g < 14; ++g) acc[f][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        __syncthreads();
+        bi_settle28(acc[0], acc[1]);                         // (v_accvgpr_write -> MFMA source: the same pad, generously)
+        bi_settle28(acc[2], acc[3]);
 
         // ================================================================ conv2: 9 taps x 8 K steps, no barrier
-        sfor<0, 3>([&](auto DR) {
+        sfor<0, 3>([&](auto DR) __attribute__((always_inline)) {
             constexpr int dr = decltype(DR)::value - 1;
+            constexpr int g0 = dr < 0 ? 1 : 0, ng = dr == 0 ? 14 : 13;      // the row above / below the image contributes zeros
             for (int dc = -1; dc <= 1; ++dc) {
                 const uint32_t tb = tbase(dc);
-                sfor<0, 8>([&](auto KS) {
-                    constexpr int ks = KS, sl = ks & 3;
-                    const uint32_t rb = (tb ^ ((uint32_t)(ks & 3) << 6)) + (ks >> 2) * 256;
+                uint32_t tl[4], th[4];
 #pragma unroll
-                    for (int g = 0; g < 14; ++g) {
-                        if (g + dr < 0 || g + dr >= BI_HW) continue;     // the row above / below the image: zeros
-                        const u32x4 b = bi_lds(smem, rb + (g + dr + 1) * 8192);
+                for (int j = 0; j < 4; ++j) { tl[j] = tb ^ ((uint32_t)j << 6); th[j] = tl[j] + 65536u; }
+                bi_pipe<8 * ng>(bf,
+                    [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                        constexpr int n = decltype(I)::value, ks = n / ng, g = g0 + n % ng, R = g + dr + 1;
+                        bi_ldsr<(R & 7) * 8192 + (ks >> 2) * 256>(d, R < 8 ? tl[ks & 3] : th[ks & 3]);
+                    },
+                    [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                        constexpr int n = decltype(I)::value, ks = n / ng, gi = n % ng, g = g0 + gi, sl = ks & 3;
+                        if constexpr (gi == 0) bi_wait_vm<12>();
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) bi_mm(acc[f][g], ar[sl][f], b);
-                    }
-                    pf(std::integral_constant<int, sl>{});
-                });
+                        for (int f = 0; f < 4; ++f) bi_mma(acc[f][g], ar[sl][f], d);
+                        if constexpr (gi == ng - 1) refill(std::integral_constant<int, sl>{}, ar);
+                    });
             }
         });
+        bi_settle28(acc[0], acc[1]);
+        bi_settle28(acc[2], acc[3]);
         __syncthreads();                                     // every wave is done reading t1
-        to_lds(a.s2, a.h2);
+        to_lds(bs2, bh2);
         __syncthreads();
 
         // ================================================================ conv3: 8 chunks of 128 channels (32 per wave), no barrier
         {
             const uint32_t tb = tbase(0);
+            uint32_t tl[4], th[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { tl[j] = tb ^ ((uint32_t)j << 6); th[j] = tl[j] + 65536u; }
             // identity / output: this lane's 8 channels of pixel (row g, column li)
             const int pcol = li < BI_HW ? li : BI_HW - 1;
-            const size_t pix_off = ((size_t)img * BI_PIX + pcol) * (BI_C * 2) + (size_t)(wave * 32 + kq * 8) * 2;
-            u32x4 ida[14], idb[14];
-            auto idload = [&](u32x4 (&r)[14], int chunk) {
+            const uint32_t idoff = (uint32_t)((pcol * BI_C + wave * 32 + kq * 8) * 2);
+            const uint32_t img_off = (uint32_t)img * (BI_PIX * BI_C * 2u);
+            u32x4 idr[14], bnr[4];
+            auto chunk_fn = [&](int chunk, auto FIRSTC) __attribute__((always_inline)) {
+                constexpr bool firstc = decltype(FIRSTC)::value != 0;
+                const unsigned char* isb = ximg + chunk * 256;
+                bi_gld<0>(idr[0], idoff, isb); bi_gld<0>(idr[1], idoff, isb + 28672); bi_gld<0>(idr[2], idoff, isb + 2 * 28672);
+                bi_gld<0>(idr[3], idoff, isb + 3 * 28672); bi_gld<0>(idr[4], idoff, isb + 4 * 28672); bi_gld<0>(idr[5], idoff, isb + 5 * 28672);
+                bi_gld<0>(idr[6], idoff, isb + 6 * 28672); bi_gld<0>(idr[7], idoff, isb + 7 * 28672); bi_gld<0>(idr[8], idoff, isb + 8 * 28672);
+                bi_gld<0>(idr[9], idoff, isb + 9 * 28672); bi_gld<0>(idr[10], idoff, isb + 10 * 28672); bi_gld<0>(idr[11], idoff, isb + 11 * 28672);
+                bi_gld<0>(idr[12], idoff, isb + 12 * 28672); bi_gld<0>(idr[13], idoff, isb + 13 * 28672);
+                bi_gld<0>(bnr[0], (uint32_t)kq * 32u, bs3 + chunk * 512); bi_gld<16>(bnr[1], (uint32_t)kq * 32u, bs3 + chunk * 512);
+                bi_gld<0>(bnr[2], (uint32_t)kq * 32u, bh3 + chunk * 512); bi_gld<16>(bnr[3], (uint32_t)kq * 32u, bh3 + chunk * 512);
+                bi_pipe<112>(bf,
+                    [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                        constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14, R = g + 1;
+                        bi_ldsr<(R & 7) * 8192 + (ks >> 2) * 256>(d, R < 8 ? tl[ks & 3] : th[ks & 3]);
+                    },
+                    [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                        constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14, sl = ks >> 1, fo = (ks & 1) * 2;
+                        // slot sl was refilled one chunk ago: behind it 12 more ring loads, 14 stores, this chunk's 18 loads
+                        if constexpr (g == 0 && (ks & 1) == 0) bi_wait_vm<(firstc ? 30 : 44)>();
+                        if constexpr (ks == 0) { bi_mma0(acc[0][g], ar[sl][fo], d); bi_mma0(acc[1][g], ar[sl][fo + 1], d); }
+                        else { bi_mma(acc[0][g], ar[sl][fo], d); bi_mma(acc[1][g], ar[sl][fo + 1], d); }
+                        if constexpr (g == 13 && (ks & 1)) refill(std::integral_constant<int, sl>{}, ar);
+                    });
+                bi_wait_vm<16>();                            // identity + BatchNorm rows (behind them: this chunk's 16 ring loads)
 #pragma unroll
-                for (int g = 0; g < 14; ++g) r[g] = *(const u32x4*)(xg + pix_off + (size_t)g * (BI_HW * BI_C * 2) + chunk * 256);
-            };
-            auto chunk_fn = [&](int chunk, u32x4 (&idc)[14], u32x4 (&idn)[14]) {
-                constexpr int half = 0;                      // (28 accumulators; a chunk's 8 steps of 2 KiB = the 4 ring slots)
-                if (chunk + 1 < 8) idload(idn, chunk + 1);
-#pragma unroll
-                for (int g = 0; g < 14; ++g) { acc[0][g] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[1][g] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-                sfor<0, 8>([&](auto KS) {
-                    constexpr int ks = KS, sl = ks >> 1, fo = (ks & 1) * 2;
-                    const uint32_t rb = (tb ^ ((uint32_t)(ks & 3) << 6)) + (ks >> 2) * 256;
-#pragma unroll
-                    for (int g = 0; g < 14; ++g) {
-                        const u32x4 b = bi_lds(smem, rb + (g + 1) * 8192);
-                        bi_mm(acc[half * 2][g], ar[sl][fo], b);
-                        bi_mm(acc[half * 2 + 1][g], ar[sl][fo + 1], b);
-                    }
-                    if constexpr (ks & 1) pf(std::integral_constant<int, sl>{});
-                });
-                const int ch = chunk * 128 + wave * 32 + kq * 8;
-                const f32x4 s0 = *(const f32x4*)(a.s3 + ch), s1 = *(const f32x4*)(a.s3 + ch + 4);
-                const f32x4 h0 = *(const f32x4*)(a.h3 + ch), h1 = *(const f32x4*)(a.h3 + ch + 4);
+                for (int g = 0; g < 14; ++g) asm volatile("" : "+v"(idr[g]));
+                asm volatile("" : "+v"(bnr[0]), "+v"(bnr[1]), "+v"(bnr[2]), "+v"(bnr[3]));
+                bi_settle28(acc[0], acc[1]);
+                const f32x4 s0 = __builtin_bit_cast(f32x4, bnr[0]), s1 = __builtin_bit_cast(f32x4, bnr[1]);
+                const f32x4 h0 = __builtin_bit_cast(f32x4, bnr[2]), h1 = __builtin_bit_cast(f32x4, bnr[3]);
+                const uint32_t so = img_off + chunk * 256;
 #pragma unroll
                 for (int g = 0; g < 14; ++g) {
-                    const u32x4 o = bi_bn8(acc[half * 2][g], acc[half * 2 + 1][g], s0, s1, h0, h1, &idc[g], rng);
-                    if (li < BI_HW) *(u32x4*)(yg + pix_off + (size_t)g * (BI_HW * BI_C * 2) + chunk * 256) = o;
+                    const u32x4 o = bi_bn8(acc[0][g], acc[1][g], s0, s1, h0, h1, &idr[g], rng);
+                    const uint32_t vo = li < BI_HW ? so + g * 28672 + idoff : 0xffffff00u;      // (junk columns: dropped by the range check)
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, vo, 0, 0);
                 }
             };
-            idload(ida, 0);
-            for (int c = 0; c < 8; c += 2) {
-                chunk_fn(c, ida, idb);
-                chunk_fn(c + 1, idb, ida);
-            }
+            chunk_fn(0, I1{});
+            for (int c = 1; c < 8; ++c) chunk_fn(c, I0{});
         }
     }
+    bi_wait_vm<0>();
     ap_rng_flush(a.range_flag, rng);
 }
 
@@ -325,6 +424,7 @@ hipError_t ap_launch_block_img_pack(const void* w1, const void* w2, const void* 
 hipError_t ap_launch_block_img(const BlkImgArgs& a, hipStream_t st) {
     static int n_cu_dev[AP_MAX_DEVICES] = {};
     if (a.N <= 0 || !a.x || !a.y || !a.wfrag || !a.s1 || !a.h1 || !a.s2 || !a.h2 || !a.s3 || !a.h3) return hipErrorInvalidValue;
+    if ((size_t)a.N * (BI_PIX * BI_C * 2) >= 0xffffff00ull) return hipErrorInvalidValue;                       // 32-bit offsets, out-of-range marker
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
