@@ -84,6 +84,7 @@ SIGNATURES = {
     "ap_block_img_nhwc": (_i, [_i] + [_vp] * 9 + [_i, _vp]),
     "ap_net_set_fuse_tail": (_i, [_vp, _i]),
     "ap_net_set_even_out": (_i, [_vp, _i]),
+    "ap_net_set_img_block": (_i, [_vp, _i]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),
     "ap_smplx_destroy": (None, [_vp]),
     "ap_smplx_num_joints_out": (_i, [_vp]),

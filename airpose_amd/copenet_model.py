@@ -363,6 +363,10 @@ class copenet(nn.Module):
         """bf16 / f16: conv1 of layer2.0 inside the kernel of layer1's last bottleneck (default) or as its own convolution."""
         self._set_knob("ap_net_set_fuse_tail", on)
 
+    def set_img_block(self, on):
+        """bf16 / f16: each layer3 identity bottleneck as one image-resident kernel (default) or as conv2 + fused pairs."""
+        self._set_knob("ap_net_set_img_block", on)
+
     def set_even_out(self, on):
         """bf16 / f16: block outputs only a stride-2 downsample reads are stored at the even pixels only (default) or in full."""
         self._set_knob("ap_net_set_even_out", on)

@@ -255,7 +255,8 @@ struct ap_net {
     // trunk
     DevBuf stem_w, stem_wpk, stem_wpk_lo, stem_scale, stem_shift;   // stem_wpk_lo: low plane of the split-bf16 stem weights
     struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false;
-                   DevBuf pair; int pair_p = 0, pair_p2 = 0, pair_c3 = 0, pair_n1 = 0; };   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
+                   DevBuf pair; int pair_p = 0, pair_p2 = 0, pair_c3 = 0, pair_n1 = 0;
+                   DevBuf imgw; };             // layer3 identity blocks: the three weight matrices as the fragment streams of block_img.hip   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
     std::vector<Block> blocks;
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
@@ -272,6 +273,7 @@ struct ap_net {
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_tail = true;         // 16-bit modes: conv1 of layer2.0 inside the kernel of layer1's last block (bottleneck2.hip, tail variant);
                                    // the block output is then stored at the even pixels only (layer2.0's stride-2 downsample reads nothing else)
+    bool img_block = true;         // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip)
     bool even_out = true;          // 16-bit modes: a pair block whose output is read by a stride-2 downsample branch ONLY stores the even pixels
     bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     bool fuse_pool = false;        // 16-bit modes: AvgPool2d(7) in the epilogue of layer4.2 conv3 (conv_lean.hip POOL variant; bit-identical).
@@ -605,6 +607,13 @@ int finalize_trunk(ap_net* h) {
             HIP_TRY(H16(h->prec, ap_launch_pair_pack)(L3.w.p, N1 ? N.c1.w.p : nullptr, A.pair.p, P, P2, C3, N1, nullptr));
             A.pair_p = P; A.pair_p2 = P2; A.pair_c3 = C3; A.pair_n1 = N1;
         }
+    // layer3 identity blocks (1024 -> 256 -> 256 -> 1024 at 14 x 14): weight streams of the image-resident kernel
+    if (h->half())
+        for (auto& B : h->blocks) {
+            if (B.has_down || B.c1.cin != 1024 || B.c1.cout != 256 || B.c2.cout != 256 || B.c2.stride != 1 || B.c3.cout != 1024) continue;
+            HIP_TRY(B.imgw.reserve(k_bf16::ap_block_img_stream_bytes()));
+            HIP_TRY(H16(h->prec, ap_launch_block_img_pack)(B.c1.w.p, B.c2.w.p, B.c3.w.p, B.imgw.p, nullptr));
+        }
     HIP_TRY(hipDeviceSynchronize());
     return AP_OK;
 }
@@ -897,6 +906,17 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
                                   w.ws_t1.p, tail && h->even_out)))
                 return rc;
             t1_ready = tail;
+            std::swap(cur, nxt);
+            continue;
+        }
+        if (bf && h->img_block && B.imgw.p && H == 14 && !t1_ready && !cur_tiled && g_conv_mode.load(std::memory_order_relaxed) < 0) {
+            // layer3 identity block: conv1 -> conv2 -> conv3 + identity in one kernel, an image per workgroup, t1 / t2 in LDS
+            BlkImgArgs a{};
+            a.x = cur; a.y = nxt; a.wfrag = B.imgw.p; a.N = n; a.range_flag = h->range_flag; a.dbg = g_conv_dbg;
+            a.s1 = B.c1.scale.as<float>(); a.h1 = B.c1.shift.as<float>();
+            a.s2 = B.c2.scale.as<float>(); a.h2 = B.c2.shift.as<float>();
+            a.s3 = B.c3.scale.as<float>(); a.h3 = B.c3.shift.as<float>();
+            HIP_TRY(H16(prec, ap_launch_block_img)(a, st));
             std::swap(cur, nxt);
             continue;
         }
@@ -1464,6 +1484,7 @@ int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const f
         return fail(AP_EINVAL, "ap_block_img_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
     BlkImgArgs a{};
     a.x = x; a.y = y; a.wfrag = wstream; a.s1 = s1; a.h1 = h1; a.s2 = s2; a.h2 = h2; a.s3 = s3; a.h3 = h3; a.N = N;
+    a.dbg = g_conv_dbg;
     HIP_TRY(H16(precision, ap_launch_block_img)(a, (hipStream_t)stream));
     return AP_OK;
 }
@@ -1621,6 +1642,12 @@ int ap_net_set_fuse_pair(ap_net* h, int on) {
 int ap_net_set_fuse_tail(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_tail = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_img_block(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->img_block = on != 0;
     return AP_OK;
 }
 

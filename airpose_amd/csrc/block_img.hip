@@ -236,10 +236,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 
     f32x4 acc[4][14];
     u32x4 bf[8];
+#ifdef AP_TRACE   // cycle stamps of wave 0 of workgroups 0 and 100, their SECOND image (24 slots each): tools/probes/blk_trace.py
+    int img_no = 0;
+#define BISTAMP(i) do { if (a.dbg && img_no == 1 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) { \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (lane == 0) a.dbg[(blockIdx.x ? 24 : 0) + (i)] = t_; } } while (0)
+#else
+#define BISTAMP(i) do { } while (0)
+#endif
 
     for (int img = blockIdx.x; img < nimg; img += gridDim.x) {
         const unsigned char* const ximg = xg + (size_t)img * (BI_PIX * BI_C * 2);
         // ================================================================ conv1: 16 chunks of 64 input channels
+        BISTAMP(0);
         u32x4 xa[7], xb[7];                                  // staging registers: even / odd chunks, two chunks ahead
         auto xload = [&](u32x4 (&r)[7], int c) __attribute__((always_inline)) {             // 7 loads, always (c >= 16: the same 16 bytes for every lane)
             const unsigned char* sp = c < 16 ? ximg + c * 128 : xg;
@@ -294,8 +303,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             c1_pair(I1{}, I2{}, I0{}, bf, ar, acc);
             __syncthreads();
         };
+        BISTAMP(1);
         c1_iter(0, I1{});
+        BISTAMP(2);
         for (int c = 2; c < 16; c += 2) c1_iter(c, I0{});
+        BISTAMP(3);
         bi_settle28(acc[0], acc[1]);                         // the last MFMA results settle before VALU reads them
         bi_settle28(acc[2], acc[3]);
         // t1 = relu(bn1(.)) -> image region (every wave is past the last barrier: nobody reads the staging ring any more)
@@ -321,6 +333,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         __syncthreads();
         bi_settle28(acc[0], acc[1]);                         // (v_accvgpr_write -> MFMA source: the same pad, generously)
         bi_settle28(acc[2], acc[3]);
+        BISTAMP(4);
 
         // ================================================================ conv2: 9 taps x 8 K steps, no barrier
         sfor<0, 3>([&](auto DR) __attribute__((always_inline)) {
@@ -345,11 +358,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     });
             }
         });
+        BISTAMP(5);
         bi_settle28(acc[0], acc[1]);
         bi_settle28(acc[2], acc[3]);
         __syncthreads();                                     // every wave is done reading t1
         to_lds(bs2, bh2);
         __syncthreads();
+        BISTAMP(6);
 
         // ================================================================ conv3: 8 chunks of 128 channels (32 per wave), no barrier
         {
@@ -385,7 +400,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                         else { bi_mma(acc[0][g], ar[sl][fo], d); bi_mma(acc[1][g], ar[sl][fo + 1], d); }
                         if constexpr (g == 13 && (ks & 1)) refill(std::integral_constant<int, sl>{}, ar);
                     });
+                if (chunk == 1) BISTAMP(8);
                 bi_wait_vm<16>();                            // identity + BatchNorm rows (behind them: this chunk's 16 ring loads)
+                if (chunk == 1) BISTAMP(9);
 #pragma unroll
                 for (int g = 0; g < 14; ++g) asm volatile("" : "+v"(idr[g]));
                 asm volatile("" : "+v"(bnr[0]), "+v"(bnr[1]), "+v"(bnr[2]), "+v"(bnr[3]));
@@ -401,8 +418,13 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 }
             };
             chunk_fn(0, I1{});
-            for (int c = 1; c < 8; ++c) chunk_fn(c, I0{});
+            BISTAMP(7);
+            for (int c = 1; c < 8; ++c) { chunk_fn(c, I0{}); if (c == 1) BISTAMP(10); }
+            BISTAMP(11);
         }
+#ifdef AP_TRACE
+        ++img_no;
+#endif
     }
     bi_wait_vm<0>();
     ap_rng_flush(a.range_flag, rng);

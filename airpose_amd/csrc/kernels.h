@@ -84,6 +84,7 @@ struct BlkImgArgs {
     const float *s1, *h1, *s2, *h2, *s3, *h3;   // BatchNorm scale / shift per conv
     int N;
     int* range_flag;              // fp16 storage, or NULL
+    unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
 };
 
 // ---- stem / pooling (stem.hip)

@@ -479,6 +479,8 @@ def main():
         net.set_fuse_pool(int(os.environ["AIRPOSE_FUSE_POOL"]))
     if os.environ.get("AIRPOSE_FUSE_TAIL"):                 # A/B aid: conv1 of layer2.0 inside layer1's last kernel (default) / own convolution
         net.set_fuse_tail(int(os.environ["AIRPOSE_FUSE_TAIL"]))
+    if os.environ.get("AIRPOSE_IMG_BLOCK"):                 # A/B aid: layer3 identity blocks as image-resident kernels (default) / conv2 + pairs
+        net.set_img_block(int(os.environ["AIRPOSE_IMG_BLOCK"]))
     if os.environ.get("AIRPOSE_EVEN_OUT"):                  # A/B aid: block outputs only a stride-2 downsample reads: even pixels (default) / in full
         net.set_even_out(int(os.environ["AIRPOSE_EVEN_OUT"]))
     if os.environ.get("AIRPOSE_FUSE_BLOCK"):                # A/B aid: layer1 blocks: 1 fused kernel each (default), 0 separate convs
@@ -629,7 +631,9 @@ def main():
         half = args.precision in ("bf16", "f16")               # the throughput kernels (either 16-bit storage type)
         pairs_on = half and os.environ.get("AIRPOSE_FUSE_PAIR", "1") != "0"
         tail_on = half and os.environ.get("AIRPOSE_FUSE_TAIL", "1") != "0"      # conv1 of layer2.0 rides in layer1's last kernel
-        launches = (((34 if pairs_on else 42) - (1 if tail_on else 0)) if half else 48) * (2 if dual else (2 * B + chunk - 1) // chunk)
+        img_on = half and os.environ.get("AIRPOSE_IMG_BLOCK", "1") != "0"       # layer3.1-3.5: one image-resident kernel per block
+        launches = (((34 if pairs_on else 42) - (1 if tail_on else 0) - ((6 if pairs_on else 10) if img_on else 0)) if half else 48) * \
+                   (2 if dual else (2 * B + chunk - 1) // chunk)
         # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12

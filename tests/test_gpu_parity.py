@@ -740,6 +740,32 @@ def test_block_img_equals_three_convs(dev, prec, N):
     assert nbad == 0                                          # same K order per output element: the same bits
 
 
+@pytest.mark.parametrize("n", [1, 3, 64])
+def test_image_resident_layer3_blocks_match_the_convolutions(net16, dev, n):
+    """layer3.1 .. 3.5 as image-resident kernels (default; block_img.hip) against conv2 + fused conv3 -> conv1 pairs: with the
+    ring kernel's conv2 (ap_set_conv_config(-4): no slab / lean kernels) every convolution sums in the same order and the trunk
+    features carry the same bits; against the default dispatch (slab conv2: another fp32 summation order) they agree to 16-bit
+    rounding noise."""
+    from airpose_amd import _native as Nn
+    gen = torch.Generator(device="cpu").manual_seed(700 + n)
+    x = torch.randn(n, 3, 224, 224, generator=gen).to(dev)
+    got = net16.forward_feat_ext(x).clone()
+    assert torch.isfinite(got).all()
+    try:
+        net16.set_img_block(0)
+        ref_default = net16.forward_feat_ext(x).clone()
+        Nn.check(Nn.lib().ap_set_conv_config(-4), "cfg")
+        ref_ring = net16.forward_feat_ext(x).clone()
+        net16.set_img_block(1)
+        got_ring = net16.forward_feat_ext(x).clone()
+    finally:
+        Nn.lib().ap_set_conv_config(-1)
+        net16.set_img_block(1)
+    assert torch.equal(got_ring, ref_ring)
+    assert rel_err(got.cpu().numpy(), ref_default.cpu().numpy()) < 2e-2
+    assert torch.equal(net16.forward_feat_ext(x), got)
+
+
 def test_submit_keeps_converted_inputs_alive(netf16, body, dev):
     """submit() with crops that are NOT fp32-contiguous (half precision, a strided view): forward_feat_ext_twoview makes fp32
     copies, and in the asynchronous form the caller's stream is not behind the trunk passes -- the copies must outlive the call
