@@ -364,7 +364,8 @@ class copenet(nn.Module):
         self._set_knob("ap_net_set_fuse_tail", on)
 
     def set_img_block(self, on):
-        """bf16 / f16: each layer3 identity bottleneck as one image-resident kernel (default) or as conv2 + fused pairs."""
+        """bf16 / f16: layer3's identity bottlenecks as one image-resident kernel each: 1 (default) when the pass fills whole rounds
+        of the chip, 2 always, 0 never (conv2 + fused pairs); same bits."""
         self._set_knob("ap_net_set_img_block", on)
 
     def set_even_out(self, on):

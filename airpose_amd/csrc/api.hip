@@ -273,7 +273,8 @@ struct ap_net {
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_tail = true;         // 16-bit modes: conv1 of layer2.0 inside the kernel of layer1's last block (bottleneck2.hip, tail variant);
                                    // the block output is then stored at the even pixels only (layer2.0's stride-2 downsample reads nothing else)
-    bool img_block = true;         // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip)
+    int img_block = 1;             // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip): 0 never,
+                                   // 1 when the pass fills whole rounds of the chip (an image per CU; same bits either way), 2 always
     bool even_out = true;          // 16-bit modes: a pair block whose output is read by a stride-2 downsample branch ONLY stores the even pixels
     bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
     bool fuse_pool = false;        // 16-bit modes: AvgPool2d(7) in the epilogue of layer4.2 conv3 (conv_lean.hip POOL variant; bit-identical).
@@ -909,7 +910,14 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             std::swap(cur, nxt);
             continue;
         }
-        if (bf && h->img_block && B.imgw.p && H == 14 && !t1_ready && !cur_tiled && g_conv_mode.load(std::memory_order_relaxed) < 0) {
+        bool img_fit = h->img_block == 2;
+        if (h->img_block == 1) {                             // an image per CU: 256 (512) images = one (two) full rounds; 300 = two rounds 59 % full
+            int cus = 0;
+            HIP_TRY(device_cus(&cus));
+            const long rounds = (n + cus - 1) / cus;
+            img_fit = (long)n * 8 >= rounds * cus * 7;
+        }
+        if (bf && img_fit && B.imgw.p && H == 14 && !t1_ready && !cur_tiled && g_conv_mode.load(std::memory_order_relaxed) == -1) {
             // layer3 identity block: conv1 -> conv2 -> conv3 + identity in one kernel, an image per workgroup, t1 / t2 in LDS
             BlkImgArgs a{};
             a.x = cur; a.y = nxt; a.wfrag = B.imgw.p; a.N = n; a.range_flag = h->range_flag; a.dbg = g_conv_dbg;
@@ -1647,7 +1655,7 @@ int ap_net_set_fuse_tail(ap_net* h, int on) {
 
 int ap_net_set_img_block(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->img_block = on != 0;
+    h->img_block = on < 0 ? 0 : (on > 2 ? 2 : on);
     return AP_OK;
 }
 

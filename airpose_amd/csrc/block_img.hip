@@ -18,7 +18,9 @@
 //   * conv2 and conv3 run without a single barrier (their B operand is the resident image, their A operand is private).
 // LDS: 258 slots x 512 B (16 zero slots + 1 above, 224 image slots, 16 + 1 below) = 129 KB; XOR swizzle chunk ^ (slot & 15) so the
 // 16 pixels of a ds_read_b128 lane group hit 16 different 16-byte bank slots for every tap shift.
-// K order per output element = the ring kernel's (tap-outer, channel-inner, K steps of 32 in order): same sums.
+// K order per output element = that of the kernels this one replaces (conv1 / conv3: K steps of 32 in order; conv2: the slab
+// kernel's 64-channel chunk outer, tap inner): the same sums, bit for bit, so the trunk may choose between the two paths by
+// problem size (an image per CU: only full rounds of the chip pay) without a pair's result depending on its batch.
 #include <type_traits>
 
 #include "ap_common.h"
@@ -53,7 +55,7 @@ __host__ __device__ __forceinline__ int bi_row_channel(int rho) {
     return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3);
 }
 
-// weight stream: wave w -> [conv1: 32 steps][conv2: 72 steps (tap-major)] of 4 fragments (64 rows) + [conv3: 8 chunks x 8 steps] of
+// weight stream: wave w -> [conv1: 32 steps][conv2: 72 steps (64-channel chunk, tap, K half)] of 4 fragments (64 rows) + [conv3: 8 chunks x 8 steps] of
 // 2 fragments (32 rows); fragment = [lane 64][8 K values]: row lane & 15, K columns 8 (lane >> 4) .. + 7 of the step's 32
 __global__ void __launch_bounds__(256) blk_img_pack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2,
                                                            const bf16_t* __restrict__ w3, unsigned char* __restrict__ dst) {
@@ -67,7 +69,10 @@ __global__ void __launch_bounds__(256) blk_img_pack_kernel(const bf16_t* __restr
         const int step = p >> 8, f = (p >> 6) & 3, lane = p & 63;
         const int ch = w * 64 + bi_row_channel(f * 16 + (lane & 15));
         if (step < 32) src = w1 + (size_t)ch * BI_C + step * 32 + (lane >> 4) * 8;
-        else src = w2 + (size_t)ch * (9 * BI_P) + (step - 32) * 32 + (lane >> 4) * 8;
+        else {                                               // conv2 in the slab kernel's K order: 64-channel chunk, tap, K half
+            const int s2 = step - 32, c64 = s2 / 18, tap = (s2 % 18) >> 1, ks = s2 & 1;
+            src = w2 + (size_t)ch * (9 * BI_P) + tap * BI_P + c64 * 64 + ks * 32 + (lane >> 4) * 8;
+        }
     } else {
         const int q = p - BI_STEPS12 * 256, step = q >> 7, f = (q >> 6) & 1, lane = q & 63;
         const int chunk = step >> 3, ks = step & 7;
@@ -146,7 +151,10 @@ template <int OFF> __device__ __forceinline__ void bi_gld(u32x4& r, uint32_t vof
     const uint64_t u = (uint64_t)sbase;
     const uint64_t su = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
                         (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    asm volatile("global_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(su), "n"(OFF) : "memory");
+    // s_nop 4: the base may come straight out of a v_readlane / v_readfirstlane (an SGPR the compiler had spilled to a VGPR lane):
+    // VALU write of an SGPR -> VMEM read of it needs 5 wait states, and hipcc pads nothing in front of an asm statement.  Without
+    // the pad the load now and then used the PREVIOUS value of the pair (seen: the identity of image row 5 added to row 6)
+    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(su), "n"(OFF) : "memory");
 }
 __device__ __forceinline__ void bi_mma(f32x4& c, const u32x4& w, const u32x4& x) {
     asm volatile(AP_MFMA16_ASM " %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
@@ -175,6 +183,25 @@ template <int NR, typename RD, typename USE> __device__ __forceinline__ void bi_
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (n + LA < NR) rd(std::integral_constant<int, n + LA>{}, b[(n + LA) & 7]);
     });
+}
+
+// conv2, one pair of 64-channel chunks = 36 K steps = 480 groups: group n -> chunk parity, tap (dr, dc), K half, pixel row
+struct BiP2 { int cpar, dr, dc, ks, g, gi, ng, step; };
+constexpr BiP2 bi_p2(int n) {
+    BiP2 r{};
+    r.cpar = n / 240;
+    const int m = n % 240;
+    int q = 0;
+    if (m < 78) { r.dr = -1; r.ng = 13; q = m; }
+    else if (m < 162) { r.dr = 0; r.ng = 14; q = m - 78; }
+    else { r.dr = 1; r.ng = 13; q = m - 162; }
+    const int st = q / r.ng;
+    r.gi = q % r.ng;
+    r.dc = st / 2 - 1;
+    r.ks = st % 2;
+    r.g = (r.dr < 0 ? 1 : 0) + r.gi;                         // the row above / below the image contributes zeros: skipped
+    r.step = r.cpar * 18 + (r.dr + 1) * 6 + st;
+    return r;
 }
 
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) blk_img_kernel(const BlkImgArgs a) {
@@ -307,6 +334,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         c1_iter(0, I1{});
         BISTAMP(2);
         for (int c = 2; c < 16; c += 2) c1_iter(c, I0{});
+        // The staging loads of the last iterations fetch nothing that is used (chunks 16 .. 18 do not exist: they keep the queue
+        // uniform).  Their destinations must nevertheless stay allocated until they have landed: a register the compiler
+        // believes dead is handed to the next value, and the late load then overwrites it (seen: one output row wrong now and then).
+        bi_wait_vm<8>();                                     // behind the last staging load: the ring loads of the last two K steps
+#pragma unroll
+        for (int j = 0; j < 7; ++j) asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));
         BISTAMP(3);
         bi_settle28(acc[0], acc[1]);                         // the last MFMA results settle before VALU reads them
         bi_settle28(acc[2], acc[3]);
@@ -335,29 +368,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         bi_settle28(acc[2], acc[3]);
         BISTAMP(4);
 
-        // ================================================================ conv2: 9 taps x 8 K steps, no barrier
-        sfor<0, 3>([&](auto DR) __attribute__((always_inline)) {
-            constexpr int dr = decltype(DR)::value - 1;
-            constexpr int g0 = dr < 0 ? 1 : 0, ng = dr == 0 ? 14 : 13;      // the row above / below the image contributes zeros
-            for (int dc = -1; dc <= 1; ++dc) {
-                const uint32_t tb = tbase(dc);
-                uint32_t tl[4], th[4];
+        // ================================================================ conv2: 4 channel chunks x 9 taps x 2 K halves, no barrier
+        for (int cp = 0; cp < 2; ++cp) {                     // chunks 2 cp, 2 cp + 1: operand chunk 8 cp + 4 cpar + 2 ks' .. -> + cp * 256 bytes
+            uint32_t tl[3][4], th[3][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { tl[j] = tb ^ ((uint32_t)j << 6); th[j] = tl[j] + 65536u; }
-                bi_pipe<8 * ng>(bf,
-                    [&](auto I, u32x4& d) __attribute__((always_inline)) {
-                        constexpr int n = decltype(I)::value, ks = n / ng, g = g0 + n % ng, R = g + dr + 1;
-                        bi_ldsr<(R & 7) * 8192 + (ks >> 2) * 256>(d, R < 8 ? tl[ks & 3] : th[ks & 3]);
-                    },
-                    [&](auto I, u32x4& d) __attribute__((always_inline)) {
-                        constexpr int n = decltype(I)::value, ks = n / ng, gi = n % ng, g = g0 + gi, sl = ks & 3;
-                        if constexpr (gi == 0) bi_wait_vm<12>();
+            for (int d = 0; d < 3; ++d) {
+                const uint32_t tb = tbase(d - 1) + cp * 256;
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) bi_mma(acc[f][g], ar[sl][f], d);
-                        if constexpr (gi == ng - 1) refill(std::integral_constant<int, sl>{}, ar);
-                    });
+                for (int j = 0; j < 4; ++j) { tl[d][j] = tb ^ ((uint32_t)j << 6); th[d][j] = tl[d][j] + 65536u; }
             }
-        });
+            bi_pipe<480>(bf,
+                [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                    constexpr BiP2 q = bi_p2(decltype(I)::value);
+                    constexpr int R = q.g + q.dr + 1, j = 2 * q.cpar + q.ks;
+                    bi_ldsr<(R & 7) * 8192>(d, R < 8 ? tl[q.dc + 1][j] : th[q.dc + 1][j]);
+                },
+                [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                    constexpr BiP2 q = bi_p2(decltype(I)::value);
+                    constexpr int sl = q.step & 3;
+                    if constexpr (q.gi == 0) bi_wait_vm<12>();
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) bi_mma(acc[f][q.g], ar[sl][f], d);
+                    if constexpr (q.gi == q.ng - 1) refill(std::integral_constant<int, sl>{}, ar);
+                });
+        }
         BISTAMP(5);
         bi_settle28(acc[0], acc[1]);
         bi_settle28(acc[2], acc[3]);
@@ -417,6 +451,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                     __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, vo, 0, 0);
                 }
             };
+#ifndef BI_EXP
+#define BI_EXP 0
+#endif
+            if (BI_EXP & 1) { __syncthreads(); asm volatile("s_sleep 30" ::: "memory"); __syncthreads(); }
+            if (BI_EXP & 2) { bi_wait_vm<0>(); chunk_fn(0, I0{}); } else
             chunk_fn(0, I1{});
             BISTAMP(7);
             for (int c = 1; c < 8; ++c) { chunk_fn(c, I0{}); if (c == 1) BISTAMP(10); }
@@ -426,7 +465,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         ++img_no;
 #endif
     }
-    bi_wait_vm<0>();
+    bi_wait_vm<0>();                                         // (the ring ran ahead into the next image: nothing may land after the exit)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ar[j][0]), "+v"(ar[j][1]), "+v"(ar[j][2]), "+v"(ar[j][3]));
     ap_rng_flush(a.range_flag, rng);
 }
 

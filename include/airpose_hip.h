@@ -317,9 +317,10 @@ int ap_net_set_fuse_tail(ap_net* h, int on);
  * (model_copenet.py:41-42, :97-102; its conv1 having been computed by the producing kernel) is stored at the even pixels only.
  * Features are bit-identical either way. */
 int ap_net_set_even_out(ap_net* h, int on);
-/* 16-bit modes: on = 1 (default) runs each layer3 identity bottleneck (layer3.1 .. 3.5) as ONE image-resident kernel
- * (ap_block_img_nhwc); on = 0 as conv2 + the fused conv3 -> conv1 pairs.  Same K order as the ring kernel: bit-identical to the
- * three-convolution path under ap_set_conv_config(-4); against the default (slab) conv2 it differs by fp32 re-association. */
+/* 16-bit modes: layer3's identity bottlenecks (layer3.1 .. 3.5) as ONE image-resident kernel each (ap_block_img_nhwc) instead
+ * of conv2 + the fused conv3 -> conv1 pairs: on = 1 (default) when the pass fills whole rounds of the chip (the kernel runs an
+ * image per CU: >= 7/8 of ceil(n / CUs) * CUs images), 2 always, 0 never.  Both paths sum in the same order (conv2: the slab
+ * kernel's): trunk features are bit-identical, so a pair's result does not depend on the batch it arrives in. */
 int ap_net_set_img_block(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);
