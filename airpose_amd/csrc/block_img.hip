@@ -172,16 +172,16 @@ __device__ __forceinline__ void bi_settle28(f32x4 (&p)[14], f32x4 (&q)[14]) {
                    "+a"(q[5]), "+a"(q[6]), "+a"(q[7]), "+a"(q[8]), "+a"(q[9]), "+a"(q[10]), "+a"(q[11]), "+a"(q[12]), "+a"(q[13]));
     __builtin_amdgcn_sched_barrier(0);
 }
-// B-fragment pipeline of one segment of NR 16-pixel groups: LA reads in flight ahead of the MFMAs, 8 fragment registers
-template <int NR, typename RD, typename USE> __device__ __forceinline__ void bi_pipe(u32x4 (&b)[8], RD&& rd, USE&& use) {
-    constexpr int LA = 7;
-    sfor<0, (NR < LA ? NR : LA)>([&](auto I) __attribute__((always_inline)) { rd(I, b[decltype(I)::value & 7]); });
+// B-fragment pipeline of one segment of NR 16-pixel groups: LA reads in flight ahead of the MFMAs (LA fragment registers in use)
+template <int NR, int LA, typename RD, typename USE> __device__ __forceinline__ void bi_pipe(u32x4 (&b)[16], RD&& rd, USE&& use) {
+    static_assert(LA >= 1 && LA <= 15, "lgkmcnt is 4 bits");
+    sfor<0, (NR < LA ? NR : LA)>([&](auto I) __attribute__((always_inline)) { rd(I, b[decltype(I)::value & 15]); });
     sfor<0, NR>([&](auto I) __attribute__((always_inline)) {
         constexpr int n = decltype(I)::value, rem = NR - 1 - n;
         bi_wait_lgkm<(rem < LA - 1 ? rem : LA - 1)>();
-        use(I, b[n & 7]);
+        use(I, b[n & 15]);
         __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + LA < NR) rd(std::integral_constant<int, n + LA>{}, b[(n + LA) & 7]);
+        if constexpr (n + LA < NR) rd(std::integral_constant<int, n + LA>{}, b[(n + LA) & 15]);
     });
 }
 
@@ -262,7 +262,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
 
     f32x4 acc[4][14];
-    u32x4 bf[8];
+    u32x4 bf[16];
 #ifdef AP_TRACE   // cycle stamps of wave 0 of workgroups 0 and 100, their SECOND image (24 slots each): tools/probes/blk_trace.py
     int img_no = 0;
 #define BISTAMP(i) do { if (a.dbg && img_no == 1 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) { \
@@ -299,11 +299,11 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         xload(xa, 2);
         __syncthreads();
         // one K half-chunk pair = two K steps of 32 out of staging buffer STAGE on ring slots SL0, SL0 + 1
-        auto c1_pair = [&](auto STAGE, auto SL0, auto FIRST, u32x4 (&b)[8], u32x4 (&r)[4][4], f32x4 (&ac)[4][14]) __attribute__((always_inline)) {
+        auto c1_pair = [&](auto STAGE, auto SL0, auto FIRST, u32x4 (&b)[16], u32x4 (&r)[4][4], f32x4 (&ac)[4][14]) __attribute__((always_inline)) {
             constexpr int stage = decltype(STAGE)::value, sl0 = decltype(SL0)::value;
             constexpr bool first = decltype(FIRST)::value != 0;
             const uint32_t ra = xs_r + stage * BI_XS_STAGE, rb = ra ^ 64u;
-            bi_pipe<28>(b,
+            bi_pipe<28, 7>(b,
                 [&](auto I, u32x4& d) __attribute__((always_inline)) { constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14; bi_ldsr<g * 2048>(d, ks ? rb : ra); },
                 [&](auto I, u32x4& d) __attribute__((always_inline)) {
                     constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14, sl = sl0 + ks;
@@ -377,7 +377,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #pragma unroll
                 for (int j = 0; j < 4; ++j) { tl[d][j] = tb ^ ((uint32_t)j << 6); th[d][j] = tl[d][j] + 65536u; }
             }
-            bi_pipe<480>(bf,
+            bi_pipe<480, 7>(bf,
                 [&](auto I, u32x4& d) __attribute__((always_inline)) {
                     constexpr BiP2 q = bi_p2(decltype(I)::value);
                     constexpr int R = q.g + q.dr + 1, j = 2 * q.cpar + q.ks;
@@ -421,7 +421,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 bi_gld<0>(idr[12], idoff, isb + 12 * 28672); bi_gld<0>(idr[13], idoff, isb + 13 * 28672);
                 bi_gld<0>(bnr[0], (uint32_t)kq * 32u, bs3 + chunk * 512); bi_gld<16>(bnr[1], (uint32_t)kq * 32u, bs3 + chunk * 512);
                 bi_gld<0>(bnr[2], (uint32_t)kq * 32u, bh3 + chunk * 512); bi_gld<16>(bnr[3], (uint32_t)kq * 32u, bh3 + chunk * 512);
-                bi_pipe<112>(bf,
+#ifndef BI_LA3
+#define BI_LA3 7
+#endif
+                bi_pipe<112, BI_LA3>(bf,
                     [&](auto I, u32x4& d) __attribute__((always_inline)) {
                         constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14, R = g + 1;
                         bi_ldsr<(R & 7) * 8192 + (ks >> 2) * 256>(d, R < 8 ? tl[ks & 3] : th[ks & 3]);

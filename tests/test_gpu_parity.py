@@ -1150,8 +1150,8 @@ def test_split_bf16_whole_pipeline_matches_oracle(netx2, body, copenet_sd, copen
 def test_regressor_fold_guard(golden, copenet_sd, copenet_inputs, dev):
     """ap_net_finalize checks the folded 145 x 2332 regressor map of the checkpoint it packs against the literal fc1 -> fc2 -> dec
     chain (fp64, fixed probe batch): the benchmark weights pass far below the 1e-5 bar; with the bar forced to 0 the same
-    checkpoint is 'rejected' -- the handle then runs the literal chain (golden parity unchanged), says so, and refuses
-    ap_net_set_fold(1)."""
+    checkpoint is 'rejected' -- the handle then runs the literal chain (golden parity unchanged), says so, and keeps it when
+    ap_net_set_fold(1) is (re-)applied (a remembered knob must not turn every later call into an error)."""
     import ctypes as C
     from airpose_amd import _native as Nn
     from airpose_amd import copenet_model
@@ -1169,8 +1169,11 @@ def test_regressor_fold_guard(golden, copenet_sd, copenet_inputs, dev):
     b = net(inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], pos, pos, iters=3)
     st, err2 = net.fold_status()
     assert st == 0 and err2 == err
-    with pytest.raises(RuntimeError, match="rejected"):
-        net.set_fold(1)
+    net.set_fold(1)                                         # a remembered knob on a rejected checkpoint: a warned no-op, not an error
+    st2, _ = net.fold_status()
+    assert st2 == 0                                         # ... and the literal chain stays
+    c = net(inp["im0"], inp["im1"], inp["bb0"], inp["bb1"], pos, pos, iters=3)
+    assert all(torch.equal(x, y) for x, y in zip(b, c))
     for x, y, key in zip(a, b, ("pose0", "betas0", "pose1", "betas1")):
         assert pose_err(x, y) < 1e-5 if "pose" in key else rel_err(x.cpu().numpy(), y.cpu().numpy()) < 1e-5
         want = g[key + "_it3"] if (key + "_it3") in g.files else None
