@@ -27,7 +27,7 @@ for li, (pl, nb) in enumerate(zip(planes, layers)):
             shapes.append(("l%d.%d.c3" % (li + 1, bi), n * Ho * Ho, pl * 4, pl, n * Ho * Ho * pl, 1))
         inpl, H = pl * 4, Ho
 k = i0 + 1
-while "conv_" not in rows[k][0] and "bneck" not in rows[k][0]:
+while "conv_" not in rows[k][0] and "bneck" not in rows[k][0] and "blk_img" not in rows[k][0]:
     print("%-40s %8.1f us" % (rows[k][0][:40], rows[k][3] / 1e3))
     k += 1
 print("%-40s %8.1f us" % (rows[i0][0][:40], rows[i0][3] / 1e3))
@@ -65,6 +65,18 @@ for si, (nm, M, N, K, inel, res) in enumerate(shapes):
         continue
     r = rows[k]
     k += 1
+    if "blk_img_kernel" in r[0]:
+        # image-resident identity block: conv1 + conv2 + conv3 + identity of THIS block in one launch (x read twice, out once)
+        blk = [shapes[j] for j in (si, si + 1, si + 2)]
+        assert nm.endswith(".c1") and blk[2][0].endswith(".c3"), (nm, blk)
+        skip.update((si + 1, si + 2))
+        fl, dur = sum(2.0 * m_ * n_ * k_ for (_, m_, n_, k_, _, _) in blk), r[3] / 1e3
+        by = (2 * M * K + M * K) * 2
+        tot += dur
+        bylayer[nm[:2]] = bylayer.get(nm[:2], 0) + dur
+        print("%-16s M=%7d (conv1+conv2+conv3+id)   %-22s grid=%6d %7.1fus %7.1f TF/s %7.1f MB %6.0f GB/s" % (
+            nm[:-3] + ".img", M, "blk_img_kernel", r[4] // 256, dur, fl / dur / 1e6, by / 1e6, by / dur / 1e3))
+        continue
     assert "conv_" in r[0], r[0]
     fl, dur = 2.0 * M * N * K, r[3] / 1e3
     by = (inel + M * N * (1 + res)) * 2
