@@ -314,6 +314,8 @@ struct ap_smplx {
     Layer dirs;                 // blend-shape GEMM operand: rows = 3V, K = 512 (fp32: exact fp32 MFMA chain)
     DevBuf dirs_split;          // the same operand as split-bf16 pairs: four-term products on the bf16 matrix pipe (default)
     DevBuf dirs_frag, jv_slot, skin_idx8, skin_w4, ws_side;   // fused contraction + skinning: directions in MFMA fragment order, joint-vertex slots / buffer
+    DevBuf ws_cnt;              // ... arrival counters of the body groups (joints by the group's last workgroup); zero between launches
+    bool fuse_joints = false;   // ap_smplx_set_fused(h, 4): joints / landmarks / projection inside the fused kernel (measured 7 us SLOWER than their own launch)
     bool blend_split = true;
     bool fused = true;          // body-only pose feature, 4 bones per vertex, split-bf16 blend: one kernel for contraction + skinning
     int fused_cut = 2;          // ... 2 = smplx_lbs_tail_kernel (round 4), 1 = smplx_lbs_fused_kernel (round 3; ap_smplx_set_fused(h, 3))
@@ -1908,7 +1910,7 @@ void ap_smplx_destroy(ap_smplx* h) {
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&h->dirs.w, &h->dirs_split, &h->dirs.scale, &h->dirs.shift, &h->j_template, &h->j_shapedirs, &h->parents, &h->depth,
                       &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A, &h->dirs_frag, &h->jv_slot, &h->skin_idx8, &h->skin_w4, &h->ws_side,
-                      &h->ws_jposed, &h->ws_post, &h->ws_vposed, &h->ws_cc})
+                      &h->ws_jposed, &h->ws_post, &h->ws_vposed, &h->ws_cc, &h->ws_cnt})
         b->release();
     h->tm.destroy();
     delete h;
@@ -1932,6 +1934,15 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     const bool fused = h->fused && h->blend_split && body_only && ap_smplx_lbs_fused_supported(m);
     if (fused) HIP_TRY(h->ws_side.reserve((size_t)n * m.n_jv * 3 * 4));
     else HIP_TRY(h->ws_vposed.reserve((size_t)n * m.ldv * 4));
+    a.grp_cnt = nullptr;
+    if (fused && h->fused_cut == 2 && h->fuse_joints) {
+        const size_t need = (size_t)((n + 31) / 32) * 4;
+        if (need > h->ws_cnt.bytes) {                        // (re)allocated: zero once; every launch leaves the counters at zero
+            HIP_TRY(h->ws_cnt.reserve(need < 4096 ? 4096 : need));
+            HIP_TRY(hipMemsetAsync(h->ws_cnt.p, 0, h->ws_cnt.bytes, st));
+        }
+        a.grp_cnt = h->ws_cnt.as<int>();
+    }
     a.coef = h->ws_coef.as<float>(); a.A = h->ws_A.as<float>(); a.jposed = h->ws_jposed.as<float>();
     a.post = (a.pose6d || a.post_rt) ? h->ws_post.as<float>() : nullptr;
     a.vposed = h->ws_vposed.as<float>();
@@ -1967,7 +1978,7 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
         HIP_TRY(ap_launch_smplx_skin(m, a, st));
         if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[3]));
     }
-    HIP_TRY(ap_launch_smplx_joints(m, a, st));
+    if (!a.grp_cnt) HIP_TRY(ap_launch_smplx_joints(m, a, st));
     if (h->tm.on) {
         HIP_TRY(h->tm.rec(st, &ev[4]));
         for (int s = 0; s < 4; ++s) { h->tm.marks[s].push_back(ev[s]); h->tm.marks[s].push_back(ev[s + 1]); }
@@ -2044,6 +2055,7 @@ int ap_smplx_set_fused(ap_smplx* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fused = on != 0;
     h->fused_cut = on == 3 ? 1 : 2;                          // 3: the first cut of the fused kernel (A/B)
+    h->fuse_joints = on == 4;                                // 4: joints stage inside the kernel, done by each group's last workgroup (A/B: slower)
     return AP_OK;
 }
 

@@ -188,6 +188,9 @@ struct SmplxFwdArgs {
     float* joints2d;              // [n][127][2] or NULL
     float* rotmat_out;            // [n][22][9] or NULL (pose6d mode)
     float* vp_side;               // fused path: v_posed of the joint vertices [n][n_jv][3]; NULL: the joints kernel reads vposed
+    int* grp_cnt;                 // fused path, second cut: per body group of 32 an arrival counter (zero between launches).  When set,
+                                  // vp_side holds the SKINNED joint vertices and the group's last workgroup computes the joints /
+                                  // landmarks / projection itself: no joints launch
 };
 hipError_t ap_launch_smplx_prep(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);
 hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, hipStream_t st);

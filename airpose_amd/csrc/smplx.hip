@@ -691,11 +691,10 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 const int bl = s * 16 + g4 * 4 + r;
                 const bool bok = b0 + bl < a.n;
                 const float x = acc[0][s][r] + tx, y = acc[1][s][r] + ty, z = acc[2][s][r] + tz;
-                if (a.vp_side && bok && (id >> 24)) {        // joint vertex: slot + 1 in the top byte (0 = none, padding rows too)
+                if (!a.grp_cnt && a.vp_side && bok && (id >> 24)) {   // joint vertex: slot + 1 in the top byte (0 = none, padding rows too)
                     float* q = (float*)(sbase + soff);
                     q[0] = x; q[1] = y; q[2] = z;
                 }
-                soff += sstep;
                 const float* Ab = bones_l + (s * 16 + r) * J12C;
                 float T[12];
 #pragma unroll
@@ -710,9 +709,18 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 }
                 const float* Pb = Ps_l + (s * 16 + r) * 16;
                 float q[3];
-                q[0] = T[0] * x + T[1] * y + T[2] * z + T[3] + Pb[12];
-                q[1] = T[4] * x + T[5] * y + T[6] * z + T[7] + Pb[13];
-                q[2] = T[8] * x + T[9] * y + T[10] * z + T[11] + Pb[14];
+                q[0] = T[0] * x + T[1] * y + T[2] * z + T[3];
+                q[1] = T[4] * x + T[5] * y + T[6] * z + T[7];
+                q[2] = T[8] * x + T[9] * y + T[10] * z + T[11];
+                if (a.grp_cnt && bok && (id >> 24)) {        // the SKINNED joint vertex (before translation / post transform: what
+                    float* sq = (float*)(sbase + soff);       // skin_point hands the joints stage), for the group's last workgroup:
+                    // write-through (sc1) stores, so that publishing needs no L2 write-back of the 250 KB of vertices beside them
+                    __hip_atomic_store(sq + 0, q[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sq + 1, q[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    __hip_atomic_store(sq + 2, q[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                soff += sstep;
+                q[0] += Pb[12]; q[1] += Pb[13]; q[2] += Pb[14];
                 if (a.post) apply_post(Pb, q);
                 if (T_ABLATE & 1) asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]));
                 else if (bok && vok) {
@@ -728,6 +736,66 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
         static_assert(T_KS & 1, "an odd number of K steps leaves the next group's first fragments in the second set");
 #pragma unroll
         for (int i = 0; i < 6; ++i) fa[i] = fb[i];           // the next group's first step (requested before the skinning)
+    }
+    // ---------------------------------------------------- joints, landmarks and projection of the 32 bodies, by the LAST of the
+    // body group's n_vr workgroups (smplx_joints_kernel's arithmetic on the skinned joint vertices the workgroups left in the
+    // side buffer): one launch less per forward.  Hand-off: write-through (sc1) payload stores -> every wave drains -> barrier ->
+    // one lane takes a ticket (relaxed, agent scope); the last ticket acquires (one L1 invalidate) and reads with plain loads.
+    // (A release fence per workgroup instead -- buffer_wbl2 over its 250 KB of freshly written vertices -- cost 13 us per launch.)
+    if (a.grp_cnt) {
+        __shared__ int s_last;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(a.grp_cnt + bg, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == n_vr - 1;
+        }
+        __syncthreads();
+        if (!s_last) return;
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            __hip_atomic_store(a.grp_cnt + bg, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+        }
+        __syncthreads();
+        const int nj = m.J + m.n_extra + m.n_lmk;
+        const int nbj = a.n_main > 0 ? a.n_main : a.n;       // bodies that have joints (the test-mode input meshes do not)
+        for (int item = tid; item < T_BB * nj; item += 64 * T_NW) {
+            const int bl = item / nj, t = item - bl * nj, b = b0 + bl;
+            if (b >= nbj) continue;
+            const float* vs = a.vp_side + (size_t)b * m.n_jv * 3;
+            const float* Pb = Ps + bl * 16;
+            float o[3];
+            if (t < m.J) {
+                for (int c = 0; c < 3; ++c) o[c] = a.jposed[((size_t)b * m.J + t) * 3 + c];
+            } else if (t < m.J + m.n_extra) {
+                const float* q = vs + 3 * m.jv_slot[m.extra_verts[t - m.J]];
+                o[0] = q[0]; o[1] = q[1]; o[2] = q[2];
+            } else {
+                const int l = t - m.J - m.n_extra;
+                int vid[3];
+                float bw[3];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) { vid[f] = m.lmk_tri[l * 3 + f]; bw[f] = m.lmk_bary[l * 3 + f]; }
+                int slot[3];
+#pragma unroll
+                for (int f = 0; f < 3; ++f) slot[f] = m.jv_slot[vid[f]];
+                o[0] = o[1] = o[2] = 0.f;
+#pragma unroll
+                for (int f = 0; f < 3; ++f) {
+                    const float* q = vs + 3 * slot[f];
+                    o[0] = fmaf(q[0], bw[f], o[0]); o[1] = fmaf(q[1], bw[f], o[1]); o[2] = fmaf(q[2], bw[f], o[2]);
+                }
+            }
+            o[0] += Pb[12]; o[1] += Pb[13]; o[2] += Pb[14];
+            if (a.post) apply_post(Pb, o);
+            float* dst = a.joints + ((size_t)b * nj + t) * 3;
+            dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2];
+            if (a.joints2d && a.cam_center) {
+                const float px = o[0] / o[2], py = o[1] / o[2];
+                a.joints2d[((size_t)b * nj + t) * 2 + 0] = a.fx * px + a.cam_center[(size_t)b * 2 + 0];
+                a.joints2d[((size_t)b * nj + t) * 2 + 1] = a.fy * py + a.cam_center[(size_t)b * 2 + 1];
+            }
+        }
     }
 }
 

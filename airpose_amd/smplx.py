@@ -262,7 +262,8 @@ class SMPLX(nn.Module):
                                                      N.PRECISIONS[precision]), "ap_smplx_set_blend_precision")
 
     def set_fused(self, on):
-        """Blend-shape contraction + skinning in one kernel where the call allows it (default) or always as two kernels."""
+        """Blend-shape contraction + skinning in one kernel where the call allows it (1, default), always as two kernels (0);
+        3: the first cut of the fused kernel, 4: the fused kernel with the joints stage inside it (A/B aids; 4 is slower)."""
         N.check(N.lib().ap_smplx_set_fused(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_smplx_set_fused")
 

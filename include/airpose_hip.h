@@ -389,7 +389,10 @@ int ap_smplx_set_blend_precision(ap_smplx* h, int precision);
 /* Blend-shape contraction + skinning as ONE kernel (default on): taken when the call carries no hand / face poses (K = 224),
  * the model has at most 4 bones per vertex and the contraction runs in split-bf16 form; v_posed then never leaves the chip.
  * 0 = always the two-kernel path (contraction GEMM writing v_posed, then the skinning kernel).  Same arithmetic per product;
- * results agree to fp32 re-association. */
+ * results agree to fp32 re-association.  3 = the first cut of the fused kernel.  4 = the fused kernel with the joints /
+ * landmarks / projection stage inside it: the LAST workgroup of each group of 32 bodies computes them from the skinned joint
+ * vertices its siblings left in a side buffer (write-through stores, arrival counter, one acquire) -- one launch less, but
+ * measured 7 us slower per forward of 512 bodies than the joints kernel as its own launch, so not the default. */
 int ap_smplx_set_fused(ap_smplx* h, int on);
 /* Test aid: fill the coefficient workspace for n bodies with 0xFF bytes (NaN patterns), as a raw allocation may hold: every slot
  * the contraction reads must be rewritten by the next forward, the zero padding included. */

@@ -1407,7 +1407,7 @@ def test_smplx_forward_matches_oracle(body, smplx_model, dev):
     assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
 
 
-@pytest.mark.parametrize("cut", [1, 3])                        # set_fused(1): the second cut (default); 3: the first cut
+@pytest.mark.parametrize("cut", [1, 3, 4])                     # set_fused(1): the default; 3: first cut; 4: joints stage inside the kernel
 @pytest.mark.parametrize("B", [3, 32, 77])
 def test_smplx_fused_lbs_matches_two_kernel_path(body, smplx_model, dev, B, cut):
     """smplx_lbs_fused_kernel (blend-shape contraction + skinning in one kernel, v_posed on chip) against the two-kernel path
@@ -1439,7 +1439,8 @@ def test_smplx_fused_lbs_matches_two_kernel_path(body, smplx_model, dev, B, cut)
     assert rel_err(one.joints[:, 55:76].cpu().numpy(), one.vertices[:, ev.to(dev)].cpu().numpy()) < 1e-6
 
 
-def test_smplx_fused_soak(body, smplx_model, dev):
+@pytest.mark.parametrize("mode", [1, 4])                       # 4: joints stage inside the kernel (hand-off between workgroups)
+def test_smplx_fused_soak(body, smplx_model, dev, mode):
     """Soak of the fused contraction + skinning kernel (an intermittent, timing-dependent wrong vertex -- about one
     in 10^4, lanes 48-63 -- appeared in an SLP-vectorised build of this kernel; a single forward per body count cannot see a
     recurrence): 120 forwards of 512 bodies, each compared ELEMENT-WISE against the two-kernel path's vertices, with a second
@@ -1454,7 +1455,8 @@ def test_smplx_fused_soak(body, smplx_model, dev):
               transl=tr.to(dev), pose2rot=False)
     try:
         body.set_fused(0)
-        v2 = body.forward(**kw).vertices.clone()
+        o2 = body.forward(**kw)
+        v2, j2 = o2.vertices.clone(), o2.joints.clone()
     finally:
         body.set_fused(1)
     noise = torch.empty(64 << 20, dtype=torch.float32, device=dev)      # 256 MiB: a copy stream beside the kernel
@@ -1464,8 +1466,15 @@ def test_smplx_fused_soak(body, smplx_model, dev):
         if rep & 1:
             with torch.cuda.stream(side):
                 noise.add_(1.0)
-        v1 = body.forward(**kw).vertices
-        err = float((v1 - v2).abs().max())
+        try:
+            body.set_fused(mode)
+            o1 = body.forward(**kw)
+        finally:
+            body.set_fused(1)
+        v1 = o1.vertices
+        # (mode 4: the joints come from the body group's LAST workgroup, across a write-through / acquire hand-off: every word
+        # of them is checked on every repeat, under even and uneven memory load)
+        err = max(float((v1 - v2).abs().max()), float((o1.joints - j2).abs().max()))
         worst = max(worst, err)
         bad_runs += err > 2e-5                              # vertices are O(1): fp32 re-association stays below 1e-6
     torch.cuda.synchronize()
