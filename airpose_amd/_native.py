@@ -56,7 +56,6 @@ SIGNATURES = {
     "ap_hmr_fwd": (_i, [_vp, _vp, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _vp]),
     "ap_conv2d_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 9 + [_vp]),
     "ap_set_conv_config": (_i, [_i]),
-    "ap_set_pair_groups": (_i, [_i]),
     "ap_abi_version": (_i, []),
     "ap_debug_set_trace": (_i, [_vp]),
     "ap_net_enable_timing": (_i, [_vp, _i]),
@@ -107,7 +106,7 @@ SIGNATURES = {
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 5          # include/airpose_hip.h: AP_ABI_VERSION
+ABI_VERSION = 6          # include/airpose_hip.h: AP_ABI_VERSION
 _lib = None
 _lib_lock = threading.Lock()
 

@@ -161,12 +161,6 @@ unsigned long long* g_conv_dbg = nullptr;   // phase-stamp buffer (ap_debug_set_
 // without the slab / lean kernels, -5 automatic without the lean kernel, 0..14 / 17 / 100 one explicit configuration);
 // dispatch_conv reads it once per launch and decodes it, so handles on different threads never see a torn setting.
 std::atomic<int> g_conv_mode{-1};
-// ap_set_pair_groups: 16-pixel groups per wave of the fused pair kernel on the layer3 shapes (P = 256): -1 automatic, 1, 2
-std::atomic<int> g_pair_groups{-1};
-inline int pair_groups(int P) {
-    const int v = g_pair_groups.load(std::memory_order_relaxed);
-    return P == 256 ? (v < 0 ? 1 : v) : 1;
-}
 void* g_zero[16] = {nullptr};   // per-device 256-byte zero line
 
 hipError_t zero_line(const void** out) {
@@ -318,7 +312,6 @@ struct ap_smplx {
     bool fuse_joints = false;   // ap_smplx_set_fused(h, 4): joints / landmarks / projection inside the fused kernel (measured 7 us SLOWER than their own launch)
     bool blend_split = true;
     bool fused = true;          // body-only pose feature, 4 bones per vertex, split-bf16 blend: one kernel for contraction + skinning
-    int fused_cut = 2;          // ... 2 = smplx_lbs_tail_kernel (round 4), 1 = smplx_lbs_fused_kernel (round 3; ap_smplx_set_fused(h, 3))
     DevBuf j_template, j_shapedirs, parents, depth, skin_idx, skin_w, extra_verts, lmk_tri, lmk_bary;
     DevBuf ws_coef, ws_A, ws_jposed, ws_post, ws_vposed, ws_cc;
     int n_out_joints = 0;
@@ -947,7 +940,6 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.s3 = L3.scale.as<float>(); a.h3 = L3.shift.as<float>();
             a.s1 = Nx.c1.scale.as<float>(); a.h1 = Nx.c1.shift.as<float>();
             a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg; a.range_flag = h->range_flag;
-            a.groups = pair_groups(B.pair_p);
             a.t2_tiled = t2_tiled; a.res_tiled = cur_tiled;
             a.out_tiled = t2_tiled && B.pair_n1 > 0 && is_pair(Nx) && !Nx.has_down;
             cur_tiled = a.out_tiled != 0;
@@ -1220,7 +1212,7 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
 // ================================================================================== C ABI
 extern "C" {
 
-const char* ap_version(void) { return "airpose_hip 0.5 (gfx950; abi 5)"; }
+const char* ap_version(void) { return "airpose_hip 0.5 (gfx950; abi 6)"; }
 int ap_abi_version(void) { return AP_ABI_VERSION; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
@@ -1523,7 +1515,7 @@ int ap_conv_pair_nhwc(int precision, const void* t2, const void* wstream, const 
     if (!k_bf16::ap_conv_pair_supported(P, 0, 4 * P, N1)) return fail(AP_ESHAPE, "ap_conv_pair_nhwc: (P, N1) must be (128,128), (128,256) or (256,256)");
     PairArgs a{};
     a.t2 = t2; a.res = res; a.wstream = wstream; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n; a.M = M;
-    a.dbg = g_conv_dbg; a.groups = pair_groups(P);
+    a.dbg = g_conv_dbg;
     HIP_TRY(H16(precision, ap_launch_conv_pair)(a, P, 0, 4 * P, N1, (hipStream_t)stream));
     return AP_OK;
 }
@@ -1539,19 +1531,13 @@ int ap_conv_pair_ds_nhwc(int precision, const void* t2, const void* x, const voi
     PairArgs a{};
     a.t2 = t2; a.x2 = x; a.wstream = wstream; a.s3 = s3; a.h3 = h3; a.s1 = s1; a.h1 = h1; a.out = out; a.t1n = t1n;
     a.M = N * Ho * Ho; a.Ho = a.Wo = Ho; a.H2 = a.W2 = Ho * stride; a.stride2 = stride;
-    a.dbg = g_conv_dbg; a.groups = pair_groups(P);
+    a.dbg = g_conv_dbg;
     HIP_TRY(H16(precision, ap_launch_conv_pair)(a, P, P2, C3, N1, (hipStream_t)stream));
     return AP_OK;
 }
 
 int ap_debug_set_trace(void* device_buf_160_u64) {
     g_conv_dbg = (unsigned long long*)device_buf_160_u64;
-    return AP_OK;
-}
-
-int ap_set_pair_groups(int groups) {
-    if (groups != -1 && groups != 1 && groups != 2) return fail(AP_EINVAL, "ap_set_pair_groups: -1 (automatic), 1 or 2");
-    g_pair_groups.store(groups, std::memory_order_relaxed);
     return AP_OK;
 }
 
@@ -1935,7 +1921,7 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     if (fused) HIP_TRY(h->ws_side.reserve((size_t)n * m.n_jv * 3 * 4));
     else HIP_TRY(h->ws_vposed.reserve((size_t)n * m.ldv * 4));
     a.grp_cnt = nullptr;
-    if (fused && h->fused_cut == 2 && h->fuse_joints) {
+    if (fused && h->fuse_joints) {
         const size_t need = (size_t)((n + 31) / 32) * 4;
         if (need > h->ws_cnt.bytes) {                        // (re)allocated: zero once; every launch leaves the counters at zero
             HIP_TRY(h->ws_cnt.reserve(need < 4096 ? 4096 : need));
@@ -1959,7 +1945,7 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     if (fused) {
         int n_cu = 0;
         HIP_TRY(device_cus(&n_cu));
-        HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, h->fused_cut, st));
+        HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, st));
         if (h->tm.on) { HIP_TRY(h->tm.rec(st, &ev[2])); ev[3] = ev[2]; }     // stage 1 = the fused kernel, stage 2 empty
     } else {
         // v_posed = v_template + [betas | expr | pose_feature] . dirs^T; hand/face rows of the pose feature are
@@ -2054,7 +2040,6 @@ int ap_smplx_debug_poison_workspace(ap_smplx* h, int n) {
 int ap_smplx_set_fused(ap_smplx* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fused = on != 0;
-    h->fused_cut = on == 3 ? 1 : 2;                          // 3: the first cut of the fused kernel (A/B)
     h->fuse_joints = on == 4;                                // 4: joints stage inside the kernel, done by each group's last workgroup (A/B: slower)
     return AP_OK;
 }

@@ -142,10 +142,9 @@ __global__ void __launch_bounds__(256) pair_pack_kernel(const bf16_t* __restrict
 // P: channels of t2 (first K segment); P2: channels of the second K segment (the folded downsample branch of a stage's first
 // block, model_copenet.py:41-42,97-102: x of the block sampled at the strided pixel, 1x1; 0 = identity block); C3: conv3
 // output channels; N1: conv1 width of the next block (0 = none: conv3 alone); RES: the block input is added before the ReLU
-// PG: pixel groups of 16 per wave.  PG = 1: two workgroups per CU (<= 256 registers).  PG = 2 (layer3, where one LDS fragment read
-// per MFMA and 16 MFMAs per barrier step left the matrix pipe at a quarter of its rate): every weight fragment read from LDS feeds
-// TWO MFMAs (pixels 0-15 and 16-31 of the wave: independent accumulators), a barrier step carries 32 MFMAs per wave, the wave
-// takes a whole SIMD's register file (accumulators in the upper half), one workgroup per CU.  Same arithmetic per pixel.
+// PG: pixel groups of 16 per wave.  Only PG = 1 is instantiated (two workgroups per CU, <= 256 registers); PG = 2 (32 pixels per
+// wave, a whole SIMD's register file, one workgroup per CU) measured 4-10 % slower on the layer3 shapes and its knob was retired
+// in round 5 -- layer3's identity blocks run on block_img.hip, which takes that idea to 224 pixels per wave.
 template <int P, int P2, int C3, int N1, bool RES, int NW, int S, int D, bool IDB, int PG>
 __global__ void __launch_bounds__(64 * NW) __attribute__((amdgpu_waves_per_eu(3 - PG, 3 - PG))) conv_pair_kernel(const PairArgs p) {
     constexpr int KA = P + P2, KP = KA / 64, HN = N1 / 128, KG = 2 * HN, NB = C3 / 128, SPC = KP + KG;
@@ -523,11 +522,6 @@ hipError_t ap_launch_pair_pack(const void* w3, const void* w1, void* dst, int P,
 hipError_t ap_launch_conv_pair(const PairArgs& a, int P, int P2, int C3, int N1, hipStream_t st) {
     if (a.M <= 0 || !a.t2 || !a.wstream || !a.out || (N1 > 0 && !a.t1n) || (P2 == 0 && !a.res) || (P2 > 0 && !a.x2))
         return hipErrorInvalidValue;
-    // a.groups: 16-pixel groups per wave: 2 = 32 pixels per wave, one workgroup per CU (layer3 shapes only); 0 / 1 = 16 pixels
-    if (a.groups == 2) {
-        if (P2 == 0 && P == 256 && N1 == 256) return launch_pair<256, 0, 1024, 256, true, 4, 4, 8, false, 2>(a, st);
-        if (P == 256 && P2 == 512 && C3 == 1024 && N1 == 0) return launch_pair<256, 512, 1024, 0, false, 4, 4, 8, false, 2>(a, st);
-    }
     // four waves per workgroup, two workgroups per CU, 4-slot ring, half a tile of fragment look-ahead.  Measured and not
     // kept (tools/pair_bench.py, 256 images): eight waves x one workgroup per CU (half the weight DMA per MFMA) is 4-10 %
     // slower; a whole tile of fragment look-ahead (64 registers) times the same

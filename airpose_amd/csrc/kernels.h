@@ -51,7 +51,6 @@ struct PairArgs {
     int Ho, Wo, H2, W2, stride2;
     int t2_tiled, res_tiled, out_tiled;   // t2 / res / out in the fragment-tiled layout [M/16][C/8][16][8] instead of NHWC rows
     int out_even;                 // `out` (NHWC only) is stored at the even (ho, wo) pixels only: its one reader is a stride-2 1x1; needs Ho, Wo
-    int groups;                   // 16-pixel groups per wave: 0 / 1 (two workgroups per CU) or 2 (layer3 shapes: one workgroup per CU)
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
     int* range_flag;              // fp16 storage, or NULL: host-mapped word set when a stored value leaves the fp16 range
 };
@@ -198,8 +197,7 @@ hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a,
 // blend-shape contraction + skinning in one kernel (K = 4 bones per vertex, body-only pose feature, split-bf16 coefficients)
 bool ap_smplx_lbs_fused_supported(const SmplxModelDev& m);
 size_t ap_smplx_dirs_frag_bytes(int V);
-// cut: 2 = second cut (smplx_lbs_tail_kernel, default), 1 = first cut (kept for A/B)
-hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, int cut, hipStream_t st);
+hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, hipStream_t st);
 
 // ---- stand-alone geometry helpers (smplx.hip)
 hipError_t ap_launch_rot6d(const float* x6, int n, float* R, hipStream_t st);

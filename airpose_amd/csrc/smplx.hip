@@ -317,241 +317,8 @@ __global__ void __launch_bounds__(256) smplx_skin_kernel(const SmplxModelDev m, 
 // at 512 bodies and reads them back: 3.6x the algorithmic traffic of the tail).  upstream lbs.lbs:
 //   v_posed = v_template + [betas | expr | pose_feature] . dirs;  T_v = sum_j w[v][j] A_j;  verts = T_v [v_posed; 1]
 // (+ transl, then transform_smpl of the caller, copenet_twoview.py:237-246).
-//
-// A workgroup is 32 bodies x a range of vertex groups (16 vertices each), four waves with ONE wave per SIMD (up to 512
-// registers each) that share nothing but the 32 bodies' bone transforms in LDS (84 KB); no barrier after the prologue.
-//   * contraction on the bf16 matrix pipe in split-bf16 form (hi.hi + hi.lo + lo.hi), rows = vertices, columns = bodies:
-//     the 32 bodies' coefficient rows are MFMA B fragments resident in registers (K = 224: 112 VGPRs), the direction rows of a
-//     vertex group stream from L2 as A fragments in register order (packed at create time: one contiguous KiB per load
-//     instruction, no LDS, no DMA); three fragment sets per group -- x, y, z of the SAME 16 vertices -- so that a lane ends up
-//     with (x, y, z) of 4 vertices x 2 bodies in its accumulators;
-//   * skinning of those 8 (vertex, body) pairs straight from the accumulators: bone rows gathered from LDS, 48 contiguous bytes
-//     per lane and body stored (192 B per body row across the four lane groups);
-//   * v_posed of the vertices the joints kernel needs (21 picks + 51 x 3 landmark corners) into a compact side buffer.
-// Blocks of one vertex range run on the same XCD (blockIdx % 8), so its direction rows (1/16 of 27 MB) are fetched from HBM
-// once and served to the 16 body groups from that XCD's L2.
-// Timing-only builds (results WRONG, times valid): -DLF_ABLATE=<bits>: 1 no vertex stores | 2 no skinning (bone gathers + blend)
-// | 4 no fragment refills in the loop | 8 no MFMAs
-#ifndef LF_ABLATE
-#define LF_ABLATE 0
-#endif
-constexpr int LF_BB = 32, LF_KS = 8, LF_NW = 8, LF_RING = 4, LF_MAXJ = 55, LF_CROW = 1040;
-static_assert(LF_KS % LF_RING == 0, "a K step keeps its ring slot from group to group");
-// LF_KS: K steps of 32 -- K = 256 covers the 20 shape / expression coefficients and the 189 body-pose features (the jaw / eye
-// features behind them are exactly zero on this path: identity rotations); LF_CROW: LDS row stride of a body's coefficients
-// (1024 B + 16: the 16 bodies of a fragment read hit 16 different 16-byte bank slots)
-
-template <int N> __device__ __forceinline__ void lf_wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-// register load the compiler does not count (its own waits for loads it counts would drain the fragment ring): the
-// destination is valid only behind the hand-placed wait
-__device__ __forceinline__ u32x4 lf_gload(const void* p) {
-    u32x4 r;
-    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
-
-typedef __attribute__((ext_vector_type(3))) uint32_t u32x3;
-__device__ __forceinline__ u32x3 lf_gload3(const void* p) {
-    u32x3 r;
-    asm volatile("global_load_dwordx3 %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
-__device__ __forceinline__ uint32_t lf_gload1(const void* p) {
-    uint32_t r;
-    asm volatile("global_load_dword %0, %1, off" : "=v"(r) : "v"(p) : "memory");
-    return r;
-}
-
-__global__ void __launch_bounds__(64 * LF_NW) __attribute__((amdgpu_waves_per_eu(2, 2)))
-smplx_lbs_fused_kernel(const SmplxModelDev m, const SmplxFwdArgs a, int n_vr, int groups_per_vr) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
-    float* bones = (float*)lf_smem;                                               // [LF_BB][J][12]
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int lr = lane & 15, g4 = lane >> 4;
-    const int vr = blockIdx.x % n_vr, bg = blockIdx.x / n_vr;
-    const int b0 = bg * LF_BB, J12 = m.J * 12;
-    unsigned char* coefs = lf_smem + LF_BB * J12 * 4;                            // [LF_BB][LF_CROW]: 8 K steps x (4 x [8 hi | 8 lo])
-    float* Ps = (float*)(coefs + LF_BB * LF_CROW);                               // [LF_BB][16]: post transform [12] | translation [3]
-    {   // bone transforms, coefficient rows, post transforms of the 32 bodies (rows past the last body: clamped duplicates, never
-        // stored).  Every load of a thread is issued before its first LDS write: a rolled load -> wait -> store loop is ten
-        // dependent L2 round trips (it was a third of the kernel)
-        constexpr int NT = 64 * LF_NW, BIT = (LF_BB * LF_MAXJ * 3 + NT - 1) / NT, CIT = LF_BB * 64 / NT;
-        const int nb = min(LF_BB, a.n - b0), n4 = nb * m.J * 3, tot = LF_BB * m.J * 3;
-        const float4* src = (const float4*)(a.A + (size_t)b0 * J12);
-        float4 tb[BIT];
-        u32x4 tc[CIT];
-#pragma unroll
-        for (int k = 0; k < BIT; ++k) { const int i = tid + k * NT; tb[k] = src[i < n4 ? i : i % n4]; }
-#pragma unroll
-        for (int k = 0; k < CIT; ++k) {
-            const int i = tid + k * NT, bb = i >> 6, c16 = i & 63, bsrc = min(b0 + bb, a.n - 1);
-            tc[k] = *(const u32x4*)((const unsigned char*)(a.coef + (size_t)bsrc * m.ncoef) + c16 * 16);
-        }
-        float pv = 0.f;
-        {
-            const int bb = tid >> 4, e = tid & 15, bsrc = min(b0 + bb, a.n - 1);
-            if (e < 12) pv = a.post ? a.post[(size_t)bsrc * 12 + e] : ((e == 0 || e == 5 || e == 10) ? 1.f : 0.f);
-            else if (e < 15) pv = a.transl ? a.transl[(size_t)bsrc * 3 + (e - 12)] : 0.f;
-        }
-#pragma unroll
-        for (int k = 0; k < BIT; ++k) { const int i = tid + k * NT; if (i < tot) ((float4*)bones)[i] = tb[k]; }
-#pragma unroll
-        for (int k = 0; k < CIT; ++k) { const int i = tid + k * NT; *(u32x4*)(coefs + (i >> 6) * LF_CROW + (i & 63) * 16) = tc[k]; }
-        Ps[tid] = pv;                                        // 512 threads = 32 bodies x 16
-    }
-    // this lane's two bodies: columns lr and 16 + lr of the 32
-    int bl[2];
-    bool bok[2];
-#pragma unroll
-    for (int s = 0; s < 2; ++s) {
-        bl[s] = s * 16 + lr;
-        bok[s] = b0 + bl[s] < a.n;
-    }
-    __syncthreads();                                         // (waits for every load above: nothing of them is in flight below)
-    const int ngroups = (m.V + 15) >> 4;
-    const int gend = min(ngroups, (vr + 1) * groups_per_vr);
-    int g = vr * groups_per_vr + wave;
-    if (g >= gend) return;
-
-    // Software pipeline of one wave: the MFMAs of vertex group g and the skinning of group g - 8 (this wave's previous one) run
-    // in the SAME instruction stream -- K step ks of the contraction is followed by the (vertex ks/2, body set ks%2) pair of the
-    // previous group's accumulators, so the matrix pipe works under the VALU / LDS gathers of the skinning instead of waiting for
-    // them (without it every part of the kernel was additive: two waves of a SIMD that run the same program in step compete for
-    // the same unit).  Fragment ring: LF_RING K steps (6 fragments each: x, y, z of the 16 vertices x hi, lo) requested ahead of
-    // the MFMAs and straight across group boundaries; the skinning operands of vertex j (bone indices, weights, template) are
-    // re-requested for the NEXT skinning round as soon as this round's second pair of vertex j is done.
-    u32x4 fr[LF_RING][6];
-    uint32_t e_id[4];
-    u32x4 e_w[4];
-    u32x3 e_t[4];
-    const unsigned char* dbase = (const unsigned char*)m.dirs_frag + (size_t)lane * 16;
-    auto frag_ptr = [&](int gg, int ks) { return dbase + ((size_t)gg * LF_KS + ks) * 6144; };
-    auto load_step = [&](auto SL, const unsigned char* pz) {
-        constexpr int sl = SL;
-#pragma unroll
-        for (int i = 0; i < 6; ++i) fr[sl][i] = lf_gload(pz + i * 1024);
-    };
-    auto load_ep = [&](auto JJ, int gg) {                    // operands of vertex gg*16 + g4*4 + j
-        constexpr int j = JJ;
-        const int v = gg * 16 + g4 * 4 + j;
-        e_id[j] = lf_gload1(m.skin_idx8 + v);
-        e_w[j] = lf_gload(m.skin_w4 + (size_t)v * 4);
-        e_t[j] = lf_gload3(m.v_template + (size_t)v * 3);
-    };
-    // skinning of one (vertex j, body set s) pair of accumulators ac (group gp): bone gather + blend, [R|t], 12-byte store
-    auto skin_pair = [&](auto JJ, auto SS, const f32x4 (&ac)[3][2], int gp) {
-        constexpr int j = JJ, s = SS;
-        const f32x4 w4 = __builtin_bit_cast(f32x4, e_w[j]);
-        const uint32_t t0 = e_t[j].x, t1 = e_t[j].y, t2 = e_t[j].z;
-        const float x = ac[0][s][j] + __builtin_bit_cast(float, t0), y = ac[1][s][j] + __builtin_bit_cast(float, t1),
-                    z = ac[2][s][j] + __builtin_bit_cast(float, t2);
-        const uint32_t id = e_id[j];
-        const int v = gp * 16 + g4 * 4 + j;
-#ifndef LF_DBG_NOSIDE
-        if (a.vp_side && bok[s] && (id >> 24)) {             // joint vertex: slot + 1 in the top byte (0 = none, padding rows too)
-            float* q = a.vp_side + ((size_t)(b0 + bl[s]) * m.n_jv + ((id >> 24) - 1)) * 3;
-            q[0] = x; q[1] = y; q[2] = z;
-        }
-#endif
-        float q[3];
-        if (LF_ABLATE & 2) {
-            q[0] = x + w4.x; q[1] = y; q[2] = z;
-        } else {
-            const float* Ab = bones + bl[s] * J12;
-            const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
-            float T[12];
-#pragma unroll
-            for (int e = 0; e < 12; ++e) T[e] = 0.f;
-#pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const float4* Ak = (const float4*)(Ab + ((id >> (6 * k)) & 0x3fu) * 12);
-                const float4 r0 = Ak[0], r1 = Ak[1], r2 = Ak[2];
-                T[0] = fmaf(wv[k], r0.x, T[0]); T[1] = fmaf(wv[k], r0.y, T[1]); T[2] = fmaf(wv[k], r0.z, T[2]); T[3] = fmaf(wv[k], r0.w, T[3]);
-                T[4] = fmaf(wv[k], r1.x, T[4]); T[5] = fmaf(wv[k], r1.y, T[5]); T[6] = fmaf(wv[k], r1.z, T[6]); T[7] = fmaf(wv[k], r1.w, T[7]);
-                T[8] = fmaf(wv[k], r2.x, T[8]); T[9] = fmaf(wv[k], r2.y, T[9]); T[10] = fmaf(wv[k], r2.z, T[10]); T[11] = fmaf(wv[k], r2.w, T[11]);
-            }
-            const float* Pb = Ps + bl[s] * 16;
-            const float4 tq = *(const float4*)(Pb + 12);     // translation as one aligned 16-byte read (x, y, z, 0)
-            q[0] = T[0] * x + T[1] * y + T[2] * z + T[3] + tq.x;
-            q[1] = T[4] * x + T[5] * y + T[6] * z + T[7] + tq.y;
-            q[2] = T[8] * x + T[9] * y + T[10] * z + T[11] + tq.z;
-            if (a.post) apply_post(Pb, q);
-        }
-        if (LF_ABLATE & 1) asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]));
-        else if (bok[s] && v < m.V) {
-            float* dst = a.vertices + ((size_t)(b0 + bl[s]) * m.V + v) * 3;
-            dst[0] = q[0]; dst[1] = q[1]; dst[2] = q[2];
-        }
-    };
-
-    lf_sfor<0, 4>([&](auto JJ) { load_ep(JJ, g); });
-    lf_sfor<0, LF_RING>([&](auto SL) { load_step(SL, frag_ptr(g, SL)); });
-    f32x4 accp[3][2];
-    int gp = g;
-    bool have_prev = false;
-    for (;; g += LF_NW) {
-        const bool has_next = g + LF_NW < gend;
-        // ------------------------------------------------ contraction of group g: 8 K steps x (3 components x 2 body sets x 3
-        // products), with the skinning of group gp between them
-        f32x4 acc[3][2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { acc[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
-        lf_sfor<0, LF_KS>([&](auto KS) {
-            constexpr int ks = KS, sl = ks % LF_RING;
-            // this step's fragments have landed: the steps requested after it (LF_RING - 1, fewer at the very end) may stay in
-            // flight; everything else in the queue (skinning operands, stores) only makes the wait conservative
-            constexpr int tail = (LF_KS - 1 - ks) < (LF_RING - 1) ? (LF_KS - 1 - ks) : (LF_RING - 1);
-            if (has_next) lf_wait_vmcnt<6 * (LF_RING - 1)>(); else lf_wait_vmcnt<6 * tail>();
-#pragma unroll
-            for (int i = 0; i < 6; ++i) asm volatile("" : "+v"(fr[sl][i]));
-            if constexpr ((ks & 1) == 0) {                   // operands of vertex ks/2 of the skinning round (requested >= 7 steps ago)
-                asm volatile("" : "+v"(e_id[ks >> 1]), "+v"(e_w[ks >> 1]), "+v"(e_t[ks >> 1]));
-            }
-            const unsigned char* cb = coefs + lr * LF_CROW + ks * 128 + g4 * 32;
-            const bf16x8 bh0 = __builtin_bit_cast(bf16x8, *(const u32x4*)cb), bl0 = __builtin_bit_cast(bf16x8, *(const u32x4*)(cb + 16));
-            const bf16x8 bh1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(cb + 16 * LF_CROW));
-            const bf16x8 bl1 = __builtin_bit_cast(bf16x8, *(const u32x4*)(cb + 16 * LF_CROW + 16));
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const bf16x8 dh = __builtin_bit_cast(bf16x8, fr[sl][2 * c]), dl = __builtin_bit_cast(bf16x8, fr[sl][2 * c + 1]);
-                if (LF_ABLATE & 8) { asm volatile("" : "+v"(acc[c][0]), "+v"(acc[c][1]) : "v"(dh), "v"(dl), "v"(bh0), "v"(bl0), "v"(bh1), "v"(bl1)); continue; }
-                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, bh0, acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, bh1, acc[c][1], 0, 0, 0);
-                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, bl0, acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dh, bl1, acc[c][1], 0, 0, 0);
-                acc[c][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, bh0, acc[c][0], 0, 0, 0);
-                acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(dl, bh1, acc[c][1], 0, 0, 0);
-            }
-            // (no scheduling barrier between the MFMAs and the pair: the compiler interleaves them)
-            if (have_prev) skin_pair(std::integral_constant<int, (ks >> 1)>{}, std::integral_constant<int, (ks & 1)>{}, accp, gp);
-            __builtin_amdgcn_sched_barrier(0);               // the requests below overwrite registers read above
-            if constexpr (ks & 1) {
-                if (have_prev) load_ep(std::integral_constant<int, (ks >> 1)>{}, g);   // vertex ks/2: both pairs done
-            }
-            if (!(LF_ABLATE & 4)) {
-                if constexpr (ks + LF_RING < LF_KS) load_step(std::integral_constant<int, sl>{}, frag_ptr(g, ks + LF_RING));
-                else { if (has_next) load_step(std::integral_constant<int, sl>{}, frag_ptr(g + LF_NW, ks + LF_RING - LF_KS)); }
-            }
-        });
-#pragma unroll
-        for (int c = 0; c < 3; ++c) { accp[c][0] = acc[c][0]; accp[c][1] = acc[c][1]; }
-        gp = g;
-        have_prev = true;
-        if (!has_next) break;
-    }
-    // drain: the last group's skinning (its operands: requested during its own contraction, or in the prologue)
-    lf_wait_vmcnt<0>();
-#pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(e_id[j]), "+v"(e_w[j]), "+v"(e_t[j]));
-    lf_sfor<0, 8>([&](auto PP) { skin_pair(std::integral_constant<int, (PP >> 1)>{}, std::integral_constant<int, (PP & 1)>{}, accp, gp); });
-}
-
-// ------------------------------------------------------------------------------------------------
-// Second cut of the fused contraction + skinning kernel (round 4; the default).  What the first cut's profile said
+// (The round-3 first cut -- rows = vertices, eight waves with a hand-counted register ring -- was retired in round 5: git history.)
+// The kernel (round 4).  What the first cut's profile said
 // (profiles/r03_lbs_fused_ablation.txt, PMC): every unit at a quarter of its rate, WRITE_SIZE twice the vertex bytes, and an
 // intermittent wrong vertex in one build of it (hand-counted asm loads with loop-carried destinations).  Changes:
 //   * ORIENTATION: rows = bodies, columns = vertices (A = coefficient rows from LDS, B = direction fragments from L2 -- the same
@@ -1009,40 +776,36 @@ hipError_t ap_launch_smplx_skin(const SmplxModelDev& m, const SmplxFwdArgs& a, h
     return hipGetLastError();
 }
 
+// T_KS_PACK: K steps of 32 in the packed direction fragments (K = 256: 20 shape / expression coefficients + 189 body-pose features +
+// the jaw / eye features, which are exactly zero on this path; the kernel multiplies the first T_KS = 7 steps)
+constexpr int T_KS_PACK = 8;
 bool ap_smplx_lbs_fused_supported(const SmplxModelDev& m) {
-    static_assert(T_BB == LF_BB && T_MAXJ == LF_MAXJ, "both cuts share the body-group size");
-    return m.K == 4 && m.J <= LF_MAXJ && m.dirs_frag != nullptr && m.skin_idx8 != nullptr && m.coef_split && m.ncoef * 4 >= LF_KS * 128;
+    return m.K == 4 && m.J <= T_MAXJ && m.dirs_frag != nullptr && m.skin_idx8 != nullptr && m.coef_split && m.ncoef * 4 >= T_KS_PACK * 128;
 }
 
-size_t ap_smplx_dirs_frag_bytes(int V) { return (size_t)((V + 15) / 16) * LF_KS * 6 * 1024; }
+size_t ap_smplx_dirs_frag_bytes(int V) { return (size_t)((V + 15) / 16) * T_KS_PACK * 6 * 1024; }
 
-hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, int cut, hipStream_t st) {
-    static bool attr_set[AP_MAX_DEVICES][2] = {};
+hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, hipStream_t st) {
+    static bool attr_set[AP_MAX_DEVICES] = {};
     if (!ap_smplx_lbs_fused_supported(m)) return hipErrorInvalidValue;
-    const bool second = cut != 1;                            // 2 (default): smplx_lbs_tail_kernel; 1: the first cut (kept for A/B)
-    const int nw = second ? T_NW : LF_NW;
-    const int lds = second ? T_BB * T_MAXJ * 12 * 4 + T_BB * T_CROW + T_BB * 64 : LF_BB * m.J * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64;
+    constexpr int lds = T_BB * T_MAXJ * 12 * 4 + T_BB * T_CROW + T_BB * 64;
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
-    if (!attr_set[dev][second]) {
-        e = second ? hipFuncSetAttribute((const void*)smplx_lbs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         T_BB * T_MAXJ * 12 * 4 + T_BB * T_CROW + T_BB * 64)
-                   : hipFuncSetAttribute((const void*)smplx_lbs_fused_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                         LF_BB * LF_MAXJ * 12 * 4 + LF_BB * LF_CROW + LF_BB * 64);
+    if (!attr_set[dev]) {
+        e = hipFuncSetAttribute((const void*)smplx_lbs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (e != hipSuccess) return e;
-        attr_set[dev][second] = true;
+        attr_set[dev] = true;
     }
     // body groups x vertex ranges ~ one workgroup per CU; 8 | n_vr keeps the blocks of one range on one XCD (block b runs on XCD
     // b % 8), so its direction rows are fetched from HBM once and served to the other body groups from that XCD's L2
-    const int bgs = (a.n + LF_BB - 1) / LF_BB, ngroups = (m.V + 15) / 16;
+    const int bgs = (a.n + T_BB - 1) / T_BB, ngroups = (m.V + 15) / 16;
     int n_vr = (n_cu + bgs - 1) / bgs;
     n_vr = n_vr >= 8 ? (n_vr / 8) * 8 : n_vr;
-    n_vr = n_vr < 1 ? 1 : (n_vr > (ngroups + nw - 1) / nw ? (ngroups + nw - 1) / nw : n_vr);
+    n_vr = n_vr < 1 ? 1 : (n_vr > (ngroups + T_NW - 1) / T_NW ? (ngroups + T_NW - 1) / T_NW : n_vr);
     const int gpv = (ngroups + n_vr - 1) / n_vr;
     n_vr = (ngroups + gpv - 1) / gpv;
-    if (second) hipLaunchKernelGGL(smplx_lbs_tail_kernel, dim3(bgs * n_vr), dim3(64 * T_NW), lds, st, m, a, n_vr, gpv);
-    else hipLaunchKernelGGL(smplx_lbs_fused_kernel, dim3(bgs * n_vr), dim3(64 * LF_NW), lds, st, m, a, n_vr, gpv);
+    hipLaunchKernelGGL(smplx_lbs_tail_kernel, dim3(bgs * n_vr), dim3(64 * T_NW), lds, st, m, a, n_vr, gpv);
     return hipGetLastError();
 }
 

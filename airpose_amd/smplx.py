@@ -263,7 +263,7 @@ class SMPLX(nn.Module):
 
     def set_fused(self, on):
         """Blend-shape contraction + skinning in one kernel where the call allows it (1, default), always as two kernels (0);
-        3: the first cut of the fused kernel, 4: the fused kernel with the joints stage inside it (A/B aids; 4 is slower)."""
+        4: the fused kernel with the joints stage inside it (A/B aid; slower)."""
         N.check(N.lib().ap_smplx_set_fused(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
                 "ap_smplx_set_fused")
 

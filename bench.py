@@ -485,9 +485,6 @@ def main():
         net.set_even_out(int(os.environ["AIRPOSE_EVEN_OUT"]))
     if os.environ.get("AIRPOSE_FUSE_BLOCK"):                # A/B aid: layer1 blocks: 1 fused kernel each (default), 0 separate convs
         net.set_fuse_block(int(os.environ["AIRPOSE_FUSE_BLOCK"]))
-    if os.environ.get("AIRPOSE_PAIR_GROUPS"):                # A/B aid: 16-pixel groups per wave of the layer3 pair kernel (ap_set_pair_groups)
-        from airpose_amd import _native as Nn
-        Nn.check(Nn.lib().ap_set_pair_groups(int(os.environ["AIRPOSE_PAIR_GROUPS"])), "ap_set_pair_groups")
     if os.environ.get("AIRPOSE_CONV_CONFIG"):                # A/B aid: tile configuration of the conv kernels (ap_set_conv_config)
         from airpose_amd import _native as Nn
         Nn.check(Nn.lib().ap_set_conv_config(int(os.environ["AIRPOSE_CONV_CONFIG"])), "ap_set_conv_config")

@@ -50,7 +50,7 @@ typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
 /* ABI number of this header: bumped whenever an exported signature changes or an entry point is removed (5: round 5 --
  * ap_conv_pair_* / ap_bottleneck64_nhwc take a leading `precision` and a caller-packed weight stream since 4).  A binding built
  * against another number must refuse to load the library (airpose_amd/_native.py does). */
-#define AP_ABI_VERSION 5
+#define AP_ABI_VERSION 6
 const char* ap_version(void);
 int ap_abi_version(void);
 const char* ap_last_error(void);
@@ -249,10 +249,6 @@ int ap_conv_pair_ds_nhwc(int precision, const void* t2, const void* x, const voi
  * Results are identical (bitwise) for every setting except 14 / the automatic choice on those layers: the slab kernel sums
  * the K range channel-chunk-outer, tap-inner instead of tap-outer, i.e. it agrees to fp32 re-association. */
 int ap_set_conv_config(int cfg);
-/* Tuning/testing knob (process-wide, one atomic word) of the fused pair kernel on the layer3 shapes (P = 256): 16-pixel groups
- * per wave -- 1: 16 pixels per wave, two workgroups per CU; 2: 32 pixels per wave (every weight fragment read from LDS feeds two
- * MFMAs, 32 MFMAs per barrier step), one workgroup per CU; -1: the library's choice.  Results are bit-identical. */
-int ap_set_pair_groups(int groups);
 /* Profiling aid: device buffer of 160 uint64 receiving per-phase cycle stamps of workgroup 0 of the pipelined
  * convolution kernel (2 waves x 8 K steps x 10 stamps); NULL (default) disables it. */
 int ap_debug_set_trace(void* device_buf_160_u64);
@@ -389,7 +385,7 @@ int ap_smplx_set_blend_precision(ap_smplx* h, int precision);
 /* Blend-shape contraction + skinning as ONE kernel (default on): taken when the call carries no hand / face poses (K = 224),
  * the model has at most 4 bones per vertex and the contraction runs in split-bf16 form; v_posed then never leaves the chip.
  * 0 = always the two-kernel path (contraction GEMM writing v_posed, then the skinning kernel).  Same arithmetic per product;
- * results agree to fp32 re-association.  3 = the first cut of the fused kernel.  4 = the fused kernel with the joints /
+ * results agree to fp32 re-association.  4 = the fused kernel with the joints /
  * landmarks / projection stage inside it: the LAST workgroup of each group of 32 bodies computes them from the skinned joint
  * vertices its siblings left in a side buffer (write-through stores, arrival counter, one acquire) -- one launch less, but
  * measured 7 us slower per forward of 512 bodies than the joints kernel as its own launch, so not the default. */

@@ -267,19 +267,9 @@ def _pair_case(dev, n, H, P, N1, seed, prec="bf16"):
     return [t.to(dev) for t in (t2, x, w3, w1, s3, h3, s1, h1)]
 
 
-@pytest.fixture(params=[1, 2])
-def pair_groups(request):
-    """Both layouts of the fused pair kernel on the layer3 shapes: 16 or 32 pixels per wave (ap_set_pair_groups); the other shapes
-    always run 16."""
-    from airpose_amd import _native as Nn
-    Nn.check(Nn.lib().ap_set_pair_groups(request.param), "ap_set_pair_groups")
-    yield request.param
-    Nn.lib().ap_set_pair_groups(-1)
-
-
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("case", PAIR_CASES)
-def test_conv_pair_equals_two_convs_and_fp64(dev, case, prec, pair_groups):
+def test_conv_pair_equals_two_convs_and_fp64(dev, case, prec):
     """conv_pair.hip: conv3 (+ identity, ReLU) of a block and conv1 of the next block in one kernel.  Bit-identical to the two
     stand-alone launches (same K order, same k-slot assignment, same epilogue expression), the block output against an fp64
     evaluation on identical operands, and rows beyond M untouched (ragged last tile)."""
@@ -355,7 +345,7 @@ def test_conv_pair_stream_is_caller_owned(dev):
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
 @pytest.mark.parametrize("case", [(3, 28, 128, 256, 128), (5, 14, 256, 512, 0), (1, 28, 128, 256, 128)])
-def test_conv_pair_stage_first_block_matches_fp64(dev, case, prec, pair_groups):
+def test_conv_pair_stage_first_block_matches_fp64(dev, case, prec):
     """conv_pair.hip on a stage's first block: conv3 with the downsample branch as a second K segment (the block input read at
     the stride-2 pixel), ReLU, and -- layer2.0 -- the next block's conv1 from the registers; against fp64 on identical operands."""
     from airpose_amd import _native as Nn
@@ -392,7 +382,7 @@ def test_conv_pair_stage_first_block_matches_fp64(dev, case, prec, pair_groups):
 
 
 @pytest.mark.parametrize("prec", ["bf16", "f16"])
-def test_conv_pair_full_size_is_deterministic(dev, prec, pair_groups):
+def test_conv_pair_full_size_is_deterministic(dev, prec):
     """BASELINE-size layer3 pair (256 images: 50 176 pixels, 784 workgroups on 512 slots, hand-counted waits under full
     memory load): repeated runs identical, equal to the two stand-alone kernels."""
     from airpose_amd import _native as Nn
@@ -422,7 +412,7 @@ def test_conv_pair_full_size_is_deterministic(dev, prec, pair_groups):
         assert torch.equal(o, ref_out) and torch.equal(t, ref_t1)
 
 
-def test_trunk_with_and_without_fused_pairs_bitwise(net16, dev, pair_groups):
+def test_trunk_with_and_without_fused_pairs_bitwise(net16, dev):
     netbf = net16
     """The trunk with the fused conv3 -> conv1 pairs (layer2 / layer3 identity blocks, layer2 -> layer3) against the same
     trunk with one convolution per launch: identical features, bit for bit; 6 images make every pair's pixel count ragged."""
@@ -1407,7 +1397,7 @@ def test_smplx_forward_matches_oracle(body, smplx_model, dev):
     assert rel_err(out.joints.cpu().numpy(), want_j.numpy()) < TOL32
 
 
-@pytest.mark.parametrize("cut", [1, 3, 4])                     # set_fused(1): the default; 3: first cut; 4: joints stage inside the kernel
+@pytest.mark.parametrize("cut", [1, 4])                        # set_fused(1): the default; 4: joints stage inside the kernel
 @pytest.mark.parametrize("B", [3, 32, 77])
 def test_smplx_fused_lbs_matches_two_kernel_path(body, smplx_model, dev, B, cut):
     """smplx_lbs_fused_kernel (blend-shape contraction + skinning in one kernel, v_posed on chip) against the two-kernel path

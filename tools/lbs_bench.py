@@ -22,7 +22,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--bodies", default="512,4096,16384")
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--fused", type=int, default=1, help="1: fused contraction + skinning (default); 4: joints stage inside the kernel too; 3: the first cut; 0: two kernels")
+    ap.add_argument("--fused", type=int, default=1, help="1: fused contraction + skinning (default); 4: joints stage inside the kernel too; 0: two kernels")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     body = smplx.SMPLX(model_data=smplx_model.make_synthetic_model(4321))

@@ -50,17 +50,12 @@ def main():
             N.check(L.ap_conv2d_nhwc(bf, p(t2), p(w3), p(s3), p(h3), p(x), p(out2), n, H, H, P, C3, 1, 1, 0, 1, st), "c3")
             N.check(L.ap_conv2d_nhwc(bf, p(out2), p(w1), p(s1), p(h1), None, p(t1b), n, H, H, C3, N1, 1, 1, 0, 1, st), "c1")
 
-        def fused2():                                        # 32 pixels per wave (layer3 shape only; elsewhere the same kernel as `fused`)
-            L.ap_set_pair_groups(2)
-            fused()
-            L.ap_set_pair_groups(-1)
-
-        res = {"fused": [], "fused2": [], "two": []}
-        for f in (fused, fused2, two):
+        res = {"fused": [], "two": []}
+        for f in (fused, two):
             for _ in range(3):
                 f()
         for _ in range(args.rounds):
-            for nm, f in (("fused", fused), ("fused2", fused2), ("two", two)):
+            for nm, f in (("fused", fused), ("two", two)):
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
                 for _ in range(args.iters):
@@ -76,9 +71,6 @@ def main():
         print("%-11s M=%7d P=%3d N1=%3d | fused %7.1f us (min %7.1f) %6.0f TF/s %5.0f GB/s | two launches %7.1f us (min %7.1f) %6.0f TF/s "
               "%5.0f GB/s | x%.2f" % (tag, M, P, N1, med["fused"], min(res["fused"]), flops / med["fused"] / 1e6, b_f / med["fused"] / 1e3,
                                       med["two"], min(res["two"]), flops / med["two"] / 1e6, b_t / med["two"] / 1e3, med["two"] / med["fused"]))
-        if P == 256:
-            print("            32 pixels per wave (ap_set_pair_groups(2)): %7.1f us (min %7.1f) %6.0f TF/s | x%.2f of the 16-pixel kernel" % (
-                med["fused2"], min(res["fused2"]), flops / med["fused2"] / 1e6, med["fused"] / med["fused2"]))
 
 
 if __name__ == "__main__":
