@@ -424,6 +424,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
 #ifndef BI_LA3
 #define BI_LA3 7
 #endif
+#ifndef BI_STAUX
+#define BI_STAUX 0                                           // cache policy of the output stores (A/B): 2 = nt
+#endif
                 bi_pipe<112, BI_LA3>(bf,
                     [&](auto I, u32x4& d) __attribute__((always_inline)) {
                         constexpr int n = decltype(I)::value, ks = n / 14, g = n % 14, R = g + 1;
@@ -451,7 +454,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 for (int g = 0; g < 14; ++g) {
                     const u32x4 o = bi_bn8(acc[0][g], acc[1][g], s0, s1, h0, h1, &idr[g], rng);
                     const uint32_t vo = li < BI_HW ? so + g * 28672 + idoff : 0xffffff00u;      // (junk columns: dropped by the range check)
-                    __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, vo, 0, 0);
+                    __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, vo, 0, BI_STAUX);
                 }
             };
 #ifndef BI_EXP
