@@ -81,6 +81,10 @@ SIGNATURES = {
     "ap_block_img_stream_bytes": (_c.c_int64, []),
     "ap_block_img_pack": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "ap_block_img_nhwc": (_i, [_i] + [_vp] * 9 + [_i, _vp]),
+    "ap_conv_pw_stream_bytes": (_c.c_int64, [_i, _i]),
+    "ap_conv_pw_pack": (_i, [_i, _vp, _i, _i, _vp, _vp]),
+    "ap_conv_pw_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 3 + [_vp]),
+    "ap_net_set_pw_conv": (_i, [_vp, _i]),
     "ap_net_set_fuse_tail": (_i, [_vp, _i]),
     "ap_net_set_even_out": (_i, [_vp, _i]),
     "ap_net_set_img_block": (_i, [_vp, _i]),
@@ -106,7 +110,7 @@ SIGNATURES = {
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 6          # include/airpose_hip.h: AP_ABI_VERSION
+ABI_VERSION = 7          # include/airpose_hip.h: AP_ABI_VERSION
 _lib = None
 _lib_lock = threading.Lock()
 

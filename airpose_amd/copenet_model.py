@@ -368,6 +368,11 @@ class copenet(nn.Module):
         of the chip, 2 always, 0 never (conv2 + fused pairs); same bits."""
         self._set_knob("ap_net_set_img_block", on)
 
+    def set_pw_conv(self, on):
+        """bf16 / f16: the pointwise layers of layer3 / layer4 no fused kernel covers on the one-wave-per-SIMD kernel (conv_pw.hip): 1 (default)
+        when their tiles fill whole rounds of the chip, 2 whenever supported, 0 never (generic kernels); same bits."""
+        self._set_knob("ap_net_set_pw_conv", on)
+
     def set_even_out(self, on):
         """bf16 / f16: block outputs only a stride-2 downsample reads are stored at the even pixels only (default) or in full."""
         self._set_knob("ap_net_set_even_out", on)

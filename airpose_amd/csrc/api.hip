@@ -76,6 +76,7 @@ struct Layer {                  // a conv or linear layer in packed device form
     int wld = 0, cout_pad = 0;
     int cin2 = 0, stride2 = 1;      // second K segment (downsample folded into conv3)
     DevBuf w, scale, shift;
+    DevBuf pw;                      // pointwise layers of layer3 / layer4: the weights as conv_pw.hip's fragment streams
 };
 
 struct Timing {
@@ -267,6 +268,9 @@ struct ap_net {
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_tail = true;         // 16-bit modes: conv1 of layer2.0 inside the kernel of layer1's last block (bottleneck2.hip, tail variant);
                                    // the block output is then stored at the even pixels only (layer2.0's stride-2 downsample reads nothing else)
+    int pw_conv = 1;               // 16-bit modes: conv1 / conv3 + identity of layer3 / layer4 bottlenecks that no fused kernel covers on the one-wave-per-SIMD
+                                   // pointwise kernel (conv_pw.hip): 0 never; 1 (default) when the tiles fill whole rounds of the chip AND the pass is
+                                   // not one of two concurrent ones; 2 whenever supported
     int img_block = 1;             // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip): 0 never,
                                    // 1 when the pass fills whole rounds of the chip (an image per CU; same bits either way), 2 always
     bool even_out = true;          // 16-bit modes: a pair block whose output is read by a stride-2 downsample branch ONLY stores the even pixels
@@ -450,8 +454,25 @@ int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const
     return AP_OK;
 }
 
+// pw: 0 = the generic kernels; 1 / 2 = conv_pw.hip where the layer has a stream and the shape fits (1: only when its tiles fill
+// at least 80 % of whole rounds of the chip) -- same bits either way, so the choice may depend on the problem size
 int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int prec,
-             hipStream_t st, int* rflag = nullptr, int y_tiled = 0) {
+             hipStream_t st, int* rflag = nullptr, int y_tiled = 0, int pw = 0) {
+    if (pw && L.pw.p && prec_half(prec) && relu && !y_tiled && L.k == 1 && L.stride == 1 &&
+        g_conv_mode.load(std::memory_order_relaxed) == -1 && k_bf16::ap_conv_pw_supported((long)N * H * W, L.cin, L.cout)) {
+        const long M = (long)N * H * W;
+        int cus = 0;
+        HIP_TRY(device_cus(&cus));
+        const int NN = L.cout >> 8, gmax = k_bf16::ap_conv_pw_grid(1L << 40, L.cout, cus);
+        const long T = ((M / 196 + 7) & ~7L) * NN, rounds = (T + gmax - 1) / gmax;
+        if (pw == 2 || T * 5 >= rounds * gmax * 4) {
+            PwArgs p{};
+            p.x = x; p.y = y; p.res = res; p.wfrag = L.pw.p; p.scale = L.scale.as<float>(); p.shift = L.shift.as<float>();
+            p.M = (int)M; p.Cin = L.cin; p.Cout = L.cout; p.relu = 1; p.range_flag = rflag;
+            HIP_TRY(H16(prec, ap_launch_conv_pw)(p, st));
+            return AP_OK;
+        }
+    }
     ConvArgs a{};
     a.range_flag = rflag;
     a.y_tiled = y_tiled;
@@ -610,6 +631,15 @@ int finalize_trunk(ap_net* h) {
             HIP_TRY(B.imgw.reserve(k_bf16::ap_block_img_stream_bytes()));
             HIP_TRY(H16(h->prec, ap_launch_block_img_pack)(B.c1.w.p, B.c2.w.p, B.c3.w.p, B.imgw.p, nullptr));
         }
+    // pointwise layers of the 14 x 14 and 7 x 7 stages: weight streams of conv_pw.hip (conv1, and conv3 of the identity blocks)
+    if (h->half())
+        for (auto& B : h->blocks)
+            for (Layer* L : {&B.c1, &B.c3}) {
+                if (L->k != 1 || L->stride != 1 || L->cin2 || L->cin < 256 || L->cin % 128 || L->cout % 256 || (L == &B.c3 && B.has_down)) continue;
+                if (L->cin * L->cout < 1024 * 256) continue;             // (layer1 / layer2: HBM-bound, and covered by the fused kernels)
+                HIP_TRY(L->pw.reserve(k_bf16::ap_conv_pw_stream_bytes(L->cin, L->cout)));
+                HIP_TRY(H16(h->prec, ap_launch_conv_pw_pack)(L->w.p, L->pw.p, L->cin, L->cout, L->wld, nullptr));
+            }
     HIP_TRY(hipDeviceSynchronize());
     return AP_OK;
 }
@@ -887,6 +917,9 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         return bf && h->fuse_pair && X.pair_p && &X != &h->blocks.back() && (!X.has_down || h->fuse_ds);
     };
     bool cur_tiled = false;                                  // layout of `cur`
+    // conv_pw.hip takes whole CUs (one wave per SIMD, all 512 registers): measured +0.7 % of the whole bench when a pass has the chip
+    // to itself, -0.5 % beside the other view's concurrent pass (whose kernels it keeps off its CUs) -- ev_out marks the latter
+    const int pw_conv = (h->pw_conv == 1 && ev_out) ? 0 : h->pw_conv;
     for (auto& B : h->blocks) {
         if (signal_at >= 2 && blk++ == signal_at - 2) HIP_TRY(hipEventRecord(h->ev_skew, st));
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
@@ -924,7 +957,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             continue;
         }
         if (!t1_ready && cur_tiled) return fail(AP_ESTATE, "trunk: conv1 of a block would read a tiled block output");
-        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, h->range_flag))) return rc;
+        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, h->range_flag, 0, pw_conv))) return rc;
         t1_ready = false;
         const bool pair = is_pair(B);
         const int t2_tiled = pair && tiling;
@@ -976,7 +1009,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
                 if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, prec, st, h->range_flag))) return rc;
                 res = w.ws_ds.p;
             }
-            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st, h->range_flag))) return rc;
+            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st, h->range_flag, 0, B.has_down ? 0 : pw_conv))) return rc;
         }
         std::swap(cur, nxt);
         H = Ho;
@@ -1212,7 +1245,7 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
 // ================================================================================== C ABI
 extern "C" {
 
-const char* ap_version(void) { return "airpose_hip 0.5 (gfx950; abi 6)"; }
+const char* ap_version(void) { return "airpose_hip 0.5 (gfx950; abi 7)"; }
 int ap_abi_version(void) { return AP_ABI_VERSION; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
@@ -1471,6 +1504,29 @@ int ap_bottleneck64_tail_nhwc(int precision, const void* x, const void* w1, cons
     return AP_OK;
 }
 
+int64_t ap_conv_pw_stream_bytes(int Cin, int Cout) {
+    return (Cin > 0 && Cout > 0 && Cin % 32 == 0 && Cout % 256 == 0) ? (int64_t)k_bf16::ap_conv_pw_stream_bytes(Cin, Cout) : -1;
+}
+
+int ap_conv_pw_pack(int precision, const void* w, int Cin, int Cout, void* wstream, void* stream) {
+    if (!prec_half(precision) || !w || !wstream || Cin <= 0 || Cout <= 0 || Cin % 32 || Cout % 256)
+        return fail(AP_EINVAL, "ap_conv_pw_pack: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16; Cin % 32 == 0, Cout % 256 == 0)");
+    HIP_TRY(H16(precision, ap_launch_conv_pw_pack)(w, wstream, Cin, Cout, Cin, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_conv_pw_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, const void* res,
+                    void* y, int M, int Cin, int Cout, void* stream) {
+    if (!prec_half(precision) || !x || !wstream || !scale || !shift || !y)
+        return fail(AP_EINVAL, "ap_conv_pw_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
+    if (!k_bf16::ap_conv_pw_supported(M, Cin, Cout))
+        return fail(AP_ESHAPE, "ap_conv_pw_nhwc: M must be a multiple of 196, Cin of 128 (>= 256), Cout of 256");
+    PwArgs p{};
+    p.x = x; p.y = y; p.res = res; p.wfrag = wstream; p.scale = scale; p.shift = shift; p.M = M; p.Cin = Cin; p.Cout = Cout; p.relu = 1;
+    HIP_TRY(H16(precision, ap_launch_conv_pw)(p, (hipStream_t)stream));
+    return AP_OK;
+}
+
 int64_t ap_block_img_stream_bytes(void) { return (int64_t)k_bf16::ap_block_img_stream_bytes(); }
 
 int ap_block_img_pack(int precision, const void* w1, const void* w2, const void* w3, void* wstream, void* stream) {
@@ -1638,6 +1694,12 @@ int ap_net_set_fuse_pair(ap_net* h, int on) {
 int ap_net_set_fuse_tail(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fuse_tail = on != 0;
+    return AP_OK;
+}
+
+int ap_net_set_pw_conv(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->pw_conv = on < 0 ? 0 : (on > 2 ? 2 : on);
     return AP_OK;
 }
 

@@ -40,20 +40,7 @@ constexpr int BI_SLOTS_TOTAL = BI_STEPS12 + 32;              // + conv3: 64 step
 constexpr size_t BI_WAVE_BYTES = (size_t)BI_SLOTS_TOTAL * 4096;   // 557 056 per wave, 2 228 224 per block
 static_assert(BI_XS + 2 * BI_XS_STAGE <= 241 * 512, "the staging ring stays clear of the zero rows");
 
-template <int I, int N, typename F> __device__ __forceinline__ void sfor(F&& f) {
-    if constexpr (I < N) {
-        f(std::integral_constant<int, I>{});
-        sfor<I + 1, N>(f);
-    }
-}
-typedef __attribute__((ext_vector_type(2))) float f32x2;
-
-// channel (within its tile) of row rho of a wave's weight tile: a lane's accumulator elements of a fragment PAIR are then 8
-// consecutive channels = one 16-byte piece of a B fragment / of an NHWC row (conv_pair.hip: pr_row_channel)
-__host__ __device__ __forceinline__ int bi_row_channel(int rho) {
-    const int f = rho >> 4, i = rho & 15;
-    return (f >> 1) * 32 + (i >> 2) * 8 + (f & 1) * 4 + (i & 3);
-}
+#include "bi_helpers.inc"
 
 // weight stream: wave w -> [conv1: 32 steps][conv2: 72 steps (64-channel chunk, tap, K half)] of 4 fragments (64 rows) + [conv3: 8 chunks x 8 steps] of
 // 2 fragments (32 rows); fragment = [lane 64][8 K values]: row lane & 15, K columns 8 (lane >> 4) .. + 7 of the step's 32
@@ -80,109 +67,6 @@ __global__ void __launch_bounds__(256) blk_img_pack_kernel(const bf16_t* __restr
         src = w3 + (size_t)ch * BI_P + ks * 32 + (lane >> 4) * 8;
     }
     *(u32x4*)(dst + idx * 16) = *(const u32x4*)src;
-}
-
-__device__ __forceinline__ uint32_t bi_cvt_pk(float a, float b) {
-    uint32_t r;
-    asm(AP_CVTPK_ASM " %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
-    return r;
-}
-__device__ __forceinline__ uint32_t bi_relu_pk(uint32_t u) {
-    uint32_t r;
-    asm("v_pk_max_i16 %0, %1, 0" : "=v"(r) : "v"(u));
-    return r;
-}
-// BN (+ identity) + ReLU + 16-bit of the 8 consecutive channels a lane holds in a fragment pair: the expression of the stand-alone
-// kernels' epilogue (fma, add, max, round)
-__device__ __forceinline__ u32x4 bi_bn8(const f32x4& lo, const f32x4& hi, const f32x4& s0, const f32x4& s1, const f32x4& h0,
-                                        const f32x4& h1, const u32x4* res, uint32_t& rng) {
-    f32x2 v0 = __builtin_elementwise_fma(lo.xy, s0.xy, h0.xy), v1 = __builtin_elementwise_fma(lo.zw, s0.zw, h0.zw);
-    f32x2 v2 = __builtin_elementwise_fma(hi.xy, s1.xy, h1.xy), v3 = __builtin_elementwise_fma(hi.zw, s1.zw, h1.zw);
-    if (res) {
-        const uint32_t r0 = (*res).x, r1 = (*res).y, r2 = (*res).z, r3 = (*res).w;
-#ifdef AP_F16
-        { float a_ = v0.x, b_ = v0.y; ap_res_add2(a_, b_, r0); v0 = f32x2{a_, b_}; }
-        { float a_ = v1.x, b_ = v1.y; ap_res_add2(a_, b_, r1); v1 = f32x2{a_, b_}; }
-        { float a_ = v2.x, b_ = v2.y; ap_res_add2(a_, b_, r2); v2 = f32x2{a_, b_}; }
-        { float a_ = v3.x, b_ = v3.y; ap_res_add2(a_, b_, r3); v3 = f32x2{a_, b_}; }
-#else
-        { float a_, b_; unpack_bf16x2(r0, a_, b_); v0 += f32x2{a_, b_}; }
-        { float a_, b_; unpack_bf16x2(r1, a_, b_); v1 += f32x2{a_, b_}; }
-        { float a_, b_; unpack_bf16x2(r2, a_, b_); v2 += f32x2{a_, b_}; }
-        { float a_, b_; unpack_bf16x2(r3, a_, b_); v3 += f32x2{a_, b_}; }
-#endif
-    }
-    u32x4 o;
-    o.x = bi_relu_pk(bi_cvt_pk(v0.x, v0.y)); o.y = bi_relu_pk(bi_cvt_pk(v1.x, v1.y));
-    o.z = bi_relu_pk(bi_cvt_pk(v2.x, v2.y)); o.w = bi_relu_pk(bi_cvt_pk(v3.x, v3.y));
-    ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);
-    return o;
-}
-__device__ __forceinline__ void bi_mm(f32x4& c, const u32x4& w, const u32x4& x) {
-    c = ap_mfma16(__builtin_bit_cast(bf16x8, w), __builtin_bit_cast(bf16x8, x), c);
-}
-__device__ __forceinline__ void bi_sts(unsigned char* smem, uint32_t off, const u32x4& v) {
-    *(u32x4*)__builtin_assume_aligned(smem + off, 16) = v;
-}
-
-// ---- hand-placed memory operations and MFMAs.  Left to hipcc (first cut of this file, bit-identical results, 3x slower) every
-// operand fragment was read right in front of its four MFMAs behind an s_waitcnt lgkmcnt(0), every weight prefetch was sunk to its
-// use behind vmcnt(0), and the accumulators wandered between the two register halves.  Here, as in the other kernels of this
-// library: loads are asm statements the compiler cannot move, a destination is valid only behind the counted wait that covers
-// it, and an MFMA updates its accumulator in place.  vmcnt / lgkmcnt retire in order per type, so a wait for "at most N younger
-// operations" is exact when N operations are known to follow the target and merely conservative when more do.
-#ifndef BI_SAFE
-#define BI_SAFE 0                                            // 1: every counted vmcnt becomes 0, 2: every counted lgkmcnt too (cross-checks)
-#endif
-template <int N> __device__ __forceinline__ void bi_wait_vm() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(BI_SAFE ? 0 : N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int N> __device__ __forceinline__ void bi_wait_lgkm() {
-    asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(BI_SAFE > 1 ? 0 : N) : "memory");
-    __builtin_amdgcn_sched_barrier(0);
-}
-template <int OFF> __device__ __forceinline__ void bi_ldsr(u32x4& r, uint32_t addr) {
-    asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(r) : "v"(addr), "n"(OFF));
-}
-// uniform base (SGPR pair) + 32-bit lane offset
-template <int OFF> __device__ __forceinline__ void bi_gld(u32x4& r, uint32_t voff, const unsigned char* sbase) {
-    // (the bases are uniform by construction; readfirstlane makes that provable where hipcc lost track: folded away otherwise)
-    const uint64_t u = (uint64_t)sbase;
-    const uint64_t su = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(u >> 32)) << 32) |
-                        (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)u);
-    // s_nop 4: the base may come straight out of a v_readlane / v_readfirstlane (an SGPR the compiler had spilled to a VGPR lane):
-    // VALU write of an SGPR -> VMEM read of it needs 5 wait states, and hipcc pads nothing in front of an asm statement.  Without
-    // the pad the load now and then used the PREVIOUS value of the pair (seen: the identity of image row 5 added to row 6)
-    asm volatile("s_nop 4\n\tglobal_load_dwordx4 %0, %1, %2 offset:%3" : "=v"(r) : "v"(voff), "s"(su), "n"(OFF) : "memory");
-}
-__device__ __forceinline__ void bi_mma(f32x4& c, const u32x4& w, const u32x4& x) {
-    asm volatile(AP_MFMA16_ASM " %0, %1, %2, %0" : "+a"(c) : "v"(w), "v"(x));
-}
-__device__ __forceinline__ void bi_mma0(f32x4& c, const u32x4& w, const u32x4& x) {      // first K step: C = 0
-    asm volatile(AP_MFMA16_ASM " %0, %1, %2, 0" : "=a"(c) : "v"(w), "v"(x));
-}
-// The last MFMAs' results must settle before a VALU instruction reads them, and hipcc pads nothing around an asm MFMA: the nops
-// name the accumulators as operands, or the compiler hoists its v_accvgpr_read above them (it did: register-only instructions
-// ignore a "memory" clobber)
-__device__ __forceinline__ void bi_settle28(f32x4 (&p)[14], f32x4 (&q)[14]) {
-    asm volatile("s_nop 15\n\ts_nop 15"
-                 : "+a"(p[0]), "+a"(p[1]), "+a"(p[2]), "+a"(p[3]), "+a"(p[4]), "+a"(p[5]), "+a"(p[6]), "+a"(p[7]), "+a"(p[8]), "+a"(p[9]),
-                   "+a"(p[10]), "+a"(p[11]), "+a"(p[12]), "+a"(p[13]), "+a"(q[0]), "+a"(q[1]), "+a"(q[2]), "+a"(q[3]), "+a"(q[4]),
-                   "+a"(q[5]), "+a"(q[6]), "+a"(q[7]), "+a"(q[8]), "+a"(q[9]), "+a"(q[10]), "+a"(q[11]), "+a"(q[12]), "+a"(q[13]));
-    __builtin_amdgcn_sched_barrier(0);
-}
-// B-fragment pipeline of one segment of NR 16-pixel groups: LA reads in flight ahead of the MFMAs (LA fragment registers in use)
-template <int NR, int LA, typename RD, typename USE> __device__ __forceinline__ void bi_pipe(u32x4 (&b)[16], RD&& rd, USE&& use) {
-    static_assert(LA >= 1 && LA <= 15, "lgkmcnt is 4 bits");
-    sfor<0, (NR < LA ? NR : LA)>([&](auto I) __attribute__((always_inline)) { rd(I, b[decltype(I)::value & 15]); });
-    sfor<0, NR>([&](auto I) __attribute__((always_inline)) {
-        constexpr int n = decltype(I)::value, rem = NR - 1 - n;
-        bi_wait_lgkm<(rem < LA - 1 ? rem : LA - 1)>();
-        use(I, b[n & 15]);
-        __builtin_amdgcn_sched_barrier(0);
-        if constexpr (n + LA < NR) rd(std::integral_constant<int, n + LA>{}, b[(n + LA) & 15]);
-    });
 }
 
 // conv2, one pair of 64-channel chunks = 36 K steps = 480 groups: group n -> chunk parity, tap (dr, dc), K half, pixel row

@@ -1,0 +1,275 @@
+// Pointwise (1 x 1, stride 1) convolution + BatchNorm (+ identity) + ReLU on block_img.hip's mainloop (16-bit storage, gfx950):
+// the K >= 512 pointwise layers the image-resident blocks do not cover -- conv1 of layer4's bottlenecks and conv3 (+ identity) of
+// its identity blocks (Bottleneck.forward, model_copenet.py:29-31 and :38-45, iterated by :64-65).
+//
+// Why a second pointwise kernel: on the 128 x 128-tile ring kernel these layers run at 670-750 TF/s (0.75 LDS operand fetches per
+// MFMA, two workgroups per CU sharing the matrix pipe, three rounds of the chip with a short last one); block_img's conv1 phase
+// does the same arithmetic at 0.32 fetches per MFMA.  This file is that phase as a kernel of its own:
+//   * a workgroup = four waves, one per SIMD, 512 registers each; tile = 196 pixels (13 groups of 16: 4 images of 7 x 7, or one of
+//     14 x 14 -- every layer3 / layer4 tensor is a whole number of tiles) x 256 output channels, 64 per wave: 52 accumulators of
+//     16 x 16 in the accumulator half of the register file;
+//   * weights never touch the LDS: a wave streams its 64 rows as MFMA A fragments from L2, packed at finalize time in consumption
+//     order (one contiguous 4-KiB piece per K step of 32), through a four-piece register ring;
+//   * x passes through a two-stage LDS ring in K chunks of 64 (register-staged two chunks ahead), 16-byte pieces at
+//     piece ^ (pixel & 7): conflict-free ds_read_b128;
+//   * the tiles of one pixel range (2 or 8 of them: Cout / 256) run on the same XCD at the same time, so x comes from HBM once;
+//   * persistent over tiles; a workgroup keeps its output-channel range, so its weight stream simply wraps and the ring runs ahead
+//     across tiles;
+//   * identity: the staging loads of the last K iteration (which have no chunk left to fetch) fetch the first half of the identity
+//     instead; the second half takes each register as the epilogue frees it.
+// K order per output element = the ring / lean kernels' (K steps of 32 in order, one MFMA chain): bit-identical results, so the
+// trunk may choose by problem size (ap_net_set_pw_conv).
+#include <type_traits>
+
+#include "ap_common.h"
+#include "kernels.h"
+
+AP_NS_BEGIN
+
+namespace {
+
+constexpr int PW_STAGE = 224 * 128;                          // one staging buffer: 224 pixel slots x 64 channels
+constexpr int PW_LDS = 2 * PW_STAGE;
+
+#include "bi_helpers.inc"
+
+// dst [N tile][wave][K step][fragment 4][lane 64][8 K values]: row (lane & 15) of fragment f = output channel
+// ntile * 256 + wave * 64 + bi_row_channel(16 f + (lane & 15)), K columns 8 (lane >> 4) .. + 7 of the step's 32
+__global__ void __launch_bounds__(256) pw_pack_kernel(const bf16_t* __restrict__ w, unsigned char* __restrict__ dst, int cin, int cout, int wld) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t per_wave = (size_t)(cin >> 5) * 256, per_nt = 4 * per_wave;
+    if (idx >= (size_t)(cout >> 8) * per_nt) return;
+    const int nt = (int)(idx / per_nt);
+    const size_t r = idx - (size_t)nt * per_nt;
+    const int wv = (int)(r / per_wave), p = (int)(r - (size_t)wv * per_wave);
+    const int step = p >> 8, f = (p >> 6) & 3, lane = p & 63;
+    const int ch = nt * 256 + wv * 64 + bi_row_channel(f * 16 + (lane & 15));
+    *(u32x4*)(dst + idx * 16) = *(const u32x4*)(w + (size_t)ch * wld + step * 32 + (lane >> 4) * 8);
+}
+
+template <int NG, bool RES>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) conv_pw_kernel(const PwArgs a) {
+    static_assert(NG == 13, "196-pixel tiles");
+    constexpr int TM = 196;
+    extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int li = lane & 15, kq = lane >> 4;
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+    uint32_t rng = 0u;
+
+    const int Cin = a.Cin, Cout = a.Cout, NN = Cout >> 8, NC = Cin >> 6, KS = Cin >> 5;
+    const int MT8 = (a.M / TM + 7) & ~7;                     // pixel tiles, rounded up to whole groups of eight (one per XCD)
+    const long T = (long)MT8 * NN;
+    // tile t -> XCD t & 7 (= blockIdx & 7: the grid is a multiple of 8 NN), N tile (t >> 3) % NN, pixel tile ((t >> 3) / NN) * 8 + XCD:
+    // the NN tiles of a pixel range are neighbours in dispatch order on ONE XCD, and t += gridDim keeps the N tile
+    const int xcd = blockIdx.x & 7, ntile = (int)((blockIdx.x >> 3) % NN);
+    const unsigned char* const xg = (const unsigned char*)a.x;
+    const unsigned char* const rg = (const unsigned char*)a.res;
+    const float* const bs = a.scale + ntile * 256 + wave * 64;
+    const float* const bh = a.shift + ntile * 256 + wave * 64;
+    const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)a.y, 0, (int)((uint32_t)a.M * (uint32_t)Cout * 2u), 0x00020000);
+    const unsigned char* const wsb = (const unsigned char*)a.wfrag + ((size_t)ntile * 4 + wave) * (size_t)KS * 4096;
+    // every kernel-argument load completes here (scalar loads share lgkmcnt with the counted fragment reads)
+    asm volatile("" ::"s"(xg), "s"(rg), "s"(bs), "s"(bh), "s"(wsb), "s"(Cin), "s"(Cout), "s"(KS));
+    const uint32_t wlane = lane * 16;
+    const unsigned char* wp = wsb;
+    int wcnt = 0;
+    u32x4 ar[4][4];
+    auto refill = [&](auto SL, u32x4 (&r)[4][4]) __attribute__((always_inline)) {           // ring slot SL <- the next piece of the stream
+        constexpr int sl = decltype(SL)::value;
+        bi_gld<0>(r[sl][0], wlane, wp); bi_gld<1024>(r[sl][1], wlane, wp);
+        bi_gld<2048>(r[sl][2], wlane, wp); bi_gld<3072>(r[sl][3], wlane, wp);
+        wp += 4096;
+        if (++wcnt == KS) { wcnt = 0; wp = wsb; }
+    };
+    sfor<0, 4>([&](auto S) __attribute__((always_inline)) { refill(S, ar); });
+
+    // ---- x staging: thread = (slot column col, 16-byte piece pc) of slot rows xr0 + 2 j, j = 0 .. 6; slot = tile pixel (slots 196 ..
+    // 223 fetch pixel 195 again: never used, always inside the tensor)
+    const int xcol = (tid >> 3) & 15, xpc = tid & 7, xr0 = tid >> 7;
+    const uint32_t xrow = (uint32_t)Cin * 2u;                // bytes per pixel row of x
+    const uint32_t xoff = (uint32_t)(xr0 * 16 + xcol) * xrow + (uint32_t)xpc * 16u;
+    const int s6 = (xr0 + 12) * 16 + xcol;
+    const uint32_t xoff6 = (uint32_t)(s6 < TM ? s6 : TM - 1) * xrow + (uint32_t)xpc * 16u;
+    const uint32_t xs_w = (uint32_t)((xr0 * 16 + xcol) * 128 + ((xpc ^ (xcol & 7)) << 4));
+    // B fragments out of a staging buffer: slot 16 g + li, piece 4 ks + kq at position piece ^ (slot & 7)
+    const uint32_t xs_r = lds0 + (uint32_t)(li * 128 + (((li >> 2) & 1) << 6) + ((kq ^ (li & 3)) << 4));
+    // identity / output: this lane's 8 channels (ntile * 256 + wave * 64 + q * 32 + 8 kq ..) of tile pixel 16 g + li
+    const uint32_t orow = (uint32_t)Cout * 2u;
+    const uint32_t ochan = (uint32_t)(ntile * 256 + wave * 64 + kq * 8) * 2u;
+    const uint32_t idoff = (uint32_t)li * orow + ochan;
+    const uint32_t idoff12 = (uint32_t)(li < 4 ? li : 3) * orow + ochan;                    // group 12: pixels 192 .. 195 + 12 junk lanes
+    using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+
+    f32x4 acc[4][14];
+    u32x4 bf[8];
+
+    for (long t = blockIdx.x; t < T; t += gridDim.x) {
+        const int mtile = (int)((t >> 3) / NN) * 8 + xcd;
+        const long m0 = (long)mtile * TM;
+        if (m0 >= a.M) continue;                             // (uniform: the padding tiles of the last group of eight)
+        const unsigned char* const xt = xg + (size_t)m0 * xrow;
+        const unsigned char* const rt = RES ? rg + (size_t)m0 * orow : xg;
+        u32x4 xa[7], xb[7];                                  // staging registers: even / odd chunks, two chunks ahead
+        // 7 loads, always: chunk c of x, or (c >= NC: nothing left to fetch) the same 16 bytes for every lane -- the queue stays uniform
+        auto xload = [&](u32x4 (&r)[7], int c) __attribute__((always_inline)) {
+            const bool real = c < NC;
+            const unsigned char* sp = real ? xt + c * 128 : xg;
+            const uint32_t vo = real ? xoff : 0u, vo6 = real ? xoff6 : 0u;
+            const uint32_t st = real ? 32u * xrow : 0u;
+            bi_gld<0>(r[0], vo, sp); bi_gld<0>(r[1], vo, sp + st); bi_gld<0>(r[2], vo, sp + 2 * (size_t)st); bi_gld<0>(r[3], vo, sp + 3 * (size_t)st);
+            bi_gld<0>(r[4], vo, sp + 4 * (size_t)st); bi_gld<0>(r[5], vo, sp + 5 * (size_t)st); bi_gld<0>(r[6], vo6, sp);   // (xoff6 carries its slot row itself)
+        };
+        // the last K iteration's staging slots fetch the identity of fragment half q = 0 instead: pixel groups GB .. GB + 6 (group 12 with
+        // its junk lanes clamped, the non-existent group 13 = the dummy load)
+        auto idload = [&](u32x4 (&r)[7], auto GB) __attribute__((always_inline)) {
+            constexpr int gb = decltype(GB)::value;
+            const unsigned char* sp = rt + (size_t)gb * 16 * orow;
+            const size_t st = 16 * (size_t)orow;
+            bi_gld<0>(r[0], idoff, sp); bi_gld<0>(r[1], idoff, sp + st); bi_gld<0>(r[2], idoff, sp + 2 * st); bi_gld<0>(r[3], idoff, sp + 3 * st);
+            bi_gld<0>(r[4], idoff, sp + 4 * st);
+            if constexpr (gb == 0) { bi_gld<0>(r[5], idoff, sp + 5 * st); bi_gld<0>(r[6], idoff, sp + 6 * st); }
+            else { bi_gld<0>(r[5], idoff12, sp + 5 * st); bi_gld<0>(r[6], 0u, xg); }
+        };
+        auto xstore = [&](u32x4 (&r)[7], int stage) __attribute__((always_inline)) {
+#pragma unroll
+            for (int j = 0; j < 7; ++j) {
+                asm volatile("" : "+v"(r[j]));
+                bi_sts(smem, xs_w + stage * PW_STAGE + j * (32 * 128), r[j]);
+            }
+        };
+        xload(xa, 0);
+        xload(xb, 1);
+        bi_wait_vm<7>();                                     // chunk 0 (and everything older: the ring, the last tile's stores)
+        __syncthreads();                                     // (every wave is past its last fragment read of the previous tile)
+        xstore(xa, 0);
+        xload(xa, 2);
+        __syncthreads();
+        // one chunk = two K steps of 32 out of staging buffer STAGE on ring slots SL0, SL0 + 1
+        auto c1_pair = [&](auto STAGE, auto SL0, auto FIRST, u32x4 (&b)[8], u32x4 (&r)[4][4], f32x4 (&ac)[4][14]) __attribute__((always_inline)) {
+            constexpr int stage = decltype(STAGE)::value, sl0 = decltype(SL0)::value;
+            constexpr bool first = decltype(FIRST)::value != 0;
+            const uint32_t ra = xs_r + stage * PW_STAGE, rb = ra ^ 64u;
+            bi_pipe<2 * NG, 7, 8>(b,
+                [&](auto I, u32x4& d) __attribute__((always_inline)) { constexpr int n = decltype(I)::value, ks = n / NG, g = n % NG; bi_ldsr<g * 2048>(d, ks ? rb : ra); },
+                [&](auto I, u32x4& d) __attribute__((always_inline)) {
+                    constexpr int n = decltype(I)::value, ks = n / NG, g = n % NG, sl = sl0 + ks;
+                    if constexpr (g == 0 && !first) bi_wait_vm<26>();       // the slot's piece: behind it 12 ring loads and 14 staging loads
+#pragma unroll
+                    for (int f = 0; f < 4; ++f) {
+                        if constexpr (first && stage == 0 && ks == 0) bi_mma0(ac[f][g], r[sl][f], d);
+                        else bi_mma(ac[f][g], r[sl][f], d);
+                    }
+                    if constexpr (g == NG - 1) refill(std::integral_constant<int, sl>{}, r);
+                });
+        };
+        auto c1_iter = [&](int c, auto FIRST, auto LAST) __attribute__((always_inline)) {
+            constexpr bool first = decltype(FIRST)::value != 0, last = decltype(LAST)::value != 0;
+            // chunk c from stage 0; chunk c + 1 -> stage 1 (free since the barrier that ended chunk c - 1); then chunk c + 3 requested
+            bi_wait_vm<(first ? 7 : 23)>();
+            xstore(xb, 1);
+            if constexpr (last && RES) idload(xb, I0{}); else xload(xb, c + 3);
+            c1_pair(I0{}, I0{}, FIRST, bf, ar, acc);
+            __syncthreads();
+            bi_wait_vm<(first ? 15 : 23)>();
+            if constexpr (!last) xstore(xa, 0);
+            if constexpr (last && RES) idload(xa, std::integral_constant<int, 7>{}); else xload(xa, c + 4);
+            c1_pair(I1{}, I2{}, I0{}, bf, ar, acc);
+            __syncthreads();
+        };
+        c1_iter(0, I1{}, I0{});                              // (NC >= 4: the first iteration is never the last)
+        for (int c = 2; c < NC - 2; c += 2) c1_iter(c, I0{}, I0{});
+        c1_iter(NC - 2, I0{}, I1{});
+        // the last iteration's staging loads (identity, or nothing) must have landed before their registers are read or reused:
+        // behind them the ring loads of the last two K steps
+        bi_wait_vm<8>();
+#pragma unroll
+        for (int j = 0; j < 7; ++j) asm volatile("" : "+v"(xa[j]), "+v"(xb[j]));
+        bi_settle28(acc[0], acc[1]);                         // the last MFMA results settle before VALU reads them
+        bi_settle28(acc[2], acc[3]);
+        // ---- epilogue: BN (+ identity) + ReLU + 16-bit, 16 bytes per lane and (pixel group, fragment half)
+        const uint32_t so = (uint32_t)((size_t)m0 * orow) + ochan;
+        sfor<0, 2>([&](auto Q) __attribute__((always_inline)) {
+            constexpr int q = decltype(Q)::value;
+            const f32x4 s0 = *(const f32x4*)(bs + q * 32 + kq * 8), s1 = *(const f32x4*)(bs + q * 32 + kq * 8 + 4);
+            const f32x4 h0 = *(const f32x4*)(bh + q * 32 + kq * 8), h1 = *(const f32x4*)(bh + q * 32 + kq * 8 + 4);
+            // store offsets: ONE running register (the 26 tile-invariant offsets hipcc otherwise hoists out of the tile loop -- and
+            // spills -- cost a scratch reload, i.e. a drained queue, per store)
+            uint32_t vrun = so + (uint32_t)li * orow + q * 64;
+            asm volatile("" : "+v"(vrun));
+            sfor<0, NG>([&](auto G) __attribute__((always_inline)) {
+                constexpr int g = decltype(G)::value;
+                u32x4& idr = g < 7 ? xb[g] : xa[g - 7];
+                if constexpr (RES && q == 1) {
+                    bi_wait_vm<2 * NG - 2 - g>();            // behind identity load g of this half: NG - 1 - g (store, load) pairs, g stores
+                    asm volatile("" : "+v"(idr));
+                }
+                const u32x4 o = bi_bn8(acc[2 * q][g], acc[2 * q + 1][g], s0, s1, h0, h1, RES ? &idr : nullptr, rng);
+                const uint32_t vo = (g < NG - 1 || li < TM - 16 * (NG - 1)) ? vrun : 0xffffff00u;     // (junk lanes: dropped by the range check)
+                __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, vo, 0, 0);
+                vrun += 16u * orow;
+                asm volatile("" : "+v"(vrun));
+                if constexpr (RES && q == 0) {               // the register is consumed: the identity of half q = 1 takes it
+                    __builtin_amdgcn_sched_barrier(0);
+                    bi_gld<64>(idr, g == NG - 1 ? idoff12 : idoff, rt + (size_t)g * 16 * orow);
+                }
+            });
+        });
+    }
+    bi_wait_vm<0>();                                         // (the ring ran ahead: nothing may land after the exit)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ar[j][0]), "+v"(ar[j][1]), "+v"(ar[j][2]), "+v"(ar[j][3]));
+    ap_rng_flush(a.range_flag, rng);
+}
+
+}  // namespace
+
+// 196 | M (whole tiles: every 14 x 14 tensor, and 7 x 7 tensors of 4 k images), K in whole pairs of 64-channel chunks, 256 | Cout
+bool ap_conv_pw_supported(long M, int Cin, int Cout) {
+    return M > 0 && M % 196 == 0 && Cin >= 256 && Cin % 128 == 0 && Cout % 256 == 0 && Cout >= 256 &&
+           (size_t)M * Cout * 2 < 0xffffff00ull && (size_t)M * Cin * 2 < 0xffffff00ull;
+}
+
+size_t ap_conv_pw_stream_bytes(int Cin, int Cout) { return (size_t)Cin * Cout * 2; }
+
+// w [Cout][wld] K-contiguous 16-bit rows (wld >= Cin) as packed for the stand-alone kernels
+hipError_t ap_launch_conv_pw_pack(const void* w, void* dst, int Cin, int Cout, int wld, hipStream_t st) {
+    if (!w || !dst || Cin % 32 || Cout % 256 || wld < Cin) return hipErrorInvalidValue;
+    const size_t pieces = (size_t)Cin * Cout / 8;
+    hipLaunchKernelGGL(pw_pack_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, st, (const bf16_t*)w, (unsigned char*)dst, Cin, Cout, wld);
+    return hipGetLastError();
+}
+
+// grid: the largest multiple of 8 * (Cout / 256) that fits the device (one workgroup per CU), capped by the tile count
+int ap_conv_pw_grid(long M, int Cout, int n_cu) {
+    const int NN = Cout >> 8, unit = 8 * NN;
+    const long T = (long)((M / 196 + 7) & ~7L) * NN;
+    long g = (long)(n_cu / unit) * unit;
+    if (g < unit) g = unit;
+    return (int)(g < T ? g : T);
+}
+
+hipError_t ap_launch_conv_pw(const PwArgs& a, hipStream_t st) {
+    static int n_cu_dev[AP_MAX_DEVICES] = {};
+    if (!a.x || !a.y || !a.wfrag || !a.scale || !a.shift || !a.relu || !ap_conv_pw_supported(a.M, a.Cin, a.Cout)) return hipErrorInvalidValue;
+    int dev = 0;
+    hipError_t e = ap_current_device(&dev);
+    if (e != hipSuccess) return e;
+    if (!n_cu_dev[dev]) {
+        int n = 0;
+        e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        if (e != hipSuccess) return e;
+        n_cu_dev[dev] = n;
+    }
+    const int grid = ap_conv_pw_grid(a.M, a.Cout, n_cu_dev[dev]);
+    if (a.res) hipLaunchKernelGGL((conv_pw_kernel<13, true>), dim3(grid), dim3(256), PW_LDS, st, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<13, false>), dim3(grid), dim3(256), PW_LDS, st, a);
+    return hipGetLastError();
+}
+
+AP_NS_END

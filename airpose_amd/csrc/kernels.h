@@ -86,6 +86,17 @@ struct BlkImgArgs {
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
 };
 
+// ---- pointwise convolution + BN (+ identity) + ReLU on the one-wave-per-SIMD mainloop (conv_pw.hip); 16-bit storage
+struct PwArgs {
+    const void* x;                // [M][Cin] NHWC pixel rows
+    void* y;                      // [M][Cout]
+    const void* res;              // [M][Cout] identity, or NULL
+    const void* wfrag;            // the weight matrix as per-wave MFMA-fragment streams (ap_launch_conv_pw_pack)
+    const float *scale, *shift;   // BatchNorm scale / shift [Cout]
+    int M, Cin, Cout, relu;       // relu must be 1
+    int* range_flag;              // fp16 storage, or NULL
+};
+
 // ---- stem / pooling (stem.hip)
 
 // ---- regressor glue (regressor.hip); all fp32

@@ -50,7 +50,7 @@ typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
 /* ABI number of this header: bumped whenever an exported signature changes or an entry point is removed (5: round 5 --
  * ap_conv_pair_* / ap_bottleneck64_nhwc take a leading `precision` and a caller-packed weight stream since 4).  A binding built
  * against another number must refuse to load the library (airpose_amd/_native.py does). */
-#define AP_ABI_VERSION 6
+#define AP_ABI_VERSION 7
 const char* ap_version(void);
 int ap_abi_version(void);
 const char* ap_last_error(void);
@@ -213,6 +213,16 @@ int ap_bottleneck64_tail_nhwc(int precision, const void* x, const void* w1, cons
  * y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x) with the intermediates rounded to the storage type exactly
  * where the three-convolution path rounds them. */
 int64_t ap_block_img_stream_bytes(void);
+/* Pointwise (1 x 1, stride 1) convolution + BatchNorm (+ identity) + ReLU for the 14 x 14 / 7 x 7 stages (conv1 and conv3 of
+ * Bottleneck.forward, model_copenet.py:29-31, 38-45) on the one-wave-per-SIMD mainloop of conv_pw.hip: x [M][Cin], res (or NULL)
+ * and y [M][Cout] NHWC pixel rows in the storage type of `precision` (AP_PREC_BF16 or AP_PREC_F16); M a multiple of 196 (whole
+ * 14 x 14 images, or 7 x 7 images in fours), Cin of 128 (>= 256), Cout of 256.  The weights are consumed as a caller-owned stream
+ * of ap_conv_pw_stream_bytes(Cin, Cout) bytes built by ap_conv_pw_pack from w [Cout][Cin] (K-contiguous rows as for
+ * ap_conv2d_nhwc).  y = relu(scale * conv(x) + shift (+ res)): bit-identical to ap_conv2d_nhwc on the same operands. */
+int64_t ap_conv_pw_stream_bytes(int Cin, int Cout);
+int ap_conv_pw_pack(int precision, const void* w, int Cin, int Cout, void* wstream, void* stream);
+int ap_conv_pw_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, const void* res,
+                    void* y, int M, int Cin, int Cout, void* stream);
 int ap_block_img_pack(int precision, const void* w1, const void* w2, const void* w3, void* wstream, void* stream);
 int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const float* s1, const float* h1, const float* s2,
                       const float* h2, const float* s3, const float* h3, void* y, int N, void* stream);
@@ -309,6 +319,12 @@ int ap_net_set_fuse_pair(ap_net* h, int on);
  * (ap_bottleneck64_tail_nhwc): the 56 x 56 x 256 block output is not read back for it (model_copenet.py:29-31 at :64).
  * Bit-identical to the stand-alone convolution. */
 int ap_net_set_fuse_tail(ap_net* h, int on);
+/* 16-bit modes: conv1 / conv3 + identity of the layer3 / layer4 bottlenecks that no fused kernel covers (layer4: all of them)
+ * on ap_conv_pw_nhwc's kernel instead of the generic 128 x 128-tile kernels: 1 (default) = when the layer's tiles fill at least
+ * 80 % of whole rounds of the chip AND the pass has the chip to itself (a one-view or chunked pass; the two concurrent passes of
+ * a two-view forward of >= 64 pairs keep the generic kernels, which share a CU with the other pass's: measured -0.5 % there,
+ * +0.7 % alone), 2 = whenever the shape is supported, 0 = never.  Features are bit-identical either way. */
+int ap_net_set_pw_conv(ap_net* h, int on);
 /* 16-bit modes: on = 1 (default): a block output whose only remaining reader is the next block's stride-2 downsample branch
  * (model_copenet.py:41-42, :97-102; its conv1 having been computed by the producing kernel) is stored at the even pixels only.
  * Features are bit-identical either way. */

@@ -727,6 +727,79 @@ def test_block_img_equals_three_convs(dev, prec, N):
     assert nbad == 0                                          # same K order per output element: the same bits
 
 
+PW_CASES = [  # (M, Cin, Cout, identity): conv1 of layer4.0 / 4.1, conv3 of a layer4 identity block, conv1 / conv3 of layer3, ragged tile counts
+    (196 * 8, 1024, 512, False), (196 * 3, 2048, 512, False), (196 * 5, 512, 2048, True), (196 * 9, 1024, 256, False),
+    (196 * 2, 256, 1024, True), (196 * 300, 1024, 512, False), (196 * 67, 512, 2048, True)]
+
+
+@pytest.mark.parametrize("case", PW_CASES)
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_conv_pw_equals_generic_kernels(dev, prec, case):
+    """conv_pw.hip (pointwise conv + BN (+ identity) + ReLU, 196-pixel x 256-channel tiles, one wave per SIMD, weights streamed from
+    L2 as MFMA fragments; conv1 / conv3 of Bottleneck.forward, model_copenet.py:29-31, 38-45) against ap_conv2d_nhwc's automatic
+    kernel on the same operands: the same K order per output element, so every bit equal -- one tile group, ragged groups of eight,
+    several tiles per workgroup (weight-stream wrap, staging ring and identity registers across tiles), 2 and 8 channel tiles."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    M, Cin, Cout, ident = case
+    bf = H16[prec]
+    g = torch.Generator().manual_seed(M + Cin)
+    x = torch.randn(M, Cin, generator=g).to(bf).to(dev)
+    w = (torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5).to(bf).to(dev)
+    res = torch.randn(M, Cout, generator=g).to(bf).to(dev) if ident else None
+    sc, sh = (torch.rand(Cout, generator=g) * 0.5 + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    B = Nn.PRECISIONS[prec]
+    ws = torch.empty(L.ap_conv_pw_stream_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_pw_pack(B, p(w), Cin, Cout, p(ws), st), "ap_conv_pw_pack")
+    y = torch.full((M, Cout), float("nan"), dtype=bf, device=dev)
+    guard = torch.full((4096,), 7.0, dtype=bf, device=dev)   # (allocated right behind y: an out-of-tile store would land here or in y's NaNs)
+    Nn.check(L.ap_conv_pw_nhwc(B, p(x), p(ws), p(sc), p(sh), p(res), p(y), M, Cin, Cout, st), "ap_conv_pw_nhwc")
+    y2 = torch.empty_like(y)
+    Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), p(res), p(y2), M // 196, 14, 14, Cin, Cout, 1, 1, 0, 1, st), "conv2d")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all() and bool((guard == 7.0).all())
+    nbad = int((y.view(torch.int16) != y2.view(torch.int16)).sum())
+    print("conv_pw vs generic: %d of %d values differ (rel err %.3e)" % (nbad, y.numel(), rel_err(y.float().cpu().numpy(), y2.float().cpu().numpy())))
+    assert nbad == 0
+    with pytest.raises(RuntimeError):
+        Nn.check(L.ap_conv_pw_nhwc(B, p(x), p(ws), p(sc), p(sh), p(res), p(y), M - 1, Cin, Cout, st), "ap_conv_pw_nhwc")
+
+
+def test_conv_pw_soak(dev):
+    """Race screen of conv_pw.hip (every load and LDS read is an asm statement behind a hand-counted wait): 40 launches of the
+    identity form on 67 x 8 tiles (three to four tiles per workgroup), odd ones beside a competing copy stream, every bit compared."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    bf, M, Cin, Cout = torch.float16, 196 * 67, 512, 2048
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(M, Cin, generator=g).to(bf).to(dev)
+    w = (torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5).to(bf).to(dev)
+    res = torch.randn(M, Cout, generator=g).to(bf).to(dev)
+    sc, sh = (torch.rand(Cout, generator=g) * 0.5 + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = Nn.stream_ptr(dev)
+    B = Nn.PRECISIONS["f16"]
+    ws = torch.empty(L.ap_conv_pw_stream_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_pw_pack(B, p(w), Cin, Cout, p(ws), st), "pack")
+    y2 = torch.empty(M, Cout, dtype=bf, device=dev)
+    Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), p(res), p(y2), M // 196, 14, 14, Cin, Cout, 1, 1, 0, 1, st), "conv2d")
+    noise = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+    bad = 0
+    for rep in range(40):
+        y = torch.full((M, Cout), float("nan"), dtype=bf, device=dev)
+        if rep & 1:
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                noise.add_(1.0)
+        Nn.check(L.ap_conv_pw_nhwc(B, p(x), p(ws), p(sc), p(sh), p(res), p(y), M, Cin, Cout, st), "pw")
+        bad += int((y.view(torch.int16) != y2.view(torch.int16)).sum())
+    torch.cuda.synchronize()
+    assert bad == 0, "%d values differ over 40 launches" % bad
+
+
 def test_block_img_soak(dev):
     """Race screen of block_img.hip (every load and LDS read of it is an asm statement behind a hand-counted wait): 40 launches of
     300 images on 256 workgroups, odd ones beside a competing copy stream, every output bit compared with the three-convolution
@@ -783,6 +856,28 @@ def test_image_resident_layer3_blocks_match_the_convolutions(net16, dev, n):
         net16.set_img_block(1)
     assert torch.isfinite(ref).all()
     assert torch.equal(got, ref)
+    assert torch.equal(net16.forward_feat_ext(x), ref)      # automatic rule: whichever path it takes
+
+
+@pytest.mark.parametrize("n", [4, 24])
+def test_pointwise_kernel_in_the_trunk_is_bit_identical(net16, dev, n):
+    """layer4's conv1 / conv3 + identity (and layer3's, with the image blocks off) on conv_pw.hip (forced on: the automatic rule only
+    takes it for passes whose tiles fill the chip) against the generic kernels: the same K order per output element, so the trunk
+    features carry the same bits (n = 4: one 196-pixel tile of 7 x 7 images; 24: six, and 24 whole 14 x 14 images)."""
+    gen = torch.Generator(device="cpu").manual_seed(720 + n)
+    x = torch.randn(n, 3, 224, 224, generator=gen).to(dev)
+    try:
+        net16.set_pw_conv(0)
+        ref = net16.forward_feat_ext(x).clone()
+        net16.set_pw_conv(2)
+        got = net16.forward_feat_ext(x).clone()
+        net16.set_img_block(0)
+        got2 = net16.forward_feat_ext(x).clone()
+    finally:
+        net16.set_pw_conv(1)
+        net16.set_img_block(1)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref) and torch.equal(got2, ref)
     assert torch.equal(net16.forward_feat_ext(x), ref)      # automatic rule: whichever path it takes
 
 

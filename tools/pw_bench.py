@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Stand-alone timing of the one-wave-per-SIMD pointwise kernel (ap_conv_pw_nhwc) against the generic kernels on layer4's shapes.
+   python tools/pw_bench.py [--images 512] [--iters 20] [--precision f16]"""
+import argparse, ctypes, os, sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from airpose_amd import _native as Nn  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--images", type=int, default=512)
+    ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--precision", default="f16")
+    a = ap.parse_args()
+    dev = torch.device("cuda", 0)
+    L = Nn.lib()
+    bf = {"bf16": torch.bfloat16, "f16": torch.float16}[a.precision]
+    B = Nn.PRECISIONS[a.precision]
+    st = Nn.stream_ptr(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    n = a.images
+    for name, M, Cin, Cout, ident in (("l4.0.c1", n * 196, 1024, 512, False), ("l4.1.c1", n * 49, 2048, 512, False),
+                                      ("l4.1.c3+id", n * 49, 512, 2048, True), ("l3.1.c1", n * 196, 1024, 256, False),
+                                      ("l3.5.c3+id", n * 196, 256, 1024, True)):
+        g = torch.Generator().manual_seed(1)
+        x = torch.randn(M, Cin, generator=g).to(bf).to(dev)
+        w = (torch.randn(Cout, Cin, generator=g) * (2.0 / Cin) ** 0.5).to(bf).to(dev)
+        res = torch.randn(M, Cout, generator=g).to(bf).to(dev) if ident else None
+        sc, sh = (torch.rand(Cout, generator=g) * 0.5 + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+        ws = torch.empty(L.ap_conv_pw_stream_bytes(Cin, Cout), dtype=torch.uint8, device=dev)
+        Nn.check(L.ap_conv_pw_pack(B, p(w), Cin, Cout, p(ws), st), "pack")
+        y, y2 = torch.empty(M, Cout, dtype=bf, device=dev), torch.empty(M, Cout, dtype=bf, device=dev)
+        flops = 2.0 * M * Cin * Cout
+        byts = (M * Cin + M * Cout * (2 if ident else 1)) * 2
+
+        def timeit(call):
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / a.iters
+        t_pw = timeit(lambda: Nn.check(L.ap_conv_pw_nhwc(B, p(x), p(ws), p(sc), p(sh), p(res), p(y), M, Cin, Cout, st), "pw"))
+        t_gen = timeit(lambda: Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), p(res), p(y2), M // 196, 14, 14, Cin, Cout, 1, 1, 0, 1, st), "conv"))
+        print("%-11s M=%7d K=%4d N=%4d | conv_pw %7.1f us %6.0f TF/s %5.0f GB/s | generic %7.1f us %6.0f TF/s | x%.2f | equal %s" % (
+            name, M, Cin, Cout, t_pw, flops / t_pw * 1e-6, byts / t_pw * 1e-3, t_gen, flops / t_gen * 1e-6, t_gen / t_pw, bool(torch.equal(y, y2))))
+
+
+if __name__ == "__main__":
+    main()
