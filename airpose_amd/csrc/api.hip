@@ -268,9 +268,9 @@ struct ap_net {
     bool fuse_pair = true;         // bf16: conv3 of an identity block + conv1 of the next block as one pixel-local kernel (conv_pair.hip)
     bool fuse_tail = true;         // 16-bit modes: conv1 of layer2.0 inside the kernel of layer1's last block (bottleneck2.hip, tail variant);
                                    // the block output is then stored at the even pixels only (layer2.0's stride-2 downsample reads nothing else)
-    int pw_conv = 1;               // 16-bit modes: conv1 / conv3 + identity of layer3 / layer4 bottlenecks that no fused kernel covers on the one-wave-per-SIMD
-                                   // pointwise kernel (conv_pw.hip): 0 never; 1 (default) when the tiles fill whole rounds of the chip AND the pass is
-                                   // not one of two concurrent ones; 2 whenever supported
+    int pw_conv = 1;               // 16-bit modes: conv1 of the layer3 / layer4 bottlenecks that no fused kernel covers on the one-wave-per-SIMD pointwise
+                                   // kernel (conv_pw.hip): 0 never; 1 (default) when its tiles fill half the chip or whole rounds of it; 2 whenever
+                                   // supported, and conv3 + identity too; 3 conv1 whenever supported
     int img_block = 1;             // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip): 0 never,
                                    // 1 when the pass fills whole rounds of the chip (an image per CU; same bits either way), 2 always
     bool even_out = true;          // 16-bit modes: a pair block whose output is read by a stride-2 downsample branch ONLY stores the even pixels
@@ -454,8 +454,8 @@ int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const
     return AP_OK;
 }
 
-// pw: 0 = the generic kernels; 1 / 2 = conv_pw.hip where the layer has a stream and the shape fits (1: only when its tiles fill
-// at least 80 % of whole rounds of the chip) -- same bits either way, so the choice may depend on the problem size
+// pw: 0 = the generic kernels; 1 / 2 / 3 = conv_pw.hip where the layer has a stream and the shape fits (1: only when its tiles fill
+// half the chip, or whole rounds of it to 80 %) -- same bits either way, so the choice may depend on the problem size
 int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int prec,
              hipStream_t st, int* rflag = nullptr, int y_tiled = 0, int pw = 0) {
     if (pw && L.pw.p && prec_half(prec) && relu && !y_tiled && L.k == 1 && L.stride == 1 &&
@@ -465,7 +465,7 @@ int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const 
         HIP_TRY(device_cus(&cus));
         const int NN = L.cout >> 8, gmax = k_bf16::ap_conv_pw_grid(1L << 40, L.cout, cus);
         const long T = ((M / 196 + 7) & ~7L) * NN, rounds = (T + gmax - 1) / gmax;
-        if (pw == 2 || T * 5 >= rounds * gmax * 4) {
+        if (pw >= 2 || (T <= gmax ? T * 2 >= gmax : T * 5 >= rounds * gmax * 4)) {     // half a round at least / whole rounds 80 % full
             PwArgs p{};
             p.x = x; p.y = y; p.res = res; p.wfrag = L.pw.p; p.scale = L.scale.as<float>(); p.shift = L.shift.as<float>();
             p.M = (int)M; p.Cin = L.cin; p.Cout = L.cout; p.relu = 1; p.range_flag = rflag;
@@ -917,9 +917,10 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         return bf && h->fuse_pair && X.pair_p && &X != &h->blocks.back() && (!X.has_down || h->fuse_ds);
     };
     bool cur_tiled = false;                                  // layout of `cur`
-    // conv_pw.hip takes whole CUs (one wave per SIMD, all 512 registers): measured +0.7 % of the whole bench when a pass has the chip
-    // to itself, -0.5 % beside the other view's concurrent pass (whose kernels it keeps off its CUs) -- ev_out marks the latter
-    const int pw_conv = (h->pw_conv == 1 && ev_out) ? 0 : h->pw_conv;
+    // conv_pw.hip: automatic rule = conv1 only (layer4 at 512 images: 156 / 70 / 71 -> 136 / 60 / 61 us; whole bench +1.0 % single
+    // pass, +0.6 % with two concurrent passes).  conv3 + identity (2: forced) is 3-9 us slower than the lean kernel and, beside a
+    // concurrent pass, turns the gain into -0.5 %: a one-wave-per-SIMD kernel keeps the other pass's workgroups off its CUs
+    const int pw_conv = h->pw_conv;
     for (auto& B : h->blocks) {
         if (signal_at >= 2 && blk++ == signal_at - 2) HIP_TRY(hipEventRecord(h->ev_skew, st));
         const int Ho = (H + 2 - 3) / B.c2.stride + 1;
@@ -1009,7 +1010,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
                 if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, prec, st, h->range_flag))) return rc;
                 res = w.ws_ds.p;
             }
-            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st, h->range_flag, 0, B.has_down ? 0 : pw_conv))) return rc;
+            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st, h->range_flag, 0, (B.has_down || pw_conv != 2) ? 0 : pw_conv))) return rc;   // (conv3 + identity: 89-95 us against the lean kernel's 86: only when forced)
         }
         std::swap(cur, nxt);
         H = Ho;
@@ -1699,7 +1700,7 @@ int ap_net_set_fuse_tail(ap_net* h, int on) {
 
 int ap_net_set_pw_conv(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->pw_conv = on < 0 ? 0 : (on > 2 ? 2 : on);
+    h->pw_conv = on < 0 ? 0 : (on > 3 ? 3 : on);               // (3: conv1 whenever supported, also beside a concurrent pass: A/B aid)
     return AP_OK;
 }
 

@@ -319,11 +319,11 @@ int ap_net_set_fuse_pair(ap_net* h, int on);
  * (ap_bottleneck64_tail_nhwc): the 56 x 56 x 256 block output is not read back for it (model_copenet.py:29-31 at :64).
  * Bit-identical to the stand-alone convolution. */
 int ap_net_set_fuse_tail(ap_net* h, int on);
-/* 16-bit modes: conv1 / conv3 + identity of the layer3 / layer4 bottlenecks that no fused kernel covers (layer4: all of them)
- * on ap_conv_pw_nhwc's kernel instead of the generic 128 x 128-tile kernels: 1 (default) = when the layer's tiles fill at least
- * 80 % of whole rounds of the chip AND the pass has the chip to itself (a one-view or chunked pass; the two concurrent passes of
- * a two-view forward of >= 64 pairs keep the generic kernels, which share a CU with the other pass's: measured -0.5 % there,
- * +0.7 % alone), 2 = whenever the shape is supported, 0 = never.  Features are bit-identical either way. */
+/* 16-bit modes: conv1 of the layer3 / layer4 bottlenecks that no fused kernel covers (layer4: all three) on ap_conv_pw_nhwc's
+ * kernel instead of the generic 128 x 128-tile kernels: 1 (default) = when the layer's 196-pixel x 256-channel tiles fill half
+ * the chip, or whole rounds of it to 80 % (BASELINE config 2: yes, +0.6 % two concurrent passes / +1.0 % one pass; 64 pairs:
+ * layer4.0 only); 2 = whenever the shape is supported, and conv3 + identity as well (slower than the lean kernel: A/B aid);
+ * 3 = conv1 whenever supported; 0 = never.  Features are bit-identical either way. */
 int ap_net_set_pw_conv(ap_net* h, int on);
 /* 16-bit modes: on = 1 (default): a block output whose only remaining reader is the next block's stride-2 downsample branch
  * (model_copenet.py:41-42, :97-102; its conv1 having been computed by the producing kernel) is stored at the even pixels only.
