@@ -492,7 +492,23 @@ int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const 
 // fused conv3 + downsample of a stage's first block: t [N][Ho][Ho][cin] (pointwise) and x [N][Hin][Hin][cin2]
 // sampled with stride2, concatenated along K
 int run_c3_ds(const Layer& L, const void* t, const void* x, int N, int Ho, int Hin, void* y, int prec,
-              hipStream_t st, int* rflag = nullptr) {
+              hipStream_t st, int* rflag = nullptr, int pw = 0) {
+    if (pw && L.pw.p && prec_half(prec) && g_conv_mode.load(std::memory_order_relaxed) == -1) {       // conv_pw.hip, as in run_conv
+        PwArgs p{};
+        p.x = t; p.y = y; p.wfrag = L.pw.p; p.scale = L.scale.as<float>(); p.shift = L.shift.as<float>();
+        p.M = N * Ho * Ho; p.Cin = L.cin; p.Cout = L.cout; p.relu = 1; p.range_flag = rflag;
+        p.x2 = x; p.Cin2 = L.cin2; p.Ho = p.Wo = Ho; p.H2 = p.W2 = Hin; p.stride2 = L.stride2;
+        if (k_bf16::ap_conv_pw_ds_supported(p)) {
+            int cus = 0;
+            HIP_TRY(device_cus(&cus));
+            const int NN = L.cout >> 8, gmax = k_bf16::ap_conv_pw_grid(1L << 40, L.cout, cus);
+            const long T = (((long)p.M / 196 + 7) & ~7L) * NN, rounds = (T + gmax - 1) / gmax;
+            if (pw >= 2 || (T <= gmax ? T * 2 >= gmax : T * 5 >= rounds * gmax * 4)) {
+                HIP_TRY(H16(prec, ap_launch_conv_pw)(p, st));
+                return AP_OK;
+            }
+        }
+    }
     ConvArgs a{};
     a.range_flag = rflag;
     a.x = t; a.w = L.w.p; a.scale = L.scale.as<float>(); a.shift = L.shift.as<float>(); a.res = nullptr; a.y = y;
@@ -640,6 +656,14 @@ int finalize_trunk(ap_net* h) {
                 HIP_TRY(L->pw.reserve(k_bf16::ap_conv_pw_stream_bytes(L->cin, L->cout)));
                 HIP_TRY(H16(h->prec, ap_launch_conv_pw_pack)(L->w.p, L->pw.p, L->cin, L->cout, L->wld, nullptr));
             }
+    // ... and conv3 + folded downsample of layer4.0 (K = [t2: 512 | x sampled with stride 2: 1024]; layer3.0's rides in a pair kernel)
+    if (h->half() && h->fuse_ds)
+        for (auto& B : h->blocks) {
+            Layer& L = B.c3ds;
+            if (!B.has_down || B.pair_p || !L.w.p || L.cin % 64 || L.cin2 % 64 || (L.cin + L.cin2) % 128 || L.cout % 256 || L.cin + L.cin2 < 1024) continue;
+            HIP_TRY(L.pw.reserve(k_bf16::ap_conv_pw_stream_bytes(L.cin + L.cin2, L.cout)));
+            HIP_TRY(H16(h->prec, ap_launch_conv_pw_pack)(L.w.p, L.pw.p, L.cin + L.cin2, L.cout, L.wld, nullptr));
+        }
     HIP_TRY(hipDeviceSynchronize());
     return AP_OK;
 }
@@ -988,7 +1012,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         } else if (cur_tiled) {                               // (cannot happen: out_tiled is only set when the next block is a pair block)
             return fail(AP_ESTATE, "trunk: a tiled block output reached a kernel that reads NHWC");
         } else if (B.has_down && h->fuse_ds) {
-            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st, h->range_flag))) return rc;
+            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st, h->range_flag, pw_conv))) return rc;
         } else if (bf && h->fuse_pool && &B == &h->blocks.back() && !B.has_down && Ho == 7 &&
                    g_conv_mode.load(std::memory_order_relaxed) == -1) {
             // last convolution of the trunk: conv3 + bn3 + identity + ReLU AND AvgPool2d(7) + view in one kernel
@@ -1524,6 +1548,19 @@ int ap_conv_pw_nhwc(int precision, const void* x, const void* wstream, const flo
         return fail(AP_ESHAPE, "ap_conv_pw_nhwc: M must be a multiple of 196, Cin of 128 (>= 256), Cout of 256");
     PwArgs p{};
     p.x = x; p.y = y; p.res = res; p.wfrag = wstream; p.scale = scale; p.shift = shift; p.M = M; p.Cin = Cin; p.Cout = Cout; p.relu = 1;
+    HIP_TRY(H16(precision, ap_launch_conv_pw)(p, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_conv_pw_ds_nhwc(int precision, const void* t2, const void* x, const void* wstream, const float* scale, const float* shift,
+                       void* y, int N, int Ho, int Cin, int Cin2, int Cout, int stride, void* stream) {
+    if (!prec_half(precision) || !t2 || !x || !wstream || !scale || !shift || !y || N <= 0 || Ho <= 0 || stride < 1 || stride > 2)
+        return fail(AP_EINVAL, "ap_conv_pw_ds_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16; stride 1 or 2)");
+    PwArgs p{};
+    p.x = t2; p.y = y; p.wfrag = wstream; p.scale = scale; p.shift = shift; p.M = N * Ho * Ho; p.Cin = Cin; p.Cout = Cout; p.relu = 1;
+    p.x2 = x; p.Cin2 = Cin2; p.Ho = p.Wo = Ho; p.H2 = p.W2 = Ho * stride; p.stride2 = stride;
+    if (!k_bf16::ap_conv_pw_ds_supported(p))
+        return fail(AP_ESHAPE, "ap_conv_pw_ds_nhwc: N Ho Ho a multiple of 196 with Ho Ho | 196, Cin and Cin2 multiples of 64 (sum: of 128), Cout of 256");
     HIP_TRY(H16(precision, ap_launch_conv_pw)(p, (hipStream_t)stream));
     return AP_OK;
 }

@@ -47,9 +47,10 @@ __global__ void __launch_bounds__(256) pw_pack_kernel(const bf16_t* __restrict__
     *(u32x4*)(dst + idx * 16) = *(const u32x4*)(w + (size_t)ch * wld + step * 32 + (lane >> 4) * 8);
 }
 
-template <int NG, bool RES>
+template <int NG, bool RES, bool SEG2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) conv_pw_kernel(const PwArgs a) {
     static_assert(NG == 13, "196-pixel tiles");
+    static_assert(!(RES && SEG2), "a stage's first block has no identity");
     constexpr int TM = 196;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -58,7 +59,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
     uint32_t rng = 0u;
 
-    const int Cin = a.Cin, Cout = a.Cout, NN = Cout >> 8, NC = Cin >> 6, KS = Cin >> 5;
+    const int Cin = a.Cin, Cout = a.Cout, NN = Cout >> 8, NC1 = Cin >> 6;
+    const int NC = SEG2 ? (Cin + a.Cin2) >> 6 : NC1, KS = 2 * NC;               // K = [x: Cin | x2: Cin2], as the weight rows have it
     const int MT8 = (a.M / TM + 7) & ~7;                     // pixel tiles, rounded up to whole groups of eight (one per XCD)
     const long T = (long)MT8 * NN;
     // tile t -> XCD t & 7 (= blockIdx & 7: the grid is a multiple of 8 NN), N tile (t >> 3) % NN, pixel tile ((t >> 3) / NN) * 8 + XCD:
@@ -71,7 +73,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const auto yrsrc = __builtin_amdgcn_make_buffer_rsrc((unsigned char*)a.y, 0, (int)((uint32_t)a.M * (uint32_t)Cout * 2u), 0x00020000);
     const unsigned char* const wsb = (const unsigned char*)a.wfrag + ((size_t)ntile * 4 + wave) * (size_t)KS * 4096;
     // every kernel-argument load completes here (scalar loads share lgkmcnt with the counted fragment reads)
-    asm volatile("" ::"s"(xg), "s"(rg), "s"(bs), "s"(bh), "s"(wsb), "s"(Cin), "s"(Cout), "s"(KS));
+    const unsigned char* const x2g = (const unsigned char*)a.x2;
+    const int hw2 = SEG2 ? a.Ho * a.Wo : 1, wo2 = SEG2 ? a.Wo : 1, sw2 = SEG2 ? a.stride2 * a.W2 : 0, st2 = SEG2 ? a.stride2 : 0, cin2 = SEG2 ? a.Cin2 : 0;
+    const uint32_t img2 = SEG2 ? (uint32_t)a.H2 * a.W2 * a.Cin2 * 2u : 0u;      // bytes per source image of the second segment
+    asm volatile("" ::"s"(xg), "s"(rg), "s"(bs), "s"(bh), "s"(wsb), "s"(Cin), "s"(Cout), "s"(KS), "s"(x2g), "s"(hw2), "s"(wo2), "s"(sw2), "s"(st2), "s"(cin2), "s"(img2), "s"(NC1));
     const uint32_t wlane = lane * 16;
     const unsigned char* wp = wsb;
     int wcnt = 0;
@@ -93,6 +98,18 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const int s6 = (xr0 + 12) * 16 + xcol;
     const uint32_t xoff6 = (uint32_t)(s6 < TM ? s6 : TM - 1) * xrow + (uint32_t)xpc * 16u;
     const uint32_t xs_w = (uint32_t)((xr0 * 16 + xcol) * 128 + ((xpc ^ (xcol & 7)) << 4));
+    // second K segment: the tile's pixels are whole output images (Ho * Wo | 196); slot -> byte offset of the strided pixel of x2
+    // relative to the tile's first source image (the same for every tile)
+    uint32_t xoff2[7];
+    if constexpr (SEG2) {
+#pragma unroll
+        for (int j = 0; j < 7; ++j) {
+            int s = (xr0 + 2 * j) * 16 + xcol;
+            s = s < TM ? s : TM - 1;
+            const int im = s / hw2, r = s - im * hw2, ho = r / wo2, wo = r - ho * wo2;
+            xoff2[j] = (uint32_t)im * img2 + (uint32_t)((ho * sw2 + wo * st2) * cin2) * 2u + (uint32_t)xpc * 16u;
+        }
+    }
     // B fragments out of a staging buffer: slot 16 g + li, piece 4 ks + kq at position piece ^ (slot & 7)
     const uint32_t xs_r = lds0 + (uint32_t)(li * 128 + (((li >> 2) & 1) << 6) + ((kq ^ (li & 3)) << 4));
     // identity / output: this lane's 8 channels (ntile * 256 + wave * 64 + q * 32 + 8 kq ..) of tile pixel 16 g + li
@@ -111,10 +128,19 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (m0 >= a.M) continue;                             // (uniform: the padding tiles of the last group of eight)
         const unsigned char* const xt = xg + (size_t)m0 * xrow;
         const unsigned char* const rt = RES ? rg + (size_t)m0 * orow : xg;
+        const unsigned char* const x2t = SEG2 ? x2g + (size_t)(m0 / hw2) * img2 : xg;
         u32x4 xa[7], xb[7];                                  // staging registers: even / odd chunks, two chunks ahead
         // 7 loads, always: chunk c of x, or (c >= NC: nothing left to fetch) the same 16 bytes for every lane -- the queue stays uniform
         auto xload = [&](u32x4 (&r)[7], int c) __attribute__((always_inline)) {
-            const bool real = c < NC;
+            if constexpr (SEG2) {
+                if (c >= NC1 && c < NC) {                    // (uniform branch: both sides issue exactly seven loads)
+                    const unsigned char* sp2 = x2t + (c - NC1) * 128;
+                    bi_gld<0>(r[0], xoff2[0], sp2); bi_gld<0>(r[1], xoff2[1], sp2); bi_gld<0>(r[2], xoff2[2], sp2); bi_gld<0>(r[3], xoff2[3], sp2);
+                    bi_gld<0>(r[4], xoff2[4], sp2); bi_gld<0>(r[5], xoff2[5], sp2); bi_gld<0>(r[6], xoff2[6], sp2);
+                    return;
+                }
+            }
+            const bool real = c < NC1;
             const unsigned char* sp = real ? xt + c * 128 : xg;
             const uint32_t vo = real ? xoff : 0u, vo6 = real ? xoff6 : 0u;
             const uint32_t st = real ? 32u * xrow : 0u;
@@ -230,6 +256,13 @@ bool ap_conv_pw_supported(long M, int Cin, int Cout) {
     return M > 0 && M % 196 == 0 && Cin >= 256 && Cin % 128 == 0 && Cout % 256 == 0 && Cout >= 256 &&
            (size_t)M * Cout * 2 < 0xffffff00ull && (size_t)M * Cin * 2 < 0xffffff00ull;
 }
+// ... with a second K segment: [x: Cin | x2: Cin2 sampled with stride2], output images of Ho x Wo pixels with Ho * Wo | 196
+bool ap_conv_pw_ds_supported(const PwArgs& a) {
+    if (!a.x2 || a.res || a.Cin % 64 || a.Cin2 % 64 || a.Cin2 <= 0 || (a.Cin + a.Cin2) % 128 || a.Ho <= 0 || a.Wo <= 0 || 196 % (a.Ho * a.Wo)) return false;
+    if (a.stride2 < 1 || (a.Ho - 1) * a.stride2 >= a.H2 || (a.Wo - 1) * a.stride2 >= a.W2) return false;
+    if ((size_t)(a.M / (a.Ho * a.Wo)) * a.H2 * a.W2 * a.Cin2 * 2 >= 0xffffff00ull) return false;
+    return ap_conv_pw_supported(a.M, a.Cin + a.Cin2, a.Cout) && (size_t)a.M * a.Cin * 2 < 0xffffff00ull;
+}
 
 size_t ap_conv_pw_stream_bytes(int Cin, int Cout) { return (size_t)Cin * Cout * 2; }
 
@@ -252,7 +285,8 @@ int ap_conv_pw_grid(long M, int Cout, int n_cu) {
 
 hipError_t ap_launch_conv_pw(const PwArgs& a, hipStream_t st) {
     static int n_cu_dev[AP_MAX_DEVICES] = {};
-    if (!a.x || !a.y || !a.wfrag || !a.scale || !a.shift || !a.relu || !ap_conv_pw_supported(a.M, a.Cin, a.Cout)) return hipErrorInvalidValue;
+    if (!a.x || !a.y || !a.wfrag || !a.scale || !a.shift || !a.relu) return hipErrorInvalidValue;
+    if (a.x2 ? !ap_conv_pw_ds_supported(a) : !ap_conv_pw_supported(a.M, a.Cin, a.Cout)) return hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
@@ -260,15 +294,18 @@ hipError_t ap_launch_conv_pw(const PwArgs& a, hipStream_t st) {
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
         if (e != hipSuccess) return e;
         n_cu_dev[dev] = n;
     }
     const int grid = ap_conv_pw_grid(a.M, a.Cout, n_cu_dev[dev]);
-    if (a.res) hipLaunchKernelGGL((conv_pw_kernel<13, true>), dim3(grid), dim3(256), PW_LDS, st, a);
-    else hipLaunchKernelGGL((conv_pw_kernel<13, false>), dim3(grid), dim3(256), PW_LDS, st, a);
+    if (a.x2) hipLaunchKernelGGL((conv_pw_kernel<13, false, true>), dim3(grid), dim3(256), PW_LDS, st, a);
+    else if (a.res) hipLaunchKernelGGL((conv_pw_kernel<13, true, false>), dim3(grid), dim3(256), PW_LDS, st, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<13, false, false>), dim3(grid), dim3(256), PW_LDS, st, a);
     return hipGetLastError();
 }
 

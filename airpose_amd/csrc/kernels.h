@@ -94,6 +94,10 @@ struct PwArgs {
     const void* wfrag;            // the weight matrix as per-wave MFMA-fragment streams (ap_launch_conv_pw_pack)
     const float *scale, *shift;   // BatchNorm scale / shift [Cout]
     int M, Cin, Cout, relu;       // relu must be 1
+    // second K segment (a stage's first block: the downsample branch folded into conv3, model_copenet.py:41-42, 97-102): x2
+    // [N][H2][W2][Cin2] sampled at (ho * stride2, wo * stride2); Ho * Wo must divide 196.  NULL: none
+    const void* x2;
+    int Cin2, Ho, Wo, H2, W2, stride2;
     int* range_flag;              // fp16 storage, or NULL
 };
 

@@ -223,6 +223,12 @@ int64_t ap_conv_pw_stream_bytes(int Cin, int Cout);
 int ap_conv_pw_pack(int precision, const void* w, int Cin, int Cout, void* wstream, void* stream);
 int ap_conv_pw_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, const void* res,
                     void* y, int M, int Cin, int Cout, void* stream);
+/* ... of a stage's first block: conv3 with the downsample branch as a second K segment (model_copenet.py:38-45 with :41-42,
+ * 97-102): y [N][Ho][Ho][Cout] = relu(scale * ([t2 | x sampled at (ho * stride, wo * stride)] . w^T) + shift), t2
+ * [N][Ho][Ho][Cin], x [N][Ho stride][Ho stride][Cin2]; the stream is ap_conv_pw_pack's of w [Cout][Cin + Cin2] (pass
+ * Cin + Cin2 as its Cin).  Ho * Ho must divide 196 (7 or 14) and N Ho Ho be a multiple of 196. */
+int ap_conv_pw_ds_nhwc(int precision, const void* t2, const void* x, const void* wstream, const float* scale, const float* shift,
+                       void* y, int N, int Ho, int Cin, int Cin2, int Cout, int stride, void* stream);
 int ap_block_img_pack(int precision, const void* w1, const void* w2, const void* w3, void* wstream, void* stream);
 int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const float* s1, const float* h1, const float* s2,
                       const float* h2, const float* s3, const float* h3, void* y, int N, void* stream);

@@ -767,6 +767,43 @@ def test_conv_pw_equals_generic_kernels(dev, prec, case):
         Nn.check(L.ap_conv_pw_nhwc(B, p(x), p(ws), p(sc), p(sh), p(res), p(y), M - 1, Cin, Cout, st), "ap_conv_pw_nhwc")
 
 
+@pytest.mark.parametrize("case", [(8, 7, 512, 1024, 2048), (3, 14, 256, 512, 1024), (36, 7, 512, 1024, 2048)])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_conv_pw_stage_first_block(dev, prec, case):
+    """conv_pw.hip with the downsample branch as a second K segment (conv3 of a stage's first block: the block input read at the
+    stride-2 pixel; model_copenet.py:38-45 with :41-42, 97-102) -- layer4.0's shape on one and on nine tiles, layer3.0's on three:
+    against fp64 on identical operands, and, for layer3.0's shape, bit for bit against the pair kernel that runs it in the trunk."""
+    from airpose_amd import _native as Nn
+    n, Ho, P, P2, C3 = case
+    L = Nn.lib()
+    g = torch.Generator().manual_seed(17 + P + n)
+    H2, M = 2 * Ho, n * Ho * Ho
+    bf = H16[prec]
+    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(bf).to(dev)
+    x = torch.randn(n, H2, H2, P2, generator=g).clamp_min(0).to(bf).to(dev)
+    w3d = (torch.randn(C3, P + P2, generator=g) * (1.0 / (P + P2)) ** 0.5).to(bf).to(dev)
+    h3 = (torch.randn(C3, generator=g) * 0.1).to(dev)
+    ones = torch.ones(C3, device=dev)                        # the BatchNorm scales are folded into w3d (pack_c3_ds)
+    p = lambda t: ctypes.c_void_p(t.data_ptr())
+    st = Nn.stream_ptr(dev)
+    B = Nn.PRECISIONS[prec]
+    ws = torch.empty(L.ap_conv_pw_stream_bytes(P + P2, C3), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_pw_pack(B, p(w3d), P + P2, C3, p(ws), st), "ap_conv_pw_pack")
+    out = torch.full((M + 8, C3), float("nan"), dtype=bf, device=dev)
+    Nn.check(L.ap_conv_pw_ds_nhwc(B, p(t2), p(x), p(ws), p(ones), p(h3), p(out), n, Ho, P, P2, C3, 2, st), "ap_conv_pw_ds_nhwc")
+    torch.cuda.synchronize()
+    assert torch.isnan(out[M:].float()).all() and torch.isfinite(out[:M].float()).all()
+    xs = x[:, ::2, ::2, :].reshape(M, P2)
+    want = (torch.cat([t2, xs], 1).double() @ w3d.double().T + h3.double()).clamp_min(0)
+    assert rel_err(out[:M].double().cpu().numpy(), want.cpu().numpy()) < (6e-3 if prec == "bf16" else 8e-4)
+    if (P, P2, C3) == (256, 512, 1024):
+        wp = _pair_stream(dev, prec, w3d, None, P, P2, 0)
+        ref = torch.empty(M, C3, dtype=bf, device=dev)
+        Nn.check(L.ap_conv_pair_ds_nhwc(B, p(t2), p(x), p(wp), p(ones), p(h3), None, None, p(ref), None, n, Ho, P, P2, 2, 0, st), "ap_conv_pair_ds_nhwc")
+        torch.cuda.synchronize()
+        assert torch.equal(out[:M].view(torch.int16), ref.view(torch.int16))
+
+
 def test_conv_pw_soak(dev):
     """Race screen of conv_pw.hip (every load and LDS read is an asm statement behind a hand-counted wait): 40 launches of the
     identity form on 67 x 8 tiles (three to four tiles per workgroup), odd ones beside a competing copy stream, every bit compared."""
