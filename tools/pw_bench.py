@@ -51,5 +51,47 @@ def main():
             name, M, Cin, Cout, t_pw, flops / t_pw * 1e-6, byts / t_pw * 1e-3, t_gen, flops / t_gen * 1e-6, t_gen / t_pw, bool(torch.equal(y, y2))))
 
 
+def ds_rows(a):
+    """conv3 + folded downsample of a stage's first block: conv_pw's two-segment form against the pair kernel (layer3.0's shape)."""
+    dev = torch.device("cuda", 0)
+    L = Nn.lib()
+    bf = {"bf16": torch.bfloat16, "f16": torch.float16}[a.precision]
+    B = Nn.PRECISIONS[a.precision]
+    st = Nn.stream_ptr(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    n, Ho, P, P2, C3 = a.images, 14, 256, 512, 1024
+    M = n * Ho * Ho
+    g = torch.Generator().manual_seed(2)
+    t2 = torch.randn(M, P, generator=g).clamp_min(0).to(bf).to(dev)
+    x = torch.randn(n, 2 * Ho, 2 * Ho, P2, generator=g).clamp_min(0).to(bf).to(dev)
+    w = (torch.randn(C3, P + P2, generator=g) * (1.0 / (P + P2)) ** 0.5).to(bf).to(dev)
+    h3, ones = (torch.randn(C3, generator=g) * 0.1).to(dev), torch.ones(C3, device=dev)
+    ws = torch.empty(L.ap_conv_pw_stream_bytes(P + P2, C3), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_pw_pack(B, p(w), P + P2, C3, p(ws), st), "pack")
+    wp = torch.empty(L.ap_conv_pair_stream_bytes(P, P2, 0), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_pair_pack(B, p(w), None, P, P2, 0, p(wp), st), "pair pack")
+    y, y2 = torch.empty(M, C3, dtype=bf, device=dev), torch.empty(M, C3, dtype=bf, device=dev)
+
+    def timeit(call):
+        for _ in range(3):
+            call()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.iters):
+            call()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / a.iters
+    t_pw = timeit(lambda: Nn.check(L.ap_conv_pw_ds_nhwc(B, p(t2), p(x), p(ws), p(ones), p(h3), p(y), n, Ho, P, P2, C3, 2, st), "pw ds"))
+    t_pr = timeit(lambda: Nn.check(L.ap_conv_pair_ds_nhwc(B, p(t2), p(x), p(wp), p(ones), p(h3), None, None, p(y2), None, n, Ho, P, P2, 2, 0, st), "pair ds"))
+    flops = 2.0 * M * (P + P2) * C3
+    print("l3.0.c3d    M=%7d K=%4d N=%4d | conv_pw %7.1f us %6.0f TF/s | pair kernel %7.1f us %6.0f TF/s | x%.2f | equal %s" % (
+        M, P + P2, C3, t_pw, flops / t_pw * 1e-6, t_pr, flops / t_pr * 1e-6, t_pr / t_pw, bool(torch.equal(y, y2))))
+
+
 if __name__ == "__main__":
     main()
+    _ap = argparse.ArgumentParser()
+    _ap.add_argument("--images", type=int, default=512); _ap.add_argument("--iters", type=int, default=20); _ap.add_argument("--precision", default="f16")
+    ds_rows(_ap.parse_args())
