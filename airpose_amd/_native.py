@@ -85,6 +85,7 @@ SIGNATURES = {
     "ap_conv_pw_pack": (_i, [_i, _vp, _i, _i, _vp, _vp]),
     "ap_conv_pw_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 3 + [_vp]),
     "ap_conv_pw_ds_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 6 + [_vp]),
+    "ap_conv_pw_k3s2_nhwc": (_i, [_i] + [_vp] * 5 + [_i] * 4 + [_vp]),
     "ap_net_set_pw_conv": (_i, [_vp, _i]),
     "ap_net_set_fuse_tail": (_i, [_vp, _i]),
     "ap_net_set_even_out": (_i, [_vp, _i]),

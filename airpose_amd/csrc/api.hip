@@ -456,20 +456,48 @@ int pack_linear(const float* W, int ld_src, int col0, int ncols, int nout, const
 
 // pw: 0 = the generic kernels; 1 / 2 / 3 = conv_pw.hip where the layer has a stream and the shape fits (1: only when its tiles fill
 // half the chip, or whole rounds of it to 80 %) -- same bits either way, so the choice may depend on the problem size
+// the size rule of conv_pw.hip's automatic choice: its 196-pixel x 256-channel tiles fill half a round of the chip at least, or whole rounds to 80 %
+bool pw_fills(long M, int cout, int pw, int* err) {
+    int cus = 0;
+    if ((*err = device_cus(&cus)) != hipSuccess) return false;
+    const int NN = cout >> 8, gmax = k_bf16::ap_conv_pw_grid(1L << 40, cout, cus);
+    const long T = ((M / 196 + 7) & ~7L) * NN, rounds = (T + gmax - 1) / gmax;
+    return pw == 2 || pw == 3 || (T <= gmax ? T * 2 >= gmax : T * 5 >= rounds * gmax * 4);
+}
+// the 3 x 3 / stride-2 convolution of a stage's first block (model_copenet.py:32-34, :18) as nine pointwise taps of conv_pw.hip?
+bool pw_k3_args(const Layer& L, int N, int H, int W, int prec, PwArgs* p) {
+    if (!L.pw.p || !prec_half(prec) || L.k != 3 || L.stride != 2 || L.pad != 1 || (H & 1) || (W & 1)) return false;
+    *p = PwArgs{};
+    p->k3 = 1; p->Ho = H / 2; p->Wo = W / 2; p->H2 = H; p->W2 = W; p->stride2 = 2;
+    p->M = N * p->Ho * p->Wo; p->Cin = L.cin; p->Cout = L.cout; p->relu = 1;
+    p->wfrag = L.pw.p; p->scale = L.scale.as<float>(); p->shift = L.shift.as<float>();
+    return k_bf16::ap_conv_pw_k3_supported(*p);
+}
+
 int run_conv(const Layer& L, const void* x, int N, int H, int W, void* y, const void* res, int relu, int prec,
              hipStream_t st, int* rflag = nullptr, int y_tiled = 0, int pw = 0) {
     if (pw && L.pw.p && prec_half(prec) && relu && !y_tiled && L.k == 1 && L.stride == 1 &&
         g_conv_mode.load(std::memory_order_relaxed) == -1 && k_bf16::ap_conv_pw_supported((long)N * H * W, L.cin, L.cout)) {
         const long M = (long)N * H * W;
-        int cus = 0;
-        HIP_TRY(device_cus(&cus));
-        const int NN = L.cout >> 8, gmax = k_bf16::ap_conv_pw_grid(1L << 40, L.cout, cus);
-        const long T = ((M / 196 + 7) & ~7L) * NN, rounds = (T + gmax - 1) / gmax;
-        if (pw >= 2 || (T <= gmax ? T * 2 >= gmax : T * 5 >= rounds * gmax * 4)) {     // half a round at least / whole rounds 80 % full
+        int err = 0;
+        const bool fills = pw_fills(M, L.cout, pw, &err);
+        HIP_TRY((hipError_t)err);
+        if (fills) {
             PwArgs p{};
             p.x = x; p.y = y; p.res = res; p.wfrag = L.pw.p; p.scale = L.scale.as<float>(); p.shift = L.shift.as<float>();
             p.M = (int)M; p.Cin = L.cin; p.Cout = L.cout; p.relu = 1; p.range_flag = rflag;
             HIP_TRY(H16(prec, ap_launch_conv_pw)(p, st));
+            return AP_OK;
+        }
+    }
+    PwArgs p3;
+    if (pw && relu && !res && !y_tiled && g_conv_mode.load(std::memory_order_relaxed) == -1 && pw_k3_args(L, N, H, W, prec, &p3)) {
+        int err = 0;
+        const bool fills = pw_fills(p3.M, L.cout, pw, &err);
+        HIP_TRY((hipError_t)err);
+        if (fills) {
+            p3.x = x; p3.y = y; p3.range_flag = rflag;
+            HIP_TRY(H16(prec, ap_launch_conv_pw)(p3, st));
             return AP_OK;
         }
     }
@@ -656,6 +684,15 @@ int finalize_trunk(ap_net* h) {
                 HIP_TRY(L->pw.reserve(k_bf16::ap_conv_pw_stream_bytes(L->cin, L->cout)));
                 HIP_TRY(H16(h->prec, ap_launch_conv_pw_pack)(L->w.p, L->pw.p, L->cin, L->cout, L->wld, nullptr));
             }
+    // ... conv2 of layer3.0 / layer4.0 (3 x 3, stride 2: K = [tap][Cin], consumed as nine pointwise taps)
+    if (h->half())
+        for (auto& B : h->blocks) {
+            Layer& L = B.c2;
+            const int cc = L.cin >> 6;
+            if (L.k != 3 || L.stride != 2 || L.pad != 1 || L.cin % 64 || cc < 2 || (cc & (cc - 1)) || L.cout % 256) continue;
+            HIP_TRY(L.pw.reserve(k_bf16::ap_conv_pw_stream_bytes(9 * L.cin, L.cout)));
+            HIP_TRY(H16(h->prec, ap_launch_conv_pw_pack)(L.w.p, L.pw.p, 9 * L.cin, L.cout, L.wld, nullptr));
+        }
     // ... and conv3 + folded downsample of layer4.0 (K = [t2: 512 | x sampled with stride 2: 1024]; layer3.0's rides in a pair kernel)
     if (h->half() && h->fuse_ds)
         for (auto& B : h->blocks) {
@@ -985,8 +1022,18 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, h->range_flag, 0, pw_conv))) return rc;
         t1_ready = false;
         const bool pair = is_pair(B);
-        const int t2_tiled = pair && tiling;
-        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, h->range_flag, t2_tiled))) return rc;
+        // conv2 of a stage's first block on conv_pw.hip (nine taps): it writes NHWC rows, so t2 stays untiled for that block's pair kernel.
+        // Automatic rule: only for a pass that has the chip to itself (l4.0.c2 164 -> 149 us, l3.0.c2 168 -> 157: +0.55 % of the whole
+        // bench there, -0.45 % beside a concurrent pass, whose workgroups a one-wave-per-SIMD kernel keeps off its CUs; ev_out marks it)
+        bool c2_pw = false;
+        if (pw_conv && pw_conv != 4 && !(pw_conv == 1 && ev_out) && B.c2.stride == 2 && g_conv_mode.load(std::memory_order_relaxed) == -1) {
+            PwArgs p3;
+            int err = 0;
+            c2_pw = pw_k3_args(B.c2, n, H, H, prec, &p3) && pw_fills(p3.M, B.c2.cout, pw_conv, &err);
+            HIP_TRY((hipError_t)err);
+        }
+        const int t2_tiled = pair && tiling && !c2_pw;
+        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, h->range_flag, t2_tiled, c2_pw ? pw_conv : 0))) return rc;
         if (pair) {
             // conv3 (+ identity | + folded downsample, ReLU) AND -- where the pair carries it -- the next block's conv1 in one
             // kernel: the block output is written once and not read back for conv1 (model_copenet.py:38-45 of this block,
@@ -1565,6 +1612,19 @@ int ap_conv_pw_ds_nhwc(int precision, const void* t2, const void* x, const void*
     return AP_OK;
 }
 
+int ap_conv_pw_k3s2_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, void* y, int N,
+                         int H, int Cin, int Cout, void* stream) {
+    if (!prec_half(precision) || !x || !wstream || !scale || !shift || !y || N <= 0 || H <= 0)
+        return fail(AP_EINVAL, "ap_conv_pw_k3s2_nhwc: bad argument (precision: AP_PREC_BF16 or AP_PREC_F16)");
+    PwArgs p{};
+    p.k3 = 1; p.Ho = p.Wo = H / 2; p.H2 = p.W2 = H; p.stride2 = 2; p.M = N * p.Ho * p.Wo; p.Cin = Cin; p.Cout = Cout; p.relu = 1;
+    p.x = x; p.y = y; p.wfrag = wstream; p.scale = scale; p.shift = shift;
+    if ((H & 1) || !k_bf16::ap_conv_pw_k3_supported(p))
+        return fail(AP_ESHAPE, "ap_conv_pw_k3s2_nhwc: H even with (H / 2)^2 | 196 (14 or 28), N (H / 2)^2 a multiple of 196, Cin / 64 a power of two >= 2, Cout a multiple of 256");
+    HIP_TRY(H16(precision, ap_launch_conv_pw)(p, (hipStream_t)stream));
+    return AP_OK;
+}
+
 int64_t ap_block_img_stream_bytes(void) { return (int64_t)k_bf16::ap_block_img_stream_bytes(); }
 
 int ap_block_img_pack(int precision, const void* w1, const void* w2, const void* w3, void* wstream, void* stream) {
@@ -1737,7 +1797,7 @@ int ap_net_set_fuse_tail(ap_net* h, int on) {
 
 int ap_net_set_pw_conv(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->pw_conv = on < 0 ? 0 : (on > 3 ? 3 : on);               // (3: conv1 whenever supported, also beside a concurrent pass: A/B aid)
+    h->pw_conv = on < 0 ? 0 : (on > 4 ? 4 : on);               // (3: 1 without the size rule; 4: 1 without the 3 x 3 / stride-2 layers -- A/B aids)
     return AP_OK;
 }
 

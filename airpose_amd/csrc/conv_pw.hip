@@ -47,10 +47,12 @@ __global__ void __launch_bounds__(256) pw_pack_kernel(const bf16_t* __restrict__
     *(u32x4*)(dst + idx * 16) = *(const u32x4*)(w + (size_t)ch * wld + step * 32 + (lane >> 4) * 8);
 }
 
-template <int NG, bool RES, bool SEG2>
+// SEG2: 0 plain | 1 a second K segment read at strided pixels | 2 a 3 x 3 / stride-2 convolution as nine pointwise taps
+template <int NG, bool RES, int SEG2>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) conv_pw_kernel(const PwArgs a) {
     static_assert(NG == 13, "196-pixel tiles");
     static_assert(!(RES && SEG2), "a stage's first block has no identity");
+    constexpr bool K3 = SEG2 == 2;
     constexpr int TM = 196;
     extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -60,7 +62,8 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     uint32_t rng = 0u;
 
     const int Cin = a.Cin, Cout = a.Cout, NN = Cout >> 8, NC1 = Cin >> 6;
-    const int NC = SEG2 ? (Cin + a.Cin2) >> 6 : NC1, KS = 2 * NC;               // K = [x: Cin | x2: Cin2], as the weight rows have it
+    const int NC = K3 ? 9 * NC1 : SEG2 ? (Cin + a.Cin2) >> 6 : NC1, KS = 2 * NC;   // K = [x: Cin | x2: Cin2] / [tap][Cin], as the weight rows have it
+    const int lcc = K3 ? 31 - __builtin_clz(NC1) : 0;       // (3 x 3: Cin / 64 is a power of two)
     const int MT8 = (a.M / TM + 7) & ~7;                     // pixel tiles, rounded up to whole groups of eight (one per XCD)
     const long T = (long)MT8 * NN;
     // tile t -> XCD t & 7 (= blockIdx & 7: the grid is a multiple of 8 NN), N tile (t >> 3) % NN, pixel tile ((t >> 3) / NN) * 8 + XCD:
@@ -74,9 +77,10 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const unsigned char* const wsb = (const unsigned char*)a.wfrag + ((size_t)ntile * 4 + wave) * (size_t)KS * 4096;
     // every kernel-argument load completes here (scalar loads share lgkmcnt with the counted fragment reads)
     const unsigned char* const x2g = (const unsigned char*)a.x2;
-    const int hw2 = SEG2 ? a.Ho * a.Wo : 1, wo2 = SEG2 ? a.Wo : 1, sw2 = SEG2 ? a.stride2 * a.W2 : 0, st2 = SEG2 ? a.stride2 : 0, cin2 = SEG2 ? a.Cin2 : 0;
-    const uint32_t img2 = SEG2 ? (uint32_t)a.H2 * a.W2 * a.Cin2 * 2u : 0u;      // bytes per source image of the second segment
-    asm volatile("" ::"s"(xg), "s"(rg), "s"(bs), "s"(bh), "s"(wsb), "s"(Cin), "s"(Cout), "s"(KS), "s"(x2g), "s"(hw2), "s"(wo2), "s"(sw2), "s"(st2), "s"(cin2), "s"(img2), "s"(NC1));
+    const int hw2 = SEG2 ? a.Ho * a.Wo : 1, wo2 = SEG2 ? a.Wo : 1, sw2 = SEG2 ? a.stride2 * a.W2 : 0, st2 = SEG2 ? a.stride2 : 0;
+    const int cin2 = K3 ? a.Cin : SEG2 ? a.Cin2 : 0, w2row = K3 ? a.W2 : 0;
+    const uint32_t img2 = SEG2 ? (uint32_t)a.H2 * a.W2 * cin2 * 2u : 0u;         // bytes per source image of the strided operand
+    asm volatile("" ::"s"(xg), "s"(rg), "s"(bs), "s"(bh), "s"(wsb), "s"(Cin), "s"(Cout), "s"(KS), "s"(x2g), "s"(hw2), "s"(wo2), "s"(sw2), "s"(st2), "s"(cin2), "s"(img2), "s"(NC1), "s"(w2row), "s"(lcc));
     const uint32_t wlane = lane * 16;
     const unsigned char* wp = wsb;
     int wcnt = 0;
@@ -101,15 +105,25 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     // second K segment: the tile's pixels are whole output images (Ho * Wo | 196); slot -> byte offset of the strided pixel of x2
     // relative to the tile's first source image (the same for every tile)
     uint32_t xoff2[7];
-    if constexpr (SEG2) {
+    uint32_t topm = 0u, leftm = 0u;                          // 3 x 3: bit j = staging slot j lies in the top row / left column of its image
+    if constexpr (SEG2 != 0) {
 #pragma unroll
         for (int j = 0; j < 7; ++j) {
             int s = (xr0 + 2 * j) * 16 + xcol;
             s = s < TM ? s : TM - 1;
             const int im = s / hw2, r = s - im * hw2, ho = r / wo2, wo = r - ho * wo2;
-            xoff2[j] = (uint32_t)im * img2 + (uint32_t)((ho * sw2 + wo * st2) * cin2) * 2u + (uint32_t)xpc * 16u;
+            xoff2[j] = (uint32_t)im * img2 + (uint32_t)((ho * sw2 + wo * st2) * cin2) * 2u + (uint32_t)xpc * 16u;   // (3 x 3: the centre tap)
+            topm |= (uint32_t)(ho == 0) << j;
+            leftm |= (uint32_t)(wo == 0) << j;
         }
     }
+    // 3 x 3: chunk c = 64 channels (c & (NC1 - 1)) of tap c >> lcc; the taps outside the image (dy = -1 in the top row, dx = -1 in the
+    // left column: stride 2, even input sizes -- nothing falls off the bottom / right) read the centre pixel instead and are zeroed
+    auto k3_tap = [&](int c, int& toff, uint32_t& inv) __attribute__((always_inline)) {
+        const int tap = c >> lcc, dy = (tap * 11) >> 5, dx = tap - 3 * dy;
+        toff = ((dy - 1) * w2row + (dx - 1)) * cin2 * 2;
+        inv = (dy == 0 ? topm : 0u) | (dx == 0 ? leftm : 0u);
+    };
     // B fragments out of a staging buffer: slot 16 g + li, piece 4 ks + kq at position piece ^ (slot & 7)
     const uint32_t xs_r = lds0 + (uint32_t)(li * 128 + (((li >> 2) & 1) << 6) + ((kq ^ (li & 3)) << 4));
     // identity / output: this lane's 8 channels (ntile * 256 + wave * 64 + q * 32 + 8 kq ..) of tile pixel 16 g + li
@@ -128,11 +142,24 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         if (m0 >= a.M) continue;                             // (uniform: the padding tiles of the last group of eight)
         const unsigned char* const xt = xg + (size_t)m0 * xrow;
         const unsigned char* const rt = RES ? rg + (size_t)m0 * orow : xg;
-        const unsigned char* const x2t = SEG2 ? x2g + (size_t)(m0 / hw2) * img2 : xg;
+        const unsigned char* const x2t = SEG2 ? (K3 ? xg : x2g) + (size_t)(m0 / hw2) * img2 : xg;
         u32x4 xa[7], xb[7];                                  // staging registers: even / odd chunks, two chunks ahead
         // 7 loads, always: chunk c of x, or (c >= NC: nothing left to fetch) the same 16 bytes for every lane -- the queue stays uniform
         auto xload = [&](u32x4 (&r)[7], int c) __attribute__((always_inline)) {
-            if constexpr (SEG2) {
+            if constexpr (K3) {                              // (selects, not a branch: seven loads either way)
+                const bool in = c < NC;
+                int toff;
+                uint32_t inv;
+                k3_tap(in ? c : 0, toff, inv);
+                const unsigned char* sp = in ? x2t + (c & (NC1 - 1)) * 128 : xg;
+                sfor<0, 7>([&](auto J) __attribute__((always_inline)) {
+                    constexpr int j = decltype(J)::value;
+                    const uint32_t v = in ? xoff2[j] + (((inv >> j) & 1u) ? 0u : (uint32_t)toff) : 0u;
+                    bi_gld<0>(r[j], v, sp);
+                });
+                return;
+            }
+            if constexpr (SEG2 == 1) {
                 if (c >= NC1 && c < NC) {                    // (uniform branch: both sides issue exactly seven loads)
                     const unsigned char* sp2 = x2t + (c - NC1) * 128;
                     bi_gld<0>(r[0], xoff2[0], sp2); bi_gld<0>(r[1], xoff2[1], sp2); bi_gld<0>(r[2], xoff2[2], sp2); bi_gld<0>(r[3], xoff2[3], sp2);
@@ -158,10 +185,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             if constexpr (gb == 0) { bi_gld<0>(r[5], idoff, sp + 5 * st); bi_gld<0>(r[6], idoff, sp + 6 * st); }
             else { bi_gld<0>(r[5], idoff12, sp + 5 * st); bi_gld<0>(r[6], 0u, xg); }
         };
-        auto xstore = [&](u32x4 (&r)[7], int stage) __attribute__((always_inline)) {
+        auto xstore = [&](u32x4 (&r)[7], int stage, int c) __attribute__((always_inline)) {         // c: the chunk the registers hold
+            int toff;
+            uint32_t inv = 0u;
+            if constexpr (K3) k3_tap(c, toff, inv);
 #pragma unroll
             for (int j = 0; j < 7; ++j) {
                 asm volatile("" : "+v"(r[j]));
+                if (K3 && ((inv >> j) & 1u)) r[j] = u32x4{0u, 0u, 0u, 0u};
                 bi_sts(smem, xs_w + stage * PW_STAGE + j * (32 * 128), r[j]);
             }
         };
@@ -169,7 +200,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         xload(xb, 1);
         bi_wait_vm<7>();                                     // chunk 0 (and everything older: the ring, the last tile's stores)
         __syncthreads();                                     // (every wave is past its last fragment read of the previous tile)
-        xstore(xa, 0);
+        xstore(xa, 0, 0);
         xload(xa, 2);
         __syncthreads();
         // one chunk = two K steps of 32 out of staging buffer STAGE on ring slots SL0, SL0 + 1
@@ -194,12 +225,12 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             constexpr bool first = decltype(FIRST)::value != 0, last = decltype(LAST)::value != 0;
             // chunk c from stage 0; chunk c + 1 -> stage 1 (free since the barrier that ended chunk c - 1); then chunk c + 3 requested
             bi_wait_vm<(first ? 7 : 23)>();
-            xstore(xb, 1);
+            xstore(xb, 1, c + 1);
             if constexpr (last && RES) idload(xb, I0{}); else xload(xb, c + 3);
             c1_pair(I0{}, I0{}, FIRST, bf, ar, acc);
             __syncthreads();
             bi_wait_vm<(first ? 15 : 23)>();
-            if constexpr (!last) xstore(xa, 0);
+            if constexpr (!last) xstore(xa, 0, c + 2);
             if constexpr (last && RES) idload(xa, std::integral_constant<int, 7>{}); else xload(xa, c + 4);
             c1_pair(I1{}, I2{}, I0{}, bf, ar, acc);
             __syncthreads();
@@ -264,6 +295,15 @@ bool ap_conv_pw_ds_supported(const PwArgs& a) {
     return ap_conv_pw_supported(a.M, a.Cin + a.Cin2, a.Cout) && (size_t)a.M * a.Cin * 2 < 0xffffff00ull;
 }
 
+// ... 3 x 3, stride 2, padding 1: x [N][H2][W2][Cin] with even H2, W2 onto Ho x Wo = H2 / 2 x W2 / 2 with Ho * Wo | 196; Cin / 64 a power of two
+bool ap_conv_pw_k3_supported(const PwArgs& a) {
+    if (!a.k3 || a.x2 || a.res || a.stride2 != 2 || a.Ho <= 0 || a.Wo <= 0 || a.H2 != 2 * a.Ho || a.W2 != 2 * a.Wo || 196 % (a.Ho * a.Wo)) return false;
+    const int cc = a.Cin >> 6;
+    if (a.Cin % 64 || cc < 2 || (cc & (cc - 1))) return false;
+    if ((size_t)(a.M / (a.Ho * a.Wo)) * a.H2 * a.W2 * a.Cin * 2 >= 0xffffff00ull) return false;
+    return ap_conv_pw_supported(a.M, 9 * a.Cin, a.Cout);
+}
+
 size_t ap_conv_pw_stream_bytes(int Cin, int Cout) { return (size_t)Cin * Cout * 2; }
 
 // w [Cout][wld] K-contiguous 16-bit rows (wld >= Cin) as packed for the stand-alone kernels
@@ -286,7 +326,7 @@ int ap_conv_pw_grid(long M, int Cout, int n_cu) {
 hipError_t ap_launch_conv_pw(const PwArgs& a, hipStream_t st) {
     static int n_cu_dev[AP_MAX_DEVICES] = {};
     if (!a.x || !a.y || !a.wfrag || !a.scale || !a.shift || !a.relu) return hipErrorInvalidValue;
-    if (a.x2 ? !ap_conv_pw_ds_supported(a) : !ap_conv_pw_supported(a.M, a.Cin, a.Cout)) return hipErrorInvalidValue;
+    if (a.k3 ? !ap_conv_pw_k3_supported(a) : a.x2 ? !ap_conv_pw_ds_supported(a) : !ap_conv_pw_supported(a.M, a.Cin, a.Cout)) return hipErrorInvalidValue;
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
@@ -294,18 +334,21 @@ hipError_t ap_launch_conv_pw(const PwArgs& a, hipStream_t st) {
         int n = 0;
         e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, true, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
         if (e != hipSuccess) return e;
-        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)conv_pw_kernel<13, false, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, PW_LDS);
         if (e != hipSuccess) return e;
         n_cu_dev[dev] = n;
     }
     const int grid = ap_conv_pw_grid(a.M, a.Cout, n_cu_dev[dev]);
-    if (a.x2) hipLaunchKernelGGL((conv_pw_kernel<13, false, true>), dim3(grid), dim3(256), PW_LDS, st, a);
-    else if (a.res) hipLaunchKernelGGL((conv_pw_kernel<13, true, false>), dim3(grid), dim3(256), PW_LDS, st, a);
-    else hipLaunchKernelGGL((conv_pw_kernel<13, false, false>), dim3(grid), dim3(256), PW_LDS, st, a);
+    if (a.k3) hipLaunchKernelGGL((conv_pw_kernel<13, false, 2>), dim3(grid), dim3(256), PW_LDS, st, a);
+    else if (a.x2) hipLaunchKernelGGL((conv_pw_kernel<13, false, 1>), dim3(grid), dim3(256), PW_LDS, st, a);
+    else if (a.res) hipLaunchKernelGGL((conv_pw_kernel<13, true, 0>), dim3(grid), dim3(256), PW_LDS, st, a);
+    else hipLaunchKernelGGL((conv_pw_kernel<13, false, 0>), dim3(grid), dim3(256), PW_LDS, st, a);
     return hipGetLastError();
 }
 

@@ -98,6 +98,10 @@ struct PwArgs {
     // [N][H2][W2][Cin2] sampled at (ho * stride2, wo * stride2); Ho * Wo must divide 196.  NULL: none
     const void* x2;
     int Cin2, Ho, Wo, H2, W2, stride2;
+    // k3 = 1: x is [N][H2][W2][Cin] and the convolution a 3 x 3 with stride stride2 and padding 1 onto Ho x Wo (conv2 of a stage's
+    // first block, model_copenet.py:32-34 with :18): K = [tap][Cin] as the weight rows have it, a chunk of 64 channels of ONE tap
+    // per staging step (im2col by address; the out-of-image taps of the top row / left column are zeroed on their way into the LDS)
+    int k3;
     int* range_flag;              // fp16 storage, or NULL
 };
 

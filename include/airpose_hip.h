@@ -229,6 +229,13 @@ int ap_conv_pw_nhwc(int precision, const void* x, const void* wstream, const flo
  * Cin + Cin2 as its Cin).  Ho * Ho must divide 196 (7 or 14) and N Ho Ho be a multiple of 196. */
 int ap_conv_pw_ds_nhwc(int precision, const void* t2, const void* x, const void* wstream, const float* scale, const float* shift,
                        void* y, int N, int Ho, int Cin, int Cin2, int Cout, int stride, void* stream);
+/* ... conv2 of a stage's first block: 3 x 3, stride 2, padding 1 (model_copenet.py:32-34 with :18) as nine pointwise taps on the
+ * same kernel (a 64-channel chunk of ONE tap per staging step; out-of-image taps zeroed on the way into the LDS): x [N][H][H][Cin]
+ * -> y [N][H/2][H/2][Cout] = relu(scale * conv(x) + shift); the stream is ap_conv_pw_pack's of w [Cout][3][3][Cin] (pass 9 Cin as
+ * its Cin).  H = 14 or 28, N (H/2)^2 a multiple of 196, Cin / 64 a power of two.  Bit-identical to ap_conv2d_nhwc(ksize 3,
+ * stride 2, pad 1) on the same operands (K in [tap][Cin] order on both). */
+int ap_conv_pw_k3s2_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, void* y, int N,
+                         int H, int Cin, int Cout, void* stream);
 int ap_block_img_pack(int precision, const void* w1, const void* w2, const void* w3, void* wstream, void* stream);
 int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const float* s1, const float* h1, const float* s2,
                       const float* h2, const float* s3, const float* h3, void* y, int N, void* stream);
@@ -325,11 +332,12 @@ int ap_net_set_fuse_pair(ap_net* h, int on);
  * (ap_bottleneck64_tail_nhwc): the 56 x 56 x 256 block output is not read back for it (model_copenet.py:29-31 at :64).
  * Bit-identical to the stand-alone convolution. */
 int ap_net_set_fuse_tail(ap_net* h, int on);
-/* 16-bit modes: conv1 of the layer3 / layer4 bottlenecks that no fused kernel covers (layer4: all three) on ap_conv_pw_nhwc's
- * kernel instead of the generic 128 x 128-tile kernels: 1 (default) = when the layer's 196-pixel x 256-channel tiles fill half
- * the chip, or whole rounds of it to 80 % (BASELINE config 2: yes, +0.6 % two concurrent passes / +1.0 % one pass; 64 pairs:
- * layer4.0 only); 2 = whenever the shape is supported, and conv3 + identity as well (slower than the lean kernel: A/B aid);
- * 3 = conv1 whenever supported; 0 = never.  Features are bit-identical either way. */
+/* 16-bit modes: conv1 of the layer3 / layer4 bottlenecks that no fused kernel covers (layer4: all three), conv3 + downsample of
+ * layer4.0 and -- in a pass that has the chip to itself -- the 3 x 3 / stride-2 conv2 of layer3.0 / layer4.0 on conv_pw.hip's kernel
+ * instead of the generic 128 x 128-tile kernels: 1 (default) = when the layer's 196-pixel x 256-channel tiles fill half the chip,
+ * or whole rounds of it to 80 % (BASELINE config 2: yes, +0.7 % two concurrent passes / +1.5 % one pass; 64 pairs: layer4.0
+ * only); 2 = whenever the shape is supported, and conv3 + identity as well (slower than the lean kernel: A/B aid); 3 = as 1 without
+ * the size rule; 4 = as 1 without the 3 x 3 layers; 0 = never.  Features are bit-identical either way. */
 int ap_net_set_pw_conv(ap_net* h, int on);
 /* 16-bit modes: on = 1 (default): a block output whose only remaining reader is the next block's stride-2 downsample branch
  * (model_copenet.py:41-42, :97-102; its conv1 having been computed by the producing kernel) is stored at the even pixels only.

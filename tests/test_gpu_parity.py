@@ -804,6 +804,38 @@ def test_conv_pw_stage_first_block(dev, prec, case):
         assert torch.equal(out[:M].view(torch.int16), ref.view(torch.int16))
 
 
+@pytest.mark.parametrize("case", [(8, 14, 512, 512), (2, 28, 256, 256), (52, 14, 512, 512), (5, 28, 128, 256)])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_conv_pw_3x3_stride2_equals_generic_kernel(dev, prec, case):
+    """conv_pw.hip as nine pointwise taps (conv2 of a stage's first block: 3 x 3, stride 2, padding 1; model_copenet.py:32-34 with
+    :18): layer4.0's shape on two and on thirteen tiles, layer3.0's on two, a 128-channel input -- every bit equal to
+    ap_conv2d_nhwc's kernel for the same convolution (K in [tap][Cin] order on both; the zero padding of the top row / left column
+    is where the two differ in mechanism)."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    n, H, Cin, Cout = case
+    bf = H16[prec]
+    g = torch.Generator().manual_seed(31 + n + Cin)
+    x = torch.randn(n, H, H, Cin, generator=g).to(bf).to(dev)
+    w = (torch.randn(Cout, 9 * Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(bf).to(dev)
+    sc, sh = (torch.rand(Cout, generator=g) * 0.5 + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    B = Nn.PRECISIONS[prec]
+    ws = torch.empty(L.ap_conv_pw_stream_bytes(9 * Cin, Cout), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_pw_pack(B, p(w), 9 * Cin, Cout, p(ws), st), "ap_conv_pw_pack")
+    Ho = H // 2
+    y = torch.full((n, Ho, Ho, Cout), float("nan"), dtype=bf, device=dev)
+    Nn.check(L.ap_conv_pw_k3s2_nhwc(B, p(x), p(ws), p(sc), p(sh), p(y), n, H, Cin, Cout, st), "ap_conv_pw_k3s2_nhwc")
+    y2 = torch.empty_like(y)
+    Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), None, p(y2), n, H, H, Cin, Cout, 3, 2, 1, 1, st), "conv2d")
+    torch.cuda.synchronize()
+    assert torch.isfinite(y.float()).all()
+    nbad = int((y.view(torch.int16) != y2.view(torch.int16)).sum())
+    print("conv_pw 3x3/2 vs generic: %d of %d values differ (rel err %.3e)" % (nbad, y.numel(), rel_err(y.float().cpu().numpy(), y2.float().cpu().numpy())))
+    assert nbad == 0
+
+
 def test_conv_pw_soak(dev):
     """Race screen of conv_pw.hip (every load and LDS read is an asm statement behind a hand-counted wait): 40 launches of the
     identity form on 67 x 8 tiles (three to four tiles per workgroup), odd ones beside a competing copy stream, every bit compared."""

@@ -51,6 +51,43 @@ def main():
             name, M, Cin, Cout, t_pw, flops / t_pw * 1e-6, byts / t_pw * 1e-3, t_gen, flops / t_gen * 1e-6, t_gen / t_pw, bool(torch.equal(y, y2))))
 
 
+def k3_rows(a):
+    """conv2 of a stage's first block (3 x 3, stride 2): nine pointwise taps on conv_pw against the generic kernel."""
+    dev = torch.device("cuda", 0)
+    L = Nn.lib()
+    bf = {"bf16": torch.bfloat16, "f16": torch.float16}[a.precision]
+    B = Nn.PRECISIONS[a.precision]
+    st = Nn.stream_ptr(dev)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    for name, H, Cin, Cout in (("l4.0.c2", 14, 512, 512), ("l3.0.c2", 28, 256, 256)):
+        n = a.images
+        g = torch.Generator().manual_seed(3)
+        x = torch.randn(n, H, H, Cin, generator=g).to(bf).to(dev)
+        w = (torch.randn(Cout, 9 * Cin, generator=g) * (2.0 / (9 * Cin)) ** 0.5).to(bf).to(dev)
+        sc, sh = (torch.rand(Cout, generator=g) * 0.5 + 0.5).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+        ws = torch.empty(L.ap_conv_pw_stream_bytes(9 * Cin, Cout), dtype=torch.uint8, device=dev)
+        Nn.check(L.ap_conv_pw_pack(B, p(w), 9 * Cin, Cout, p(ws), st), "pack")
+        Ho = H // 2
+        y, y2 = torch.empty(n, Ho, Ho, Cout, dtype=bf, device=dev), torch.empty(n, Ho, Ho, Cout, dtype=bf, device=dev)
+
+        def timeit(call):
+            for _ in range(3):
+                call()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(a.iters):
+                call()
+            e1.record()
+            torch.cuda.synchronize()
+            return e0.elapsed_time(e1) * 1e3 / a.iters
+        t_pw = timeit(lambda: Nn.check(L.ap_conv_pw_k3s2_nhwc(B, p(x), p(ws), p(sc), p(sh), p(y), n, H, Cin, Cout, st), "pw k3"))
+        t_gen = timeit(lambda: Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), None, p(y2), n, H, H, Cin, Cout, 3, 2, 1, 1, st), "conv"))
+        flops = 2.0 * n * Ho * Ho * 9 * Cin * Cout
+        print("%-11s M=%7d K=%4d N=%4d | conv_pw %7.1f us %6.0f TF/s | generic %7.1f us %6.0f TF/s | x%.2f | equal %s" % (
+            name, n * Ho * Ho, 9 * Cin, Cout, t_pw, flops / t_pw * 1e-6, t_gen, flops / t_gen * 1e-6, t_gen / t_pw, bool(torch.equal(y, y2))))
+
+
 def ds_rows(a):
     """conv3 + folded downsample of a stage's first block: conv_pw's two-segment form against the pair kernel (layer3.0's shape)."""
     dev = torch.device("cuda", 0)
@@ -95,3 +132,4 @@ if __name__ == "__main__":
     _ap = argparse.ArgumentParser()
     _ap.add_argument("--images", type=int, default=512); _ap.add_argument("--iters", type=int, default=20); _ap.add_argument("--precision", default="f16")
     ds_rows(_ap.parse_args())
+    k3_rows(_ap.parse_args())
