@@ -8,9 +8,10 @@ from airpose_amd import copenet_model, pipeline, smplx, smplx_model, weights as 
 
 def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+    prec = sys.argv[2] if len(sys.argv) > 2 else "f16"     # also: fp32, bf16x2, bf16 (stem_direct_kernel / the fp32 kernels beside a second pass)
     dev = torch.device("cuda", 0)
     MEAN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..", "airpose_amd", "data", "smpl_mean_params.npz")
-    net = copenet_model.getcopenet(MEAN, precision="f16").eval()
+    net = copenet_model.getcopenet(MEAN, precision=prec).eval()
     net.load_state_dict(W.to_torch(W.copenet_state_dict(1234, MEAN)))
     body = smplx.SMPLX(model_data=smplx_model.make_synthetic_model(4321))
     pipe = pipeline.TwoViewInference(net, body)
