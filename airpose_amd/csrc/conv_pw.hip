@@ -17,8 +17,18 @@
 //     across tiles;
 //   * identity: the staging loads of the last K iteration (which have no chunk left to fetch) fetch the first half of the identity
 //     instead; the second half takes each register as the epilogue frees it.
-// K order per output element = the ring / lean kernels' (K steps of 32 in order, one MFMA chain): bit-identical results, so the
-// trunk may choose by problem size (ap_net_set_pw_conv).
+// Three operand forms, one mainloop (template parameter SEG2):
+//   0  x [M][Cin]                                             conv1 of layer4's bottlenecks; conv3 + identity (RES) only when forced;
+//   1  [t2 [M][Cin] | x2 sampled at (ho stride, wo stride)]   conv3 + folded downsample of layer4.0 (model_copenet.py:41-42, 97-102);
+//   2  nine taps of x [N][2 Ho][2 Wo][Cin], padding 1         the 3 x 3 / stride-2 conv2 of layer3.0 / layer4.0 (:32-34 with :18): a 64-channel
+//                                                             chunk of ONE tap per staging step (im2col by address), out-of-image taps
+//                                                             zeroed on their way into the LDS.
+// K order per output element = the ring / lean / pair kernels' (K steps of 32 in order -- [tap][Cin] for the 3 x 3 -- one MFMA chain):
+// bit-identical results, so the trunk may choose by problem size and by whether the pass shares the chip (ap_net_set_pw_conv;
+// a one-wave-per-SIMD kernel keeps another pass's workgroups off its CUs: api.hip, trunk_chunk).
+// Measured (512 images, in the pass): conv1 128 / 57 / 56 us (ring kernel 156 / 70 / 71), conv3 + downsample 171 (208), 3 x 3 / 2
+// 148 / 131 (179 / 153); what bounds it is the latency budget of a staging load: vmcnt retires in order, so a load is waited for at
+// the next ring wait behind it, four K steps after its issue, however deep it was requested.
 #include <type_traits>
 
 #include "ap_common.h"
