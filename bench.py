@@ -671,10 +671,13 @@ def main():
                                      "stream-ordered: every step complete on the caller's stream before the next starts (the reference's forward() semantics)",
                        "sharding": "whole pairs per GPU, no data-path collective"},
             "roofline": {"bound": "mfma",
-                         "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of the trunk in %d launches per step: conv_pipe_kernel "
-                                   "(dominant instance <T,128,128,2,4,2>; stride-1 3x3 layers in the 16-bit modes: conv_slab_kernel; conv3 of layer2-3 blocks together with the next block's conv1: conv_pair_kernel; "
-                                   "conv3 of the layer4 identity blocks: conv_lean_kernel) + the fused layer1 bottlenecks in the 16-bit modes "
-                                   "(bneck2_kernel<ds> / <identity>); time = HIP events around the conv stack on the streams that run "
+                         "kernel": "the 52 fused conv+BN(+residual)+ReLU layers of the trunk in %d launches per step; in the 16-bit modes, by share of "
+                                   "the stack's time: blk_img_kernel (layer3's five identity bottlenecks, one image-resident kernel each), "
+                                   "conv_pair_kernel (conv3 of the layer2 blocks / layer3.0 together with the next block's conv1), bneck2_kernel (layer1's "
+                                   "three bottlenecks, the last one with conv1 of layer2.0), conv_slab_kernel (stride-1 3x3 of layer2 / layer4), "
+                                   "conv_pw_kernel (conv1 and conv3+downsample of layer4; alone on the chip also the 3x3/2 of layer3.0 / 4.0), "
+                                   "conv_pipe_kernel<T,128,128,2,4,2> (the remaining stride-2 3x3 layers), conv_lean_kernel (conv3 of the layer4 "
+                                   "identity blocks); time = HIP events around the conv stack on the streams that run "
                                    "it: stream-ordered steps: the span over both concurrent passes; steps issued through submit (the "
                                    "passes of consecutive steps run free of each other and drift apart): the mean of the two passes' "
                                    "own durations, each of which shares the chip with the other stream throughout (equal to the "
