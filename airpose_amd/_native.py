@@ -15,6 +15,7 @@ LIB_PATH = os.environ.get("AIRPOSE_HIP_LIB", os.path.join(_HERE, "libairpose_hip
 
 AP_PREC_FP32, AP_PREC_BF16, AP_PREC_BF16X2, AP_PREC_F16 = 0, 1, 2, 3
 AP_ERANGE = -5
+AP_RANGE_SLOTS = 8                                          # include/airpose_hip.h
 # fp32: exact fp32 MFMA chain | bf16: throughput kernels, bf16 storage | f16: the same kernels with fp16 storage (11 significand
 # bits instead of 8 at the same MFMA rate: under the 1e-4 bar; |value| <= 65504) | bf16x2: split-bf16 pairs (fast parity mode)
 PRECISIONS = {"fp32": AP_PREC_FP32, "bf16": AP_PREC_BF16, "f16": AP_PREC_F16, "bf16x2": AP_PREC_BF16X2}
@@ -43,11 +44,19 @@ SIGNATURES = {
     "ap_net_precision": (_i, [_vp]),
     "ap_net_set_range_check": (_i, [_vp, _i]),
     "ap_net_range_status": (_i, [_vp, _vp, _i]),
+    "ap_net_range_peek": (_i, [_vp]),
+    "ap_net_last_conv_launches": (_i, [_vp]),
+    "ap_net_range_mark_next": (_i, [_vp, _i]),
+    "ap_net_range_slot": (_i, [_vp, _i]),
+    "ap_net_parity_probe": (_i, [_vp, _i, _c.c_uint64, _c.POINTER(_c.c_double), _vp]),
     "ap_trunk_fwd": (_i, [_vp, _vp, _i, _vp, _vp]),
     "ap_trunk_fwd_twoview": (_i, [_vp, _vp, _vp, _i, _vp, _vp]),
     "ap_trunk_fwd_twoview_async": (_i, [_vp, _vp, _vp, _i, _vp, _vp, _vp]),
     "ap_regressor_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_regressor_step": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
+    "ap_regressor_feat_part": (_i, [_vp, _vp, _i, _vp, _vp]),
+    "ap_regressor_step_local": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _vp]),
+    "ap_regressor_step_finish": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ap_copenet_fwd": (_i, [_vp] + [_vp] * 6 + [_vp, _i] * 4 + [_i, _i] + [_vp] * 4 + [_vp]),
     "ap_singleview_fwd": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ap_singleview_reg": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _vp]),
@@ -112,7 +121,7 @@ SIGNATURES = {
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 7          # include/airpose_hip.h: AP_ABI_VERSION
+ABI_VERSION = 8          # include/airpose_hip.h: AP_ABI_VERSION
 _lib = None
 _lib_lock = threading.Lock()
 

@@ -43,16 +43,24 @@ class copenet(nn.Module):
     """SMPL-X iterative regressor with ResNet-50 trunk and cross-view fusion, on MI355X."""
 
     variant = 0            # ap_net_create variant (0: two-view copenet)
+    AUTO_ORDER = ("f16", "bf16", "bf16x2", "fp32")          # fastest first (bench.py: 47k / 48k / 15.7k / 6.9k pairs/s at 256 pairs)
+    AUTO_BAR = 1e-4                                          # north_star: outputs within 1e-4 of the fp32 path
+    AUTO_PAIRS = 8
     fc1_extra = 3 + 3 + 6 + 21 * 6 + 10 + 21 * 6 + 10
 
     def __init__(self, block=Bottleneck, layers=(3, 4, 6, 3), smpl_mean_params=None, precision="f16"):
         super().__init__()
         if tuple(layers) != (3, 4, 6, 3):
             raise ValueError("only the ResNet-50 layout [3, 4, 6, 3] of the reference is supported")
-        if precision not in N.PRECISIONS:
-            raise ValueError("precision must be 'bf16' / 'f16' (throughput; bf16 or fp16 storage), 'bf16x2' (split-bf16: fast parity mode) or "
-                             "'fp32' (exact fp32 MFMA chain)")
-        self.precision = precision
+        if precision not in N.PRECISIONS and precision != "auto":
+            raise ValueError("precision must be 'bf16' / 'f16' (throughput; bf16 or fp16 storage), 'bf16x2' (split-bf16: fast parity mode), "
+                             "'fp32' (exact fp32 MFMA chain) or 'auto' (the fastest of these whose parity probe holds AUTO_BAR on the "
+                             "loaded checkpoint)")
+        # precision="auto": resolved when the weights are packed (first forward after load_state_dict), by parity_probe() of each
+        # candidate in AUTO_ORDER on THIS checkpoint; self.precision is then the chosen mode, self.auto_report what every tried one measured
+        self.precision_requested = precision
+        self.precision = self.AUTO_ORDER[0] if precision == "auto" else precision
+        self.auto_report = None
         self.inplanes = 64
         npose = 21 * 6
         self.conv1 = nn.Conv2d(3, 64, kernel_size=7, stride=2, padding=3, bias=False)
@@ -120,11 +128,41 @@ class copenet(nn.Module):
         self._packed_sig = None
 
     def _native(self, device):
-        """(Re)pack the current parameters into the library when they changed."""
+        """(Re)pack the current parameters into the library when they changed.  precision="auto": pack as each candidate mode in turn
+        (fastest first) and keep the first whose GPU parity probe against the exact-fp32 trunk of the same weights holds AUTO_BAR."""
         N.require_gpu()
         sig = (device.index, self._signature())
         if self._handle is not None and sig == self._packed_sig:
             return self._handle
+        if self.precision_requested != "auto" or self.variant != 0:
+            return self._pack(device, sig)
+        report = {}
+        for prec in self.AUTO_ORDER:
+            if self._handle is not None and prec != self.precision:
+                self._L().ap_net_destroy(self._handle)       # another storage type: another handle
+                self._handle = None
+            self.precision = prec
+            sig = (device.index, self._signature())
+            try:
+                self._pack(device, sig)
+                report[prec] = self._probe_locked(device, self.AUTO_PAIRS, 20240601)
+            except N.RangeError as e:                        # fp16 storage cannot hold this checkpoint (weights or probe activations)
+                report[prec] = {"error": str(e)[:200], "holds": False}
+                if self._handle is not None:
+                    self._L().ap_net_range_status(self._handle, N.stream_ptr(device), 1)
+                continue
+            except RuntimeError as e:
+                if "exceeds the fp16 range" not in str(e):
+                    raise
+                report[prec] = {"error": str(e)[:200], "holds": False}
+                continue
+            report[prec]["holds"] = report[prec]["max_rel_err"] < self.AUTO_BAR
+            if report[prec]["holds"]:
+                break
+        self.auto_report = {"chosen": self.precision, "bar": self.AUTO_BAR, "pairs": self.AUTO_PAIRS, "tried": report}
+        return self._handle
+
+    def _pack(self, device, sig):
         L = self._L()
         if self._handle is not None and getattr(self, "_hdev", device.index) != device.index:
             # the handle (packed weights, workspace, per-device launch state) belongs to the device of the first call
@@ -294,6 +332,91 @@ class copenet(nn.Module):
                     "ap_regressor_step")
         return pose_out, betas_out
 
+    PROBE_SLICES = ("theta.trans", "theta.rot6d", "betas", "proj(trans)")
+
+    def _probe_locked(self, dev, n_pairs, seed):
+        err = (ctypes.c_double * 8)()
+        import time
+        t0 = time.perf_counter()
+        N.check(self._L().ap_net_parity_probe(self._handle, int(n_pairs), ctypes.c_uint64(seed), err, N.stream_ptr(dev)),
+                "ap_net_parity_probe")
+        ms = (time.perf_counter() - t0) * 1e3
+        rel = dict(zip(self.PROBE_SLICES, err[0:4]))
+        return {"max_rel_err": max(rel.values()), "rel_err_by_slice": rel, "elementwise_err_by_slice": dict(zip(self.PROBE_SLICES, err[4:8])),
+                "pairs": int(n_pairs), "seed": int(seed), "ms": ms, "precision": self.precision,
+                "reference": "exact-fp32 trunk of the same weights on the GPU (ap_net_parity_probe)"}
+
+    def parity_probe(self, n_pairs=8, seed=20240601):
+        """What this handle's precision costs on the LOADED checkpoint: a seeded probe batch through the handle's trunk and through an
+        exact-fp32 trunk packed from the same weights, both followed by the fp32 regressor (3 IEF iterations), compared on the host
+        in fp64.  Returns the norm-wise error per slice (translation, 6-D rotations, betas, projected translation), the element-wise
+        error and the wall time; the first call after a (re)load also packs the fp32 reference trunk."""
+        self._check_eval()
+        dev = torch.device("cuda", torch.cuda.current_device())
+        with self._lock, torch.cuda.device(dev):
+            self._native(dev)
+            return self._probe_locked(dev, n_pairs, seed)
+
+    def regressor_feat_part(self, xf):
+        """bf + Wf[:, :2048] xf: the part of a folded regressor step that is constant over the IEF iterations -> (B, 148)."""
+        self._check_eval()
+        dev = self._dev(xf)
+        xf = N.f32c(xf, dev)
+        if xf.dim() != 2 or xf.shape[1] != 2048:
+            raise RuntimeError("regressor_feat_part: xf (B,2048)")
+        out = torch.empty(xf.shape[0], 148, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(self._L().ap_regressor_feat_part(h, N.dptr(xf), xf.shape[0], N.dptr(out), N.stream_ptr(dev)), "ap_regressor_feat_part")
+        return out
+
+    def regressor_step_local(self, hfeat, bb, pose, betas):
+        """The partner-independent columns of one forward_reg step (model_copenet.py:185: xf | bb | pos | orient | art | shape): runs
+        while the partner's 136 floats are still on the wire -> partial (B, 148)."""
+        dev = self._dev(hfeat)
+        B = hfeat.shape[0]
+        hfeat, bb, pose, betas = (N.f32c(t, dev) for t in (hfeat, bb, pose, betas))
+        if hfeat.shape != (B, 148) or bb.shape != (B, 3) or pose.shape != (B, 135) or betas.shape != (B, 10):
+            raise RuntimeError("regressor_step_local: hfeat (B,148), bb (B,3), pose (B,135), betas (B,10)")
+        out = torch.empty(B, 148, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(self._L().ap_regressor_step_local(h, N.dptr(hfeat), N.dptr(bb), N.dptr(pose), N.dptr(betas), B, N.dptr(out),
+                                                      N.stream_ptr(dev)), "ap_regressor_step_local")
+        return out
+
+    def regressor_step_finish(self, partial, pose, betas, partner):
+        """partial + the partner's 136 columns + the residual add -> (pose (B,135), betas (B,10)) of the step."""
+        dev = self._dev(partial)
+        B = partial.shape[0]
+        partial, pose, betas, partner = (N.f32c(t, dev) for t in (partial, pose, betas, partner))
+        if partial.shape != (B, 148) or pose.shape != (B, 135) or betas.shape != (B, 10) or partner.shape != (B, 136):
+            raise RuntimeError("regressor_step_finish: partial (B,148), pose (B,135), betas (B,10), partner (B,136)")
+        pose_out = torch.empty(B, 135, device=dev, dtype=torch.float32)
+        betas_out = torch.empty(B, 10, device=dev, dtype=torch.float32)
+        with self._lock, torch.cuda.device(dev):
+            h = self._native(dev)
+            N.check(self._L().ap_regressor_step_finish(h, N.dptr(partial), N.dptr(pose), N.dptr(betas), N.dptr(partner), 136, B,
+                                                       N.dptr(pose_out), N.dptr(betas_out), N.stream_ptr(dev)), "ap_regressor_step_finish")
+        return pose_out, betas_out
+
+    # ------------------------------------------------------------------ fp16 range sentinel
+    def range_mark_next(self, slot):
+        """The next trunk-running call snapshots the range words of its pass streams into per-handle slot ``slot`` (behind its own
+        last kernels: later batches cannot leak into it)."""
+        dev = torch.device("cuda", torch.cuda.current_device())
+        with self._lock:
+            N.check(self._L().ap_net_range_mark_next(self._native(dev), int(slot)), "ap_net_range_mark_next")
+
+    def range_slot(self, slot):
+        """Raise RangeError if the snapshot of ``slot`` saw a range word set.  No synchronisation: wait for an event recorded behind
+        the marked call first."""
+        N.check(self._L().ap_net_range_slot(self._handle, int(slot)), "ap_net_range_slot")
+
+    def range_peek(self):
+        """Raise RangeError if the flag is set right now.  No synchronisation."""
+        N.check(self._L().ap_net_range_peek(self._handle), "ap_net_range_peek")
+
     # ------------------------------------------------------------------ measurement hooks (bench.py)
     def enable_timing(self, on=True):
         N.check(self._L().ap_net_enable_timing(self._native(torch.device("cuda", torch.cuda.current_device())), int(on)),
@@ -304,6 +427,10 @@ class copenet(nn.Module):
         n = ctypes.c_int64()
         N.check(self._L().ap_net_timing(self._handle, ms, ctypes.byref(n), int(reset)), "ap_net_timing")
         return {"stem_ms": ms[0], "conv_ms": ms[1], "avgpool_ms": ms[2], "regressor_ms": ms[3], "passes": n.value}
+
+    def last_conv_launches(self):
+        """Kernel launches of the conv stack in the most recent trunk-running call (all passes): what the library chose."""
+        return int(self._L().ap_net_last_conv_launches(self._handle))
 
     @staticmethod
     def _L():
@@ -370,7 +497,9 @@ class copenet(nn.Module):
 
     def set_pw_conv(self, on):
         """bf16 / f16: the pointwise layers of layer3 / layer4 no fused kernel covers on the one-wave-per-SIMD kernel (conv_pw.hip): 1 (default)
-        when their tiles fill whole rounds of the chip, 2 whenever supported, 0 never (generic kernels); same bits."""
+        when their tiles fill whole rounds of the chip (conv1 layers, conv3 + folded downsample; alone on the chip also the stride-2
+        3 x 3 of a stage's first block); 2 whenever supported, conv3 + identity too; 3 conv1 whenever supported; 4 as 1 without the
+        stride-2 3 x 3; 0 never (generic kernels).  Same bits in every setting."""
         self._set_knob("ap_net_set_pw_conv", on)
 
     def set_even_out(self, on):

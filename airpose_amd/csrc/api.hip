@@ -247,6 +247,9 @@ struct ap_net {
     int device = 0, prec = AP_PREC_BF16, variant = 0;
     bool finalized = false;
     std::map<std::string, HostTensor> tensors;
+    const ap_net* tensors_of = nullptr;                      // the fp32 reference handle of ap_net_parity_probe packs its owner's host tensors
+    ap_net* probe_ref = nullptr;                             // ... that handle (trunk only), valid for the current packing
+    DevBuf probe_x, probe_bb, probe_pos, probe_feat, probe_out;
     // trunk
     DevBuf stem_w, stem_wpk, stem_wpk_lo, stem_scale, stem_shift;   // stem_wpk_lo: low plane of the split-bf16 stem weights
     struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false;
@@ -280,7 +283,8 @@ struct ap_net {
     DevBuf mean_pose, mean_shape, mean_cam;
     // workspace
     int chunk = 0;
-    struct TrunkWs { DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds; };
+    struct TrunkWs { DevBuf ws_stem, ws_a, ws_b, ws_t1, ws_t2, ws_ds;
+                     int* rflag = nullptr; };   // the range word the kernels of THIS pass stream set (AP_PREC_F16; ap_net::range_flag + q)
     TrunkWs tw[4];                 // [1..]: the other concurrent passes when the views run on several streams
     DevBuf ws_feat;
     // two-view forward: view 0 and view 1 as two concurrent trunk passes on two internal streams (an HBM-bound layer of
@@ -300,8 +304,19 @@ struct ap_net {
     // AP_PREC_F16 range sentinel: host-mapped word the pooling stage sets when a trunk feature is not finite (NULL otherwise).
     // range_mode 1 (default): sticky, reported by the NEXT call on the handle and by ap_net_range_status (no sync on the hot path);
     // 2: every trunk-running call synchronises its stream and reports its own pass
-    int* range_flag = nullptr;
+    // One word per pass stream (tw[q].rflag = range_flag + q): a snapshot taken on pass stream q behind a batch's last kernel there sees
+    // exactly the kernels of this and earlier batches, whatever the sibling stream is already running (ap_net_range_mark_next)
+    int* range_flag = nullptr;                               // [4]
+    int* range_slots = nullptr;                              // [AP_RANGE_SLOTS][4] host-mapped words: stream-ordered snapshots of the pass words
+    int conv_launches = 0;                                   // kernel launches of the conv stack in the most recent trunk call, all passes (ap_net_last_conv_launches)
+    int mark_slot = -1;                                      // ap_net_range_mark_next: the next trunk-running call snapshots into this slot
     int range_mode = 1;
+    bool range_any() const {
+        if (!range_flag) return false;
+        int v = 0;
+        for (int q = 0; q < 4; ++q) v |= __atomic_load_n(range_flag + q, __ATOMIC_RELAXED);
+        return v != 0;
+    }
     bool f16_overflow = false;                               // AP_PREC_F16: a packed weight left the fp16 range (ap_net_finalize refuses)
     uint16_t h16(float f) { return prec == AP_PREC_F16 ? host_f32_to_f16(f, &f16_overflow) : host_f32_to_bf16(f); }
 };
@@ -333,8 +348,9 @@ namespace {
 
 // ---------------------------------------------------------------------------------- packing
 const HostTensor* find(const ap_net* h, const std::string& name) {
-    auto it = h->tensors.find(name);
-    return it == h->tensors.end() ? nullptr : &it->second;
+    const ap_net* src = h->tensors_of ? h->tensors_of : h;
+    auto it = src->tensors.find(name);
+    return it == src->tensors.end() ? nullptr : &it->second;
 }
 
 int bn_fold(const ap_net* h, const std::string& p, int c, std::vector<float>& scale, std::vector<float>& shift) {
@@ -590,6 +606,18 @@ int run_gemm(const Layer& L, const float* x, int ldx, int K, int M, float* y, in
     return AP_OK;
 }
 
+// every device buffer a trunk block owns (packed rows, BatchNorm vectors, the weight streams of conv_pair / block_img / conv_pw):
+// DevBuf has no destructor, so whoever drops a Block releases it first (re-finalize and ap_net_destroy)
+void release_layer(Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); L.pw.release(); }
+void release_blocks(ap_net* h) {
+    for (auto& B : h->blocks) {
+        for (Layer* L : {&B.c1, &B.c2, &B.c3, &B.down, &B.c3ds}) release_layer(*L);
+        B.pair.release();
+        B.imgw.release();
+    }
+    h->blocks.clear();
+}
+
 int finalize_trunk(ap_net* h) {
     // stem: [64][3][7][7] -> [k = (r,s,c)][64] fp32 for the direct kernel
     const HostTensor* w = find(h, "conv1.weight");
@@ -630,7 +658,8 @@ int finalize_trunk(ap_net* h) {
     HIP_TRY(upload(h->stem_shift, sh.data(), sh.size() * 4));
 
     static const int layers[4] = {3, 4, 6, 3}, planes[4] = {64, 128, 256, 512};
-    h->blocks.clear();
+    HIP_TRY(hipDeviceSynchronize());                        // (a re-finalize: no pass of the previous packing may still be in flight)
+    release_blocks(h);
     h->blocks.resize(16);
     int inpl = 64, bi_all = 0;
     for (int li = 0; li < 4; ++li)
@@ -943,7 +972,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
         HIP_TRY(H16(prec, ap_launch_stem_pool)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                               w.ws_a.p, n, h->range_flag, st));
+                                               w.ws_a.p, n, w.rflag, st));
     } else if (bf) {
         HIP_TRY(H16(prec, ap_launch_stem_conv_mfma)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
                                                     h->stem_shift.as<float>(), w.ws_stem.p, n, st));
@@ -961,7 +990,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             HIP_TRY(k_bf16::ap_launch_stem_conv(x1, h->stem_w.as<float>(), h->stem_scale.as<float>(), h->stem_shift.as<float>(),
                                         (char*)w.ws_stem.p + (size_t)n0 * 112 * 112 * 64 * es, n1, kind, st));
     }
-    if (!(h->fuse_stem && (bf || kind == AP_PREC_BF16X2))) HIP_TRY(H16(prec, ap_launch_maxpool)(w.ws_stem.p, w.ws_a.p, n, kind, h->range_flag, st));
+    if (!(h->fuse_stem && (bf || kind == AP_PREC_BF16X2))) HIP_TRY(H16(prec, ap_launch_maxpool)(w.ws_stem.p, w.ws_a.p, n, kind, w.rflag, st));
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e1));
     if (signal_at == 1) HIP_TRY(hipEventRecord(h->ev_skew, st));
     void *cur = w.ws_a.p, *nxt = w.ws_b.p;
@@ -994,9 +1023,10 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             const ap_net::Block* Nx = &B != &h->blocks.back() ? &B + 1 : nullptr;
             const bool tail = h->fuse_tail && !B.has_down && Nx && Nx->has_down && Nx->c1.cin == 256 && Nx->c1.cout == 128 &&
                               Nx->c2.stride == 2 && Nx->down.stride == 2 && g_conv_mode.load(std::memory_order_relaxed) < 0;
-            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, prec, st, h->range_flag, tail ? &Nx->c1 : nullptr,
+            if ((rc = run_bneck64(B.c1, B.c2, L3, B.has_down, cur, n, H, nxt, prec, st, w.rflag, tail ? &Nx->c1 : nullptr,
                                   w.ws_t1.p, tail && h->even_out)))
                 return rc;
+            ++h->conv_launches;
             t1_ready = tail;
             std::swap(cur, nxt);
             continue;
@@ -1011,16 +1041,18 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         if (bf && img_fit && B.imgw.p && H == 14 && !t1_ready && !cur_tiled && g_conv_mode.load(std::memory_order_relaxed) == -1) {
             // layer3 identity block: conv1 -> conv2 -> conv3 + identity in one kernel, an image per workgroup, t1 / t2 in LDS
             BlkImgArgs a{};
-            a.x = cur; a.y = nxt; a.wfrag = B.imgw.p; a.N = n; a.range_flag = h->range_flag; a.dbg = g_conv_dbg;
+            a.x = cur; a.y = nxt; a.wfrag = B.imgw.p; a.N = n; a.range_flag = w.rflag; a.dbg = g_conv_dbg;
             a.s1 = B.c1.scale.as<float>(); a.h1 = B.c1.shift.as<float>();
             a.s2 = B.c2.scale.as<float>(); a.h2 = B.c2.shift.as<float>();
             a.s3 = B.c3.scale.as<float>(); a.h3 = B.c3.shift.as<float>();
             HIP_TRY(H16(prec, ap_launch_block_img)(a, st));
+            ++h->conv_launches;
             std::swap(cur, nxt);
             continue;
         }
         if (!t1_ready && cur_tiled) return fail(AP_ESTATE, "trunk: conv1 of a block would read a tiled block output");
-        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, h->range_flag, 0, pw_conv))) return rc;
+        if (!t1_ready && (rc = run_conv(B.c1, cur, n, H, H, w.ws_t1.p, nullptr, 1, prec, st, w.rflag, 0, pw_conv))) return rc;
+        h->conv_launches += (t1_ready ? 0 : 1) + 2 + ((!is_pair(B) && B.has_down && !h->fuse_ds) ? 1 : 0);   // conv1, conv2, conv3 (+ an unfused downsample)
         t1_ready = false;
         const bool pair = is_pair(B);
         // conv2 of a stage's first block on conv_pw.hip (nine taps): it writes NHWC rows, so t2 stays untiled for that block's pair kernel.
@@ -1034,7 +1066,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             HIP_TRY((hipError_t)err);
         }
         const int t2_tiled = pair && tiling && !c2_pw;
-        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, h->range_flag, t2_tiled, c2_pw ? pw_conv : 0))) return rc;
+        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, w.rflag, t2_tiled, c2_pw ? pw_conv : 0))) return rc;
         if (pair) {
             // conv3 (+ identity | + folded downsample, ReLU) AND -- where the pair carries it -- the next block's conv1 in one
             // kernel: the block output is written once and not read back for conv1 (model_copenet.py:38-45 of this block,
@@ -1045,7 +1077,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.t2 = w.ws_t2.p; a.wstream = B.pair.p;
             a.s3 = L3.scale.as<float>(); a.h3 = L3.shift.as<float>();
             a.s1 = Nx.c1.scale.as<float>(); a.h1 = Nx.c1.shift.as<float>();
-            a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg; a.range_flag = h->range_flag;
+            a.out = nxt; a.t1n = w.ws_t1.p; a.M = n * Ho * Ho; a.dbg = g_conv_dbg; a.range_flag = w.rflag;
             a.t2_tiled = t2_tiled; a.res_tiled = cur_tiled;
             a.out_tiled = t2_tiled && B.pair_n1 > 0 && is_pair(Nx) && !Nx.has_down;
             cur_tiled = a.out_tiled != 0;
@@ -1060,7 +1092,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         } else if (cur_tiled) {                               // (cannot happen: out_tiled is only set when the next block is a pair block)
             return fail(AP_ESTATE, "trunk: a tiled block output reached a kernel that reads NHWC");
         } else if (B.has_down && h->fuse_ds) {
-            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st, h->range_flag, pw_conv))) return rc;
+            if ((rc = run_c3_ds(B.c3ds, w.ws_t2.p, cur, n, Ho, H, nxt, prec, st, w.rflag, pw_conv))) return rc;
         } else if (bf && h->fuse_pool && &B == &h->blocks.back() && !B.has_down && Ho == 7 &&
                    g_conv_mode.load(std::memory_order_relaxed) == -1) {
             // last convolution of the trunk: conv3 + bn3 + identity + ReLU AND AvgPool2d(7) + view in one kernel
@@ -1070,25 +1102,25 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             a.N = n; a.H = a.W = a.Ho = a.Wo = Ho; a.Cin = B.c3.cin; a.Cout = B.c3.cout;
             a.KH = a.KW = 1; a.stride = 1; a.pad = 0; a.M = n * Ho * Ho;
             a.ldx = B.c3.cin; a.ldy = B.c3.cout; a.ldr = B.c3.cout; a.wld = B.c3.wld; a.relu = 1;
-            a.pool_out = feat; a.range_flag = h->range_flag;
+            a.pool_out = feat; a.range_flag = w.rflag;
             HIP_TRY(zero_line(&a.zero));
             if (k_bf16::ap_conv_lean_supported(a, kind)) {
                 HIP_TRY(H16(prec, ap_launch_conv_lean)(a, st));
                 pooled = true;
-            } else if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, cur, 1, prec, st, h->range_flag))) return rc;
+            } else if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, cur, 1, prec, st, w.rflag))) return rc;
         } else {
             const void* res = cur;
             if (B.has_down) {
-                if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, prec, st, h->range_flag))) return rc;
+                if ((rc = run_conv(B.down, cur, n, H, H, w.ws_ds.p, nullptr, 0, prec, st, w.rflag))) return rc;
                 res = w.ws_ds.p;
             }
-            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st, h->range_flag, 0, (B.has_down || pw_conv != 2) ? 0 : pw_conv))) return rc;   // (conv3 + identity: 89-95 us against the lean kernel's 86: only when forced)
+            if ((rc = run_conv(B.c3, w.ws_t2.p, n, Ho, Ho, nxt, res, 1, prec, st, w.rflag, 0, (B.has_down || pw_conv != 2) ? 0 : pw_conv))) return rc;   // (conv3 + identity: 89-95 us against the lean kernel's 86: only when forced)
         }
         std::swap(cur, nxt);
         H = Ho;
     }
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &e2));
-    if (!pooled) HIP_TRY(H16(prec, ap_launch_avgpool)(cur, feat, n, 2048, kind, h->range_flag, st));
+    if (!pooled) HIP_TRY(H16(prec, ap_launch_avgpool)(cur, feat, n, 2048, kind, w.rflag, st));
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e3));
     if (ev_out) {                                            // the caller combines the events of two concurrent passes
         ev_out[0] = e0; ev_out[1] = e1; ev_out[2] = e2; ev_out[3] = e3;
@@ -1111,14 +1143,14 @@ int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float
     if (!st_out) st_out = st;
     if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
     if (n0 <= 0 || n1 < 0 || !x0 || (n1 && !x1) || !feat) return fail(AP_EINVAL, "ap_trunk_fwd: bad arguments");
-    if (h->range_flag && h->range_mode && __atomic_load_n(h->range_flag, __ATOMIC_RELAXED))
+    if (h->range_mode && h->range_any())
         return fail(AP_ERANGE, "AP_PREC_F16: an earlier trunk pass of this handle produced non-finite features (a stored activation left "
                                "the fp16 range); clear with ap_net_range_status(h, stream, 1) and use AP_PREC_BF16 for this checkpoint");
     int rc_pass = trunk_passes(h, x0, n0, x1, n1, feat, st, st_out);
     if (rc_pass) return rc_pass;
     if (h->range_flag && h->range_mode == 2) {
         HIP_TRY(hipStreamSynchronize(st_out));
-        if (__atomic_load_n(h->range_flag, __ATOMIC_RELAXED))
+        if (h->range_any())
             return fail(AP_ERANGE, "AP_PREC_F16: non-finite trunk features (a stored activation left the fp16 range); use AP_PREC_BF16 "
                                    "for this checkpoint");
     }
@@ -1127,6 +1159,7 @@ int trunk_fwd(ap_net* h, const float* x0, int n0, const float* x1, int n1, float
 
 int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, float* feat, hipStream_t st, hipStream_t st_out) {
     const int n_img = n0 + n1;
+    h->conv_launches = 0;
     const int chunk = h->chunk > 0 ? h->chunk : 512;
     const size_t IMG_ELEMS = (size_t)3 * 224 * 224;
     if (h->dual_stream && !n1 && n0 >= 128) {                // one list of images (forward_feat_ext, the single-view heads): its two
@@ -1182,6 +1215,11 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
                                  &ev[((size_t)q * rounds + r) * 4], (q == 0 && np == 2 && r == 0) ? h->dual_skew : 0);
             }
         }
+        // ap_net_range_mark_next: each pass stream snapshots ITS range word behind its last kernel of this call
+        const int mslot = h->mark_slot;
+        h->mark_slot = -1;
+        if (mslot >= 0 && h->range_flag)
+            for (int q = 0; q < forked; ++q) HIP_TRY(ap_launch_word_copy(h->range_flag + q, h->range_slots + 4 * mslot + q, h->aux[q]));
         // join every stream that forked, also after a failed launch: later calls reuse tw[q] on the caller's stream order
         for (int q = 0; q < forked; ++q) {
             HIP_TRY(hipEventRecord(h->ev_join[q], h->aux[q]));
@@ -1226,6 +1264,8 @@ int trunk_passes(ap_net* h, const float* x0, int n0, const float* x1, int n1, fl
                              feat + (size_t)i0 * 2048, st);
         if (rc) return rc;
     }
+    if (h->mark_slot >= 0 && h->range_flag) HIP_TRY(ap_launch_word_copy(h->range_flag, h->range_slots + 4 * h->mark_slot, st));
+    h->mark_slot = -1;
     if (h->tm.on) h->tm.passes++;
     return AP_OK;
 }
@@ -1318,7 +1358,7 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
 // ================================================================================== C ABI
 extern "C" {
 
-const char* ap_version(void) { return "airpose_hip 0.5 (gfx950; abi 7)"; }
+const char* ap_version(void) { return "airpose_hip 0.6 (gfx950; abi 8)"; }
 int ap_abi_version(void) { return AP_ABI_VERSION; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
@@ -1329,9 +1369,13 @@ int ap_net_create(ap_net** out, int device, int precision, int variant) {
     ap_net* h = new ap_net();
     h->device = device; h->prec = precision; h->variant = variant;
     if (precision == AP_PREC_F16) {
-        hipError_t e = hipHostMalloc((void**)&h->range_flag, sizeof(int), hipHostMallocMapped);
+        hipError_t e = hipHostMalloc((void**)&h->range_flag, 4 * sizeof(int), hipHostMallocMapped);
         if (e != hipSuccess) { delete h; return fail((int)e, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
-        *h->range_flag = 0;
+        for (int q = 0; q < 4; ++q) h->range_flag[q] = 0;
+        e = hipHostMalloc((void**)&h->range_slots, AP_RANGE_SLOTS * 4 * sizeof(int), hipHostMallocMapped);
+        if (e != hipSuccess) { (void)hipHostFree(h->range_flag); delete h; return fail((int)e, std::string("hipHostMalloc: ") + hipGetErrorString(e)); }
+        for (int i = 0; i < AP_RANGE_SLOTS * 4; ++i) h->range_slots[i] = 0;
+        for (int q = 0; q < 4; ++q) h->tw[q].rflag = h->range_flag + q;
     }
     *out = h;
     return AP_OK;
@@ -1348,8 +1392,8 @@ void ap_net_destroy(ap_net* h) {
                       &h->tw[3].ws_ds, &h->ws_feat, &h->ws_H, &h->ws_S, &h->ws_T1, &h->ws_T2,
                       &h->ws_D, &h->ws_state})
         b->release();
-    auto rel = [](Layer& L) { L.w.release(); L.scale.release(); L.shift.release(); };
-    for (auto& B : h->blocks) { rel(B.c1); rel(B.c2); rel(B.c3); rel(B.down); rel(B.c3ds); B.pair.release(); }
+    auto rel = [](Layer& L) { release_layer(L); };
+    release_blocks(h);
     rel(h->fc1_feat); rel(h->fc1_state); rel(h->fc2); rel(h->dec); rel(h->fold_feat); rel(h->fold_state);
     h->foldT_feat.release(); h->foldT_state.release(); h->fold_bias.release();
     h->tm.destroy();
@@ -1361,6 +1405,9 @@ void ap_net_destroy(ap_net* h) {
     if (h->ev_in) (void)hipEventDestroy(h->ev_in);
     if (h->ev_skew) (void)hipEventDestroy(h->ev_skew);
     if (h->range_flag) (void)hipHostFree(h->range_flag);
+    if (h->range_slots) (void)hipHostFree(h->range_slots);
+    if (h->probe_ref) { ap_net* r = h->probe_ref; h->probe_ref = nullptr; ap_net_destroy(r); }
+    for (DevBuf* b : {&h->probe_x, &h->probe_bb, &h->probe_pos, &h->probe_feat, &h->probe_out}) b->release();
     delete h;
 }
 
@@ -1383,6 +1430,7 @@ int ap_net_finalize(ap_net* h) {
     if (!h) return fail(AP_EINVAL, "null handle");
     HIP_TRY(hipSetDevice(h->device));
     h->f16_overflow = false;
+    if (h->probe_ref) { ap_net* r = h->probe_ref; h->probe_ref = nullptr; ap_net_destroy(r); }   // (packed from the previous tensors)
     int rc = finalize_trunk(h);
     if (rc) return rc;
     if ((rc = finalize_regressor(h))) return rc;
@@ -1407,9 +1455,36 @@ int ap_net_range_status(ap_net* h, void* stream, int reset) {
     if (!h->range_flag) return AP_OK;                        // only fp16 storage has a range to leave
     HIP_TRY(hipSetDevice(h->device));
     HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
-    const int bad = __atomic_load_n(h->range_flag, __ATOMIC_RELAXED);
-    if (reset) __atomic_store_n(h->range_flag, 0, __ATOMIC_RELAXED);
+    const int bad = h->range_any();
+    if (reset) for (int q = 0; q < 4; ++q) __atomic_store_n(h->range_flag + q, 0, __ATOMIC_RELAXED);
     if (bad) return fail(AP_ERANGE, "AP_PREC_F16: a trunk pass produced non-finite features (a stored activation left the fp16 range)");
+    return AP_OK;
+}
+
+int ap_net_last_conv_launches(const ap_net* h) { return h ? h->conv_launches : AP_EINVAL; }
+
+int ap_net_range_peek(const ap_net* h) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    if (h->range_any())
+        return fail(AP_ERANGE, "AP_PREC_F16: a trunk pass of this handle left the fp16 range (flag read without a stream sync)");
+    return AP_OK;
+}
+
+int ap_net_range_mark_next(ap_net* h, int slot) {
+    if (!h || slot < -1 || slot >= AP_RANGE_SLOTS) return fail(AP_EINVAL, "ap_net_range_mark_next: handle, slot in [-1, AP_RANGE_SLOTS)");
+    h->mark_slot = h->range_flag ? slot : -1;
+    // (the slot's previous batch is done -- the caller waited for it before reusing the slot -- so the host may clear its words)
+    if (h->mark_slot >= 0) for (int q = 0; q < 4; ++q) __atomic_store_n(h->range_slots + 4 * slot + q, 0, __ATOMIC_RELAXED);
+    return AP_OK;
+}
+
+int ap_net_range_slot(const ap_net* h, int slot) {
+    if (!h || slot < 0 || slot >= AP_RANGE_SLOTS) return fail(AP_EINVAL, "ap_net_range_slot: handle, slot in [0, AP_RANGE_SLOTS)");
+    int v = 0;
+    if (h->range_slots) for (int q = 0; q < 4; ++q) v |= __atomic_load_n(h->range_slots + 4 * slot + q, __ATOMIC_RELAXED);
+    if (v)
+        return fail(AP_ERANGE, "AP_PREC_F16: a stored activation of this batch's trunk passes (or of an earlier batch's) left the fp16 "
+                               "range; use precision bf16 / bf16x2 for this checkpoint");
     return AP_OK;
 }
 
@@ -1449,6 +1524,109 @@ int ap_regressor_step(ap_net* h, const float* xf, const float* bb, const float* 
     RegInputs in{xf, nullptr, bb, nullptr, pose_in, nullptr, pose_in + 3, nullptr, betas_in, nullptr, 135, 0, 10, 0};
     return regressor_run(h, in, B, 1, 0, partner, partner_ld, 135, pose_out, betas_out, nullptr, nullptr,
                          (hipStream_t)stream);
+}
+
+int ap_regressor_feat_part(ap_net* h, const float* xf, int B, float* hfeat, void* stream) {
+    if (!h || !xf || !hfeat || B <= 0) return fail(AP_EINVAL, "ap_regressor_feat_part: bad argument");
+    if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
+    if (h->variant != 0 || !h->fold)
+        return fail(AP_ESTATE, "ap_regressor_feat_part / _step_local / _step_finish evaluate the folded two-view map (ap_net_fold_status == 1); "
+                               "this handle runs the literal chain: use ap_regressor_step");
+    HIP_TRY(h->ws_H.reserve((size_t)ap_reg_fold_part_floats(B) * 4));
+    HIP_TRY(ap_launch_reg_feat_part(xf, B, h->foldT_feat.as<float>(), h->fold_bias.as<float>(), h->ws_H.as<float>(), hfeat, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_regressor_step_local(ap_net* h, const float* hfeat, const float* bb, const float* pose_in, const float* betas_in, int B,
+                            float* partial, void* stream) {
+    if (!h || !hfeat || !bb || !pose_in || !betas_in || !partial || B <= 0) return fail(AP_EINVAL, "ap_regressor_step_local: bad argument");
+    if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
+    if (h->variant != 0 || !h->fold) return fail(AP_ESTATE, "ap_regressor_step_local needs the folded two-view map (ap_net_fold_status == 1)");
+    HIP_TRY(ap_launch_reg_step_local(hfeat, bb, pose_in, betas_in, B, h->foldT_state.as<float>(), partial, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_regressor_step_finish(ap_net* h, const float* partial, const float* pose_in, const float* betas_in, const float* partner,
+                             int partner_ld, int B, float* pose_out, float* betas_out, void* stream) {
+    if (!h || !partial || !pose_in || !betas_in || !partner || !pose_out || !betas_out || partner_ld < 136 || B <= 0)
+        return fail(AP_EINVAL, "ap_regressor_step_finish: bad argument");
+    if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
+    if (h->variant != 0 || !h->fold) return fail(AP_ESTATE, "ap_regressor_step_finish needs the folded two-view map (ap_net_fold_status == 1)");
+    HIP_TRY(ap_launch_reg_step_finish(partial, pose_in, betas_in, partner, partner_ld, B, h->foldT_state.as<float>(), pose_out, betas_out,
+                                      (hipStream_t)stream));
+    return AP_OK;
+}
+
+// The handle's arithmetic against the exact-fp32 mode of the SAME weights on a seeded probe batch, on the GPU: what the 1e-4 claim of a
+// 16-bit mode is worth on THIS checkpoint.  Only the trunk differs between the modes (the regressor is fp32 everywhere), so the
+// reference is an fp32 trunk packed from the handle's own host tensors (kept until the next ap_net_finalize) and both feature sets
+// go through the handle's regressor.
+int ap_net_parity_probe(ap_net* h, int n_pairs, uint64_t seed, double* err8, void* stream) {
+    if (!h || !err8 || n_pairs < 1 || n_pairs > 64) return fail(AP_EINVAL, "ap_net_parity_probe: handle, 1 <= n_pairs <= 64, err8");
+    if (!h->finalized) return fail(AP_ESTATE, "ap_net_finalize has not been called");
+    if (h->variant != 0) return fail(AP_ESTATE, "ap_net_parity_probe: two-view copenet handles only");
+    hipStream_t st = (hipStream_t)stream;
+    HIP_TRY(hipSetDevice(h->device));
+    for (int i = 0; i < 8; ++i) err8[i] = 0.0;
+    if (h->prec == AP_PREC_FP32) return AP_OK;               // the reference itself
+    if (!h->probe_ref) {
+        ap_net* r = new ap_net();
+        r->device = h->device; r->prec = AP_PREC_FP32; r->variant = h->variant; r->tensors_of = h;
+        const int rc = finalize_trunk(r);
+        if (rc) { ap_net_destroy(r); return rc; }
+        r->finalized = true;                                 // (trunk only: its regressor is never called)
+        h->probe_ref = r;
+    }
+    const int B = n_pairs;
+    const size_t IMG = (size_t)3 * 224 * 224;
+    HIP_TRY(h->probe_x.reserve(2 * B * IMG * 4));
+    HIP_TRY(h->probe_bb.reserve((size_t)2 * B * 3 * 4));
+    HIP_TRY(h->probe_pos.reserve((size_t)B * 3 * 4));
+    HIP_TRY(h->probe_feat.reserve((size_t)2 * 2 * B * 2048 * 4));
+    HIP_TRY(h->probe_out.reserve((size_t)2 * 2 * B * 145 * 4));
+    float *x = h->probe_x.as<float>(), *bb = h->probe_bb.as<float>(), *pos = h->probe_pos.as<float>();
+    HIP_TRY(ap_launch_probe_inputs(x, 2 * B * IMG, bb, 2 * B, seed, st));
+    std::vector<float> hp((size_t)B * 3);
+    for (int b = 0; b < B; ++b) { hp[3 * b] = 0.f; hp[3 * b + 1] = 0.f; hp[3 * b + 2] = 10.f * 0.05f; }   // copenet_twoview.py:184,201-203
+    HIP_TRY(hipMemcpyAsync(pos, hp.data(), hp.size() * 4, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));                       // (hp is a local)
+    std::vector<float> out[2];
+    for (int m = 0; m < 2; ++m) {
+        ap_net* net = m ? h->probe_ref : h;
+        float* feat = h->probe_feat.as<float>() + (size_t)m * 2 * B * 2048;
+        float* o = h->probe_out.as<float>() + (size_t)m * 2 * B * 145;
+        int rc = trunk_fwd(net, x, B, x + B * IMG, B, feat, st);
+        if (rc) return rc;
+        RegInputs in{feat, feat + (size_t)B * 2048, bb, bb + (size_t)B * 3, pos, pos, nullptr, nullptr, nullptr, nullptr, 0, 0, 0, 0};
+        float *p0 = o, *p1 = o + (size_t)B * 135, *b0 = o + (size_t)2 * B * 135, *b1 = b0 + (size_t)B * 10;
+        if ((rc = regressor_run(h, in, B, 3, 1, nullptr, 0, 3, p0, b0, p1, b1, st))) return rc;
+        out[m].resize((size_t)2 * B * 145);
+        HIP_TRY(hipMemcpyAsync(out[m].data(), o, out[m].size() * 4, hipMemcpyDeviceToHost, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    if (h->range_any())
+        return fail(AP_ERANGE, "ap_net_parity_probe: the probe batch left the fp16 range");
+    // slices: translation (3), 6-D rotations (132), betas (10), projected root u = f tx / tz + cx, v likewise (the 2-D error is the
+    // translation error seen through the camera: f = 1475, centre (960, 540), constants.py:7-11); norm-wise max|a-b| / max|b| in
+    // err8[0..3], element-wise max |a-b| / (1e-2 + |b|) in err8[4..7]
+    double num[4] = {0, 0, 0, 0}, den[4] = {0, 0, 0, 0}, el[4] = {0, 0, 0, 0};
+    auto acc = [&](int sl, double a, double b) {
+        num[sl] = std::max(num[sl], std::fabs(a - b));
+        den[sl] = std::max(den[sl], std::fabs(b));
+        el[sl] = std::max(el[sl], std::fabs(a - b) / (1e-2 + std::fabs(b)));
+    };
+    for (int r = 0; r < 2 * B; ++r) {
+        const float *pa = &out[0][(size_t)r * 135], *pb = &out[1][(size_t)r * 135];
+        for (int e = 0; e < 135; ++e) acc(e < 3 ? 0 : 1, pa[e], pb[e]);
+        const float *ba = &out[0][(size_t)2 * B * 135 + (size_t)r * 10], *bbv = &out[1][(size_t)2 * B * 135 + (size_t)r * 10];
+        for (int e = 0; e < 10; ++e) acc(2, ba[e], bbv[e]);
+        if (std::fabs(pb[2]) > 1e-6 && std::fabs(pa[2]) > 1e-6) {
+            acc(3, 1475.0 * pa[0] / pa[2] + 960.0, 1475.0 * pb[0] / pb[2] + 960.0);
+            acc(3, 1475.0 * pa[1] / pa[2] + 540.0, 1475.0 * pb[1] / pb[2] + 540.0);
+        }
+    }
+    for (int sl = 0; sl < 4; ++sl) { err8[sl] = den[sl] > 0 ? num[sl] / den[sl] : 0.0; err8[4 + sl] = el[sl]; }
+    return AP_OK;
 }
 
 int ap_singleview_fwd(ap_net* h, const float* x, const float* bb, const float* pos, const float* init_theta,
@@ -1854,9 +2032,17 @@ int ap_net_set_fold(ap_net* h, int on) {
 int ap_net_set_fold_bar(ap_net* h, double bar) {
     if (!h || !(bar >= 0.0)) return fail(AP_EINVAL, "ap_net_set_fold_bar: handle, bar >= 0");
     h->fold_bar = bar;
-    // the bar is applied by ap_net_finalize: re-run it here when the handle holds a packed checkpoint, so the handle never
-    // sits in a silently un-finalized state (a forward would fail with "ap_net_finalize has not been called")
-    if (h->finalized) return ap_net_finalize(h);
+    // the bar is applied by the regressor's finalize step (the fold probe): re-run THAT step when the handle holds a packed
+    // checkpoint -- behind a device sync (passes in flight read the maps it rebuilds), and with the handle marked un-finalized
+    // while it runs, so a failure leaves it in a state every later call reports
+    if (h->finalized) {
+        HIP_TRY(hipSetDevice(h->device));
+        HIP_TRY(hipDeviceSynchronize());
+        h->finalized = false;
+        const int rc = finalize_regressor(h);
+        if (rc) return rc;
+        h->finalized = true;
+    }
     return AP_OK;
 }
 

@@ -128,6 +128,16 @@ hipError_t ap_launch_reg_fold_ief(const RegInitArgs& a, const float* xf0, const 
                                   const float* wt_state, const float* bias, float* part, int iters, int two_view,
                                   float* pose0, float* betas0, float* pose1, float* betas1, hipStream_t st);
 int ap_reg_fold_part_floats(int rows);
+hipError_t ap_launch_word_copy(const int* src, int* dst, hipStream_t st);                 // host-mapped word -> host-mapped word, stream-ordered
+hipError_t ap_launch_probe_inputs(float* x, size_t n, float* bb, int rows, uint64_t seed, hipStream_t st);   // ap_net_parity_probe's batch
+// view-split step in two halves (regressor.hip): feature part once per forward, the 148 partner-independent state columns, then
+// the 136 partner columns + residual; hfeat / partial: [B][148] fp32
+hipError_t ap_launch_reg_feat_part(const float* xf, int B, const float* wt_feat, const float* bias, float* part, float* hfeat,
+                                   hipStream_t st);
+hipError_t ap_launch_reg_step_local(const float* hfeat, const float* bb, const float* pose_in, const float* betas_in, int B,
+                                    const float* wt_state, float* partial, hipStream_t st);
+hipError_t ap_launch_reg_step_finish(const float* partial, const float* pose_in, const float* betas_in, const float* partner,
+                                     int partner_ld, int B, const float* wt_state, float* pose_out, float* betas_out, hipStream_t st);
 // state (+= delta[:, :145] if delta) ; S[row] = [bb3 pos3 orient6 art126 shape10 art_other126 shape_other10 0 0 0 0]
 hipError_t ap_launch_reg_update_assemble(float* state, const float* delta, int ldd, const float* bb0, const float* bb1,
                                          const float* partner, int partner_ld,

@@ -201,6 +201,59 @@ __global__ void __launch_bounds__(OLD * KQ) reg_fold_ief_kernel(const RegInitArg
     }
 }
 
+// ---- view-split step in two halves (fc1 is linear, so the step splits by columns of the folded map) --------------
+//   hfeat[b]   = bf + Wf[:, :2048] xf[b]                                   (once per forward: ap_regressor_feat_part)
+//   partial[b] = hfeat[b] + Wf[:, 2048:2196] [bb | pos | orient | art | shape]   (partner-independent: runs while the exchange is in flight)
+//   out[b]     = state[b] + partial[b] + Wf[:, 2196:2332] partner[b]             (the 136 partner columns + the residual add)
+__global__ void __launch_bounds__(OLD * KQ) reg_feat_sum_kernel(const float* __restrict__ part, int rows, const float* __restrict__ bias,
+                                                                float* __restrict__ hfeat) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * OLD) return;
+    const int row = i / OLD, oo = i - row * OLD;
+    float h = oo < 145 ? bias[oo] : 0.f;
+    for (int ks = 0; ks < KSPLIT; ++ks) h += part[((size_t)ks * rows + row) * OLD + oo];
+    hfeat[i] = h;
+}
+
+// K0 .. K0 + KN of the k-major state map against one assembled row per sample; thread = (output o, k-quarter q)
+template <int K0, int KN, bool FINISH>
+__global__ void __launch_bounds__(OLD * KQ) reg_step_half_kernel(const float* __restrict__ base /* hfeat | partial: [B][OLD] */,
+                                                                 const float* __restrict__ bb, const float* __restrict__ pose_in,
+                                                                 const float* __restrict__ betas_in, const float* __restrict__ partner,
+                                                                 int partner_ld, const float* __restrict__ wst,
+                                                                 float* __restrict__ out /* partial [B][OLD] */, float* __restrict__ pose_out,
+                                                                 float* __restrict__ betas_out) {
+    constexpr int KPT = (KN + KQ - 1) / KQ;
+    __shared__ float S[KQ * KPT];
+    __shared__ float red[KQ][OLD];
+    const int b = blockIdx.x, o = threadIdx.x % OLD, q = threadIdx.x / OLD;
+    for (int i = threadIdx.x; i < KQ * KPT; i += blockDim.x) {
+        float val = 0.f;
+        if (i < KN) {
+            const int e = K0 + i;                            // column of the assembled row [bb3 | pose135 | betas10 | partner136]
+            if (e < 3) val = bb[(size_t)b * 3 + e];
+            else if (e < 138) val = pose_in[(size_t)b * 135 + (e - 3)];
+            else if (e < 148) val = betas_in[(size_t)b * 10 + (e - 138)];
+            else val = partner[(size_t)b * partner_ld + (e - 148)];
+        }
+        S[i] = val;
+    }
+    __syncthreads();
+    float d = 0.f;
+    const float* w = wst + (size_t)(K0 + q * KPT) * OLD + o;
+    for (int k = 0; k < KPT; ++k)
+        if (q * KPT + k < KN) d = fmaf(w[(size_t)k * OLD], S[q * KPT + k], d);
+    red[q][o] = d;
+    __syncthreads();
+    if (threadIdx.x < 145) {
+        const int oo = threadIdx.x;
+        const float v = base[(size_t)b * OLD + oo] + ((red[0][oo] + red[1][oo]) + (red[2][oo] + red[3][oo]));
+        if (!FINISH) out[(size_t)b * OLD + oo] = v;
+        else if (oo < 135) pose_out[(size_t)b * 135 + oo] = pose_in[(size_t)b * 135 + oo] + v;
+        else betas_out[(size_t)b * 10 + (oo - 135)] = betas_in[(size_t)b * 10 + (oo - 135)] + v;
+    }
+}
+
 // ---- single-view HMR head (model_hmr.py:112-172): state = pose132 | shape10 | cam3 (145), row stride 160
 __global__ void hmr_init_kernel(const float* __restrict__ theta, int theta_bs, const float* __restrict__ shape,
                                 int shape_bs, const float* __restrict__ cam, int cam_bs,
@@ -247,6 +300,37 @@ __global__ void hmr_output_kernel(const float* __restrict__ state, float* __rest
     }
 }
 
+// ---- small helpers of api.hip ---------------------------------------------------------------------------------------
+// snapshot of the fp16 range flag (host-mapped word) into a per-slot host-mapped word, in stream order (ap_net_range_mark)
+__global__ void word_copy_kernel(const int* __restrict__ src, int* __restrict__ dst) {
+    if (threadIdx.x == 0) __hip_atomic_store(dst, __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM), __ATOMIC_RELAXED,
+                                             __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// probe batch of ap_net_parity_probe: crops ~ N(0, 1) (post-normalisation statistics), counter-based (splitmix64 +
+// Box-Muller: element i depends on (seed, i) only)
+__device__ __forceinline__ uint64_t splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ull;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__global__ void probe_normal_kernel(float* __restrict__ x, size_t n, uint64_t seed) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t r = splitmix64(seed * 0x100000001B3ull + i);
+    const float u = ((float)(uint32_t)(r >> 40) + 0.5f) * (1.0f / 16777216.0f);          // (0, 1)
+    const float v = (float)(uint32_t)((r >> 16) & 0xffffffu) * (1.0f / 16777216.0f);
+    x[i] = sqrtf(-2.0f * logf(u)) * cosf(6.2831853071795865f * v);
+}
+// bb = [U(-.5, .5), U(-.5, .5), U(.2, 1)] per row
+__global__ void probe_bb_kernel(float* __restrict__ bb, int rows, uint64_t seed) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * 3) return;
+    const uint64_t r = splitmix64(seed * 0x9E3779B1ull + 0x5bd1e995ull + (uint64_t)i);
+    const float u = (float)(uint32_t)(r >> 40) * (1.0f / 16777216.0f);
+    bb[i] = (i % 3) < 2 ? u - 0.5f : 0.2f + 0.8f * u;
+}
+
 }  // namespace
 
 hipError_t ap_launch_hmr_init(const float* theta, int theta_bs, const float* shape, int shape_bs, const float* cam,
@@ -280,6 +364,28 @@ hipError_t ap_launch_reg_fold_ief(const RegInitArgs& a, const float* xf0, const 
 }
 int ap_reg_fold_part_floats(int rows) { return KSPLIT * rows * OLD; }
 
+hipError_t ap_launch_reg_feat_part(const float* xf, int B, const float* wt_feat, const float* bias, float* part, float* hfeat,
+                                   hipStream_t st) {
+    hipLaunchKernelGGL(reg_feat_splitk_kernel, dim3((B + FROWS - 1) / FROWS, KSPLIT), dim3(OLD * KQ), 0, st, xf, xf, B, B, wt_feat, part);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(reg_feat_sum_kernel, dim3((B * OLD + OLD * KQ - 1) / (OLD * KQ)), dim3(OLD * KQ), 0, st, part, B, bias, hfeat);
+    return hipGetLastError();
+}
+hipError_t ap_launch_reg_step_local(const float* hfeat, const float* bb, const float* pose_in, const float* betas_in, int B,
+                                    const float* wt_state, float* partial, hipStream_t st) {
+    hipLaunchKernelGGL((reg_step_half_kernel<0, 148, false>), dim3(B), dim3(OLD * KQ), 0, st, hfeat, bb, pose_in, betas_in,
+                       (const float*)nullptr, 0, wt_state, partial, (float*)nullptr, (float*)nullptr);
+    return hipGetLastError();
+}
+hipError_t ap_launch_reg_step_finish(const float* partial, const float* pose_in, const float* betas_in, const float* partner,
+                                     int partner_ld, int B, const float* wt_state, float* pose_out, float* betas_out, hipStream_t st) {
+    hipLaunchKernelGGL((reg_step_half_kernel<148, 136, true>), dim3(B), dim3(OLD * KQ), 0, st, partial, (const float*)nullptr, pose_in,
+                       betas_in, partner, partner_ld, wt_state, (float*)nullptr, pose_out, betas_out);
+    return hipGetLastError();
+}
+
+
 hipError_t ap_launch_reg_init(const RegInitArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(reg_init_kernel, dim3(a.rows), dim3(64), 0, st, a);
     return hipGetLastError();
@@ -297,5 +403,17 @@ hipError_t ap_launch_reg_output(const float* state, float* pose0, float* betas0,
                                 int two_view, hipStream_t st) {
     hipLaunchKernelGGL(reg_output_kernel, dim3(two_view ? 2 * B : B), dim3(64), 0, st, state, pose0, betas0, pose1,
                        betas1, B, two_view);
+    return hipGetLastError();
+}
+
+hipError_t ap_launch_word_copy(const int* src, int* dst, hipStream_t st) {
+    hipLaunchKernelGGL(word_copy_kernel, dim3(1), dim3(64), 0, st, src, dst);
+    return hipGetLastError();
+}
+hipError_t ap_launch_probe_inputs(float* x, size_t n, float* bb, int rows, uint64_t seed, hipStream_t st) {
+    hipLaunchKernelGGL(probe_normal_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, x, n, seed);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(probe_bb_kernel, dim3((rows * 3 + 63) / 64), dim3(64), 0, st, bb, rows, seed);
     return hipGetLastError();
 }

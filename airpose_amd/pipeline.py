@@ -23,8 +23,8 @@ class Pending(object):
     stream.  ``wait()`` makes a stream (default: the current one) wait for it, ``synchronize()`` blocks the host; reading ``out``
     before either is a race, exactly as with any tensor produced on another stream."""
 
-    def __init__(self, out, done, stream, model=None):
-        self.out, self._done, self._stream, self._model = out, done, stream, model
+    def __init__(self, out, done, stream, model=None, slot=None):
+        self.out, self._done, self._stream, self._model, self._slot = out, done, stream, model, slot
 
     def wait(self, stream=None):
         stream = stream if stream is not None else torch.cuda.current_stream(self._stream.device)
@@ -37,13 +37,14 @@ class Pending(object):
         return self.out
 
     def synchronize(self):
-        """Block the host until the batch is done.  precision="f16": raises RangeError if a stored activation of THIS or an earlier
-        pass of the handle left the fp16 range (the deferred sentinel of ap_net_set_range_check would otherwise only speak up
-        at the next forward -- never, for the last batch of a run)."""
+        """Block the host until THIS batch is done -- the batches submitted after it keep running.  precision="f16": raises
+        RangeError if a stored activation of this or an earlier batch's trunk passes left the fp16 range: ``submit`` has every pass
+        stream snapshot its range word behind the batch's last kernel there (ap_net_range_mark_next: a later batch cannot leak
+        into it), and the slot is read here, behind the batch's own event, without touching any stream (the deferred sentinel
+        alone would only speak up at the next forward -- never, for the last batch of a run)."""
         self._done.synchronize()
-        if self._model is not None and getattr(self._model, "precision", None) == "f16":
-            with torch.cuda.stream(self._stream):
-                self._model.range_status()
+        if self._model is not None and self._slot is not None and getattr(self._model, "precision", None) == "f16":
+            self._model.range_slot(self._slot)
         return self.wait()                                   # (the event is complete: only the allocator bookkeeping of wait() remains)
 
 
@@ -73,10 +74,23 @@ class TwoViewInference(object):
         pos = self.init_position(B, dev)
         return self.model(x0=im0, x1=im1, bb0=bb0, bb1=bb1, init_position0=pos, init_position1=pos, iters=self.iters)
 
-    def __call__(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False):
+    CALL_SLOT = N.AP_RANGE_SLOTS - 1                         # range-flag snapshot slot of __call__ (submit uses 0 .. DEPTH - 1)
+
+    def __call__(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False, check_range=True):
+        """The reference's stream-ordered forward.  precision="f16" and check_range (default): the call snapshots the handle's range
+        flag behind its own trunk passes, waits for the current stream and raises RangeError if a stored activation of THIS forward
+        left the fp16 range -- a one-shot caller never gets AP_OK with garbage (check_range=False: the deferred sentinel only, i.e.
+        the NEXT forward on the handle raises)."""
         im0, im1 = batch["im0"], batch["im1"]
+        f16 = check_range and getattr(self.model, "precision", None) == "f16"
+        if f16:
+            self.model.range_mark_next(self.CALL_SLOT)
         p0, b0, p1, b1 = self.forward_net(im0, im1, batch["bb0"], batch["bb1"])
-        return self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
+        out = self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
+        if f16:
+            torch.cuda.current_stream(im0.device).synchronize()
+            self.model.range_slot(self.CALL_SLOT)
+        return out
 
     def submit_net(self, im0, im1, bb0, bb1):
         """``forward_net`` issued as ``submit`` issues the whole forward: Pending.out = (pred_pose0, pred_betas0, pred_pose1,
@@ -113,6 +127,9 @@ class TwoViewInference(object):
             st["done"][slot].synchronize()
         pos = self.init_position(B, dev)
         st["keep"][slot] = batch
+        f16 = getattr(self.model, "precision", None) == "f16"
+        if f16:                                              # each pass stream snapshots its range word behind this batch's last kernel
+            self.model.range_mark_next(slot)
         feat = self.model.forward_feat_ext_twoview(im0, im1, out=st["feat"][slot], out_stream=side)
         with torch.cuda.stream(side):
             out = self.model.forward_ief(feat[0], feat[1], batch["bb0"], batch["bb1"], pos, pos, iters=self.iters)
@@ -120,7 +137,7 @@ class TwoViewInference(object):
                 out = self._tail(*out, batch, want_rotmat, want_angles, want_input_mesh)
             st["done"][slot].record(side)
         st["busy"][slot] = True
-        return Pending(out, st["done"][slot], side, self.model)
+        return Pending(out, st["done"][slot], side, self.model, slot if f16 else None)
 
     def _tail(self, p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh):
         B, dev = p0.shape[0], p0.device

@@ -13,6 +13,8 @@ exercised (the reference defaults 0/1/1/0 would hide folding bugs):
   conv      N(0, sqrt(2 / (k*k*C_out)))
   bn        gamma~U(.5,1.5) (last BN of a block: U(.25,.75)), beta~N(0,.1),
             running_mean~N(0,.1), running_var~U(.5,1.5)
+            bn="survey": gamma~U(.5,1.5) on EVERY BatchNorm, exactly SURVEY 8(d)'s recipe (the residual
+            branches then add at full gain through all 16 blocks); bn="wide": gamma, var~U(.25,2)
   fc1, fc2  U(-1/sqrt(in), 1/sqrt(in)) weight and bias (nn.Linear default)
   dec*      xavier_uniform(gain=0.01) weight, Linear-default bias
 """
@@ -37,6 +39,9 @@ def _conv(rs, cout, cin, k):
 def _bn(rs, sd, prefix, c, last=False, wide=False):
     # wide: the second statistics range of the parity sweeps (gamma, var ~ U(.25, 2): scales from 0.18 to 4 per channel instead of
     # 0.4 to 2.1; the last BN of a block keeps half the gamma range so that 16 residual blocks do not blow the activations up)
+    # wide == "survey": SURVEY 8(d) to the letter -- gamma ~ U(.5, 1.5) on every BatchNorm, the last one of a block included
+    if wide == "survey":
+        last, wide = False, False
     lo, hi = ((0.125, 1.0) if last else (0.25, 2.0)) if wide else ((0.25, 0.75) if last else (0.5, 1.5))
     sd[prefix + ".weight"] = rs.uniform(lo, hi, size=c).astype(np.float32)
     sd[prefix + ".bias"] = rs.normal(0.0, 0.1, size=c).astype(np.float32)
@@ -84,11 +89,14 @@ def load_mean_params(path):
             d["cam"].astype(np.float32)[None])
 
 
-def copenet_state_dict(seed, mean_params_path, variant="copenet", wide_bn=False):
+def copenet_state_dict(seed, mean_params_path, variant="copenet", wide_bn=False, bn=None):
     """Full state_dict (numpy arrays) for the two-view ``copenet`` (or ``hmr`` / ``copenet_singleview``) module.
-    wide_bn: BatchNorm gamma / running_var from U(.25, 2) instead of U(.5, 1.5) (same random stream positions)."""
+    wide_bn: BatchNorm gamma / running_var from U(.25, 2) instead of U(.5, 1.5) (same random stream positions).
+    bn: "default" | "wide" (= wide_bn) | "survey" (gamma ~ U(.5, 1.5) on every BatchNorm: SURVEY 8(d) exactly)."""
     rs = np.random.RandomState(seed)
-    sd = trunk_state_dict(rs, wide_bn)
+    if bn not in (None, "default", "wide", "survey"):
+        raise ValueError(bn)
+    sd = trunk_state_dict(rs, "survey" if bn == "survey" else (wide_bn or bn == "wide"))
     if variant not in ("copenet", "hmr", "singleview", "muhmr"):
         raise ValueError(variant)
     fc1_in = {"copenet": FC1_IN, "hmr": HMR_FC1_IN, "singleview": 2048 + 3 + 135 + 10, "muhmr": 2048 + 3 + 132 + 10 + 136}[variant]

@@ -1,24 +1,31 @@
 #!/usr/bin/env python
 """Headline benchmark: two-view frames (pairs) per second of the AirPose inference hot path on MI355X.
 
-  python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W     (N > 1 without WORLD_SIZE in the environment: re-launches itself through
+                                                     torch.distributed.run, one rank per GPU; the driver's own torchrun command
+                                                     works unchanged)
 
 One step = one pass of the whole hot path over one batch of synthetic input resident in HBM:
 copenet_twoview forward (ResNet-50 trunk on both views, 3 IEF iterations with cross-view fusion)
 -> in-place translation un-scale -> rot6d -> SMPL-X LBS (10475 verts) -> root transform -> 2-D
-projection, at 256 pairs per GPU in bf16 (BASELINE.json metric: "two-view frames/sec at batch 256").
-Pairs are independent units: every rank owns its own 256 pairs, no data-path collective (weak scaling).
+projection, at 256 pairs per GPU (BASELINE.json metric: "two-view frames/sec at batch 256"), in the 16-bit throughput mode named
+by --precision (default f16: fp16 storage; `dtype` of the line).  Pairs are independent units: every rank owns its own 256 pairs,
+no data-path collective (weak scaling).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with extra objects:
-  roofline      dominant kernel = the bf16 implicit-GEMM conv (52 launches per trunk chunk); algorithmic
-                FLOPs of those launches / their HIP-event time measured live in the timed region
+  roofline      SURVEY 8(d): pairs/s x 16.3916 GFLOP per pair against the dense bf16 / fp16 MFMA peak (whole step time); the conv
+                stack alone (its launch count read back from the library, HIP events on the streams that run it) beside it;
+                `traffic` = HBM bytes per STEP from the latest committed PMC pass
   cpu_baseline  the CPU oracle (a torch restatement pinned to the reference) timed on this box's host
                 cores on a bounded sample -- a reported baseline, not the target
   repeat_blocks the K-step block repeated (same fences) after the contract's block: median / min / max pairs/s
-  parity_mode   throughput of the mode that meets the 1e-4 bar + the measured per-slice error of both modes against
+  parity_mode   throughput of the modes that meet the 1e-4 bar + the measured per-slice error of every mode against
                 the CPU oracle on the first pairs of the batch
+  parity_sweep  every mode x 5 checkpoints (3 weight seeds, a wide BatchNorm range, SURVEY 8(d)'s exact recipe) against the CPU
+                oracle, next to what the GPU parity probe (ap_net_parity_probe) says about the same checkpoint and what
+                precision="auto" picks for it
   view_split    (N >= 2 ranks) BASELINE config 4: one view per rank, the 136-float partner state exchanged over
-                RCCL pair groups before IEF iterations 2 and 3
+                RCCL pair groups before IEF iterations 2 and 3, hidden behind the partner-independent half of the step
 Every `frac` recomputes from `stage_ms_per_step` and the byte / FLOP constants stated next to it.
 """
 import argparse
@@ -62,12 +69,13 @@ REG_FLOPS_PER_PAIR = 2 * 3 * 2 * (2332 * 1024 + 1024 * 1024 + 1024 * 145)
 
 
 def pmc_traffic():
-    """HBM bytes per conv launch from the latest committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
+    """HBM bytes per STEP of 256 pairs from the latest committed rocprofv3 PMC passes (FETCH_SIZE x2-corrected + WRITE_SIZE,
     profiles/r*_pmc_hbm_traffic.csv via tools/collect_profiles.sh): counters cannot be collected inside the timed run."""
     try:
         import glob
         with open(sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic.json")))[-1]) as f:
-            return json.load(f)["traffic_bytes_per_launch"]
+            d = json.load(f)
+        return d["fetch_bytes_per_step_x2"] + d["write_bytes_per_step"]
     except Exception:
         return None
 
@@ -162,23 +170,29 @@ def timed_mode_parity(sd, md, pipe, dev, n_threads, seeds=(4321, 777), pairs_per
 
 
 def parity_sweep(args, md, body, dev, n_threads, pairs_per_cell=16):
-    """the parity claim as a property, not a sample.  EVERY mode (the two 16-bit storage types and the two
-    parity-grade modes) against the fp32 CPU oracle over 3 weight seeds x 2 input seeds plus a second BatchNorm-statistics range
-    (gamma, running_var ~ U(.25, 2)): worst slice-max error and worst element-wise error per mode and per checkpoint."""
+    """The parity claim as a property of the CHECKPOINT.  EVERY mode against the fp32 CPU oracle over
+    5 checkpoints x 2 input seeds: three weight seeds of the benchmark's family, a second BatchNorm-statistics range (gamma,
+    running_var ~ U(.25, 2)) and SURVEY 8(d)'s recipe to the letter (gamma ~ U(.5, 1.5) on EVERY BatchNorm; the benchmark family
+    halves it on the last BatchNorm of a block).  Per (mode, checkpoint): worst slice-max and element-wise error against the oracle
+    AND what the GPU parity probe (ap_net_parity_probe: the mode's trunk against the exact-fp32 trunk of the same weights, no CPU
+    involved) measured, so the probe's verdict can be held against the oracle's; per checkpoint: what precision="auto" picks."""
     import torch
+    from airpose_amd import _native as Nn
     from airpose_amd import copenet_model, pipeline
     from airpose_amd import weights as W
     from oracle import pipeline_ref
-    ckpts = [("seed20240901", 20240901, False), ("seed7", 7, False), ("seed99", 99, False), ("seed20240901_widebn", 20240901, True)]
+    ckpts = [("seed20240901", 20240901, "default"), ("seed7", 7, "default"), ("seed99", 99, "default"),
+             ("seed20240901_widebn", 20240901, "wide"), ("seed20240901_survey8d", 20240901, "survey")]
     in_seeds = (4321, 777)
     modes = ("f16", "bf16", "bf16x2", "fp32")
     n_all = torch.get_num_threads()
     res = {m: {"max_rel_err": 0.0, "max_elementwise_err": 0.0, "by_checkpoint": {}, "worst_slice": None} for m in modes}
+    auto = {}
     t0 = time.perf_counter()
     nets = {}
     try:
-        for name, wseed, wide in ckpts:
-            sdw = W.to_torch(W.copenet_state_dict(wseed, MEAN, wide_bn=wide))
+        for name, wseed, bn in ckpts:
+            sdw = W.to_torch(W.copenet_state_dict(wseed, MEAN, bn=bn))
             cells = []
             torch.set_num_threads(n_threads)
             for s in in_seeds:
@@ -193,32 +207,72 @@ def parity_sweep(args, md, body, dev, n_threads, pairs_per_cell=16):
                 net = nets[m]
                 net.load_state_dict(sdw)
                 pipe = pipeline.TwoViewInference(net, body, iters=3)
-                worst, worst_el, wslice = 0.0, 0.0, None
-                for inp, want in cells:
-                    got = {k: v.float().cpu() for k, v in pipe({k: v.to(dev) for k, v in inp.items()}, want_rotmat=True).items()}
-                    e, el = slice_errs(got, want), slice_errs(got, want, elementwise_atol=1e-2)
-                    ks = max(e, key=e.get)
-                    if e[ks] > worst:
-                        worst, wslice = e[ks], ks
-                    worst_el = max(worst_el, max(el.values()))
-                if m == "f16":
-                    net.range_status()
-                res[m]["by_checkpoint"][name] = {"max_rel_err": worst, "max_elementwise_err": worst_el}
+                worst, worst_el, wslice, err_txt, probe = 0.0, 0.0, None, None, None
+                try:
+                    pr = net.parity_probe(8)
+                    probe = {"max_rel_err": pr["max_rel_err"], "worst_slice": max(pr["rel_err_by_slice"], key=pr["rel_err_by_slice"].get),
+                             "ms": pr["ms"], "holds": pr["max_rel_err"] < 1e-4}
+                    for inp, want in cells:
+                        got = {k: v.float().cpu() for k, v in pipe({k: v.to(dev) for k, v in inp.items()}, want_rotmat=True).items()}
+                        e, el = slice_errs(got, want), slice_errs(got, want, elementwise_atol=1e-2)
+                        ks = max(e, key=e.get)
+                        if e[ks] > worst:
+                            worst, wslice = e[ks], ks
+                        worst_el = max(worst_el, max(el.values()))
+                    if m == "f16":
+                        net.range_status()
+                except Nn.RangeError as ex:                   # fp16 storage cannot hold this checkpoint: reported, and the flag cleared
+                    err_txt = "fp16 range: " + str(ex)[:120]
+                    worst = worst_el = float("inf")
+                    try:
+                        net.range_status(reset=True)
+                    except Nn.RangeError:
+                        pass
+                except RuntimeError as ex:
+                    if "fp16 range" not in str(ex):
+                        raise
+                    err_txt = "fp16 range (weights): " + str(ex)[:120]
+                    worst = worst_el = float("inf")
+                cell = {"max_rel_err": None if err_txt else worst, "max_elementwise_err": None if err_txt else worst_el,
+                        "meets_bar": (not err_txt) and worst < 1e-4, "probe": probe}
+                if err_txt:
+                    cell["error"] = err_txt
+                    if probe is None:
+                        cell["probe"] = {"holds": False, "error": "fp16 range"}
+                res[m]["by_checkpoint"][name] = cell
                 if worst > res[m]["max_rel_err"]:
-                    res[m]["max_rel_err"], res[m]["worst_slice"] = worst, "%s @ %s" % (wslice, name)
+                    res[m]["max_rel_err"], res[m]["worst_slice"] = worst, "%s @ %s" % (wslice or "range", name)
                 res[m]["max_elementwise_err"] = max(res[m]["max_elementwise_err"], worst_el)
                 del pipe
+            # what the run-time guard does with this checkpoint
+            na = copenet_model.getcopenet(MEAN, precision="auto").eval()
+            na.load_state_dict(sdw)
+            na.forward_feat_ext(torch.zeros(1, 3, 224, 224, device=dev))
+            chosen = na.auto_report["chosen"]
+            auto[name] = {"chosen": chosen, "chosen_meets_bar_vs_oracle": res[chosen]["by_checkpoint"][name]["meets_bar"],
+                          "fastest_mode_that_meets_bar_vs_oracle": next((m for m in na.AUTO_ORDER if res[m]["by_checkpoint"][name]["meets_bar"]), None)}
+            del na
     finally:
         torch.set_num_threads(n_all)
     del nets
     torch.cuda.empty_cache()
+    agree = tot = 0
     for m in modes:
-        res[m]["meets_bar"] = res[m]["max_rel_err"] < 1e-4
-    return {"modes": res, "bar": 1e-4, "checkpoints": [c[0] for c in ckpts], "input_seeds": list(in_seeds),
+        r = res[m]
+        r["meets_bar"] = r["max_rel_err"] < 1e-4
+        for c in r["by_checkpoint"].values():
+            if c.get("probe"):
+                tot += 1
+                agree += int(bool(c["probe"]["holds"]) == bool(c["meets_bar"]))
+        if r["max_rel_err"] == float("inf"):
+            r["max_rel_err"] = r["max_elementwise_err"] = None
+    return {"modes": res, "auto": auto, "probe_agrees_with_oracle": "%d of %d (mode, checkpoint) cells" % (agree, tot),
+            "bar": 1e-4, "checkpoints": [c[0] for c in ckpts], "input_seeds": list(in_seeds),
             "pairs_per_checkpoint": len(in_seeds) * pairs_per_cell, "checked_pairs_per_mode": len(ckpts) * len(in_seeds) * pairs_per_cell,
             "error_measure": "max|a-b| / max|b| per semantic slice; elementwise: max |a-b| / (1e-2 + |b|)",
-            "checkpoints_note": "copenet_state_dict(seed) of airpose_amd/weights.py; widebn: BatchNorm gamma / running_var ~ U(.25, 2) "
-                                "(last BN of a block: gamma ~ U(.125, 1)) instead of U(.5, 1.5)",
+            "checkpoints_note": "copenet_state_dict(seed, bn=...) of airpose_amd/weights.py; widebn: BatchNorm gamma / running_var ~ U(.25, 2) "
+                                "(last BN of a block: gamma ~ U(.125, 1)); survey8d: gamma ~ U(.5, 1.5) on every BatchNorm, the last one of a "
+                                "block included (SURVEY 8(d) to the letter: trunk features of order 5e3, stored activations near the fp16 range)",
             "seconds": time.perf_counter() - t0}
 
 
@@ -274,6 +328,7 @@ def b64_block(args, sd, body, dev):
         dt = time.perf_counter() - t0
         tm = net.timing(reset=True)
         net.enable_timing(0)
+        n_launch = net.last_conv_launches()
         # the same steps issued as a serving loop (TwoViewInference.submit_net: passes of step i+1 behind those of step i, IEF loop
         # on a second stream)
         for _ in range(3):
@@ -289,7 +344,7 @@ def b64_block(args, sd, body, dev):
         tf = conv_stack_flops_per_image() * 2 * B / (conv_ms * 1e-3) / 1e12
         res[prec] = {"pairs_per_s": B * steps / dt, "ms_per_step": 1e3 * dt / steps,
                      "submit_pairs_per_s": B * steps / dts, "submit_ms_per_step": 1e3 * dts / steps, "conv_stack_ms": conv_ms,
-                     "conv_stack_tflops": tf, "conv_stack_frac": tf / PEAK_BF16_DENSE_TFLOPS}
+                     "conv_stack_tflops": tf, "conv_stack_frac": tf / PEAK_BF16_DENSE_TFLOPS, "conv_launches_per_step": n_launch}
         del pipe, net
         torch.cuda.empty_cache()
     return res
@@ -355,45 +410,75 @@ def view_split_block(args, net, batch, dev, rank, world):
     if world % 2:
         return None
     groups = D.make_pair_groups(world, timeout_s=120)
-    ief = D.ViewSplitIEF(net.regressor_step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
+    split = (net.regressor_feat_part, net.regressor_step_local, net.regressor_step_finish) if net.fold_status()[0] == 1 else None
+    ief = D.ViewSplitIEF(net.regressor_step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1), split_step=split)
     v = rank % 2
     im, bb = batch["im%d" % v], batch["bb%d" % v]
     B = im.shape[0]
     pos = torch.tensor([0.0, 0.0, 10.0], device=dev).expand(B, -1).contiguous() * 0.05
     th, sh = net.init_pose.to(dev), net.init_shape.to(dev)
 
-    def vstep():
-        return ief.run(net.forward_feat_ext(im), bb, pos, th, sh, iters=3, shared_init=True)
-
     def fence():
         torch.cuda.synchronize()
         dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(2):
-        vstep()
+    def timed(fn, n):
+        for _ in range(2):
+            fn()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        fence()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n
+
     n0 = ief.n_exchanges
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        vstep()
-    fence()
-    t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
-    dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    n_ex = (ief.n_exchanges - n0) // args.steps
-    pose, betas = vstep()
-    fence()
-    t1 = time.perf_counter()
-    for _ in range(50):
-        ief.exchange(pose, betas)
-    fence()
-    tx = torch.tensor([(time.perf_counter() - t1) / 50], device=dev, dtype=torch.float64)
-    dist.all_reduce(tx, op=dist.ReduceOp.MAX)
-    return {"pairs_per_s": (world // 2) * B * args.steps / float(t.item()), "ms_per_step": 1e3 * float(t.item()) / args.steps,
-            "exchange_us": 1e6 * float(tx.item()), "n_exchanges": n_ex, "bytes_per_exchange": B * 136 * 4,
+    t_ov = timed(lambda: ief.run(net.forward_feat_ext(im), bb, pos, th, sh, iters=3, shared_init=True), args.steps)
+    n_ex = (ief.n_exchanges - n0) // (args.steps + 2)
+    # the IEF loop alone from resident features: with the exchange hidden behind the local half of the step, waited for in line, and
+    # not issued at all (the partner's rows taken from a buffer: what the loop costs without a wire)
+    xf = net.forward_feat_ext(im)
+    pose, betas = ief.run(xf, bb, pos, th, sh, iters=3, shared_init=True)
+    t_ief_ov = timed(lambda: ief.run(xf, bb, pos, th, sh, iters=3, shared_init=True), 50) if split else None
+    t_ief_sync = timed(lambda: ief.run(xf, bb, pos, th, sh, iters=3, shared_init=True, overlap=False), 50)
+    partner = torch.cat([pose[:, 9:], betas], 1).contiguous()
+
+    def no_wire():
+        p, b = pose, betas
+        for _ in range(3):
+            p, b = net.regressor_step(xf, bb, p, b, partner)
+
+    t_ief_nowire = timed(no_wire, 50)
+    tx = timed(lambda: ief.exchange(pose, betas), 50)
+    return {"pairs_per_s": (world // 2) * B / t_ov, "ms_per_step": 1e3 * t_ov,
+            "exchange_us": 1e6 * tx, "n_exchanges": n_ex, "bytes_per_exchange": B * 136 * 4,
+            "ief_loop_us": {"exchange_hidden_behind_local_half": None if t_ief_ov is None else 1e6 * t_ief_ov,
+                            "exchange_waited_in_line": 1e6 * t_ief_sync, "no_exchange": 1e6 * t_ief_nowire},
+            "exchange_exposed_us_per_forward": {"overlapped": None if t_ief_ov is None else 1e6 * (t_ief_ov - t_ief_nowire),
+                                                "in_line": 1e6 * (t_ief_sync - t_ief_nowire)},
+            "overlap": "exchange_start before the 2196 partner-independent columns (ap_regressor_step_local), exchange_wait before the 136 "
+                       "partner columns (ap_regressor_step_finish)" if split else "off: the handle runs the literal chain",
             "topology": "%d pair groups of 2 ranks, one view per rank, %d pairs per group" % (world // 2, B),
             "collective": "2-rank all_gather on the pair group, torch.distributed backend %s%s" % (
                 dist.get_backend(), " (= RCCL over xGMI)" if dist.get_backend() == "nccl" else " (host-staged: test aid)")}
+
+
+def self_launch(argv, n):
+    """`python bench.py --gpus N` without a launcher's environment: become `python -m torch.distributed.run --standalone`-style
+    (explicit 127.0.0.1 rendezvous on a free port: the container hostname may not resolve) with N ranks of this script."""
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.stdout.flush()
+    os.execvp(cmd[0], cmd)
 
 
 def main():
@@ -423,6 +508,8 @@ def main():
     ap.add_argument("--other-form", type=int, default=1, help="0: skip the extra block that times the other step-issue form (profiling runs)")
     ap.add_argument("--b64", type=int, default=1, help="also time BASELINE config 1 (batch 64, network only, bf16 and f16): 0 = skip")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:     # the plain command: launch the N ranks ourselves (never returns)
+        self_launch(sys.argv[1:], args.gpus)
 
     import torch
     import torch.distributed as dist
@@ -435,7 +522,22 @@ def main():
     if world > 1:                                           # N ranks generate their weights / inputs side by side: share the host cores
         torch.set_num_threads(max(1, (os.cpu_count() or 8) // world))
     if world != args.gpus:
-        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (launch N>1 with torch.distributed.run)" % (args.gpus, world))
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d (a launcher started another number of ranks than --gpus names)" % (args.gpus, world))
+    if os.environ.get("AIRPOSE_BENCH_LAUNCH_ONLY") == "1":
+        # test aid (tests/test_abi.py, no GPU): everything up to the point the GPU is needed -- the launcher, the rendezvous, one
+        # collective over all ranks -- then one JSON line from rank 0
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.ones(1)
+        if world > 1:
+            dist.all_reduce(t)
+        if rank == 0:
+            print(json.dumps({"launcher": "ok", "n_gpus": world, "n_ranks_seen": int(t.item()), "local_rank": local_rank}))
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
     assert torch.cuda.is_available(), "bench.py needs the MI355X; there is no CPU fallback"
     # test aid (a 1-GPU box cannot host two RCCL ranks): AIRPOSE_BENCH_SHARE_GPU=1 puts every rank on cuda:0 with the gloo
     # backend, so the N > 1 code paths (max-over-ranks timing, view_split block) can be exercised on one GPU
@@ -453,6 +555,11 @@ def main():
         else:
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
+    n_ranks_seen = 1
+    if use_dist:
+        t = torch.ones(1, device=dev)
+        dist.all_reduce(t)
+        n_ranks_seen = int(t.item())
     B = args.batch
     sd = W.to_torch(W.copenet_state_dict(20240901, MEAN))
     md = smplx_model.make_synthetic_model(4321)
@@ -526,6 +633,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tm = net.timing(reset=True)
+    launches_timed = net.last_conv_launches()                # conv-stack launches of the last timed step, all passes (ap_net_last_conv_launches)
     # the same block again, a few times: spread of the headline inside one process (the contract's `value` stays the
     # first block; the timed region of 20 steps is only ~0.14 s)
     blocks = [world * B * args.steps / elapsed]
@@ -625,14 +733,8 @@ def main():
         # two-view forwards of >= 64 pairs run the two views as two concurrent trunk passes (two internal streams):
         # twice the launches at half the images each; conv_ms is then the span over both passes
         dual = bool(args.dual_stream) and B >= 64 and chunk >= 128    # (views above chunk / 2 images: slices of chunk / 2 per pass stream)
-        # bf16: 3 fused layer1 bottlenecks + 13 blocks x 3 convs = 42 launches per pass, minus the 8 conv1 layers that ride in a
-        # fused conv3 -> conv1 pair (layer2.0-2.3, layer3.1-3.4 as producers): 34
         half = args.precision in ("bf16", "f16")               # the throughput kernels (either 16-bit storage type)
-        pairs_on = half and os.environ.get("AIRPOSE_FUSE_PAIR", "1") != "0"
-        tail_on = half and os.environ.get("AIRPOSE_FUSE_TAIL", "1") != "0"      # conv1 of layer2.0 rides in layer1's last kernel
-        img_on = half and os.environ.get("AIRPOSE_IMG_BLOCK", "1") != "0"       # layer3.1-3.5: one image-resident kernel per block
-        launches = (((34 if pairs_on else 42) - (1 if tail_on else 0) - ((6 if pairs_on else 10) if img_on else 0)) if half else 48) * \
-                   (2 if dual else (2 * B + chunk - 1) // chunk)
+        launches = launches_timed                                # read back from the library behind the timed region: what it chose for this batch
         # bf16x2 runs on the bf16 matrix pipe (3 MFMA products per algorithmic product): priced against the same peak
         peak = PEAK_FP32_TFLOPS if args.precision == "fp32" else PEAK_BF16_DENSE_TFLOPS
         achieved = conv_flops_step / (conv_ms_step * 1e-3) / 1e12
@@ -691,7 +793,7 @@ def main():
                          "conv_stack_span_of": "the stream-ordered block of this run (HIP events bracket both lock-step passes of a step)",
                          "conv_stack_own_ms": conv_ms_step, "conv_stack_own_frac": achieved / peak,
                          "frac_of_step_time": conv_flops_step / (elapsed / args.steps) / 1e12 / peak,
-                         "traffic": pmc_traffic(),
+                         "traffic": pmc_traffic(), "traffic_unit": "HBM bytes per step of %d pairs (FETCH_SIZE x 2 + WRITE_SIZE over the conv-stack kernels)" % 256,
                          "traffic_source": "latest committed rocprofv3 PMC pass (profiles/r*_pmc_traffic.json): counters cannot be collected inside the timed run",
                          "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,
                          "avg_launch_ms": (span_ms if span_ms is not None else conv_ms_step) / launches},
@@ -774,10 +876,10 @@ def main():
             res["view_split"] = vs
         if cpu is not None:
             res["cpu_baseline"] = cpu
-            # BASELINE.md publishes no throughput for this metric and names the CPU path measured on the target box as the
-            # baseline (section 1 / 3): vs_baseline = value / that measurement, same unit (null when the CPU leg is skipped)
-            res["vs_baseline"] = res["value"] / cpu["value"]
-            res["vs_baseline_of"] = "cpu_baseline.value (BASELINE.md: no published number; baseline = the CPU path on this box)"
+            # BASELINE.md publishes no throughput for this metric: vs_baseline stays null (the contract); the ratio to the CPU path
+            # measured on this box is reported under its own name
+            res["gpu_over_cpu_baseline"] = res["value"] / cpu["value"]
+        res["n_ranks_seen"] = n_ranks_seen
         print(json.dumps(res))
     if use_dist:
         dist.barrier()

@@ -38,19 +38,22 @@ extern "C" {
                           * hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (three MFMAs per 8 K elements), fp32 accumulate:
                           * the fast parity mode (meets the 1e-4 bar at ~5x the fp32-MFMA rate) */
 #define AP_PREC_F16 3 /* IEEE fp16 storage (v_mfma_f32_16x16x32_f16), fp32 accumulate and epilogues: the throughput kernels of
-                       * AP_PREC_BF16 at the same MFMA rate with 11 instead of 8 significand bits -- 5.5e-5 against the reference's
-                       * CPU path, under the 1e-4 bar.  Range: |stored value| <= 65504.  ap_net_finalize refuses a checkpoint whose
-                       * (BatchNorm-folded) weights leave that range, and every trunk pass checks its pooled features: a non-finite
-                       * value (an activation that overflowed to inf somewhere in the stack reaches them as inf / NaN) makes
-                       * ap_trunk_fwd and every forward built on it return AP_ERANGE (see there) */
+                       * AP_PREC_BF16 at the same MFMA rate with 11 instead of 8 significand bits.  Against the reference's CPU path:
+                       * 2.6e-5 .. 6.2e-5 on the benchmark checkpoints (under the 1e-4 bar), 1.8e-3 on a checkpoint with a wider
+                       * BatchNorm-statistics range -- the bar is a property of the CHECKPOINT, which ap_net_parity_probe measures
+                       * on the GPU (airpose_amd: precision="auto" picks the fastest mode whose probe holds it).
+                       * Range: |stored value| <= 65504.  ap_net_finalize refuses a checkpoint whose (BatchNorm-folded) weights
+                       * leave that range; at run time EVERY epilogue folds the values it stores into a range sentinel (see
+                       * ap_net_set_range_check below): an activation that overflows makes the handle report AP_ERANGE */
 
 typedef struct ap_net ap_net;     /* ResNet-50 trunk + IEF regressor */
 typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
 
-/* ABI number of this header: bumped whenever an exported signature changes or an entry point is removed (5: round 5 --
- * ap_conv_pair_* / ap_bottleneck64_nhwc take a leading `precision` and a caller-packed weight stream since 4).  A binding built
- * against another number must refuse to load the library (airpose_amd/_native.py does). */
-#define AP_ABI_VERSION 7
+/* ABI number of this header: bumped whenever an exported signature changes or an entry point is added or removed
+ * (8: round 6 -- ap_net_parity_probe, ap_net_range_peek / _mark_next / _slot, ap_regressor_feat_part / _step_local / _step_finish;
+ *  7: ap_conv_pw_*, ap_block_img_*; 6: ap_set_pair_groups removed).  A binding built against another number must refuse to load
+ * the library (airpose_amd/_native.py does). */
+#define AP_ABI_VERSION 8
 const char* ap_version(void);
 int ap_abi_version(void);
 const char* ap_last_error(void);
@@ -87,6 +90,38 @@ int ap_net_precision(const ap_net* h);
  * ap_net_range_status once its stream is done (airpose_amd: Pending.synchronize() and copenet.range_status() do). */
 int ap_net_set_range_check(ap_net* h, int mode);
 int ap_net_range_status(ap_net* h, void* stream, int reset);
+/* The same flag without any synchronisation, for callers that have already waited for the work they ask about (an event of their
+ * own): AP_OK or AP_ERANGE.
+ * A serving loop with several batches in flight must not synchronise the handle's streams to learn about ONE batch, and must not
+ * blame batch i for what batch i+1 did.  The flag is therefore one word per internal pass stream, and
+ *   ap_net_range_mark_next(h, slot)  makes the NEXT trunk-running call on the handle snapshot, on each of its pass streams behind
+ *                                    its last kernel there, that stream's word into slot `slot` (of AP_RANGE_SLOTS): the snapshot
+ *                                    sees the kernels of this batch and of earlier ones -- never a later batch's, whichever stream
+ *                                    runs ahead.  slot = -1 cancels.  The slot's previous user must be complete (its words are cleared).
+ *   ap_net_range_slot(h, slot)       reads the slot (no sync; the caller has waited for an event recorded behind that call's output
+ *                                    stream): AP_OK or AP_ERANGE.
+ * airpose_amd.pipeline: submit() marks the batch's slot, Pending.synchronize() reads it after the batch's own event;
+ * TwoViewInference.__call__ marks, waits for its stream and reads: a one-shot forward reports its own pass. */
+#define AP_RANGE_SLOTS 8
+/* Kernel launches of the conv stack (layer1 .. layer4: everything between the stem + pool kernel and the average pool) in the most
+ * recent trunk-running call on the handle, summed over its passes -- what the library actually chose for that batch size (fused
+ * blocks, pairs, image-resident blocks), for bench.py's per-launch figures. */
+int ap_net_last_conv_launches(const ap_net* h);
+int ap_net_range_peek(const ap_net* h);
+int ap_net_range_mark_next(ap_net* h, int slot);
+int ap_net_range_slot(const ap_net* h, int slot);
+
+/* What the handle's precision costs on THIS checkpoint (the 1e-4 bar of north_star as a run-time check, not a
+ * benchmark-checkpoint sample).  Runs a seeded probe batch of n_pairs two-view pairs (crops ~ N(0,1), bb / init_position as in
+ * SURVEY 8d, 3 IEF iterations: copenet.forward, model_copenet.py:112-159) through the handle's trunk AND through an exact-fp32
+ * trunk packed from the same host tensors (AP_PREC_FP32 kernels; built on first use, kept until the next ap_net_finalize), both
+ * followed by the handle's own fp32 regressor, synchronises `stream` and compares on the host in fp64:
+ *   err8[0..3]  max|a-b| / max|b| over the slices  translation (pose[:, :3]) | 6-D rotations (pose[:, 3:]) | betas |
+ *               projected translation (u, v) = 1475 t_xy / t_z + (960, 540)  (the 2-D joints see the translation error through the
+ *               camera: constants.py:7-11, geometry.py:63-91)
+ *   err8[4..7]  max |a-b| / (1e-2 + |b|) over the same slices (element-wise)
+ * AP_PREC_FP32 handles return zeros.  Returns AP_ERANGE when the probe batch leaves the fp16 range.  1 <= n_pairs <= 64. */
+int ap_net_parity_probe(ap_net* h, int n_pairs, uint64_t seed, double* err8, void* stream);
 
 /* copenet.forward_feat_ext (model_copenet.py:161-176).
  * x: [n_img][3][224][224] NCHW fp32 (the reference input contract); feat: [n_img][2048] fp32.
@@ -124,6 +159,20 @@ int ap_regressor_fwd(ap_net* h, const float* xf0, const float* xf1, const float*
  * the other view's art pose (126) | shape (10); outputs as above. */
 int ap_regressor_step(ap_net* h, const float* xf, const float* bb, const float* pose_in, const float* betas_in,
                       const float* partner, int partner_ld, int B, float* pose_out, float* betas_out, void* stream);
+
+/* ap_regressor_step in two halves, so that the cross-view exchange hides behind the partner-independent columns (SURVEY 8e;
+ * model_copenet.py:185-193: xc = [xf 2048 | bb 3 | pos 3 | orient 6 | art 126 | shape 10 || partner's art 126 | shape 10], and
+ * fc1 -> fc2 -> dec is one affine map Wf (145 x 2332), so a step is a sum over column groups):
+ *   ap_regressor_feat_part    hfeat[b]   = bf + Wf[:, :2048] xf[b]                 once per forward (constant over the iterations)
+ *   ap_regressor_step_local   partial[b] = hfeat[b] + Wf[:, 2048:2196] [bb | pose_in | betas_in]     while the exchange is in flight
+ *   ap_regressor_step_finish  out[b]     = [pose_in | betas_in] + partial[b] + Wf[:, 2196:2332] partner[b]
+ * hfeat, partial: [B][148] fp32, caller-owned.  Same result as ap_regressor_step up to fp32 summation order.  The folded map must
+ * be in use (ap_net_fold_status == 1, two-view handle): AP_ESTATE otherwise -- such a handle steps through ap_regressor_step. */
+int ap_regressor_feat_part(ap_net* h, const float* xf, int B, float* hfeat, void* stream);
+int ap_regressor_step_local(ap_net* h, const float* hfeat, const float* bb, const float* pose_in, const float* betas_in, int B,
+                            float* partial, void* stream);
+int ap_regressor_step_finish(ap_net* h, const float* partial, const float* pose_in, const float* betas_in, const float* partner,
+                             int partner_ld, int B, float* pose_out, float* betas_out, void* stream);
 
 /* copenet_singleview baseline (models/model_copenet_singleview.py:108-168; needs a variant-2 handle: fc1 is 1024 x 2196,
  * xc = [xf | bb | pose135 | shape10]): trunk + `iters` regressor evaluations for ONE view, no cross-view input.

@@ -145,3 +145,26 @@ def test_one_library_carries_both_16bit_storage_types():
     # the stand-alone 16-bit operators take AP_PREC_BF16 / AP_PREC_F16 only (argument check comes before any launch)
     assert L.ap_conv_pair_pack(Nn.AP_PREC_FP32, None, None, 128, 0, 128, None, None) == -1
     assert L.ap_net_range_status(None, None, 0) == -1 and L.ap_net_set_range_check(None, 1) == -1
+
+
+def test_bench_launches_itself_for_n_gpus():
+    """`python bench.py --gpus 2` with no launcher environment (the shape of the driver's plain command) must start its own ranks
+    (it used to die with SystemExit before touching a GPU).  AIRPOSE_BENCH_LAUNCH_ONLY=1 stops each rank where the GPU
+    would be needed: self-launch through torch.distributed.run, gloo rendezvous on 127.0.0.1, one all_reduce, ONE JSON line."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["AIRPOSE_BENCH_LAUNCH_ONLY"] = "1"
+    env["OMP_NUM_THREADS"] = "1"
+    out = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, out.stdout
+    rec = json.loads(lines[0])
+    assert rec["launcher"] == "ok" and rec["n_gpus"] == 2 and rec["n_ranks_seen"] == 2
+    # and a launcher that started another number of ranks than --gpus names is refused loudly
+    env2 = dict(env, WORLD_SIZE="3", RANK="0", LOCAL_RANK="0")
+    bad = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2"], env=env2, capture_output=True, text=True, timeout=300)
+    assert bad.returncode != 0 and "WORLD_SIZE=3" in (bad.stderr + bad.stdout)

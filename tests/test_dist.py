@@ -63,8 +63,26 @@ def _worker(rank, world, port, out_dir):
         h = copenet_ref._lin(copenet_ref._lin(xc, sd, "fc1"), sd, "fc2")
         return pose + copenet_ref._lin(h, sd, "decpose"), betas + copenet_ref._lin(h, sd, "decshape")
 
+    # the same step in its partner-independent and partner-dependent halves (fc1 -> fc2 -> dec is affine: model_copenet.py:186-202):
+    # delta(xc) = dec(fc2(fc1(xc))); local = delta([xf | bb | state | 0]), finish adds delta([0 | 0 | 0 | partner]) - delta(0)
+    def delta(xc):
+        h = copenet_ref._lin(copenet_ref._lin(xc, sd, "fc1"), sd, "fc2")
+        return torch.cat([copenet_ref._lin(h, sd, "decpose"), copenet_ref._lin(h, sd, "decshape")], 1)
+
+    def step_local(hfeat, bb_v, pose, betas):
+        return delta(torch.cat([hfeat, bb_v, pose, betas, torch.zeros(pose.shape[0], 136)], 1))
+
+    def step_finish(partial, pose, betas, partner):
+        z = torch.zeros(pose.shape[0], 2332)
+        zp = z.clone()
+        zp[:, 2196:] = partner
+        d = partial + (delta(zp) - delta(z))
+        return pose + d[:, :135], betas + d[:, 135:]
+
     groups = D.make_pair_groups(world)
     ief = D.ViewSplitIEF(step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1))
+    ief_ov = D.ViewSplitIEF(step, groups[rank // 2], (2 * (rank // 2), 2 * (rank // 2) + 1),
+                            split_step=(lambda xf_v: xf_v, step_local, step_finish))
     with torch.no_grad():
         pose, betas = ief.run(xf[v], bb[v], pos[v], sd["init_pose"], sd["init_shape"], iters=3, shared_init=True)
         assert ief.n_exchanges == 2            # both views start from the model's mean state: none before iteration 1
@@ -76,6 +94,11 @@ def _worker(rank, world, port, out_dir):
         assert ief.n_exchanges == 4
         want_c = copenet_ref.ief(sd, xf[0], xf[1], bb[0], bb[1], pos[0], pos[1], init_theta0=th[0], init_theta1=th[1],
                                  init_shape0=sh[0], init_shape1=sh[1], iters=2)
+        # the overlapped form (exchange issued before the partner-independent half of the step, waited for before the other half)
+        pose_o, betas_o = ief_ov.run(xf[v], bb[v], pos[v], sd["init_pose"], sd["init_shape"], iters=3, shared_init=True)
+        assert ief_ov.n_exchanges == 2
+        pose_oc, betas_oc = ief_ov.run(xf[v], bb[v], pos[v], th[v], sh[v], iters=2, shared_init=False)
+        assert ief_ov.n_exchanges == 4
         # the partner rows handed out by exchange() belong to the caller: a later exchange must not change them
         # (they used to be a view of the cached gather buffer)
         p1 = ief.exchange(pose, betas)
@@ -85,7 +108,8 @@ def _worker(rank, world, port, out_dir):
         assert p1.data_ptr() != p2.data_ptr()
     np.savez(os.path.join(out_dir, "r%d.npz" % rank), pose=pose.numpy(), betas=betas.numpy(),
              want_pose=want[2 * v].numpy(), want_betas=want[2 * v + 1].numpy(),
-             pose_c=pose_c.numpy(), betas_c=betas_c.numpy(),
+             pose_c=pose_c.numpy(), betas_c=betas_c.numpy(), pose_o=pose_o.numpy(), betas_o=betas_o.numpy(),
+             pose_oc=pose_oc.numpy(), betas_oc=betas_oc.numpy(),
              want_pose_c=want_c[2 * v].numpy(), want_betas_c=want_c[2 * v + 1].numpy())
     # default sharding: no collective on the data path -- only the bench's barrier / max-reduce
     t = torch.tensor([float(rank + 1)])
@@ -109,6 +133,8 @@ def test_view_split_ief_matches_two_view_oracle(tmp_path, world):
         assert np.allclose(d["betas"], d["want_betas"], rtol=0, atol=2e-6)
         assert np.allclose(d["pose_c"], d["want_pose_c"], rtol=0, atol=2e-6)
         assert np.allclose(d["betas_c"], d["want_betas_c"], rtol=0, atol=2e-6)
+        assert np.allclose(d["pose_o"], d["want_pose"], rtol=0, atol=2e-6) and np.allclose(d["betas_o"], d["want_betas"], rtol=0, atol=2e-6)
+        assert np.allclose(d["pose_oc"], d["want_pose_c"], rtol=0, atol=2e-6) and np.allclose(d["betas_oc"], d["want_betas_c"], rtol=0, atol=2e-6)
         poses.append(d["pose"])
     if world == 4:                                            # the groups really carried different pairs
         assert not np.allclose(poses[0], poses[2])
