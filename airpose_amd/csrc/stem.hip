@@ -344,6 +344,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         const int i = tid + k * 448;
         if (i < WBYTES / 16) ((u32x4*)wsm)[i] = wreg[k];
     }
+    uint32_t rng_in = 0u;                                    // fp16 range sentinel over the converted crop values
 #pragma unroll
     for (int k = 0; k < XIT; ++k) {                         // three channel planes -> 4 x [c0 c1 c2 0]
         const int i = tid + k * 448, x4 = i % 56, row = i / 56;
@@ -356,6 +357,10 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         d[1] = make_uint2(pack_bf16x2(v0.y, v1.y), pack_bf16x2(v2.y, 0.f));
         d[2] = make_uint2(pack_bf16x2(v0.z, v1.z), pack_bf16x2(v2.z, 0.f));
         d[3] = make_uint2(pack_bf16x2(v0.w, v1.w), pack_bf16x2(v2.w, 0.f));
+        // fp16 storage: a crop value beyond +-65504 becomes +-inf HERE, and what it turns into downstream (NaN with the sign bit set) is
+        // cleared by the ReLU before any epilogue's sentinel could see it -- the conversion of the input is watched like a store
+        ap_rng_note4(rng_in, d[0].x, d[0].y, d[1].x, d[1].y, false);
+        ap_rng_note4(rng_in, d[2].x, d[2].y, d[3].x, d[3].y, false);
     }
     for (int i = tid; i < FROWS * 8; i += 448) {           // left 3 / right 5 pad pixels of every row
         const int q = i % 8, row = i / 8;
@@ -466,6 +471,7 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
         if (STEM_ABLATE & 8) asm volatile("" ::"v"(o)); else
         *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
     }
+    ap_rng_note(rng, rng_in);
     ap_rng_flush(range_flag, rng);
 }
 

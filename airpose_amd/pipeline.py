@@ -48,6 +48,44 @@ class Pending(object):
         return self.wait()                                   # (the event is complete: only the allocator bookkeeping of wait() remains)
 
 
+class Outputs(dict):
+    """The output dict of ``TwoViewInference.__call__`` for fp16 storage: reading an entry for the first time waits for the forward's
+    event and raises RangeError if a stored activation of that forward left the fp16 range (a result must never be read out of a
+    forward that overflowed; the wait is the one a reader of the results needs anyway).  Afterwards a plain dict."""
+
+    def __init__(self, data, pipe, slot, done):
+        super().__init__(data)
+        self._chk = (pipe, slot, done)
+
+    def _settle(self):
+        chk, self._chk = self._chk, None
+        if chk is not None:
+            pipe, slot, done = chk
+            done.synchronize()
+            pipe._unread[:] = [e for e in pipe._unread if e[1] is not done]
+            pipe.model.range_slot(slot)
+
+    def __getitem__(self, k):
+        self._settle()
+        return super().__getitem__(k)
+
+    def get(self, k, default=None):
+        self._settle()
+        return super().get(k, default)
+
+    def items(self):
+        self._settle()
+        return super().items()
+
+    def values(self):
+        self._settle()
+        return super().values()
+
+    def pop(self, *a):
+        self._settle()
+        return super().pop(*a)
+
+
 class TwoViewInference(object):
     def __init__(self, model, smplx, iters=3, focal_length=FOCAL_LENGTH):
         self.model, self.smplx, self.iters, self.focal_length = model, smplx, iters, focal_length
@@ -74,23 +112,41 @@ class TwoViewInference(object):
         pos = self.init_position(B, dev)
         return self.model(x0=im0, x1=im1, bb0=bb0, bb1=bb1, init_position0=pos, init_position1=pos, iters=self.iters)
 
-    CALL_SLOT = N.AP_RANGE_SLOTS - 1                         # range-flag snapshot slot of __call__ (submit uses 0 .. DEPTH - 1)
+    CALL_SLOTS = (N.AP_RANGE_SLOTS - 2, N.AP_RANGE_SLOTS - 1)   # range-flag snapshot slots of __call__, alternating (submit uses 0 .. DEPTH - 1)
 
     def __call__(self, batch, want_rotmat=True, want_angles=False, want_input_mesh=False, check_range=True):
-        """The reference's stream-ordered forward.  precision="f16" and check_range (default): the call snapshots the handle's range
-        flag behind its own trunk passes, waits for the current stream and raises RangeError if a stored activation of THIS forward
-        left the fp16 range -- a one-shot caller never gets AP_OK with garbage (check_range=False: the deferred sentinel only, i.e.
-        the NEXT forward on the handle raises)."""
+        """The reference's stream-ordered forward: returns at once, the outputs are complete in the order of the current stream.
+        precision="f16" and check_range (default): the forward snapshots the handle's range words behind its OWN trunk passes, and
+        the returned dict checks that snapshot the first time an entry is read (``Outputs``: it waits for the forward's event --
+        which a caller reading results does anyway -- and raises RangeError if a stored activation of THIS forward left the fp16
+        range), so a one-shot caller never reads garbage out of an AP_OK; a loop that never looks at a result is told by a later
+        call (the snapshots of unread forwards are read as soon as they are complete; the host runs at most two such forwards
+        ahead).  check_range="sync": wait for the stream and check before returning; check_range=False: the handle's deferred
+        sentinel only."""
         im0, im1 = batch["im0"], batch["im1"]
-        f16 = check_range and getattr(self.model, "precision", None) == "f16"
+        dev = im0.device
+        f16 = bool(check_range) and getattr(self.model, "precision", None) == "f16"
+        pend = self.__dict__.setdefault("_unread", [])       # forwards nobody has looked at yet: (slot, event), oldest first
+        while pend and (pend[0][1].query() or len(pend) >= len(self.CALL_SLOTS)):
+            slot0, ev0 = pend.pop(0)                         # complete by now -- or its slot comes round: settle it (the host is then
+            ev0.synchronize()                                # two forwards ahead of the GPU; nothing idles)
+            self.model.range_slot(slot0)
         if f16:
-            self.model.range_mark_next(self.CALL_SLOT)
+            self._call_no = getattr(self, "_call_no", 0) + 1
+            slot = self.CALL_SLOTS[self._call_no % len(self.CALL_SLOTS)]
+            self.model.range_mark_next(slot)
         p0, b0, p1, b1 = self.forward_net(im0, im1, batch["bb0"], batch["bb1"])
         out = self._tail(p0, b0, p1, b1, batch, want_rotmat, want_angles, want_input_mesh)
-        if f16:
-            torch.cuda.current_stream(im0.device).synchronize()
-            self.model.range_slot(self.CALL_SLOT)
-        return out
+        if not f16:
+            return out
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(dev))
+        if check_range == "sync":
+            done.synchronize()
+            self.model.range_slot(slot)
+            return out
+        pend.append((slot, done))
+        return Outputs(out, self, slot, done)
 
     def submit_net(self, im0, im1, bb0, bb1):
         """``forward_net`` issued as ``submit`` issues the whole forward: Pending.out = (pred_pose0, pred_betas0, pred_pose1,

@@ -2438,10 +2438,22 @@ def test_call_reports_the_overflow_of_its_own_pass(copenet_sd, body, dev):
     bad.load_state_dict(sd)
     batch = {k: torch.from_numpy(v).to(dev) for k, v in W.synthetic_inputs(3, 2).items()}
     pipe = pipeline.TwoViewInference(bad, body)
+    out = pipe(batch)                                        # stream-ordered: returns at once ...
+    with pytest.raises(Nn.RangeError, match="fp16 range"):   # ... and the first read of a result checks the forward's own snapshot
+        out["pred_pose0"]
+    with pytest.raises(Nn.RangeError):
+        bad.range_status(reset=True)
     with pytest.raises(Nn.RangeError, match="fp16 range"):
+        pipe(batch, check_range="sync")
+    with pytest.raises(Nn.RangeError):
+        bad.range_status(reset=True)
+    pipe(batch)                                              # never read ...
+    torch.cuda.synchronize()
+    with pytest.raises(Nn.RangeError):                       # ... the next call tells
         pipe(batch)
     with pytest.raises(Nn.RangeError):
         bad.range_status(reset=True)
+    pipe._unread.clear()
     pipe(batch, check_range=False)                           # deferred: returns ...
     torch.cuda.synchronize()
     with pytest.raises(Nn.RangeError):                       # ... and the next forward refuses
@@ -2465,7 +2477,7 @@ def test_pending_synchronize_blames_the_right_batch(copenet_sd, body, dev, B):
     net.load_state_dict(copenet_sd)
     pipe = pipeline.TwoViewInference(net, body)
     good = {k: torch.from_numpy(v).to(dev) for k, v in W.synthetic_inputs(5, B).items()}
-    hot = dict(good, im0=good["im0"] * 1.0e7, im1=good["im1"] * 1.0e7)
+    hot = dict(good, im0=good["im0"] * 1.0e7, im1=good["im1"] * 1.0e7)   # (beyond fp16 at the stem's input conversion already)
     pipe.submit(good).synchronize()                          # warm-up (packs)
     for _ in range(3):
         p_good = pipe.submit(good)
