@@ -326,13 +326,15 @@ struct ap_smplx {
     SmplxModelDev m{};
     Layer dirs;                 // blend-shape GEMM operand: rows = 3V, K = 512 (fp32: exact fp32 MFMA chain)
     DevBuf dirs_split;          // the same operand as split-bf16 pairs: four-term products on the bf16 matrix pipe (default)
-    DevBuf dirs_frag, jv_slot, skin_idx8, skin_w4, ws_side;   // fused contraction + skinning: directions in MFMA fragment order, joint-vertex slots / buffer
+    DevBuf dirs_frag, jv_slot, skin_idx8, skin_w4, skin_idx8b, skin_w4b, ws_side;   // fused contraction + skinning: directions in MFMA fragment order, joint-vertex slots / buffer
     DevBuf ws_cnt;              // ... arrival counters of the body groups (joints by the group's last workgroup); zero between launches
+    bool fold_post = true;      // ... and with the post transform composed into those 22 transforms by the prep kernel (A22); ap_smplx_set_fused(h, 7): off (A/B)
+    int merge_bones = 1;        // (0: off, 1: on, 2: with 64 bodies per workgroup -- A/B, slower) body-only calls: the fused kernel skins over the 22 posed transforms (merged skin table); ap_smplx_set_fused(h, 6): all 55 (A/B)
     bool fuse_joints = false;   // ap_smplx_set_fused(h, 4): joints / landmarks / projection inside the fused kernel (measured 7 us SLOWER than their own launch)
     bool blend_split = true;
     bool fused = true;          // body-only pose feature, 4 bones per vertex, split-bf16 blend: one kernel for contraction + skinning
     DevBuf j_template, j_shapedirs, parents, depth, skin_idx, skin_w, extra_verts, lmk_tri, lmk_bary;
-    DevBuf ws_coef, ws_A, ws_jposed, ws_post, ws_vposed, ws_cc;
+    DevBuf ws_coef, ws_A, ws_A22, ws_jposed, ws_post, ws_vposed, ws_cc;
     int n_out_joints = 0;
     Timing tm;
 };
@@ -2213,6 +2215,41 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
         }
         e = upload(h->skin_idx8, i8.data(), i8.size() * 4);
         if (e == hipSuccess) e = upload(h->skin_w4, w4.data(), w4.size() * 4);
+        // body-only table: every joint >= 22 (jaw, eyes, fingers: identity rotation without a hand / face pose) skins exactly like its
+        // nearest ancestor < 22, so a vertex needs at most as many DISTINCT transforms as it has bones -- usually fewer (a finger
+        // vertex: one).  Bones merged by representative, weights summed in double, heaviest first; unused slots repeat slot 0's bone
+        // with weight 0 (the kernel skips zero weights).
+        const int NBODY = 22;
+        if (e == hipSuccess && J >= NBODY) {
+            std::vector<int> rep(J);
+            for (int j = 0; j < J; ++j) { int r = j; while (r >= NBODY) r = par[r]; rep[j] = r; }
+            std::vector<uint32_t> i8b(vp, 0);
+            std::vector<float> w4b((size_t)vp * 4, 0.f);
+            for (int v = 0; v < V; ++v) {
+                int bj[4]; double bw[4]; int nbn = 0;
+                for (int k = 0; k < 4; ++k) {
+                    const float w = sw[(size_t)v * 4 + k];
+                    if (w == 0.f) continue;
+                    const int r = rep[sidx[(size_t)v * 4 + k]];
+                    int q = 0;
+                    while (q < nbn && bj[q] != r) ++q;
+                    if (q == nbn) { bj[nbn] = r; bw[nbn] = 0.0; ++nbn; }
+                    bw[q] += (double)w;
+                }
+                for (int a2 = 0; a2 < nbn; ++a2)             // heaviest first (stable)
+                    for (int b2 = a2 + 1; b2 < nbn; ++b2)
+                        if (bw[b2] > bw[a2]) { std::swap(bw[a2], bw[b2]); std::swap(bj[a2], bj[b2]); }
+                if (nbn == 0) { bj[0] = 0; bw[0] = 0.0; nbn = 1; }
+                for (int k = 0; k < 4; ++k) {
+                    i8b[v] |= (uint32_t)((k < nbn ? bj[k] : bj[0]) & 0x3f) << (6 * k);
+                    w4b[(size_t)v * 4 + k] = k < nbn ? (float)bw[k] : 0.f;
+                }
+                i8b[v] |= i8[v] & 0xff000000u;
+            }
+            e = upload(h->skin_idx8b, i8b.data(), i8b.size() * 4);
+            if (e == hipSuccess) e = upload(h->skin_w4b, w4b.data(), w4b.size() * 4);
+            if (e == hipSuccess) m.nb = NBODY;
+        }
     }
     if (e == hipSuccess) e = upload(h->j_shapedirs, jsd.data(), jsd.size() * 4);
     if (e == hipSuccess) e = upload(h->parents, par.data(), par.size() * 4);
@@ -2232,6 +2269,7 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
     m.n_extra = md->num_extra; m.n_lmk = md->num_landmarks;
     m.dirs_frag = h->dirs_frag.p; m.v_template = h->dirs.shift.as<float>(); m.jv_slot = h->jv_slot.as<int>();
     m.skin_idx8 = h->skin_idx8.as<uint32_t>(); m.skin_w4 = h->skin_w4.as<float>();
+    m.skin_idx8b = h->skin_idx8b.as<uint32_t>(); m.skin_w4b = h->skin_w4b.as<float>();
     h->n_out_joints = J + md->num_extra + md->num_landmarks;
     *out = h;
     return AP_OK;
@@ -2242,7 +2280,7 @@ void ap_smplx_destroy(ap_smplx* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&h->dirs.w, &h->dirs_split, &h->dirs.scale, &h->dirs.shift, &h->j_template, &h->j_shapedirs, &h->parents, &h->depth,
-                      &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A, &h->dirs_frag, &h->jv_slot, &h->skin_idx8, &h->skin_w4, &h->ws_side,
+                      &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A, &h->ws_A22, &h->dirs_frag, &h->jv_slot, &h->skin_idx8, &h->skin_w4, &h->skin_idx8b, &h->skin_w4b, &h->ws_side,
                       &h->ws_jposed, &h->ws_post, &h->ws_vposed, &h->ws_cc, &h->ws_cnt})
         b->release();
     h->tm.destroy();
@@ -2278,6 +2316,11 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     }
     a.coef = h->ws_coef.as<float>(); a.A = h->ws_A.as<float>(); a.jposed = h->ws_jposed.as<float>();
     a.post = (a.pose6d || a.post_rt) ? h->ws_post.as<float>() : nullptr;
+    a.A22 = nullptr;
+    if (fused && h->fold_post && h->merge_bones && a.post && !a.transl && !a.grp_cnt && m.nb == 22) {
+        HIP_TRY(h->ws_A22.reserve((size_t)n * 22 * 12 * 4));
+        a.A22 = h->ws_A22.as<float>();
+    }
     a.vposed = h->ws_vposed.as<float>();
     a.vp_side = fused ? h->ws_side.as<float>() : nullptr;
     if (a.n_main > 0 && a.intr0) {                           // camera centres resolved by the prep kernel
@@ -2292,7 +2335,7 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     if (fused) {
         int n_cu = 0;
         HIP_TRY(device_cus(&n_cu));
-        HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, st));
+        HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, h->merge_bones, st));
         if (h->tm.on) { HIP_TRY(h->tm.rec(st, &ev[2])); ev[3] = ev[2]; }     // stage 1 = the fused kernel, stage 2 empty
     } else {
         // v_posed = v_template + [betas | expr | pose_feature] . dirs^T; hand/face rows of the pose feature are
@@ -2388,6 +2431,8 @@ int ap_smplx_set_fused(ap_smplx* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->fused = on != 0;
     h->fuse_joints = on == 4;                                // 4: joints stage inside the kernel, done by each group's last workgroup (A/B: slower)
+    h->merge_bones = on == 6 ? 0 : (on == 8 ? 2 : 1);        // 6: every joint's transform in LDS (round 5's form); 8: merged table, 64 bodies per workgroup (A/B: slower)
+    h->fold_post = on != 7;                                  // 7: merged table, post transform applied per vertex instead of composed into the bones (A/B)
     return AP_OK;
 }
 

@@ -177,6 +177,12 @@ struct SmplxModelDev {
     const float* skin_w4;         // [V padded to 16][4]
     const int* jv_slot;           // [V]: slot of the vertex in the joint-vertex side buffer, -1 = none
     int n_jv;                     // slots (distinct vertices among the 21 picks and the 51 landmark triangles)
+    // body-only calls (no hand / jaw / eye pose: joints nb .. J-1 keep the identity rotation, so A_j == A_rep(j) for the nearest
+    // posed ancestor rep(j) < nb: G_j = G_p [I | J_j - J_p] and A_j = G_j [I | -J_j] = G_p [I | -J_p]): the skin table over the nb
+    // transforms that differ, duplicate bones merged (weights summed), heaviest first, zero weights last
+    int nb;                       // 22 = root + 21 body joints (0 = no such table)
+    const uint32_t* skin_idx8b;   // as skin_idx8 with bone indices < nb
+    const float* skin_w4b;
 };
 struct SmplxFwdArgs {
     int n;                        // bodies
@@ -207,6 +213,7 @@ struct SmplxFwdArgs {
     // workspace
     float* coef;                  // [n][ncoef]
     float* A;                     // [n][J][12]
+    float* A22;                   // [n][22][12] or NULL: post transform o A_j of the 22 posed joints (what the fused kernel's merged form skins with)
     float* jposed;                // [n][J][3]
     float* post;                  // [n][12] resolved post transform
     const float* vposed;          // [n][ldv]
@@ -226,7 +233,7 @@ hipError_t ap_launch_smplx_joints(const SmplxModelDev& m, const SmplxFwdArgs& a,
 // blend-shape contraction + skinning in one kernel (K = 4 bones per vertex, body-only pose feature, split-bf16 coefficients)
 bool ap_smplx_lbs_fused_supported(const SmplxModelDev& m);
 size_t ap_smplx_dirs_frag_bytes(int V);
-hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, hipStream_t st);
+hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, int merged, hipStream_t st);
 
 // ---- stand-alone geometry helpers (smplx.hip)
 hipError_t ap_launch_rot6d(const float* x6, int n, float* R, hipStream_t st);

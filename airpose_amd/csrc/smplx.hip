@@ -44,6 +44,7 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
     __shared__ float G[64][12];
     __shared__ float Jr[64][3];
     __shared__ float cf[20];
+    __shared__ float Psh[12];                                // the body's post transform (root lane), for A22
     float* coef = a.coef + (size_t)b * m.ncoef;
     // test-mode input mesh (copenet_twoview.py:258-279): body sb's rotations, zero betas, [I | in_smpltrans]
     const bool inmesh = a.n_main > 0 && b >= a.n_main;
@@ -130,6 +131,7 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
                     P[rr * 4 + 1] = inmesh ? (rr == 1 ? 1.f : 0.f) : Rj[rr * 3 + 1];
                     P[rr * 4 + 2] = inmesh ? (rr == 2 ? 1.f : 0.f) : Rj[rr * 3 + 2];
                     P[rr * 4 + 3] = t3[rr];
+                    Psh[rr * 4 + 0] = P[rr * 4 + 0]; Psh[rr * 4 + 1] = P[rr * 4 + 1]; Psh[rr * 4 + 2] = P[rr * 4 + 2]; Psh[rr * 4 + 3] = t3[rr];
                 }
                 if (cc) {
                     a.cc_ws[(size_t)b * 2 + 0] = ccx;
@@ -147,7 +149,7 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
         if (j == 0 && a.post) {
             float* P = a.post + (size_t)b * 12;
 #pragma unroll
-            for (int e = 0; e < 12; ++e) P[e] = prt[e];
+            for (int e = 0; e < 12; ++e) { P[e] = prt[e]; Psh[e] = prt[e]; }
         }
     }
     if (j >= 1 && j < m.J) {
@@ -194,11 +196,24 @@ __global__ void __launch_bounds__(64) smplx_prep_kernel(const SmplxModelDev m, c
     if (j < m.J) {
         float* Aj = a.A + ((size_t)b * m.J + j) * 12;
         float* jp = a.jposed + ((size_t)b * m.J + j) * 3;
+        float Av[12];
         for (int rr = 0; rr < 3; ++rr) {
             const float g0 = G[j][rr * 4 + 0], g1 = G[j][rr * 4 + 1], g2 = G[j][rr * 4 + 2], g3 = G[j][rr * 4 + 3];
-            Aj[rr * 4 + 0] = g0; Aj[rr * 4 + 1] = g1; Aj[rr * 4 + 2] = g2;
-            Aj[rr * 4 + 3] = g3 - (g0 * Jr[j][0] + g1 * Jr[j][1] + g2 * Jr[j][2]);
+            Av[rr * 4 + 0] = g0; Av[rr * 4 + 1] = g1; Av[rr * 4 + 2] = g2;
+            Av[rr * 4 + 3] = g3 - (g0 * Jr[j][0] + g1 * Jr[j][1] + g2 * Jr[j][2]);
+            Aj[rr * 4 + 0] = Av[rr * 4 + 0]; Aj[rr * 4 + 1] = Av[rr * 4 + 1]; Aj[rr * 4 + 2] = Av[rr * 4 + 2]; Aj[rr * 4 + 3] = Av[rr * 4 + 3];
             jp[rr] = g3;
+        }
+        // the posed body transforms with the caller's post transform composed in (P o A_j; skinning weights sum to one, so
+        // sum_j w_j (P o A_j) = P o sum_j w_j A_j): what the vertex-stationary kernel skins with -- no per-vertex post transform
+        if (a.A22 && j < 22) {
+            float* Bj = a.A22 + ((size_t)b * 22 + j) * 12;
+            for (int rr = 0; rr < 3; ++rr) {
+                const float p0 = Psh[rr * 4 + 0], p1 = Psh[rr * 4 + 1], p2 = Psh[rr * 4 + 2], p3 = Psh[rr * 4 + 3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    Bj[rr * 4 + c] = p0 * Av[c] + p1 * Av[4 + c] + p2 * Av[8 + c] + (c == 3 ? p3 : 0.f);
+            }
         }
     }
 }
@@ -332,26 +347,36 @@ __global__ void __launch_bounds__(256) smplx_skin_kernel(const SmplxModelDev m, 
 //     register ring -- every load is a plain load the compiler counts (no inline-asm destinations, nothing loop-carried in
 //     flight), the next K step's fragments are requested before the current step's MFMAs.
 // Same arithmetic per product as the first cut and the two-kernel path (hi.hi + lo.hi + hi.lo on the bf16 pipe, fp32 skinning).
-constexpr int T_BB = 32, T_KS = 7, T_NW = 16, T_CROW = T_KS * 128 + 16, T_MAXJ = 55;
+constexpr int T_KS = 7, T_NW = 16, T_CROW = T_KS * 128 + 16, T_MAXJ = 55;
 // Timing-only builds (results WRONG, times valid): -DT_ABLATE=<bits>: 1 no vertex stores | 2 no bone gathers / blend | 4 direction
 // fragments loaded once per group instead of once per K step | 8 no MFMAs | 16 no prologue copies
 #ifndef T_ABLATE
 #define T_ABLATE 0
 #endif
 
+// NBJ = bone transforms per body held in LDS: T_MAXJ (all joints, skin_idx8 / skin_w4) or 22 (body-only calls: the merged table
+// skin_idx8b / skin_w4b over root + 21 body joints -- every hand / face joint skins like its posed ancestor; 34 instead of 84 KB
+// of bone tables, and a vertex gathers only the transforms that differ: zero weights are skipped)
+// BB = bodies per workgroup: 32, or 64 = two halves of 32 handled by wave pairs (w, w + 8) that walk the SAME vertex groups: the
+// direction fragments -- the kernel's L2 stream, 42 KB per group of 16 vertices -- are then requested by both waves of a pair at
+// about the same time, and half as many body groups pull the 27.6 MB of fragments through L2
+template <int NBJ, int BB>
 __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxModelDev m, const SmplxFwdArgs a, int n_vr, int groups_per_vr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lf_smem[];
-    float* bones = (float*)lf_smem;                                               // [T_BB][J][12]
+    constexpr bool MERGED = NBJ < T_MAXJ;
+    float* bones = (float*)lf_smem;                                               // [BB][NBJ][12]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, g4 = lane >> 4;
+    constexpr int GW = T_NW / (BB / 32);                                          // waves that share the groups of a body half
+    const int hb = wave / GW;                                                     // this wave's half of the workgroup's bodies
     const int vr = blockIdx.x % n_vr, bg = blockIdx.x / n_vr;
-    const int b0 = bg * T_BB, J12 = m.J * 12;
-    // bone tables at the compile-time stride [T_BB][T_MAXJ][12]: a body's table is then an immediate offset from ONE per-lane base
+    const int b0 = bg * BB, J12 = m.J * 12;
+    // bone tables at the compile-time stride [BB][T_MAXJ][12]: a body's table is then an immediate offset from ONE per-lane base
     // (with the runtime stride J * 12 hipcc kept eight per-body addresses in registers across the group loop)
-    constexpr int J12C = T_MAXJ * 12;
-    unsigned char* coefs = lf_smem + T_BB * J12C * 4;                             // [T_BB][T_CROW]: 7 K steps x (4 x [8 hi | 8 lo])
-    float* Ps = (float*)(coefs + T_BB * T_CROW);                                  // [T_BB][16]: post transform [12] | translation [3]
+    constexpr int J12C = NBJ * 12;
+    unsigned char* coefs = lf_smem + BB * J12C * 4;                             // [BB][T_CROW]: 7 K steps x (4 x [8 hi | 8 lo])
+    float* Ps = (float*)(coefs + BB * T_CROW);                                  // [BB][16]: post transform [12] | translation [3]
     const int ngroups = (m.V + 15) >> 4;
     const int gend = min(ngroups, (vr + 1) * groups_per_vr);
     const unsigned char* dbase = (const unsigned char*)m.dirs_frag + (size_t)lane * 16;
@@ -361,47 +386,53 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
     // group's last one is the next group's first: its loads fly under the skinning), all six of a step back to back: with one set
     // hipcc serialised load -> s_waitcnt vmcnt(0) -> MFMA pairs inside a step (three to four dependent L2 round trips per K step).
     // Plain loads, counted by the compiler; the address of a prefetch past the last group is clamped to the group itself.
-    int g = vr * groups_per_vr + wave;
+    int g = vr * groups_per_vr + wave % GW;
     u32x4 fa[6], fb[6];
 #pragma unroll
     for (int i = 0; i < 6; ++i) fa[i] = frag(min(g, ngroups - 1), 0, i);           // (issued ahead of the prologue's own loads)
     {   // bone transforms, coefficient rows, post transforms of the 32 bodies (rows past the last body: clamped duplicates, never
         // stored); every load of a thread is issued before its first LDS write
-        constexpr int NT = 64 * T_NW, BIT = (T_BB * T_MAXJ * 3 + NT - 1) / NT, CCH = T_KS * 8, CIT = (T_BB * CCH + NT - 1) / NT;
-        const int nb = min(T_BB, a.n - b0), n4 = nb * m.J * 3, tot = T_BB * m.J * 3;
-        const float4* src = (const float4*)(a.A + (size_t)b0 * J12);
+        constexpr int NT = 64 * T_NW, BIT = (BB * NBJ * 3 + NT - 1) / NT, CCH = T_KS * 8, CIT = (BB * CCH + NT - 1) / NT;
+        const int jl = MERGED ? NBJ : m.J;                   // joints of a body that go to LDS (the first jl of its J)
+        const int nb = min(BB, a.n - b0), n4 = nb * jl * 3, tot = BB * jl * 3;
+        // MERGED with a.A22: the 22 posed transforms with the post transform composed in (smplx_prep_kernel): one contiguous run
+        const float4* src = (MERGED && a.A22) ? (const float4*)(a.A22 + (size_t)b0 * (NBJ * 12)) : (const float4*)(a.A + (size_t)b0 * J12);
         float4 tb[BIT];
         u32x4 tc[CIT];
 #pragma unroll
-        for (int k = 0; k < BIT; ++k) { const int i = tid + k * NT; tb[k] = src[i < n4 ? i : i % n4]; }
+        for (int k = 0; k < BIT; ++k) {
+            const int i = tid + k * NT, ic = i < n4 ? i : i % n4;
+            if constexpr (MERGED) { const int bb = ic / (NBJ * 3); tb[k] = a.A22 ? src[ic] : src[bb * (m.J * 3) + (ic - bb * (NBJ * 3))]; }
+            else tb[k] = src[ic];
+        }
 #pragma unroll
         for (int k = 0; k < CIT; ++k) {
-            const int i = min(tid + k * NT, T_BB * CCH - 1), bb = i / CCH, c16 = i - bb * CCH, bsrc = min(b0 + bb, a.n - 1);
+            const int i = min(tid + k * NT, BB * CCH - 1), bb = i / CCH, c16 = i - bb * CCH, bsrc = min(b0 + bb, a.n - 1);
             tc[k] = *(const u32x4*)((const unsigned char*)(a.coef + (size_t)bsrc * m.ncoef) + c16 * 16);
         }
         float pv = 0.f;
-        if (tid < T_BB * 16) {
+        if (tid < BB * 16) {
             const int bb = tid >> 4, e = tid & 15, bsrc = min(b0 + bb, a.n - 1);
             if (e < 12) pv = a.post ? a.post[(size_t)bsrc * 12 + e] : ((e == 0 || e == 5 || e == 10) ? 1.f : 0.f);
             else if (e < 15) pv = a.transl ? a.transl[(size_t)bsrc * 3 + (e - 12)] : 0.f;
         }
 #pragma unroll
         for (int k = 0; k < BIT; ++k) {
-            const int i = tid + k * NT, J3 = m.J * 3, bb = i / J3;
-            if (i < tot) ((float4*)bones)[bb * (T_MAXJ * 3) + (i - bb * J3)] = tb[k];
+            const int i = tid + k * NT, J3 = jl * 3, bb = i / J3;
+            if (i < tot) ((float4*)bones)[bb * (NBJ * 3) + (i - bb * J3)] = tb[k];
         }
 #pragma unroll
         for (int k = 0; k < CIT; ++k) {
             const int i = tid + k * NT;
-            if (i < T_BB * CCH) { const int bb = i / CCH, c16 = i - bb * CCH; *(u32x4*)(coefs + bb * T_CROW + c16 * 16) = tc[k]; }
+            if (i < BB * CCH) { const int bb = i / CCH, c16 = i - bb * CCH; *(u32x4*)(coefs + bb * T_CROW + c16 * 16) = tc[k]; }
         }
-        if (tid < T_BB * 16) Ps[tid] = pv;
+        if (tid < BB * 16) Ps[tid] = pv;
     }
     __syncthreads();
-    const unsigned char* ca = coefs + lr * T_CROW + g4 * 32;                       // this lane's A rows: bodies lr and 16 + lr
-    const float* const bones_l = bones + g4 * 4 * J12C;                            // this lane's skinning bodies: 4 g4 + r (+ 16)
-    const float* const Ps_l = Ps + g4 * 4 * 16;
-    for (; g < gend; g += T_NW) {
+    const unsigned char* ca = coefs + (hb * 32 + lr) * T_CROW + g4 * 32;           // this lane's A rows: bodies lr and 16 + lr (of its half)
+    const float* const bones_l = bones + (hb * 32 + g4 * 4) * J12C;                // this lane's skinning bodies: 4 g4 + r (+ 16)
+    const float* const Ps_l = Ps + (hb * 32 + g4 * 4) * 16;
+    for (; g < gend; g += GW) {
         // ------------------------------------------------ contraction: acc[c][s][r] = v_posed component c of vertex 16 g + lr
         // for body s * 16 + 4 g4 + r
         f32x4 acc[3][2];
@@ -409,10 +440,10 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
         for (int c = 0; c < 3; ++c) { acc[c][0] = f32x4{0.f, 0.f, 0.f, 0.f}; acc[c][1] = f32x4{0.f, 0.f, 0.f, 0.f}; }
         // this lane's vertex: bone ids (6 bits each, + joint-vertex slot), weights, template (requested under the contraction)
         const int v = g * 16 + lr;
-        const uint32_t id = m.skin_idx8[v];
-        const float4 w4 = *(const float4*)(m.skin_w4 + (size_t)v * 4);
+        const uint32_t id = (MERGED ? m.skin_idx8b : m.skin_idx8)[v];
+        const float4 w4 = *(const float4*)((MERGED ? m.skin_w4b : m.skin_w4) + (size_t)v * 4);
         const float tx = m.v_template[(size_t)v * 3], ty = m.v_template[(size_t)v * 3 + 1], tz = m.v_template[(size_t)v * 3 + 2];
-        const int gn = g + T_NW < gend ? g + T_NW : g;
+        const int gn = g + GW < gend ? g + GW : g;
         lf_sfor<0, T_KS>([&](auto KS) {
             constexpr int ks = decltype(KS)::value;
             u32x4 (&cur)[6] = (ks & 1) ? fb : fa;
@@ -446,16 +477,16 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
         // set took their registers, and a scratch reload sits behind every earlier store of the wave)
         char* const vbase = (char*)(a.vertices + (size_t)b0 * m.V * 3);
         const uint32_t vstep = (uint32_t)m.V * 12u;
-        uint32_t voff = ((uint32_t)(g4 * 4) * (uint32_t)m.V + (uint32_t)v) * 12u;
+        uint32_t voff = ((uint32_t)(hb * 32 + g4 * 4) * (uint32_t)m.V + (uint32_t)v) * 12u;
         char* const sbase = (char*)(a.vp_side + (size_t)b0 * m.n_jv * 3);          // joint-vertex side buffer, same scheme
         const uint32_t sstep = (uint32_t)m.n_jv * 12u;
-        uint32_t soff = ((uint32_t)(g4 * 4) * (uint32_t)m.n_jv + ((id >> 24) - 1u)) * 12u;   // (only used when id >> 24 != 0)
+        uint32_t soff = ((uint32_t)(hb * 32 + g4 * 4) * (uint32_t)m.n_jv + ((id >> 24) - 1u)) * 12u;   // (only used when id >> 24 != 0)
         asm volatile("" : "+v"(voff), "+v"(soff));           // opaque: hipcc otherwise hoists eight per-body offsets out of the group loop (and spills them)
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
-                const int bl = s * 16 + g4 * 4 + r;
+                const int bl = hb * 32 + s * 16 + g4 * 4 + r;
                 const bool bok = b0 + bl < a.n;
                 const float x = acc[0][s][r] + tx, y = acc[1][s][r] + ty, z = acc[2][s][r] + tz;
                 if (!a.grp_cnt && a.vp_side && bok && (id >> 24)) {   // joint vertex: slot + 1 in the top byte (0 = none, padding rows too)
@@ -468,6 +499,7 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 for (int e = 0; e < 12; ++e) T[e] = (T_ABLATE & 2) ? wv[e & 3] : 0.f;
 #pragma unroll
                 for (int k = 0; k < ((T_ABLATE & 2) ? 0 : 4); ++k) {
+                    if (MERGED && k > 0 && wv[k] == 0.f) continue;               // (heaviest first: the zero weights are the last ones)
                     const float4* Ak = (const float4*)(Ab + ((id >> (6 * k)) & 0x3fu) * 12);
                     const float4 r0 = Ak[0], r1 = Ak[1], r2 = Ak[2];
                     T[0] = fmaf(wv[k], r0.x, T[0]); T[1] = fmaf(wv[k], r0.y, T[1]); T[2] = fmaf(wv[k], r0.z, T[2]); T[3] = fmaf(wv[k], r0.w, T[3]);
@@ -487,8 +519,10 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                     __hip_atomic_store(sq + 2, q[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 }
                 soff += sstep;
-                q[0] += Pb[12]; q[1] += Pb[13]; q[2] += Pb[14];
-                if (a.post) apply_post(Pb, q);
+                if (!(MERGED && a.A22)) {                    // (A22: the bones carry the post transform; such calls have no translation)
+                    q[0] += Pb[12]; q[1] += Pb[13]; q[2] += Pb[14];
+                    if (a.post) apply_post(Pb, q);
+                }
                 if (T_ABLATE & 1) asm volatile("" ::"v"(q[0]), "v"(q[1]), "v"(q[2]));
                 else if (bok && vok) {
                     float* dst = (float*)(vbase + voff);
@@ -526,7 +560,7 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
         __syncthreads();
         const int nj = m.J + m.n_extra + m.n_lmk;
         const int nbj = a.n_main > 0 ? a.n_main : a.n;       // bodies that have joints (the test-mode input meshes do not)
-        for (int item = tid; item < T_BB * nj; item += 64 * T_NW) {
+        for (int item = tid; item < BB * nj; item += 64 * T_NW) {
             const int bl = item / nj, t = item - bl * nj, b = b0 + bl;
             if (b >= nbj) continue;
             const float* vs = a.vp_side + (size_t)b * m.n_jv * 3;
@@ -785,27 +819,38 @@ bool ap_smplx_lbs_fused_supported(const SmplxModelDev& m) {
 
 size_t ap_smplx_dirs_frag_bytes(int V) { return (size_t)((V + 15) / 16) * T_KS_PACK * 6 * 1024; }
 
-hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, hipStream_t st) {
+hipError_t ap_launch_smplx_lbs_fused(const SmplxModelDev& m, const SmplxFwdArgs& a, int n_cu, int merged, hipStream_t st) {
     static bool attr_set[AP_MAX_DEVICES] = {};
     if (!ap_smplx_lbs_fused_supported(m)) return hipErrorInvalidValue;
-    constexpr int lds = T_BB * T_MAXJ * 12 * 4 + T_BB * T_CROW + T_BB * 64;
+    constexpr int NBM = 22;
+    auto lds_of = [](int nbj, int bb) { return bb * nbj * 12 * 4 + bb * T_CROW + bb * 64; };
+    // merged: the 22 posed transforms (body-only skin table); 2 = ... with 64 bodies per workgroup (A/B: measured slower, profiles/r06_lbs_ab.txt)
+    const bool mg = merged && m.nb == NBM && m.skin_idx8b && m.skin_w4b;
+    const bool wide = mg && merged == 2 && a.n >= 256;
     int dev = 0;
     hipError_t e = ap_current_device(&dev);
     if (e != hipSuccess) return e;
     if (!attr_set[dev]) {
-        e = hipFuncSetAttribute((const void*)smplx_lbs_tail_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        e = hipFuncSetAttribute((const void*)smplx_lbs_tail_kernel<T_MAXJ, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_of(T_MAXJ, 32));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)smplx_lbs_tail_kernel<NBM, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_of(NBM, 32));
+        if (e != hipSuccess) return e;
+        e = hipFuncSetAttribute((const void*)smplx_lbs_tail_kernel<NBM, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_of(NBM, 64));
         if (e != hipSuccess) return e;
         attr_set[dev] = true;
     }
     // body groups x vertex ranges ~ one workgroup per CU; 8 | n_vr keeps the blocks of one range on one XCD (block b runs on XCD
     // b % 8), so its direction rows are fetched from HBM once and served to the other body groups from that XCD's L2
-    const int bgs = (a.n + T_BB - 1) / T_BB, ngroups = (m.V + 15) / 16;
+    const int bb = wide ? 64 : 32, gw = T_NW / (bb / 32);
+    const int bgs = (a.n + bb - 1) / bb, ngroups = (m.V + 15) / 16;
     int n_vr = (n_cu + bgs - 1) / bgs;
     n_vr = n_vr >= 8 ? (n_vr / 8) * 8 : n_vr;
-    n_vr = n_vr < 1 ? 1 : (n_vr > (ngroups + T_NW - 1) / T_NW ? (ngroups + T_NW - 1) / T_NW : n_vr);
+    n_vr = n_vr < 1 ? 1 : (n_vr > (ngroups + gw - 1) / gw ? (ngroups + gw - 1) / gw : n_vr);
     const int gpv = (ngroups + n_vr - 1) / n_vr;
     n_vr = (ngroups + gpv - 1) / gpv;
-    hipLaunchKernelGGL(smplx_lbs_tail_kernel, dim3(bgs * n_vr), dim3(64 * T_NW), lds, st, m, a, n_vr, gpv);
+    if (wide) hipLaunchKernelGGL((smplx_lbs_tail_kernel<NBM, 64>), dim3(bgs * n_vr), dim3(64 * T_NW), lds_of(NBM, 64), st, m, a, n_vr, gpv);
+    else if (mg) hipLaunchKernelGGL((smplx_lbs_tail_kernel<NBM, 32>), dim3(bgs * n_vr), dim3(64 * T_NW), lds_of(NBM, 32), st, m, a, n_vr, gpv);
+    else hipLaunchKernelGGL((smplx_lbs_tail_kernel<T_MAXJ, 32>), dim3(bgs * n_vr), dim3(64 * T_NW), lds_of(T_MAXJ, 32), st, m, a, n_vr, gpv);
     return hipGetLastError();
 }
 
