@@ -326,7 +326,7 @@ struct ap_smplx {
     SmplxModelDev m{};
     Layer dirs;                 // blend-shape GEMM operand: rows = 3V, K = 512 (fp32: exact fp32 MFMA chain)
     DevBuf dirs_split;          // the same operand as split-bf16 pairs: four-term products on the bf16 matrix pipe (default)
-    DevBuf dirs_frag, jv_slot, skin_idx8, skin_w4, skin_idx8b, skin_w4b, ws_side;   // fused contraction + skinning: directions in MFMA fragment order, joint-vertex slots / buffer
+    DevBuf dirs_frag, jv_slot, skin_idx8, skin_w4, skin_idx8b, skin_w4b, jt_pack, ws_side;   // fused contraction + skinning: directions in MFMA fragment order, joint-vertex slots / buffer
     DevBuf ws_cnt;              // ... arrival counters of the body groups (joints by the group's last workgroup); zero between launches
     bool fold_post = true;      // ... and with the post transform composed into those 22 transforms by the prep kernel (A22); ap_smplx_set_fused(h, 7): off (A/B)
     int merge_bones = 1;        // (0: off, 1: on, 2: with 64 bodies per workgroup -- A/B, slower) body-only calls: the fused kernel skins over the 22 posed transforms (merged skin table); ap_smplx_set_fused(h, 6): all 55 (A/B)
@@ -2215,6 +2215,26 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
         }
         e = upload(h->skin_idx8, i8.data(), i8.size() * 4);
         if (e == hipSuccess) e = upload(h->skin_w4, w4.data(), w4.size() * 4);
+        if (e == hipSuccess) {
+            // the joints kernel's record per output joint beyond the chain (21 vertex picks, 51 landmarks): its three corner
+            // vertices' side-buffer slots, packed bone ids, weights and barycentric weights in 6 x 16 bytes -- one load level
+            const int nj2 = md->num_extra + md->num_landmarks;
+            std::vector<float> pk((size_t)std::max(nj2, 1) * 24, 0.f);
+            for (int t = 0; t < nj2; ++t) {
+                float* r = &pk[(size_t)t * 24];
+                for (int f = 0; f < 3; ++f) {
+                    const bool lm = t >= md->num_extra;
+                    const int v = lm ? tri[(t - md->num_extra) * 3 + f] : ev[t];
+                    const int sl = slot[v];
+                    const uint32_t id = i8[v] & 0x00ffffffu;
+                    memcpy(&r[f], &sl, 4);
+                    memcpy(&r[4 + f], &id, 4);
+                    memcpy(&r[8 + 4 * f], &w4[(size_t)v * 4], 16);
+                    r[20 + f] = lm ? md->lmk_bary_coords[(t - md->num_extra) * 3 + f] : (f == 0 ? 1.f : 0.f);
+                }
+            }
+            e = upload(h->jt_pack, pk.data(), pk.size() * 4);
+        }
         // body-only table: every joint >= 22 (jaw, eyes, fingers: identity rotation without a hand / face pose) skins exactly like its
         // nearest ancestor < 22, so a vertex needs at most as many DISTINCT transforms as it has bones -- usually fewer (a finger
         // vertex: one).  Bones merged by representative, weights summed in double, heaviest first; unused slots repeat slot 0's bone
@@ -2270,6 +2290,7 @@ int ap_smplx_create(ap_smplx** out, const ap_smplx_model* md, int device) {
     m.dirs_frag = h->dirs_frag.p; m.v_template = h->dirs.shift.as<float>(); m.jv_slot = h->jv_slot.as<int>();
     m.skin_idx8 = h->skin_idx8.as<uint32_t>(); m.skin_w4 = h->skin_w4.as<float>();
     m.skin_idx8b = h->skin_idx8b.as<uint32_t>(); m.skin_w4b = h->skin_w4b.as<float>();
+    m.jt_pack = h->jt_pack.as<float4>();
     h->n_out_joints = J + md->num_extra + md->num_landmarks;
     *out = h;
     return AP_OK;
@@ -2280,7 +2301,7 @@ void ap_smplx_destroy(ap_smplx* h) {
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
     for (DevBuf* b : {&h->dirs.w, &h->dirs_split, &h->dirs.scale, &h->dirs.shift, &h->j_template, &h->j_shapedirs, &h->parents, &h->depth,
-                      &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A, &h->ws_A22, &h->dirs_frag, &h->jv_slot, &h->skin_idx8, &h->skin_w4, &h->skin_idx8b, &h->skin_w4b, &h->ws_side,
+                      &h->skin_idx, &h->skin_w, &h->extra_verts, &h->lmk_tri, &h->lmk_bary, &h->ws_coef, &h->ws_A, &h->ws_A22, &h->dirs_frag, &h->jv_slot, &h->skin_idx8, &h->skin_w4, &h->skin_idx8b, &h->skin_w4b, &h->jt_pack, &h->ws_side,
                       &h->ws_jposed, &h->ws_post, &h->ws_vposed, &h->ws_cc, &h->ws_cnt})
         b->release();
     h->tm.destroy();

@@ -177,6 +177,7 @@ struct SmplxModelDev {
     const float* skin_w4;         // [V padded to 16][4]
     const int* jv_slot;           // [V]: slot of the vertex in the joint-vertex side buffer, -1 = none
     int n_jv;                     // slots (distinct vertices among the 21 picks and the 51 landmark triangles)
+    const float4* jt_pack;        // [n_extra + n_lmk][6]: per output joint {slot x3 | packed bone ids x3 | weights x3 | barycentric} of its three corner vertices
     // body-only calls (no hand / jaw / eye pose: joints nb .. J-1 keep the identity rotation, so A_j == A_rep(j) for the nearest
     // posed ancestor rep(j) < nb: G_j = G_p [I | J_j - J_p] and A_j = G_j [I | -J_j] = G_p [I | -J_p]): the skin table over the nb
     // transforms that differ, duplicate bones merged (weights summed), heaviest first, zero weights last

@@ -626,28 +626,17 @@ __global__ void __launch_bounds__(128) smplx_joints_kernel(const SmplxModelDev m
     const float* vp = a.vposed + (size_t)b * m.ldv;
     const float* vs = a.vp_side ? a.vp_side + (size_t)b * m.n_jv * 3 : nullptr;    // fused path: [slot][3], slot = m.jv_slot[v]
     float o[3];
-    if (vs && m.K == 4 && m.skin_idx8 && t >= m.J) {
-        // fused path, four bones per vertex: the thread's 1 (vertex pick) or 3 (landmark corners) vertices in three batches of
-        // loads -- vertex ids and barycentric weights | slot, packed bone ids, weights | v_posed -- instead of a dependent chain
-        // per corner and per bone (~10 L2 round trips); same blend order and arithmetic as skin_point_dyn with K = 4
-        const bool lm = t >= m.J + m.n_extra;
-        const int l = lm ? t - m.J - m.n_extra : 0;
-        int vid[3];
-        float bw[3];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            vid[f] = lm ? m.lmk_tri[l * 3 + f] : m.extra_verts[t - m.J];
-            bw[f] = lm ? m.lmk_bary[l * 3 + f] : 0.f;
-        }
-        int slot[3];
-        uint32_t id8[3];
-        float4 w4[3];
-#pragma unroll
-        for (int f = 0; f < 3; ++f) {
-            slot[f] = m.jv_slot[vid[f]];
-            id8[f] = m.skin_idx8[vid[f]];
-            w4[f] = *(const float4*)(m.skin_w4 + (size_t)vid[f] * 4);
-        }
+    if (vs && m.K == 4 && m.jt_pack && t >= m.J) {
+        // fused path, four bones per vertex: the thread's three corner vertices (a vertex pick = the same vertex three times with
+        // barycentric weights 1, 0, 0) from ONE packed record per output joint (slots, packed bone ids, weights, barycentric
+        // weights: built at ap_smplx_create) -- two dependent load levels (record | v_posed of the corners) instead of four
+        // (vertex ids -> slot / ids / weights -> v_posed); same blend order and arithmetic as skin_point_dyn with K = 4
+        const float4* rec = m.jt_pack + (size_t)(t - m.J) * 6;
+        const float4 r0 = rec[0], r1 = rec[1], wa = rec[2], wb = rec[3], wc = rec[4], r5 = rec[5];
+        const int slot[3] = {__builtin_bit_cast(int, r0.x), __builtin_bit_cast(int, r0.y), __builtin_bit_cast(int, r0.z)};
+        const uint32_t id8[3] = {__builtin_bit_cast(uint32_t, r1.x), __builtin_bit_cast(uint32_t, r1.y), __builtin_bit_cast(uint32_t, r1.z)};
+        const float4 w4[3] = {wa, wb, wc};
+        const float bw[3] = {r5.x, r5.y, r5.z};
         float q[3][3];
 #pragma unroll
         for (int f = 0; f < 3; ++f) {
@@ -660,7 +649,7 @@ __global__ void __launch_bounds__(128) smplx_joints_kernel(const SmplxModelDev m
             const float w[4] = {w4[f].x, w4[f].y, w4[f].z, w4[f].w};
             skin_point<4>(As, idx, w, q[f][0], q[f][1], q[f][2], pf[f]);
         }
-        if (lm) {
+        if (t >= m.J + m.n_extra) {
             o[0] = o[1] = o[2] = 0.f;
 #pragma unroll
             for (int f = 0; f < 3; ++f) {

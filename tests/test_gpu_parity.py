@@ -2177,6 +2177,37 @@ def test_fitting_trajectory_follows_oracle(fit_problem, body, smplx_model, dev):
     assert hist[-1, :3].sum().item() < hist[0, :3].sum().item()
 
 
+def test_fitting_at_the_size_of_config_5(body, smplx_model, dev):
+    """BASELINE config 5 at ITS OWN size (64 frames were only ever timed): the 64-frame problem, 30 Adam steps
+    straddling the optimiser switch against the fp64 autograd oracle; then the full 300 iterations of the bench: finite,
+    bit-deterministic over two runs, and the windowed objective (means over 50 iterations) never rises by more than 5 %."""
+    from airpose_amd.fitting import AirPosePlusFitter
+    from oracle import fitting_ref
+    vp, init, data, _ = fitting_ref.synthetic_problem(smplx_model, L=64, seed=78, dtype=torch.float64)
+    fitter = AirPosePlusFitter(vp, body, dev)
+    args = (data["j2d"], data["robust"], data["intr"], data["extr"][:, :3])
+    got, hist = fitter.run(init, *args, n_iters=30, switch_iter=15, want_loss=True)
+    old = fitting_ref.SWITCH_ITER
+    fitting_ref.SWITCH_ITER = 15
+    try:
+        want, _ = fitting_ref.fit(vp, smplx_model, init, data, n_iters=30)
+    finally:
+        fitting_ref.SWITCH_ITER = old
+    for k in ("z", "phi0", "phi1", "tau0", "tau1", "beta"):
+        e = rel_err(got[k].cpu().numpy(), want[k].numpy())
+        print("L = 64, after 30 steps %-5s rel err %.3e" % (k, e))
+        assert e < 5e-3, k
+    runs = [fitter.run(init, *args, n_iters=300, want_loss=True) for _ in range(2)]
+    for k in ("z", "phi0", "phi1", "tau0", "tau1", "beta"):
+        assert torch.isfinite(runs[0][0][k]).all(), k
+        assert torch.equal(runs[0][0][k], runs[1][0][k]), k
+    loss = runs[0][1][:, :3].sum(1).cpu().numpy()
+    assert np.isfinite(loss).all()
+    win = loss.reshape(6, 50).mean(1)
+    print("L = 64, 300 iterations: windowed objective", ["%.3f" % w for w in win])
+    assert all(win[i + 1] <= win[i] * 1.05 for i in range(5)) and win[-1] < 0.5 * win[0]
+
+
 # ------------------------------------------------------------------------------------------------ K > 4 bones per vertex
 @pytest.mark.parametrize("max_bones", [6, 9])
 def test_smplx_more_than_four_bones_per_vertex(max_bones, dev):
