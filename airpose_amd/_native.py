@@ -90,6 +90,9 @@ SIGNATURES = {
     "ap_block_img_stream_bytes": (_c.c_int64, []),
     "ap_block_img_pack": (_i, [_i, _vp, _vp, _vp, _vp, _vp]),
     "ap_block_img_nhwc": (_i, [_i] + [_vp] * 9 + [_i, _vp]),
+    "ap_conv_img3_stream_bytes": (_c.c_int64, []),
+    "ap_conv_img3_pack": (_i, [_i, _vp, _vp, _vp]),
+    "ap_conv_img3_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ap_conv_pw_stream_bytes": (_c.c_int64, [_i, _i]),
     "ap_conv_pw_pack": (_i, [_i, _vp, _i, _i, _vp, _vp]),
     "ap_conv_pw_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 3 + [_vp]),
@@ -99,6 +102,7 @@ SIGNATURES = {
     "ap_net_set_fuse_tail": (_i, [_vp, _i]),
     "ap_net_set_even_out": (_i, [_vp, _i]),
     "ap_net_set_img_block": (_i, [_vp, _i]),
+    "ap_net_set_img3": (_i, [_vp, _i]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),
     "ap_smplx_destroy": (None, [_vp]),
     "ap_smplx_num_joints_out": (_i, [_vp]),

@@ -495,6 +495,11 @@ class copenet(nn.Module):
         of the chip, 2 always, 0 never (conv2 + fused pairs); same bits."""
         self._set_knob("ap_net_set_img_block", on)
 
+    def set_img3(self, on):
+        """bf16 / f16: conv2 of the layer2 identity blocks with half an image resident in LDS (conv_img3.hip): 1 (default) when the pass
+        fills whole rounds of the chip, 2 always, 0 never (slab kernel); same bits."""
+        self._set_knob("ap_net_set_img3", on)
+
     def set_pw_conv(self, on):
         """bf16 / f16: the pointwise layers of layer3 / layer4 no fused kernel covers on the one-wave-per-SIMD kernel (conv_pw.hip): 1 (default)
         when their tiles fill whole rounds of the chip (conv1 layers, conv3 + folded downsample; alone on the chip also the stride-2

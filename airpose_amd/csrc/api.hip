@@ -254,7 +254,8 @@ struct ap_net {
     DevBuf stem_w, stem_wpk, stem_wpk_lo, stem_scale, stem_shift;   // stem_wpk_lo: low plane of the split-bf16 stem weights
     struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false;
                    DevBuf pair; int pair_p = 0, pair_p2 = 0, pair_c3 = 0, pair_n1 = 0;
-                   DevBuf imgw; };             // layer3 identity blocks: the three weight matrices as the fragment streams of block_img.hip   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
+                   DevBuf imgw;
+                   DevBuf c2img; };            // layer2 identity blocks: conv2's weights as the fragment streams of conv_img3.hip             // layer3 identity blocks: the three weight matrices as the fragment streams of block_img.hip   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
     std::vector<Block> blocks;
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
@@ -274,6 +275,8 @@ struct ap_net {
     int pw_conv = 1;               // 16-bit modes: conv1 of the layer3 / layer4 bottlenecks that no fused kernel covers on the one-wave-per-SIMD pointwise
                                    // kernel (conv_pw.hip): 0 never; 1 (default) when its tiles fill half the chip or whole rounds of it; 2 whenever
                                    // supported, and conv3 + identity too; 3 conv1 whenever supported
+    int img3 = 1;                  // 16-bit modes: conv2 of the layer2 identity blocks on the half-image-resident kernel (conv_img3.hip): 0 never, 1 when the
+                                   // pass fills whole rounds of the chip with half images (same bits either way), 2 always
     int img_block = 1;             // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip): 0 never,
                                    // 1 when the pass fills whole rounds of the chip (an image per CU; same bits either way), 2 always
     bool even_out = true;          // 16-bit modes: a pair block whose output is read by a stride-2 downsample branch ONLY stores the even pixels
@@ -616,6 +619,7 @@ void release_blocks(ap_net* h) {
         for (Layer* L : {&B.c1, &B.c2, &B.c3, &B.down, &B.c3ds}) release_layer(*L);
         B.pair.release();
         B.imgw.release();
+        B.c2img.release();
     }
     h->blocks.clear();
 }
@@ -706,6 +710,14 @@ int finalize_trunk(ap_net* h) {
             if (B.has_down || B.c1.cin != 1024 || B.c1.cout != 256 || B.c2.cout != 256 || B.c2.stride != 1 || B.c3.cout != 1024) continue;
             HIP_TRY(B.imgw.reserve(k_bf16::ap_block_img_stream_bytes()));
             HIP_TRY(H16(h->prec, ap_launch_block_img_pack)(B.c1.w.p, B.c2.w.p, B.c3.w.p, B.imgw.p, nullptr));
+        }
+    // stride-1 3 x 3 of the 28 x 28 stage (layer2.1 - 2.3 conv2): weight streams of the half-image-resident kernel
+    if (h->half())
+        for (auto& B : h->blocks) {
+            const Layer& L = B.c2;
+            if (!k_bf16::ap_conv_img3_supported(28, 28, L.cin, L.cout, L.k, L.stride, L.pad) || L.wld != 9 * L.cin) continue;
+            HIP_TRY(B.c2img.reserve(k_bf16::ap_conv_img3_stream_bytes()));
+            HIP_TRY(H16(h->prec, ap_launch_conv_img3_pack)(L.w.p, B.c2img.p, nullptr));
         }
     // pointwise layers of the 14 x 14 and 7 x 7 stages: weight streams of conv_pw.hip (conv1, and conv3 of the identity blocks)
     if (h->half())
@@ -1068,7 +1080,23 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             HIP_TRY((hipError_t)err);
         }
         const int t2_tiled = pair && tiling && !c2_pw;
-        if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, w.rflag, t2_tiled, c2_pw ? pw_conv : 0))) return rc;
+        bool c2_img = false;
+        if (bf && h->img3 && B.c2img.p && H == 28 && B.c2.stride == 1 && g_conv_mode.load(std::memory_order_relaxed) == -1) {
+            c2_img = h->img3 == 2;
+            if (h->img3 == 1) {                              // half an image per CU: whole rounds of the chip
+                int cus = 0;
+                HIP_TRY(device_cus(&cus));
+                const long units = 2L * n, rounds = (units + cus - 1) / cus;
+                c2_img = units * 8 >= rounds * cus * 7;
+            }
+        }
+        if (c2_img) {
+            ConvImg3Args ca{};
+            ca.x = w.ws_t1.p; ca.y = w.ws_t2.p; ca.wfrag = B.c2img.p; ca.scale = B.c2.scale.as<float>(); ca.shift = B.c2.shift.as<float>();
+            ca.N = n; ca.y_tiled = t2_tiled; ca.range_flag = w.rflag;
+            HIP_TRY(zero_line(&ca.zero));
+            HIP_TRY(H16(prec, ap_launch_conv_img3)(ca, st));
+        } else if ((rc = run_conv(B.c2, w.ws_t1.p, n, H, H, w.ws_t2.p, nullptr, 1, prec, st, w.rflag, t2_tiled, c2_pw ? pw_conv : 0))) return rc;
         if (pair) {
             // conv3 (+ identity | + folded downsample, ReLU) AND -- where the pair carries it -- the next block's conv1 in one
             // kernel: the block output is written once and not read back for conv1 (model_copenet.py:38-45 of this block,
@@ -1826,6 +1854,25 @@ int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const f
     return AP_OK;
 }
 
+int64_t ap_conv_img3_stream_bytes(void) { return (int64_t)k_bf16::ap_conv_img3_stream_bytes(); }
+
+int ap_conv_img3_pack(int precision, const void* w2, void* wstream, void* stream) {
+    if (!prec_half(precision) || !w2 || !wstream) return fail(AP_EINVAL, "ap_conv_img3_pack: 16-bit precision, w2 [128][3][3][128], stream buffer");
+    HIP_TRY(H16(precision, ap_launch_conv_img3_pack)(w2, wstream, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_conv_img3_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, void* y, int N,
+                      int y_tiled, void* stream) {
+    if (!prec_half(precision) || !x || !wstream || !scale || !shift || !y || N <= 0)
+        return fail(AP_EINVAL, "ap_conv_img3_nhwc: bad argument");
+    ConvImg3Args a{};
+    a.x = x; a.y = y; a.wfrag = wstream; a.scale = scale; a.shift = shift; a.N = N; a.y_tiled = y_tiled != 0;
+    HIP_TRY(zero_line(&a.zero));
+    HIP_TRY(H16(precision, ap_launch_conv_img3)(a, (hipStream_t)stream));
+    return AP_OK;
+}
+
 // The fused pair kernel consumes its two weight matrices as ONE stream of 16-KiB tiles in consumption order.  The stream is
 // CALLER-OWNED: packed once by ap_conv_pair_pack into a buffer of ap_conv_pair_stream_bytes, handed to every launch -- the
 // library keeps no hidden copy keyed by weight addresses (an allocator may reuse an address for new contents).
@@ -1979,6 +2026,12 @@ int ap_net_set_fuse_tail(ap_net* h, int on) {
 int ap_net_set_pw_conv(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->pw_conv = on < 0 ? 0 : (on > 4 ? 4 : on);               // (3: 1 without the size rule; 4: 1 without the 3 x 3 / stride-2 layers -- A/B aids)
+    return AP_OK;
+}
+
+int ap_net_set_img3(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->img3 = on < 0 ? 0 : (on > 2 ? 2 : on);
     return AP_OK;
 }
 

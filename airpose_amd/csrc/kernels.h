@@ -86,6 +86,19 @@ struct BlkImgArgs {
     unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds; NULL otherwise)
 };
 
+// ---- stride-1 3x3 + BN + ReLU of layer2 (128 -> 128 at 28 x 28), half an image resident in LDS (conv_img3.hip); 16-bit storage
+struct ConvImg3Args {
+    const void* x;                // [N][28][28][128] NHWC
+    void* y;                      // [N][28][28][128] NHWC, or fragment-tiled (y_tiled)
+    const void* wfrag;            // the weights as per-wave MFMA-fragment streams (ap_launch_conv_img3_pack)
+    const float *scale, *shift;   // BatchNorm
+    const void* zero;             // 256 bytes of zeros (DMA source of the slots outside the image)
+    int N;
+    int y_tiled;
+    int nhalf_pad;                // filled by the launcher
+    int* range_flag;              // fp16 storage, or NULL
+};
+
 // ---- pointwise convolution + BN (+ identity) + ReLU on the one-wave-per-SIMD mainloop (conv_pw.hip); 16-bit storage
 struct PwArgs {
     const void* x;                // [M][Cin] NHWC pixel rows

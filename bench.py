@@ -588,6 +588,8 @@ def main():
         net.set_fuse_tail(int(os.environ["AIRPOSE_FUSE_TAIL"]))
     if os.environ.get("AIRPOSE_PW_CONV"):                   # A/B aid: layer4's pointwise layers on conv_pw.hip (1: by size, default; 2 always) / generic kernels (0)
         net.set_pw_conv(int(os.environ["AIRPOSE_PW_CONV"]))
+    if os.environ.get("AIRPOSE_IMG3"):                      # A/B aid: layer2's 3x3 with half an image resident in LDS (default) / slab kernel
+        net.set_img3(int(os.environ["AIRPOSE_IMG3"]))
     if os.environ.get("AIRPOSE_IMG_BLOCK"):                 # A/B aid: layer3 identity blocks as image-resident kernels (default) / conv2 + pairs
         net.set_img_block(int(os.environ["AIRPOSE_IMG_BLOCK"]))
     if os.environ.get("AIRPOSE_EVEN_OUT"):                  # A/B aid: block outputs only a stride-2 downsample reads: even pixels (default) / in full

@@ -262,6 +262,16 @@ int ap_bottleneck64_tail_nhwc(int precision, const void* x, const void* w1, cons
  * y = relu(bn3(conv3(relu(bn2(conv2(relu(bn1(conv1(x)))))))) + x) with the intermediates rounded to the storage type exactly
  * where the three-convolution path rounds them. */
 int64_t ap_block_img_stream_bytes(void);
+/* conv2 of a layer2 bottleneck (3 x 3, stride 1, 128 -> 128 channels at 28 x 28; model_copenet.py:32-34 with :18) + bn2 + ReLU with
+ * HALF AN IMAGE resident in the LDS of one CU (conv_img3.hip: 14 of the 28 columns over all rows + a halo column either side; the
+ * conv2 phase of the image-resident layer3 block as a kernel of its own).  Operator form for tests and benches: x, y [N][28][28][128]
+ * 16-bit NHWC (y_tiled != 0: y in the fragment-tiled layout the pair kernel reads); wstream = ap_conv_img3_pack of the K-contiguous
+ * rows [128][3][3][128] (ap_conv_img3_stream_bytes bytes, caller-owned).  Sums in conv_slab's K order: same bits as ap_conv2d_nhwc. */
+int64_t ap_conv_img3_stream_bytes(void);
+int ap_conv_img3_pack(int precision, const void* w2, void* wstream, void* stream);
+int ap_conv_img3_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, void* y, int N,
+                      int y_tiled, void* stream);
+
 /* Pointwise (1 x 1, stride 1) convolution + BatchNorm (+ identity) + ReLU for the 14 x 14 / 7 x 7 stages (conv1 and conv3 of
  * Bottleneck.forward, model_copenet.py:29-31, 38-45) on the one-wave-per-SIMD mainloop of conv_pw.hip: x [M][Cin], res (or NULL)
  * and y [M][Cout] NHWC pixel rows in the storage type of `precision` (AP_PREC_BF16 or AP_PREC_F16); M a multiple of 196 (whole
@@ -396,6 +406,8 @@ int ap_net_set_even_out(ap_net* h, int on);
  * of conv2 + the fused conv3 -> conv1 pairs: on = 1 (default) when the pass fills whole rounds of the chip (the kernel runs an
  * image per CU: >= 7/8 of ceil(n / CUs) * CUs images), 2 always, 0 never.  Both paths sum in the same order (conv2: the slab
  * kernel's): trunk features are bit-identical, so a pair's result does not depend on the batch it arrives in. */
+int ap_net_set_img3(ap_net* h, int on);          /* conv2 of the layer2 identity blocks on conv_img3.hip: 1 (default) when the pass fills whole rounds of
+                                                 * the chip with half images, 2 always, 0 never (slab kernel); same bits */
 int ap_net_set_img_block(ap_net* h, int on);
 /* images per depth-first trunk chunk (0 = library default); tuning knob, results are unaffected */
 int ap_net_set_chunk(ap_net* h, int images_per_chunk);

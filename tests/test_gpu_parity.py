@@ -2519,3 +2519,99 @@ def test_pending_synchronize_blames_the_right_batch(copenet_sd, body, dev, B):
         with pytest.raises(Nn.RangeError):                   # the handle's own flag is sticky until reset
             net.range_status(reset=True)
     assert torch.isfinite(pipe.submit(good).synchronize()["pred_j3d_cam0"]).all()
+
+
+# ------------------------------------------------------------------------------------------------ round 6: half-image-resident 3x3 of layer2
+def _img3_case(dev, N, seed, prec):
+    bf = {"bf16": torch.bfloat16, "f16": torch.float16}[prec]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 28, 28, 128, generator=g).to(bf).to(dev)
+    w = (torch.randn(128, 3, 3, 128, generator=g) * (2.0 / 1152) ** 0.5).to(bf).to(dev)     # [Cout][kh][kw][Cin]: K-contiguous rows
+    sc = (torch.rand(128, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(128, generator=g) * 0.1).to(dev)
+    return x, w, sc, sh
+
+
+@pytest.mark.parametrize("N", [1, 3, 8, 21, 300])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_conv_img3_equals_slab_kernel(dev, prec, N):
+    """conv_img3.hip (layer2's 3x3 with half an image resident in LDS) against the stand-alone convolution of the same operands
+    (ap_conv2d_nhwc: the slab kernel, whose K order it follows): the same bits, in NHWC and in the fragment-tiled output layout;
+    N = 1 / 3 / 21: groups of 16 half images only partly filled; 300: the persistent loop (600 half images on 256 workgroups)."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    B = Nn.PRECISIONS[prec]
+    x, w, sc, sh = _img3_case(dev, N, 60 + N, prec)
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    want = torch.empty_like(x)
+    Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), None, p(want), N, 28, 28, 128, 128, 3, 1, 1, 1, st), "conv2d")
+    ws = torch.empty(L.ap_conv_img3_stream_bytes(), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_img3_pack(B, p(w), p(ws), st), "pack")
+    got = torch.full_like(x, 7.0)
+    Nn.check(L.ap_conv_img3_nhwc(B, p(x), p(ws), p(sc), p(sh), p(got), N, 0, st), "img3")
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    bad = (got.view(torch.int16) != want.view(torch.int16))
+    assert not bad.any(), "%d of %d values differ; first at %s" % (int(bad.sum()), bad.numel(), bad.nonzero()[0].tolist())
+    tiled = torch.full_like(x, 7.0)
+    Nn.check(L.ap_conv_img3_nhwc(B, p(x), p(ws), p(sc), p(sh), p(tiled), N, 1, st), "img3 tiled")
+    torch.cuda.synchronize()
+    M = N * 784
+    back = tiled.view(M // 16, 16, 16, 8).permute(0, 2, 1, 3).reshape(N, 28, 28, 128)
+    assert torch.equal(back.view(torch.int16), want.view(torch.int16))
+    # against fp64 on the same operands
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().permute(0, 3, 1, 2).cpu(), padding=1)
+    ref = torch.relu(ref * sc.double().cpu().view(1, -1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    assert rel_err(got.float().cpu().numpy(), ref.numpy()) < (2e-2 if prec == "bf16" else 3e-3)
+
+
+def test_conv_img3_soak(dev):
+    """The hand-counted waits of conv_img3.hip under a second stream that keeps the memory system busy: 40 launches of 512 images,
+    each compared bit for bit with the first result."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    B = Nn.PRECISIONS["f16"]
+    N = 512
+    x, w, sc, sh = _img3_case(dev, N, 5, "f16")
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    ws = torch.empty(L.ap_conv_img3_stream_bytes(), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_img3_pack(B, p(w), p(ws), st), "pack")
+    want = torch.empty_like(x)
+    Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), None, p(want), N, 28, 28, 128, 128, 3, 1, 1, 1, st), "conv2d")
+    noise = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+    got = torch.empty_like(x)
+    for rep in range(40):
+        if rep & 1:
+            with torch.cuda.stream(side):
+                noise.add_(1.0)
+        got.fill_(3.0)
+        Nn.check(L.ap_conv_img3_nhwc(B, p(x), p(ws), p(sc), p(sh), p(got), N, 0, st), "img3")
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16)), rep
+
+
+@pytest.mark.parametrize("n", [1, 3, 64, 130])
+def test_half_image_resident_layer2_conv2_in_the_trunk_is_bit_identical(net16, dev, n):
+    """layer2.1 .. 2.3 conv2 on conv_img3.hip (forced on: the automatic rule takes it for passes that fill whole rounds of the chip
+    with half images; n = 130 does by itself: 260 half images, tiled and untiled t2 both occur in the trunk) against the slab kernel:
+    the same K order, so the trunk features carry the same bits; with the fused pairs off the untiled-output form is exercised."""
+    gen = torch.Generator(device="cpu").manual_seed(900 + n)
+    x = torch.randn(n, 3, 224, 224, generator=gen).to(dev)
+    try:
+        net16.set_img3(0)
+        ref = net16.forward_feat_ext(x).clone()
+        net16.set_img3(2)
+        got = net16.forward_feat_ext(x).clone()
+        net16.set_fuse_pair(0)
+        got_nopair = net16.forward_feat_ext(x).clone()
+        net16.set_fuse_pair(1)
+        net16.set_img3(1)
+        auto = net16.forward_feat_ext(x).clone()
+    finally:
+        net16.set_img3(1)
+        net16.set_fuse_pair(1)
+    assert torch.isfinite(ref).all()
+    assert torch.equal(got, ref) and torch.equal(got_nopair, ref) and torch.equal(auto, ref)
