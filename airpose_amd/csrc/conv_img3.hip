@@ -36,6 +36,14 @@ constexpr size_t CI_WAVE_BYTES = (size_t)CI_STEPS * 4096;    // per channel half
 
 #include "bi_helpers.inc"
 
+// Timing-only builds (results WRONG, times valid): -DCI_ABLATE=<bits>: 1 no image DMA after the first | 2 no output stores | 4 no MFMAs
+#ifndef CI_ABLATE
+#define CI_ABLATE 0
+#endif
+#ifndef CI_RING
+#define CI_RING 4                                            // weight pieces (K steps) in flight per wave
+#endif
+
 // weight stream: channel half cw -> [step (64-channel chunk, tap, K half)] of 4 fragments (64 rows); fragment = [lane 64][8 K values]:
 // row lane & 15, K columns 8 (lane >> 4) .. + 7 of the step's 32.  w2: [128][3][3][128] K-contiguous rows (as packed for conv_slab)
 __global__ void __launch_bounds__(256) conv_img3_pack_kernel(const bf16_t* __restrict__ w2, unsigned char* __restrict__ dst) {
@@ -97,15 +105,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const uint32_t wlane = lane * 16;
     const unsigned char* wp = wsb;
     int wcnt = 0;
-    u32x4 ar[4][4];
-    auto refill = [&](auto SL, u32x4 (&r)[4][4]) __attribute__((always_inline)) {           // ring slot SL <- the next piece of the stream
+    u32x4 ar[CI_RING][4];
+    auto refill = [&](auto SL, u32x4 (&r)[CI_RING][4]) __attribute__((always_inline)) {           // ring slot SL <- the next piece of the stream
         constexpr int sl = decltype(SL)::value;
         bi_gld<0>(r[sl][0], wlane, wp); bi_gld<1024>(r[sl][1], wlane, wp);
         bi_gld<2048>(r[sl][2], wlane, wp); bi_gld<3072>(r[sl][3], wlane, wp);
         wp += 4096;
         if (++wcnt == CI_STEPS) { wcnt = 0; wp = wsb; }
     };
-    sfor<0, 4>([&](auto S) __attribute__((always_inline)) { refill(S, ar); });
+    sfor<0, CI_RING>([&](auto S) __attribute__((always_inline)) { refill(S, ar); });
 
     // ---- image DMA: wave w fetches rows w, w + 4, ..; per row four 1-KiB pieces of four slots; lane = (slot of the piece, chunk position p):
     // LDS position (slot S, p) <- global chunk p ^ S of pixel (row, c0 - 1 + S), or of the zero line where that column is outside the image
@@ -170,13 +178,14 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 bi_ldsr<(g + q.dr + 1) * 4096>(d, tl[q.dc + 1][2 * q.c64 + q.ks]);
             },
             [&](auto I, u32x4& d) __attribute__((always_inline)) {
-                constexpr int n = decltype(I)::value, step = n / 14, g = n % 14, sl = step & 3;
+                constexpr int n = decltype(I)::value, step = n / 14, g = n % 14, sl = step % CI_RING;
                 // the ring pieces of steps 0 .. 3 were requested during the previous half image and are older than its DMA and stores: the
                 // wait behind those covered them; from step 4 on: the piece of this step, three younger pieces behind it
-                if constexpr (g == 0 && step >= 4) bi_wait_vm<12>();
+                if constexpr (g == 0 && step >= CI_RING) bi_wait_vm<4 * (CI_RING - 1)>();
 #pragma unroll
                 for (int f = 0; f < 4; ++f) {
-                    if constexpr (step == 0) bi_mma0(acc[f][g], ar[sl][f], d);
+                    if constexpr ((CI_ABLATE & 4) != 0 && step != 0) asm volatile("" : "+a"(acc[f][g]) : "v"(ar[sl][f]), "v"(d));
+                    else if constexpr (step == 0) bi_mma0(acc[f][g], ar[sl][f], d);
                     else bi_mma(acc[f][g], ar[sl][f], d);
                 }
                 if constexpr (g == 13) refill(std::integral_constant<int, sl>{}, ar);
@@ -185,7 +194,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         bi_settle28(acc[2], acc[3]);
         __syncthreads();                                     // every wave is done reading this half image
         const int hn = hi + (int)gridDim.x;
-        if (hn < nhalf) dma_half(hn);                        // the next one: in flight under the epilogue
+        if (hn < nhalf && !(CI_ABLATE & 1)) dma_half(hn);    // the next one: in flight under the epilogue
         // ================================================================ bn2 + ReLU + 16-bit, 28 stores of 16 bytes per lane
         const bool live = img < a.N && li < CI_HALF;
         const uint32_t col = (uint32_t)(half * CI_HALF + li);
@@ -198,7 +207,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
                 const uint32_t m = ((uint32_t)img * CI_H + (uint32_t)(rh * CI_HALF + g)) * CI_H + col;     // linear pixel index
                 const uint32_t off = a.y_tiled ? (uint32_t)(((m >> 4) * (CI_P >> 3) + (uint32_t)(ch >> 3)) * 256u + (m & 15u) * 16u)
                                                : (uint32_t)(m * (CI_P * 2u) + (uint32_t)ch * 2u);
-                __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, live ? off : 0xffffff00u, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(o, yrsrc, (live && !(CI_ABLATE & 2)) ? off : 0xffffff00u, 0, 0);
             }
         }
         // the next half image has landed: vector-memory operations retire in order and only this wave's 28 stores are younger than its DMA
@@ -207,7 +216,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     }
     bi_wait_vm<0>();                                         // (the ring ran ahead: nothing may land after the exit)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) asm volatile("" : "+v"(ar[j][0]), "+v"(ar[j][1]), "+v"(ar[j][2]), "+v"(ar[j][3]));
+    for (int j = 0; j < CI_RING; ++j) asm volatile("" : "+v"(ar[j][0]), "+v"(ar[j][1]), "+v"(ar[j][2]), "+v"(ar[j][3]));
     ap_rng_flush(a.range_flag, rng);
 }
 
