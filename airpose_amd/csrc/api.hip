@@ -1079,18 +1079,17 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
             c2_pw = pw_k3_args(B.c2, n, H, H, prec, &p3) && pw_fills(p3.M, B.c2.cout, pw_conv, &err);
             HIP_TRY((hipError_t)err);
         }
-        int t2_tiled = pair && tiling && !c2_pw;
+        const int t2_tiled = pair && tiling && !c2_pw;
         bool c2_img = false;
         if (bf && h->img3 && B.c2img.p && H == 28 && B.c2.stride == 1 && g_conv_mode.load(std::memory_order_relaxed) == -1) {
             c2_img = h->img3 == 2;
-            if (h->img3 == 1 || h->img3 == 3) {                              // half an image per CU: whole rounds of the chip
+            if (h->img3 == 1) {                              // half an image per CU: whole rounds of the chip
                 int cus = 0;
                 HIP_TRY(device_cus(&cus));
                 const long units = 2L * n, rounds = (units + cus - 1) / cus;
                 c2_img = units * 8 >= rounds * cus * 7;
             }
         }
-        if (c2_img && h->img3 == 3) t2_tiled = 0;           // (A/B: NHWC t2 out of the half-image kernel, the pair kernel reads it untiled)
         if (c2_img) {
             ConvImg3Args ca{};
             ca.x = w.ws_t1.p; ca.y = w.ws_t2.p; ca.wfrag = B.c2img.p; ca.scale = B.c2.scale.as<float>(); ca.shift = B.c2.shift.as<float>();
@@ -2032,7 +2031,7 @@ int ap_net_set_pw_conv(ap_net* h, int on) {
 
 int ap_net_set_img3(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->img3 = on < 0 ? 0 : (on > 3 ? 3 : on);
+    h->img3 = on < 0 ? 0 : (on > 2 ? 2 : on);
     return AP_OK;
 }
 
