@@ -13,7 +13,8 @@ import sys
 R = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 tag = sys.argv[1]
 O = os.path.join(R, "gpurun_out")
-CONV = ("conv_pipe_kernel", "conv_slab_kernel", "conv_lean_kernel", "conv_pair_kernel", "conv_igemm_kernel", "bneck256_kernel", "bneck64ds_kernel", "bneck2_kernel", "blk_img_kernel")
+CONV = ("conv_pipe_kernel", "conv_slab_kernel", "conv_lean_kernel", "conv_pair_kernel", "conv_igemm_kernel", "bneck256_kernel", "bneck64ds_kernel", "bneck2_kernel", "blk_img_kernel",
+        "conv_pw_kernel", "conv_img3_kernel")
 
 
 def is_trunk_conv(name):     # the bf16 conv-stack kernels (the fp32 instances are the blend-shape GEMM)
