@@ -58,6 +58,9 @@ class copenet(nn.Module):
                              "loaded checkpoint)")
         # precision="auto": resolved when the weights are packed (first forward after load_state_dict), by parity_probe() of each
         # candidate in AUTO_ORDER on THIS checkpoint; self.precision is then the chosen mode, self.auto_report what every tried one measured
+        if precision == "auto" and self.variant != 0:
+            raise ValueError("precision='auto' needs the two-view copenet head (ap_net_parity_probe runs copenet.forward); "
+                             "pick a mode for the hmr / muhmr / copenet_singleview heads")
         self.precision_requested = precision
         self.precision = self.AUTO_ORDER[0] if precision == "auto" else precision
         self.auto_report = None
@@ -134,7 +137,7 @@ class copenet(nn.Module):
         sig = (device.index, self._signature())
         if self._handle is not None and sig == self._packed_sig:
             return self._handle
-        if self.precision_requested != "auto" or self.variant != 0:
+        if self.precision_requested != "auto":
             return self._pack(device, sig)
         report = {}
         for prec in self.AUTO_ORDER:
