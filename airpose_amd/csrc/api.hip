@@ -2403,14 +2403,17 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
         a.cam_center = a.cc_ws;
     }
     size_t ev[5] = {0, 0, 0, 0, 0};
+    // tm.on == 1: an event between every two kernels (per-stage times; each record costs a bubble of several microseconds on the
+    // stream); 2: one event in front of the first kernel and one behind the last (the tail's span, no bubbles inside: reported in slot 0)
+    const bool stages = h->tm.on == 1;
     if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[0]));
     HIP_TRY(ap_launch_smplx_prep(m, a, st));
-    if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[1]));
+    if (stages) HIP_TRY(h->tm.rec(st, &ev[1]));
     if (fused) {
         int n_cu = 0;
         HIP_TRY(device_cus(&n_cu));
         HIP_TRY(ap_launch_smplx_lbs_fused(m, a, n_cu, h->merge_bones, st));
-        if (h->tm.on) { HIP_TRY(h->tm.rec(st, &ev[2])); ev[3] = ev[2]; }     // stage 1 = the fused kernel, stage 2 empty
+        if (stages) { HIP_TRY(h->tm.rec(st, &ev[2])); ev[3] = ev[2]; }        // stage 1 = the fused kernel, stage 2 empty
     } else {
         // v_posed = v_template + [betas | expr | pose_feature] . dirs^T; hand/face rows of the pose feature are
         // identically zero when no extra pose is supplied, so the contraction stops after the 21 body joints
@@ -2424,14 +2427,15 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
         g.N = n; g.H = g.W = g.Ho = g.Wo = 1; g.Cin = K; g.Cout = h->dirs.cout; g.KH = g.KW = 1; g.stride = 1; g.pad = 0;
         g.M = n; g.ldx = m.ncoef; g.ldy = m.ldv; g.ldr = 0; g.wld = h->dirs.wld; g.relu = 0;
         HIP_TRY(dispatch_conv(g, h->blend_split ? AP_PREC_BF16X2 : AP_PREC_FP32, st));
-        if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[2]));
+        if (stages) HIP_TRY(h->tm.rec(st, &ev[2]));
         HIP_TRY(ap_launch_smplx_skin(m, a, st));
-        if (h->tm.on) HIP_TRY(h->tm.rec(st, &ev[3]));
+        if (stages) HIP_TRY(h->tm.rec(st, &ev[3]));
     }
     if (!a.grp_cnt) HIP_TRY(ap_launch_smplx_joints(m, a, st));
     if (h->tm.on) {
         HIP_TRY(h->tm.rec(st, &ev[4]));
-        for (int s = 0; s < 4; ++s) { h->tm.marks[s].push_back(ev[s]); h->tm.marks[s].push_back(ev[s + 1]); }
+        if (stages) for (int s = 0; s < 4; ++s) { h->tm.marks[s].push_back(ev[s]); h->tm.marks[s].push_back(ev[s + 1]); }
+        else { h->tm.marks[0].push_back(ev[0]); h->tm.marks[0].push_back(ev[4]); }
         h->tm.passes++;
     }
     return AP_OK;
@@ -2512,7 +2516,7 @@ int ap_smplx_set_fused(ap_smplx* h, int on) {
 
 int ap_smplx_enable_timing(ap_smplx* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->tm.on = on != 0;
+    h->tm.on = on < 0 ? 0 : (on > 2 ? 2 : on);               // 1: per-stage events; 2: the span of the whole tail (two events)
     return AP_OK;
 }
 

@@ -268,6 +268,7 @@ class SMPLX(nn.Module):
                 "ap_smplx_set_fused")
 
     def enable_timing(self, on=True):
+        """True / 1: per-stage events; 2: only the span of the whole tail (timing()["prep_ms"] then holds it); False: off."""
         N.check(N.lib().ap_smplx_enable_timing(self._native(torch.device("cuda", torch.cuda.current_device())),
                                                int(on)), "ap_smplx_enable_timing")
 

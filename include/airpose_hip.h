@@ -484,8 +484,11 @@ int ap_smplx_set_fused(ap_smplx* h, int on);
 /* Test aid: fill the coefficient workspace for n bodies with 0xFF bytes (NaN patterns), as a raw allocation may hold: every slot
  * the contraction reads must be rewritten by the next forward, the zero padding included. */
 int ap_smplx_debug_poison_workspace(ap_smplx* h, int n);
+/* on = 1: a HIP event between every two kernels of a forward (per-stage times; every record costs a bubble of several microseconds on
+ * the stream); on = 2: one event in front of the first kernel and one behind the last -- the span of the whole tail without bubbles
+ * inside, reported in ms[0]; 0: off */
 int ap_smplx_enable_timing(ap_smplx* h, int on);
-/* ms[0]=prep/chain, ms[1]=blend-shape GEMM, ms[2]=skin, ms[3]=joints+projection */
+/* ms[0]=prep/chain (on = 2: the whole tail), ms[1]=blend-shape GEMM / fused contraction + skinning, ms[2]=skin, ms[3]=joints+projection */
 int ap_smplx_timing(ap_smplx* h, double ms[4], int64_t* passes, int reset);
 
 /* ---------------------------------------------------------------------------------------------
