@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Soak of the bf16 trunk with every hand-counted kernel on (bottleneck2, pair, slab, lean, fused stem): N forward passes over
+"""Soak of the 16-bit trunk with every hand-counted kernel on (bottleneck2, pair, slab, lean, fused stem, image-resident layer3 blocks,
+half-image-resident layer2 3x3, conv_pw): N forward passes over
 512 images (256 per view, two concurrent passes), each compared bit for bit with the separate-convolution path of the first
 pass.  A rare miss of a counted wait shows up as a mismatch.   python tools/probes/soak_trunk.py [iterations] [f16|bf16]"""
 import os
@@ -18,9 +19,14 @@ net = copenet_model.getcopenet(mean, precision=prec).eval()
 net.load_state_dict(W.to_torch(W.copenet_state_dict(3, mean)))
 g = torch.Generator().manual_seed(1)
 x = torch.randn(512, 3, 224, 224, generator=g).to(dev)
-net.set_fuse_block(0); net.set_fuse_pair(0)
+def reference(on):
+    """on = False: the separate-convolution path (no fused block, pair, image-resident or one-wave-per-SIMD kernel)."""
+    net.set_fuse_block(int(on)); net.set_fuse_pair(int(on)); net.set_img_block(int(on)); net.set_img3(int(on)); net.set_pw_conv(int(on))
+
+
+reference(False)
 ref = net.forward_feat_ext(x).clone()
-net.set_fuse_block(1); net.set_fuse_pair(1)
+reference(True)
 bad = 0
 for i in range(it):
     y = net.forward_feat_ext(x)
@@ -32,9 +38,9 @@ print("soak, one pass of 512 images: %d iterations, %d mismatching" % (it, bad))
 B = 256
 bb = torch.rand(B, 3, generator=g).to(dev)
 pos = torch.zeros(B, 3, device=dev)
-net.set_fuse_block(0); net.set_fuse_pair(0)
+reference(False)
 ref2 = [t.clone() for t in net(x[:B], x[B:], bb, bb, pos, pos, iters=3)]
-net.set_fuse_block(1); net.set_fuse_pair(1)
+reference(True)
 bad2 = 0
 for i in range(it):
     out = net(x[:B], x[B:], bb, bb, pos, pos, iters=3)
