@@ -2379,6 +2379,7 @@ int smplx_run(ap_smplx* h, SmplxFwdArgs a, bool body_only, hipStream_t st) {
     const bool fused = h->fused && h->blend_split && body_only && ap_smplx_lbs_fused_supported(m);
     if (fused) HIP_TRY(h->ws_side.reserve((size_t)n * m.n_jv * 3 * 4));
     else HIP_TRY(h->ws_vposed.reserve((size_t)n * m.ldv * 4));
+    a.dbg = g_conv_dbg;
     a.grp_cnt = nullptr;
     if (fused && h->fuse_joints) {
         const size_t need = (size_t)((n + 31) / 32) * 4;

@@ -236,6 +236,7 @@ struct SmplxFwdArgs {
     float* joints;                // [n][J+21+51][3]
     float* joints2d;              // [n][127][2] or NULL
     float* rotmat_out;            // [n][22][9] or NULL (pose6d mode)
+    unsigned long long* dbg;      // optional cycle stamps (AP_TRACE builds of smplx.hip; NULL otherwise)
     float* vp_side;               // fused path: v_posed of the joint vertices [n][n_jv][3]; NULL: the joints kernel reads vposed
     int* grp_cnt;                 // fused path, second cut: per body group of 32 an arrival counter (zero between launches).  When set,
                                   // vp_side holds the SKINNED joint vertices and the group's last workgroup computes the joints /

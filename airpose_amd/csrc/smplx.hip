@@ -432,7 +432,16 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
     const unsigned char* ca = coefs + (hb * 32 + lr) * T_CROW + g4 * 32;           // this lane's A rows: bodies lr and 16 + lr (of its half)
     const float* const bones_l = bones + (hb * 32 + g4 * 4) * J12C;                // this lane's skinning bodies: 4 g4 + r (+ 16)
     const float* const Ps_l = Ps + (hb * 32 + g4 * 4) * 16;
+#ifdef AP_TRACE   // cycle stamps of wave 0 of workgroups 0 and 100, their SECOND vertex group (24 slots each): tools/probes/lbs_trace.py
+    int grp_no = 0;
+#define LSTAMP(i) do { if (a.dbg && grp_no == 1 && wave == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) { \
+        const unsigned long long t_ = __builtin_readcyclecounter(); \
+        if (lane == 0) a.dbg[(blockIdx.x ? 24 : 0) + (i)] = t_; } } while (0)
+#else
+#define LSTAMP(i) do { } while (0)
+#endif
     for (; g < gend; g += GW) {
+        LSTAMP(0);
         // ------------------------------------------------ contraction: acc[c][s][r] = v_posed component c of vertex 16 g + lr
         // for body s * 16 + 4 g4 + r
         f32x4 acc[3][2];
@@ -468,6 +477,7 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 acc[c][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah1, dl, acc[c][1], 0, 0, 0);
             }
             __builtin_amdgcn_sched_barrier(0);               // keep the K steps in order: nothing of step ks + 2 before step ks is done
+            LSTAMP(1 + ks);
         });
         // ------------------------------------------------ skinning of the lane's vertex for its 8 bodies
         const float wv[4] = {w4.x, w4.y, w4.z, w4.w};
@@ -530,6 +540,7 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
                 }
                 voff += vstep;
                 __builtin_amdgcn_sched_barrier(0);           // one body at a time: the 8 bodies' bone rows all in flight spill
+                LSTAMP(8 + s * 4 + r);
             }
             voff += 12u * vstep;                             // bodies 16 + 4 g4 ...
             soff += 12u * sstep;
@@ -537,6 +548,10 @@ __global__ void __launch_bounds__(64 * T_NW) smplx_lbs_tail_kernel(const SmplxMo
         static_assert(T_KS & 1, "an odd number of K steps leaves the next group's first fragments in the second set");
 #pragma unroll
         for (int i = 0; i < 6; ++i) fa[i] = fb[i];           // the next group's first step (requested before the skinning)
+        LSTAMP(16);
+#ifdef AP_TRACE
+        ++grp_no;
+#endif
     }
     // ---------------------------------------------------- joints, landmarks and projection of the 32 bodies, by the LAST of the
     // body group's n_vr workgroups (smplx_joints_kernel's arithmetic on the skinned joint vertices the workgroups left in the
