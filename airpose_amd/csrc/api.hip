@@ -280,7 +280,8 @@ struct ap_net {
     int img_block = 1;             // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip): 0 never,
                                    // 1 when the pass fills whole rounds of the chip (an image per CU; same bits either way), 2 always
     bool even_out = true;          // 16-bit modes: a pair block whose output is read by a stride-2 downsample branch ONLY stores the even pixels
-    bool fuse_stem = true;         // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path)
+    int fuse_stem = 1;             // bf16 / bf16x2: conv1+bn1+relu+maxpool in one kernel (bit-identical to the two-kernel path); 16-bit
+                                   // modes: 1 = the persistent form of stem.hip (default), 2 = a workgroup per strip (the round-4 form)
     bool fuse_pool = false;        // 16-bit modes: AvgPool2d(7) in the epilogue of layer4.2 conv3 (conv_lean.hip POOL variant; bit-identical).
                                    // Off by default: measured neutral (fp16) to -0.5 % (bf16) in the two-stream trunk, profiles/r04_fuse_pool_ab.txt
     DevBuf mean_pose, mean_shape, mean_cam;
@@ -986,7 +987,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
         HIP_TRY(H16(prec, ap_launch_stem_pool)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                               w.ws_a.p, n, w.rflag, st));
+                                               w.ws_a.p, n, w.rflag, h->fuse_stem == 2 ? 1 : 2, st));
     } else if (bf) {
         HIP_TRY(H16(prec, ap_launch_stem_conv_mfma)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
                                                     h->stem_shift.as<float>(), w.ws_stem.p, n, st));
@@ -2067,7 +2068,7 @@ int ap_net_set_tiled(ap_net* h, int on) {
 
 int ap_net_set_fuse_stem(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
-    h->fuse_stem = on != 0;
+    h->fuse_stem = on == 2 ? 2 : on != 0;
     return AP_OK;
 }
 

@@ -297,6 +297,119 @@ __global__ void __launch_bounds__(256) stem_mfma_split_kernel(const float* __res
 #endif
 constexpr int FPW = 232;                                   // patch row stride in pixels (230 used, even)
 constexpr int FROWS = 15;                                  // input rows of a strip
+// The compute part of a strip (one of the 7 waves that own a 16-column segment each): K loop over the 7 kernel rows, then BatchNorm +
+// ReLU + the vertical 3-maximum of the two pooled rows into vm (XOR-swizzled 128-byte rows).  Shared by the strip kernel (vm lies
+// over the dead patch: OVERLAY, a workgroup barrier in between) and the persistent kernel (vm is a buffer of its own).
+// row0_valid: conv row 2 py0 - 1 exists (not the first strip of an image)
+template <bool OVERLAY>
+__device__ __forceinline__ void stem_strip_compute(const bf16_t* patch, const bf16_t* wsm, const float* sbn, bf16_t* vm, int wave,
+                                                   int lane, bool row0_valid) {
+    const int lr = lane & 15, g = lane >> 4;
+    const int xo = wave * 16 + lr;                          // conv column of this lane
+    // AP_STEM_PASSES = 1: all 64 output channels in one pass over K (80 accumulator registers, 124 VGPRs, no
+    // spill as long as the K-block loop is NOT unrolled: unrolling makes hipcc pre-compute every fragment address
+    // and spill accumulators to scratch).  = 2: two passes of 32 channels (79 VGPRs), measured 15 % slower.
+    constexpr int NH = AP_STEM_PASSES, FNH = 4 / NH;
+    static_assert(NH == 1, "the pooled rows may reuse the patch's LDS: a second pass would read a clobbered patch");
+#pragma unroll 1
+    for (int half = 0; half < NH; ++half) {
+        f32x4 acc[5][FNH];
+#pragma unroll
+        for (int fm = 0; fm < 5; ++fm)
+#pragma unroll
+            for (int fn = 0; fn < FNH; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
+        // k-block = kernel row (order: stem_kb_of); lane group g = taps 2g, 2g+1.  xf[(fm + rot) % 5] holds input row 2 fm + kb
+        u32x4 xf[5];
+        const bf16_t* xbase = patch + (2 * xo + 2 * g) * 4;
+        const bf16_t* wbase = wsm + (half * FNH * 16 + lr) * SWLD + g * 8;
+        stem_sfor<0, SKB>([&](auto ST) {
+            constexpr int step = decltype(ST)::value, kb = stem_kb_of(step);
+            constexpr bool first = step == 0 || step == 4;   // first step of a parity: all five rows; then one new row per step
+            constexpr int rot = first ? 0 : (step < 4 ? step : step - 4);
+            u32x4 wf[FNH];
+#pragma unroll
+            for (int fn = 0; fn < FNH; ++fn) {
+                if (STEM_ABLATE & 128) wf[fn] = u32x4{0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                else wf[fn] = *(const u32x4*)(wbase + fn * 16 * SWLD + kb * 32);
+            }
+            if constexpr (first) {
+#pragma unroll
+                for (int fm = 0; fm < 5; ++fm) {
+                    if (STEM_ABLATE & 128) xf[fm] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
+                    else xf[fm] = *(const u32x4*)(xbase + (2 * fm + kb) * FPW * 4);
+                }
+            } else {
+                // rows 2 fm + kb for fm = 0..3 are the previous step's rows of fm + 1; the slot the previous fm = 0 left takes row 8 + kb
+                if (STEM_ABLATE & 128) xf[(4 + rot) % 5] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
+                else xf[(4 + rot) % 5] = *(const u32x4*)(xbase + (8 + kb) * FPW * 4);
+            }
+#pragma unroll
+            for (int fm = 0; fm < 5; ++fm)
+#pragma unroll
+                for (int fn = 0; fn < FNH; ++fn) {
+                    if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[(fm + rot) % 5]));
+                    else acc[fm][fn] = ap_mfma16(
+                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[(fm + rot) % 5]), acc[fm][fn]);
+                }
+            __builtin_amdgcn_sched_barrier(0);               // one kernel row at a time (hoisted reads of later rows spill the accumulators)
+        });
+        if constexpr (OVERLAY) __syncthreads();              // every wave is done with the patch: vm may overwrite it
+#pragma unroll
+        for (int fn = 0; fn < FNH; ++fn) {
+            if (STEM_ABLATE & 32) { asm volatile("" ::"v"(acc[0][fn]), "v"(acc[1][fn]), "v"(acc[2][fn]), "v"(acc[3][fn]), "v"(acc[4][fn])); continue; }
+            const int ch = (half * FNH + fn) * 16 + g * 4;
+            const float4 sc = *(const float4*)(sbn + ch), sh = *(const float4*)(sbn + 64 + ch);
+            float v[5][4];
+#pragma unroll
+            for (int fm = 0; fm < 5; ++fm) {
+                v[fm][0] = fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f);
+                v[fm][1] = fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f);
+                v[fm][2] = fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f);
+                v[fm][3] = fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f);
+            }
+            if (!row0_valid) { v[0][0] = v[0][1] = v[0][2] = v[0][3] = 0.f; }
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                uint2 o;
+                o.x = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][0], v[2 * pr + 1][0]), v[2 * pr + 2][0]),
+                                  fmaxf(fmaxf(v[2 * pr][1], v[2 * pr + 1][1]), v[2 * pr + 2][1]));
+                o.y = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][2], v[2 * pr + 1][2]), v[2 * pr + 2][2]),
+                                  fmaxf(fmaxf(v[2 * pr][3], v[2 * pr + 1][3]), v[2 * pr + 2][3]));
+                // rows of 128 B: 16-byte chunk index XOR-swizzled by the pixel (a lane's 16 pixels would all hit one bank)
+                *(uint2*)(vm + ((pr * SO + xo) * SC + ((((ch >> 3) ^ (xo & 7)) << 3) | (ch & 7)))) = o;
+            }
+        }
+    }
+}
+
+// The pooling pass of a strip by NT threads (t0 = this thread's index among them): horizontal 3-maximum over vm, 16-byte stores of
+// the two pooled rows py0, py0 + 1 of image n; rng: the caller's fp16 range sentinel (the pooled maxima carry an overflow)
+template <int NT>
+__device__ __forceinline__ void stem_strip_pool(const bf16_t* vm, bf16_t* __restrict__ y, int n, int py0, int t0, uint32_t& rng) {
+    // horizontal 3-maximum on the PACKED 16-bit values: every pooled candidate is a post-ReLU value (>= +0), and for non-negative
+    // bf16 / fp16 the integer order of the bit patterns is the order of the values, so one v_pk_max_i16 per two channels and
+    // neighbour replaces the unpack (conversion), two fp32 maxima and the re-packing (52 -> 8 VALU per 8-channel item)
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    auto pkmax = [](uint32_t a, uint32_t b) -> uint32_t {
+        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+    };
+    for (int i = t0; i < 2 * PO * 8; i += NT) {             // (pr, px, 8-channel chunk)
+        if (STEM_ABLATE & 16) break;
+        const int c8 = i & 7, t = i >> 3, px = t % PO, pr = t / PO;
+        u32x4 o = u32x4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int cx = 2 * px + dx;
+            if (cx < 0) continue;
+            const u32x4 q = *(const u32x4*)(vm + ((pr * SO + cx) * SC + ((c8 ^ (cx & 7)) << 3)));
+            o.x = pkmax(o.x, q.x); o.y = pkmax(o.y, q.y); o.z = pkmax(o.z, q.z); o.w = pkmax(o.w, q.w);
+        }
+        ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);
+        if (STEM_ABLATE & 8) asm volatile("" ::"v"(o)); else
+        *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
+    }
+}
+
 __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
                                                         int n_split, const bf16_t* __restrict__ wpk,
                                                         const float* __restrict__ scale,
@@ -370,109 +483,116 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
     if (tid < 32) patch[FROWS * FPW * 4 + tid] = 0;
     __syncthreads();
 
-    const int lr = lane & 15, g = lane >> 4;
-    const int xo = wave * 16 + lr;                          // conv column of this lane
-    const bool row0_valid = py0 > 0;                        // conv row 2*py0-1 exists
-    // AP_STEM_PASSES = 1: all 64 output channels in one pass over K (80 accumulator registers, 124 VGPRs, no
-    // spill as long as the K-block loop is NOT unrolled: unrolling makes hipcc pre-compute every fragment address
-    // and spill accumulators to scratch).  = 2: two passes of 32 channels (79 VGPRs), measured 15 % slower.
-    constexpr int NH = AP_STEM_PASSES, FNH = 4 / NH;
-    static_assert(NH == 1, "the pooled rows reuse the patch's LDS: a second pass would read a clobbered patch");
-#pragma unroll 1
-    for (int half = 0; half < NH; ++half) {
-        f32x4 acc[5][FNH];
-#pragma unroll
-        for (int fm = 0; fm < 5; ++fm)
-#pragma unroll
-            for (int fn = 0; fn < FNH; ++fn) acc[fm][fn] = f32x4{0.f, 0.f, 0.f, 0.f};
-        // k-block = kernel row (order: stem_kb_of); lane group g = taps 2g, 2g+1.  xf[(fm + rot) % 5] holds input row 2 fm + kb
-        u32x4 xf[5];
-        const bf16_t* xbase = patch + (2 * xo + 2 * g) * 4;
-        const bf16_t* wbase = wsm + (half * FNH * 16 + lr) * SWLD + g * 8;
-        stem_sfor<0, SKB>([&](auto ST) {
-            constexpr int step = decltype(ST)::value, kb = stem_kb_of(step);
-            constexpr bool first = step == 0 || step == 4;   // first step of a parity: all five rows; then one new row per step
-            constexpr int rot = first ? 0 : (step < 4 ? step : step - 4);
-            u32x4 wf[FNH];
-#pragma unroll
-            for (int fn = 0; fn < FNH; ++fn) {
-                if (STEM_ABLATE & 128) wf[fn] = u32x4{0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-                else wf[fn] = *(const u32x4*)(wbase + fn * 16 * SWLD + kb * 32);
-            }
-            if constexpr (first) {
-#pragma unroll
-                for (int fm = 0; fm < 5; ++fm) {
-                    if (STEM_ABLATE & 128) xf[fm] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
-                    else xf[fm] = *(const u32x4*)(xbase + (2 * fm + kb) * FPW * 4);
-                }
-            } else {
-                // rows 2 fm + kb for fm = 0..3 are the previous step's rows of fm + 1; the slot the previous fm = 0 left takes row 8 + kb
-                if (STEM_ABLATE & 128) xf[(4 + rot) % 5] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
-                else xf[(4 + rot) % 5] = *(const u32x4*)(xbase + (8 + kb) * FPW * 4);
-            }
-#pragma unroll
-            for (int fm = 0; fm < 5; ++fm)
-#pragma unroll
-                for (int fn = 0; fn < FNH; ++fn) {
-                    if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[(fm + rot) % 5]));
-                    else acc[fm][fn] = ap_mfma16(
-                        __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[(fm + rot) % 5]), acc[fm][fn]);
-                }
-            __builtin_amdgcn_sched_barrier(0);               // one kernel row at a time (hoisted reads of later rows spill the accumulators)
-        });
-        __syncthreads();                                     // every wave is done with the patch: vm may overwrite it
-#pragma unroll
-        for (int fn = 0; fn < FNH; ++fn) {
-            if (STEM_ABLATE & 32) { asm volatile("" ::"v"(acc[0][fn]), "v"(acc[1][fn]), "v"(acc[2][fn]), "v"(acc[3][fn]), "v"(acc[4][fn])); continue; }
-            const int ch = (half * FNH + fn) * 16 + g * 4;
-            const float4 sc = *(const float4*)(sbn + ch), sh = *(const float4*)(sbn + 64 + ch);
-            float v[5][4];
-#pragma unroll
-            for (int fm = 0; fm < 5; ++fm) {
-                v[fm][0] = fmaxf(acc[fm][fn][0] * sc.x + sh.x, 0.f);
-                v[fm][1] = fmaxf(acc[fm][fn][1] * sc.y + sh.y, 0.f);
-                v[fm][2] = fmaxf(acc[fm][fn][2] * sc.z + sh.z, 0.f);
-                v[fm][3] = fmaxf(acc[fm][fn][3] * sc.w + sh.w, 0.f);
-            }
-            if (!row0_valid) { v[0][0] = v[0][1] = v[0][2] = v[0][3] = 0.f; }
-#pragma unroll
-            for (int pr = 0; pr < 2; ++pr) {
-                uint2 o;
-                o.x = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][0], v[2 * pr + 1][0]), v[2 * pr + 2][0]),
-                                  fmaxf(fmaxf(v[2 * pr][1], v[2 * pr + 1][1]), v[2 * pr + 2][1]));
-                o.y = pack_bf16x2(fmaxf(fmaxf(v[2 * pr][2], v[2 * pr + 1][2]), v[2 * pr + 2][2]),
-                                  fmaxf(fmaxf(v[2 * pr][3], v[2 * pr + 1][3]), v[2 * pr + 2][3]));
-                // rows of 128 B: 16-byte chunk index XOR-swizzled by the pixel (a lane's 16 pixels would all hit one bank)
-                *(uint2*)(vm + ((pr * SO + xo) * SC + ((((ch >> 3) ^ (xo & 7)) << 3) | (ch & 7)))) = o;
-            }
-        }
-    }
+    stem_strip_compute<true>(patch, wsm, sbn, vm, wave, lane, py0 > 0);
     __syncthreads();
-    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h): the pooled maxima carry an overflow
-    // horizontal 3-maximum on the PACKED 16-bit values: every pooled candidate is a post-ReLU value (>= +0), and for non-negative
-    // bf16 / fp16 the integer order of the bit patterns is the order of the values, so one v_pk_max_i16 per two channels and
-    // neighbour replaces the unpack (conversion), two fp32 maxima and the re-packing (52 -> 8 VALU per 8-channel item)
-    typedef short s16x2 __attribute__((ext_vector_type(2)));
-    auto pkmax = [](uint32_t a, uint32_t b) -> uint32_t {
-        return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
-    };
-    for (int i = tid; i < 2 * PO * 8; i += 448) {           // (pr, px, 8-channel chunk)
-        if (STEM_ABLATE & 16) break;
-        const int c8 = i & 7, t = i >> 3, px = t % PO, pr = t / PO;
-        u32x4 o = u32x4{0u, 0u, 0u, 0u};
-#pragma unroll
-        for (int dx = -1; dx <= 1; ++dx) {
-            const int cx = 2 * px + dx;
-            if (cx < 0) continue;
-            const u32x4 q = *(const u32x4*)(vm + ((pr * SO + cx) * SC + ((c8 ^ (cx & 7)) << 3)));
-            o.x = pkmax(o.x, q.x); o.y = pkmax(o.y, q.y); o.z = pkmax(o.z, q.z); o.w = pkmax(o.w, q.w);
-        }
-        ap_rng_note2(rng, o.x, o.y); ap_rng_note2(rng, o.z, o.w);
-        if (STEM_ABLATE & 8) asm volatile("" ::"v"(o)); else
-        *(u32x4*)(y + (((size_t)n * PO + py0 + pr) * PO + px) * SC + c8 * 8) = o;
-    }
+    uint32_t rng = 0u;                                       // fp16 range sentinel (ap_common.h)
+    stem_strip_pool<448>(vm, y, n, py0, tid, rng);
     ap_rng_note(rng, rng_in);
     ap_rng_flush(range_flag, rng);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the fused stem + max-pool (round 6): one workgroup per CU walks a contiguous range of strips (an image at the
+// size of a pass), its 11 waves split by role.  Waves 0-6 run stem_strip_compute on strip i (the same MFMA sequence as the strip
+// kernel: same bits); waves 7-10 meanwhile convert the crop rows of strip i + 1 into the other patch buffer (their global loads were
+// issued an iteration earlier and have had a whole strip to land), issue the loads of strip i + 2, and pool + store strip i - 1 out
+// of the other vm buffer.  ONE workgroup barrier per strip.  The 29 KB of weights are read once per workgroup instead of once per
+// strip, the rows a strip shares with the one above come out of the L2 the same workgroup filled two strips earlier, and nothing a
+// strip kernel serialises (load round trip -> conversion -> K loop -> epilogue -> pooling pass -> stores) is on the compute waves'
+// path except the K loop and the epilogue.
+constexpr int S2_CT = 448, S2_HT = 256, S2_NT = S2_CT + S2_HT;
+constexpr int S2_WBYTES = 64 * SWLD * 2, S2_PBYTES = (FROWS * FPW * 4 + 32) * 2, S2_VBYTES = 2 * SO * SC * 2;
+constexpr int S2_LDS = S2_WBYTES + 2 * S2_PBYTES + 2 * S2_VBYTES + 128 * 4;          // 140 KB
+constexpr int S2_XIT = (FROWS * 56 + S2_HT - 1) / S2_HT;                              // (row, 4 pixels) items per helper thread
+__global__ void __launch_bounds__(S2_NT) stem_pool2_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int n_split,
+                                                           const bf16_t* __restrict__ wpk, const float* __restrict__ scale,
+                                                           const float* __restrict__ shift, bf16_t* __restrict__ y, int* range_flag,
+                                                           int total, int per) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
+    bf16_t* wsm = (bf16_t*)lds2;
+    unsigned char* pbase = lds2 + S2_WBYTES;
+    unsigned char* vbase = pbase + 2 * S2_PBYTES;
+    float* sbn = (float*)(vbase + 2 * S2_VBYTES);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int L0 = blockIdx.x * per, nit = (total - L0 < per ? total - L0 : per);
+    if (nit <= 0) return;
+    for (int i = tid; i < S2_WBYTES / 16; i += S2_NT) ((u32x4*)wsm)[i] = ((const u32x4*)wpk)[i];
+    if (tid < 128) sbn[tid] = tid < 64 ? scale[tid] : shift[tid - 64];
+    for (int i = tid; i < 2 * FROWS * 8; i += S2_NT) {      // left 3 / right 5 pad pixels of every row of both patches: written once
+        const int q = i % 8, row = (i / 8) % FROWS, b = i / (8 * FROWS);
+        const int px = q < 3 ? q : 227 + (q - 3);
+        *(uint2*)((bf16_t*)(pbase + b * S2_PBYTES) + (row * FPW + px) * 4) = make_uint2(0u, 0u);
+    }
+    if (tid < 64) ((bf16_t*)(pbase + (tid >> 5) * S2_PBYTES))[FROWS * FPW * 4 + (tid & 31)] = 0;
+
+    if (wave >= S2_CT / 64) {
+        // ---- helper waves: crop rows in, pooled rows out
+        const int ht = tid - S2_CT;
+        float4 xr[S2_XIT][3];
+        uint32_t rng_in = 0u, rng = 0u;                      // fp16 range sentinel: converted crop values | pooled maxima
+        auto issue = [&](int L) {
+            const int n = L / (PO / 2), iy0 = 8 * (L - n * (PO / 2)) - 5;
+            const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
+#pragma unroll
+            for (int k = 0; k < S2_XIT; ++k) {
+                const int i0 = ht + k * S2_HT, i = i0 < FROWS * 56 ? i0 : FROWS * 56 - 1;
+                const int x4 = i % 56, row = i / 56, iy = iy0 + row, iyc = iy < 0 ? 0 : iy > IMG - 1 ? IMG - 1 : iy;
+                const float* src = xin + (size_t)iyc * IMG + 4 * x4;
+                if (STEM_ABLATE & 1) { xr[k][0] = xr[k][1] = xr[k][2] = make_float4(0.5f, 0.25f, 0.125f, 1.f); continue; }
+                xr[k][0] = *(const float4*)src;
+                xr[k][1] = *(const float4*)(src + (size_t)IMG * IMG);
+                xr[k][2] = *(const float4*)(src + (size_t)2 * IMG * IMG);
+            }
+        };
+        auto fill = [&](int L, bf16_t* patch) {
+            const int n = L / (PO / 2), iy0 = 8 * (L - n * (PO / 2)) - 5;
+#pragma unroll
+            for (int k = 0; k < S2_XIT; ++k) {
+                const int i = ht + k * S2_HT, x4 = i % 56, row = i / 56;
+                if (i >= FROWS * 56) continue;
+                const bool inside = (unsigned)(iy0 + row) < (unsigned)IMG;
+                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+                const float4 v0 = inside ? xr[k][0] : zero4, v1 = inside ? xr[k][1] : zero4, v2 = inside ? xr[k][2] : zero4;
+                uint2* d = (uint2*)(patch + (row * FPW + 4 * x4 + 3) * 4);
+                d[0] = make_uint2(pack_bf16x2(v0.x, v1.x), pack_bf16x2(v2.x, 0.f));
+                d[1] = make_uint2(pack_bf16x2(v0.y, v1.y), pack_bf16x2(v2.y, 0.f));
+                d[2] = make_uint2(pack_bf16x2(v0.z, v1.z), pack_bf16x2(v2.z, 0.f));
+                d[3] = make_uint2(pack_bf16x2(v0.w, v1.w), pack_bf16x2(v2.w, 0.f));
+                ap_rng_note4(rng_in, d[0].x, d[0].y, d[1].x, d[1].y, false);   // the conversion of the input is watched like a store
+                ap_rng_note4(rng_in, d[2].x, d[2].y, d[3].x, d[3].y, false);
+            }
+        };
+        auto pool = [&](int L, const bf16_t* vm) {
+            const int n = L / (PO / 2);
+            stem_strip_pool<S2_HT>(vm, y, n, 2 * (L - n * (PO / 2)), ht, rng);
+        };
+        issue(L0);
+        fill(L0, (bf16_t*)pbase);
+        if (nit > 1) issue(L0 + 1);
+        __syncthreads();
+#pragma unroll 1
+        for (int it = 0; it < nit; ++it) {
+            if (it + 1 < nit) {
+                fill(L0 + it + 1, (bf16_t*)(pbase + ((it + 1) & 1) * S2_PBYTES));
+                if (it + 2 < nit) issue(L0 + it + 2);
+            }
+            if (it >= 1) pool(L0 + it - 1, (const bf16_t*)(vbase + ((it - 1) & 1) * S2_VBYTES));
+            __syncthreads();
+        }
+        pool(L0 + nit - 1, (const bf16_t*)(vbase + ((nit - 1) & 1) * S2_VBYTES));
+        ap_rng_note(rng, rng_in);
+        ap_rng_flush(range_flag, rng);
+    } else {
+        // ---- compute waves
+        __syncthreads();
+#pragma unroll 1
+        for (int it = 0; it < nit; ++it) {
+            const int L = L0 + it;
+            stem_strip_compute<false>((const bf16_t*)(pbase + (it & 1) * S2_PBYTES), wsm, sbn, (bf16_t*)(vbase + (it & 1) * S2_VBYTES),
+                                      wave, lane, L % (PO / 2) > 0);
+            __syncthreads();
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -883,7 +1003,27 @@ hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int 
 #endif
 
 hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
-                                const float* shift, void* y_pooled, int n_img, int* range_flag, hipStream_t st) {
+                                const float* shift, void* y_pooled, int n_img, int* range_flag, int form, hipStream_t st) {
+    if (form == 2) {                                         // persistent form: one workgroup per CU, contiguous ranges of strips
+        static int n_cu_dev[AP_MAX_DEVICES] = {};
+        int dev = 0;
+        hipError_t e = ap_current_device(&dev);
+        if (e != hipSuccess) return e;
+        if (!n_cu_dev[dev]) {
+            int n = 0;
+            e = hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+            if (e != hipSuccess) return e;
+            e = hipFuncSetAttribute((const void*)stem_pool2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, S2_LDS);
+            if (e != hipSuccess) return e;
+            n_cu_dev[dev] = n > 0 ? n : 1;
+        }
+        const int total = n_img * (PO / 2);
+        const int per = (total + n_cu_dev[dev] - 1) / n_cu_dev[dev];
+        const int grid = (total + per - 1) / per;
+        hipLaunchKernelGGL(stem_pool2_kernel, dim3(grid), dim3(S2_NT), S2_LDS, st, x0, x1, n_split, (const bf16_t*)w_packed, scale,
+                           shift, (bf16_t*)y_pooled, range_flag, total, per);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(stem_pool_kernel, dim3(PO / 2, n_img), dim3(448), 0, st, x0, x1, n_split,
                        (const bf16_t*)w_packed, scale, shift, (bf16_t*)y_pooled, range_flag);
     return hipGetLastError();

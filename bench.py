@@ -590,6 +590,8 @@ def main():
         net.set_pw_conv(int(os.environ["AIRPOSE_PW_CONV"]))
     if os.environ.get("AIRPOSE_IMG3"):                      # A/B aid: layer2's 3x3 with half an image resident in LDS (default) / slab kernel
         net.set_img3(int(os.environ["AIRPOSE_IMG3"]))
+    if os.environ.get("AIRPOSE_STEM"):                      # A/B aid: stem + pool as persistent workgroups (1, default) / a workgroup per strip (2)
+        net.set_fuse_stem(int(os.environ["AIRPOSE_STEM"]))
     if os.environ.get("AIRPOSE_IMG_BLOCK"):                 # A/B aid: layer3 identity blocks as image-resident kernels (default) / conv2 + pairs
         net.set_img_block(int(os.environ["AIRPOSE_IMG_BLOCK"]))
     if os.environ.get("AIRPOSE_EVEN_OUT"):                  # A/B aid: block outputs only a stride-2 downsample reads: even pixels (default) / in full

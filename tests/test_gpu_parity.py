@@ -1344,7 +1344,7 @@ def test_trunk_bf16_close_to_golden(golden, netbf, copenet_inputs, dev):
     assert e0 < TOLBF
 
 
-@pytest.mark.parametrize("n", [1, 5, 64])
+@pytest.mark.parametrize("n", [1, 5, 64, 300])
 def test_fused_stem_pool_is_bit_identical(net16, dev, n):
     """conv1+bn1+relu+maxpool fused kernel == stem kernel followed by the max-pool kernel, bit for bit, in both 16-bit types."""
     gen = torch.Generator(device="cpu").manual_seed(500 + n)
@@ -1353,10 +1353,13 @@ def test_fused_stem_pool_is_bit_identical(net16, dev, n):
     try:
         net16.set_fuse_stem(0)
         ref = net16.forward_feat_ext(x).clone()
+        net16.set_fuse_stem(2)                                # a workgroup per strip (round 4)
+        strip = net16.forward_feat_ext(x).clone()
     finally:
-        net16.set_fuse_stem(1)
+        net16.set_fuse_stem(1)                                # persistent workgroups, waves split by role (round 6, default)
     got = net16.forward_feat_ext(x)
     assert torch.isfinite(ref).all()
+    assert torch.equal(strip, ref)
     assert torch.equal(got, ref)
 
 
