@@ -201,6 +201,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // hipFuncSetAttribute and the CU count are per DEVICE: launch-side caches are keyed by the current device id
 // (two nets of one process on two GPUs, e.g. copenet_sep, each get their >64 KiB dynamic-LDS opt-in).
 #define AP_MAX_DEVICES 16
+#define AP_STEM_WLD 240                                      // row stride (elements) of the stem's packed MFMA weights (api.hip packs, stem.hip reads)
 static inline hipError_t ap_current_device(int* dev) {
     hipError_t e = hipGetDevice(dev);
     if (e != hipSuccess) return e;

@@ -636,16 +636,16 @@ int finalize_trunk(ap_net* h) {
             for (int r = 0; r < 7; ++r)
                 for (int s = 0; s < 7; ++s) sw[((r * 7 + s) * 3 + c) * 64 + o] = w->data[((o * 3 + c) * 7 + r) * 7 + s];
     HIP_TRY(upload(h->stem_w, sw.data(), sw.size() * 4));
-    {   // MFMA stem operand: [64][232] bf16, k' = r*32 + s*4 + c (zero elsewhere: 4th channel slot, 8th tap, row pad)
-        std::vector<uint16_t> pk(64 * 232, 0);
+    {   // MFMA stem operand: [64][AP_STEM_WLD] bf16, k' = r*32 + s*4 + c (zero elsewhere: 4th channel slot, 8th tap, row pad)
+        std::vector<uint16_t> pk(64 * AP_STEM_WLD, 0);
         for (int o = 0; o < 64; ++o)
             for (int c = 0; c < 3; ++c)
                 for (int r = 0; r < 7; ++r)
                     for (int s2 = 0; s2 < 7; ++s2)
-                        pk[o * 232 + r * 32 + s2 * 4 + c] = h->h16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
+                        pk[o * AP_STEM_WLD + r * 32 + s2 * 4 + c] = h->h16(w->data[((o * 3 + c) * 7 + r) * 7 + s2]);
         HIP_TRY(upload(h->stem_wpk, pk.data(), pk.size() * 2));
         if (h->prec == AP_PREC_BF16X2) {                    // low plane: bf16(w - hi) at the same positions
-            std::vector<uint16_t> pl(64 * 232, 0);
+            std::vector<uint16_t> pl(64 * AP_STEM_WLD, 0);
             for (int o = 0; o < 64; ++o)
                 for (int c = 0; c < 3; ++c)
                     for (int r = 0; r < 7; ++r)
@@ -653,7 +653,7 @@ int finalize_trunk(ap_net* h) {
                             const float wv = w->data[((o * 3 + c) * 7 + r) * 7 + s2];
                             uint16_t hi, lo;
                             host_split_parts(wv, &hi, &lo);
-                            pl[o * 232 + r * 32 + s2 * 4 + c] = lo;
+                            pl[o * AP_STEM_WLD + r * 32 + s2 * 4 + c] = lo;
                         }
             HIP_TRY(upload(h->stem_wpk_lo, pl.data(), pl.size() * 2));
         }
@@ -987,7 +987,7 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
     if (h->tm.on == 1) HIP_TRY(h->tm.rec(st, &e0));
     if (bf && h->fuse_stem) {
         HIP_TRY(H16(prec, ap_launch_stem_pool)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(), h->stem_shift.as<float>(),
-                                               w.ws_a.p, n, w.rflag, h->fuse_stem == 2 ? 1 : 2, st));
+                                               w.ws_a.p, n, w.rflag, h->fuse_stem == 2 ? 1 : 2, st, g_conv_dbg));
     } else if (bf) {
         HIP_TRY(H16(prec, ap_launch_stem_conv_mfma)(x0, x1, n0, h->stem_wpk.p, h->stem_scale.as<float>(),
                                                     h->stem_shift.as<float>(), w.ws_stem.p, n, st));

@@ -109,7 +109,10 @@ template <int I, int N, typename F> __device__ __forceinline__ void stem_sfor(F&
 // 65 % of its LDS cycles as bank conflicts).  No im2col buffer; k' slots without a tap meet zero weights.
 constexpr int SP = 37;                       // patch rows / cols for a 16x16 output tile
 constexpr int SPW = 38;                      // patch row stride in pixels (even: every fragment 16-byte aligned)
-constexpr int SWLD = 232;                    // packed weight row stride (bf16): 464 B, conflict-free b128 reads
+constexpr int SWLD = AP_STEM_WLD;            // packed weight row stride (bf16): 480 B.  ds_read_b128 serves a wave in the lane groups
+                                             // {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, .. (MI355X_MICROARCH.md, LDS): with rows of 464 B
+                                             // (232, rounds 2-5: chosen for contiguous groups of 16) every group met a bank twice --
+                                             // PMC: a third of the persistent kernel's LDS cycles -- with 480 B none does
 constexpr int SKB = 7;                       // 7 x 32 = 224 padded K: one k-block per kernel row
 
 __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
@@ -180,7 +183,7 @@ __global__ void __launch_bounds__(256) stem_mfma_kernel(const float* __restrict_
 
 // ------------------------------------------------------------------------------------------------
 // Split-bf16 MFMA stem (bf16x2 parity mode): the same tile program as stem_mfma_kernel with every operand as a
-// (hi, lo) bf16 pair held in two planes -- two weight images [64][232] and two input patches -- and each product as
+// (hi, lo) bf16 pair held in two planes -- two weight images [64][240] and two input patches -- and each product as
 // hi*hi + hi*lo + lo*hi on the bf16 matrix pipe (the lo*lo term, 2^-18 relative, is dropped: the planes are separate
 // fragments here, so the three MFMAs are explicit).  Output: split-bf16 pairs, NHWC.
 __global__ void __launch_bounds__(256) stem_mfma_split_kernel(const float* __restrict__ x0, const float* __restrict__ x1,
@@ -493,105 +496,240 @@ __global__ void __launch_bounds__(448, 4) stem_pool_kernel(const float* __restri
 
 // ------------------------------------------------------------------------------------------------
 // Persistent form of the fused stem + max-pool (round 6): one workgroup per CU walks a contiguous range of strips (an image at the
-// size of a pass), its 11 waves split by role.  Waves 0-6 run stem_strip_compute on strip i (the same MFMA sequence as the strip
-// kernel: same bits); waves 7-10 meanwhile convert the crop rows of strip i + 1 into the other patch buffer (their global loads were
-// issued an iteration earlier and have had a whole strip to land), issue the loads of strip i + 2, and pool + store strip i - 1 out
-// of the other vm buffer.  ONE workgroup barrier per strip.  The 29 KB of weights are read once per workgroup instead of once per
-// strip, the rows a strip shares with the one above come out of the L2 the same workgroup filled two strips earlier, and nothing a
-// strip kernel serialises (load round trip -> conversion -> K loop -> epilogue -> pooling pass -> stores) is on the compute waves'
-// path except the K loop and the epilogue.
-constexpr int S2_CT = 448, S2_HT = 256, S2_NT = S2_CT + S2_HT;
-constexpr int S2_WBYTES = 64 * SWLD * 2, S2_PBYTES = (FROWS * FPW * 4 + 32) * 2, S2_VBYTES = 2 * SO * SC * 2;
-constexpr int S2_LDS = S2_WBYTES + 2 * S2_PBYTES + 2 * S2_VBYTES + 128 * 4;          // 140 KB
-constexpr int S2_XIT = (FROWS * 56 + S2_HT - 1) / S2_HT;                              // (row, 4 pixels) items per helper thread
+// size of a pass), its 12 waves split by role.
+//   waves 0-7   compute.  Wave w owns the conv columns 14 w - 1 .. 14 w + 14 -- the three conv columns of each of its 7 pooled
+//               columns, so the horizontal 3-maximum is finished in registers (DPP row shifts) and stored from there; eight waves
+//               = two per SIMD (seven 16-column waves leave one SIMD half empty: the two extra columns cost no time).  A strip is
+//               4 conv rows, not 5: the conv row a strip shares with the one above (the top row of its upper pooling window) is
+//               CARRIED in registers from the previous strip of the same walk (its BatchNorm output, 16 values per lane), which
+//               takes a fifth off the MFMAs and the epilogue.  A walk that starts inside an image computes the strip above its
+//               first one without storing it.  Every conv output is the same MFMA sequence on the same operands as in the
+//               strip kernel and every maximum sees the same values: same bits.
+//   waves 8-11  feed: convert the 13 crop rows of strip i + 1 into the other patch buffer (their global loads were issued an
+//               iteration earlier and have had a whole strip to land) and issue the loads of strip i + 2.
+// ONE workgroup barrier per strip.  The weights are read once per workgroup instead of once per strip, the rows a strip shares with
+// the one above come out of the L2 the same workgroup filled two strips earlier, and of what a strip kernel serialises (load round
+// trip -> conversion -> K loop -> epilogue -> pooling pass through LDS -> stores) only the K loop and the epilogue are left on the
+// compute waves' path.  What bounds it (cycle stamps, tools/probes/stem_trace.py; PMC): the SIMD's VALU issue port -- MFMAs (16
+// cycles each), the epilogue's and the feeding waves' VALU instructions hardly overlap, so the kernel is written to need few of
+// each: packed BatchNorm (v_pk_fma_f32), ReLU after the vertical maximum, no accumulator zeroing (constant C operand in the first
+// K step), the input's fp16 range sentinel on the fp32 values, 32-bit address arithmetic in the feeding waves.
+constexpr int S2_CW = 8, S2_CT = S2_CW * 64, S2_HT = 256, S2_NT = S2_CT + S2_HT;
+constexpr int S2_ROWS = 13;                                                            // crop rows of a 4-conv-row strip
+constexpr int S2_WBYTES = 64 * SWLD * 2, S2_PBYTES = (S2_ROWS * FPW * 4 + 32) * 2;
+constexpr int S2_LDS = S2_WBYTES + 2 * S2_PBYTES + 128 * 4;                           // 78 KB
+constexpr int S2_XIT = (S2_ROWS * 56 + S2_HT - 1) / S2_HT;                            // (row, 4 pixels) items per feeding thread
 __global__ void __launch_bounds__(S2_NT) stem_pool2_kernel(const float* __restrict__ x0, const float* __restrict__ x1, int n_split,
                                                            const bf16_t* __restrict__ wpk, const float* __restrict__ scale,
                                                            const float* __restrict__ shift, bf16_t* __restrict__ y, int* range_flag,
-                                                           int total, int per) {
+                                                           int total, int per, unsigned long long* dbg) {
+#ifdef AP_TRACE   // cycle stamps of workgroup 3, strips 8-11 of its range: wave 0 (compute) slots 0.., wave 8 (feed) slots 64.. (tools/probes/stem_trace.py)
+#define S2STAMP(base, slot) do { if (dbg && blockIdx.x == 3 && lane == 0 && it >= 8 && it < 12) dbg[(base) + (it - 8) * 8 + (slot)] = __builtin_amdgcn_s_memtime(); } while (0)
+#else
+#define S2STAMP(base, slot) do { } while (0)
+#endif
     extern __shared__ __attribute__((aligned(16))) unsigned char lds2[];
     bf16_t* wsm = (bf16_t*)lds2;
     unsigned char* pbase = lds2 + S2_WBYTES;
-    unsigned char* vbase = pbase + 2 * S2_PBYTES;
-    float* sbn = (float*)(vbase + 2 * S2_VBYTES);
+    float* sbn = (float*)(pbase + 2 * S2_PBYTES);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int L0 = blockIdx.x * per, nit = (total - L0 < per ? total - L0 : per);
-    if (nit <= 0) return;
+    const int Lfirst = blockIdx.x * per, nstore = (total - Lfirst < per ? total - Lfirst : per);
+    if (nstore <= 0) return;
+    const int warm = Lfirst % (PO / 2) ? 1 : 0;             // the walk starts inside an image: the strip above it runs first, unstored
+    const int L0 = Lfirst - warm, nit = nstore + warm;
     for (int i = tid; i < S2_WBYTES / 16; i += S2_NT) ((u32x4*)wsm)[i] = ((const u32x4*)wpk)[i];
     if (tid < 128) sbn[tid] = tid < 64 ? scale[tid] : shift[tid - 64];
-    for (int i = tid; i < 2 * FROWS * 8; i += S2_NT) {      // left 3 / right 5 pad pixels of every row of both patches: written once
-        const int q = i % 8, row = (i / 8) % FROWS, b = i / (8 * FROWS);
+    for (int i = tid; i < 2 * S2_ROWS * 8; i += S2_NT) {    // left 3 / right 5 pad pixels of every row of both patches: written once
+        const int q = i % 8, row = (i / 8) % S2_ROWS, b = i / (8 * S2_ROWS);
         const int px = q < 3 ? q : 227 + (q - 3);
         *(uint2*)((bf16_t*)(pbase + b * S2_PBYTES) + (row * FPW + px) * 4) = make_uint2(0u, 0u);
     }
-    if (tid < 64) ((bf16_t*)(pbase + (tid >> 5) * S2_PBYTES))[FROWS * FPW * 4 + (tid & 31)] = 0;
+    if (tid < 64) ((bf16_t*)(pbase + (tid >> 5) * S2_PBYTES))[S2_ROWS * FPW * 4 + (tid & 31)] = 0;
 
-    if (wave >= S2_CT / 64) {
-        // ---- helper waves: crop rows in, pooled rows out
+    if (wave >= S2_CW) {
+        // ---- feeding waves: crop rows 8 s - 3 .. 8 s + 9 of strip s in
         const int ht = tid - S2_CT;
         float4 xr[S2_XIT][3];
-        uint32_t rng_in = 0u, rng = 0u;                      // fp16 range sentinel: converted crop values | pooled maxima
+        float rng_abs = 0.f;                                 // fp16 range sentinel: largest |crop value| converted (NaN propagates)
+        uint32_t ioff[S2_XIT], poff[S2_XIT];                 // (row, 4-pixel group) of the item / its byte offset in the patch
+#pragma unroll
+        for (int k = 0; k < S2_XIT; ++k) {
+            const int i0 = ht + k * S2_HT, i = i0 < S2_ROWS * 56 ? i0 : S2_ROWS * 56 - 1;
+            ioff[k] = (uint32_t)(i / 56) << 16 | (uint32_t)(i % 56);
+            poff[k] = (uint32_t)(((i / 56) * FPW + 4 * (i % 56) + 3) * 8);
+        }
         auto issue = [&](int L) {
-            const int n = L / (PO / 2), iy0 = 8 * (L - n * (PO / 2)) - 5;
-            const float* xin = (n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
+            const int n = L / (PO / 2), iy0 = 8 * (L - n * (PO / 2)) - 3;
+            const char* xin = (const char*)(n < n_split ? x0 + (size_t)n * 3 * IMG * IMG : x1 + (size_t)(n - n_split) * 3 * IMG * IMG);
 #pragma unroll
             for (int k = 0; k < S2_XIT; ++k) {
-                const int i0 = ht + k * S2_HT, i = i0 < FROWS * 56 ? i0 : FROWS * 56 - 1;
-                const int x4 = i % 56, row = i / 56, iy = iy0 + row, iyc = iy < 0 ? 0 : iy > IMG - 1 ? IMG - 1 : iy;
-                const float* src = xin + (size_t)iyc * IMG + 4 * x4;
+                const int x4 = ioff[k] & 0xffff, iy = iy0 + (int)(ioff[k] >> 16), iyc = iy < 0 ? 0 : iy > IMG - 1 ? IMG - 1 : iy;
+                const uint32_t off = (uint32_t)(iyc * IMG + 4 * x4) * 4u;
                 if (STEM_ABLATE & 1) { xr[k][0] = xr[k][1] = xr[k][2] = make_float4(0.5f, 0.25f, 0.125f, 1.f); continue; }
-                xr[k][0] = *(const float4*)src;
-                xr[k][1] = *(const float4*)(src + (size_t)IMG * IMG);
-                xr[k][2] = *(const float4*)(src + (size_t)2 * IMG * IMG);
+                xr[k][0] = *(const float4*)(xin + off);
+                xr[k][1] = *(const float4*)(xin + (off + (uint32_t)(IMG * IMG * 4)));
+                xr[k][2] = *(const float4*)(xin + (off + (uint32_t)(2 * IMG * IMG * 4)));
             }
         };
-        auto fill = [&](int L, bf16_t* patch) {
-            const int n = L / (PO / 2), iy0 = 8 * (L - n * (PO / 2)) - 5;
+        auto fill = [&](int L, unsigned char* patch) {
+            const int n = L / (PO / 2), strip = L - n * (PO / 2), iy0 = 8 * strip - 3;
+            const bool edge = strip == 0 || strip == PO / 2 - 1;   // only these strips have rows outside the image
 #pragma unroll
             for (int k = 0; k < S2_XIT; ++k) {
-                const int i = ht + k * S2_HT, x4 = i % 56, row = i / 56;
-                if (i >= FROWS * 56) continue;
-                const bool inside = (unsigned)(iy0 + row) < (unsigned)IMG;
-                const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-                const float4 v0 = inside ? xr[k][0] : zero4, v1 = inside ? xr[k][1] : zero4, v2 = inside ? xr[k][2] : zero4;
-                uint2* d = (uint2*)(patch + (row * FPW + 4 * x4 + 3) * 4);
-                d[0] = make_uint2(pack_bf16x2(v0.x, v1.x), pack_bf16x2(v2.x, 0.f));
-                d[1] = make_uint2(pack_bf16x2(v0.y, v1.y), pack_bf16x2(v2.y, 0.f));
-                d[2] = make_uint2(pack_bf16x2(v0.z, v1.z), pack_bf16x2(v2.z, 0.f));
-                d[3] = make_uint2(pack_bf16x2(v0.w, v1.w), pack_bf16x2(v2.w, 0.f));
-                ap_rng_note4(rng_in, d[0].x, d[0].y, d[1].x, d[1].y, false);   // the conversion of the input is watched like a store
-                ap_rng_note4(rng_in, d[2].x, d[2].y, d[3].x, d[3].y, false);
+                if (ht + k * S2_HT >= S2_ROWS * 56) continue;
+                float4 v0 = xr[k][0], v1 = xr[k][1], v2 = xr[k][2];
+                if (edge && (unsigned)(iy0 + (int)(ioff[k] >> 16)) >= (unsigned)IMG) v0 = v1 = v2 = make_float4(0.f, 0.f, 0.f, 0.f);
+#ifdef AP_F16
+                asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(rng_abs) : "v"(v0.x), "v"(v0.y));
+                asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(rng_abs) : "v"(v0.z), "v"(v0.w));
+                asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(rng_abs) : "v"(v1.x), "v"(v1.y));
+                asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(rng_abs) : "v"(v1.z), "v"(v1.w));
+                asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(rng_abs) : "v"(v2.x), "v"(v2.y));
+                asm("v_maximum3_f32 %0, %0, |%1|, |%2|" : "+v"(rng_abs) : "v"(v2.z), "v"(v2.w));
+#endif
+                // a lane's four pixels are 32 contiguous bytes at 24 mod 32: 8 + 16 + 8 bytes (the 16-byte store is aligned)
+                unsigned char* d = patch + poff[k];
+                *(uint2*)d = make_uint2(pack_bf16x2(v0.x, v1.x), pack_bf16x2(v2.x, 0.f));
+                *(u32x4*)(d + 8) = u32x4{pack_bf16x2(v0.y, v1.y), pack_bf16x2(v2.y, 0.f), pack_bf16x2(v0.z, v1.z), pack_bf16x2(v2.z, 0.f)};
+                *(uint2*)(d + 24) = make_uint2(pack_bf16x2(v0.w, v1.w), pack_bf16x2(v2.w, 0.f));
             }
-        };
-        auto pool = [&](int L, const bf16_t* vm) {
-            const int n = L / (PO / 2);
-            stem_strip_pool<S2_HT>(vm, y, n, 2 * (L - n * (PO / 2)), ht, rng);
         };
         issue(L0);
-        fill(L0, (bf16_t*)pbase);
+        fill(L0, pbase);
         if (nit > 1) issue(L0 + 1);
         __syncthreads();
 #pragma unroll 1
         for (int it = 0; it < nit; ++it) {
+            if (wave == S2_CW) S2STAMP(64, 0);
+#ifdef AP_TRACE
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (wave == S2_CW) S2STAMP(64, 1);
+#endif
             if (it + 1 < nit) {
-                fill(L0 + it + 1, (bf16_t*)(pbase + ((it + 1) & 1) * S2_PBYTES));
+                fill(L0 + it + 1, pbase + ((it + 1) & 1) * S2_PBYTES);
+                if (wave == S2_CW) S2STAMP(64, 2);
                 if (it + 2 < nit) issue(L0 + it + 2);
             }
-            if (it >= 1) pool(L0 + it - 1, (const bf16_t*)(vbase + ((it - 1) & 1) * S2_VBYTES));
+            if (wave == S2_CW) S2STAMP(64, 3);
             __syncthreads();
+            if (wave == S2_CW) S2STAMP(64, 4);
         }
-        pool(L0 + nit - 1, (const bf16_t*)(vbase + ((nit - 1) & 1) * S2_VBYTES));
-        ap_rng_note(rng, rng_in);
-        ap_rng_flush(range_flag, rng);
+#ifdef AP_F16
+        // a crop value of 65520 or more (or a NaN) leaves the fp16 range at the conversion: what it turns into downstream (NaN with the
+        // sign bit set) is cleared by the ReLU before any epilogue's sentinel could see it, so the input is watched here
+        if (range_flag && !(rng_abs < 65520.f)) __hip_atomic_store(range_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+#endif
     } else {
         // ---- compute waves
+        typedef float f32x2 __attribute__((ext_vector_type(2)));
+        typedef short s16x2 __attribute__((ext_vector_type(2)));
+        auto pkmax = [](uint32_t a, uint32_t b) -> uint32_t {
+            return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
+        };
+        const int lr = lane & 15, g = lane >> 4;
+        const int xo = 14 * wave - 1 + lr;                   // conv column of this lane (-1: the pool's left border; 112: never used)
+        const bool centre = (lr & 1) && lr < 14;             // lanes 1, 3, .. 13: pooled column 7 w + lr / 2 = conv columns xo - 1 .. xo + 1
+        const bool col_valid = xo >= 0;
+        const int px = 7 * wave + (lr >> 1);
+        uint32_t rng = 0u;                                   // fp16 range sentinel over the pooled maxima
+        f32x2 carry[4][2];                                   // BatchNorm output of the previous strip's last conv row (channels fn * 16 + g * 4 ..)
+#pragma unroll
+        for (int fn = 0; fn < 4; ++fn) carry[fn][0] = carry[fn][1] = f32x2{0.f, 0.f};
+        const uint32_t xoff = (uint32_t)((2 * xo + 2 * g) * 8);                       // byte offsets: patch pixel 2 xo + tap, weights row lr
+        const bf16_t* wbase = wsm + lr * SWLD + g * 8;
         __syncthreads();
 #pragma unroll 1
         for (int it = 0; it < nit; ++it) {
-            const int L = L0 + it;
-            stem_strip_compute<false>((const bf16_t*)(pbase + (it & 1) * S2_PBYTES), wsm, sbn, (bf16_t*)(vbase + (it & 1) * S2_VBYTES),
-                                      wave, lane, L % (PO / 2) > 0);
+            const int L = L0 + it, n = L / (PO / 2), strip = L - n * (PO / 2);
+            if (wave == 0) S2STAMP(0, 0);
+            // K loop: kernel rows in the order 0, 2, 4, 6, 1, 3, 5 (stem_kb_of: the summation order of every 16-bit stem); conv row fm at
+            // kernel row kb reads patch row 2 fm + kb, so within a parity one new row fragment per step (xf rotates)
+            f32x4 acc[4][4];
+            const unsigned char* xb = pbase + (it & 1) * S2_PBYTES + xoff;
+            u32x4 xf[4];
+            stem_sfor<0, SKB>([&](auto ST) {
+                constexpr int step = decltype(ST)::value, kb = stem_kb_of(step);
+                constexpr bool first = step == 0 || step == 4;
+                constexpr int rot = first ? 0 : (step < 4 ? step : step - 4);
+                u32x4 wf[4];
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) {
+                    if (STEM_ABLATE & 128) wf[fn] = u32x4{0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+                    else wf[fn] = *(const u32x4*)(wbase + fn * 16 * SWLD + kb * 32);
+                }
+                if constexpr (first) {
+#pragma unroll
+                    for (int fm = 0; fm < 4; ++fm) {
+                        if (STEM_ABLATE & 128) xf[fm] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
+                        else xf[fm] = *(const u32x4*)(xb + (2 * fm + kb) * FPW * 8);
+                    }
+                } else {
+                    if (STEM_ABLATE & 128) xf[(3 + rot) % 4] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
+                    else xf[(3 + rot) % 4] = *(const u32x4*)(xb + (6 + kb) * FPW * 8);
+                }
+#pragma unroll
+                for (int fm = 0; fm < 4; ++fm)
+#pragma unroll
+                    for (int fn = 0; fn < 4; ++fn) {
+                        if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[(fm + rot) % 4]));
+                        else acc[fm][fn] = ap_mfma16(
+                            __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[(fm + rot) % 4]),
+                            step == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn]);   // (first step: an inline-constant C operand, no zeroing pass)
+                    }
+                __builtin_amdgcn_sched_barrier(0);
+            });
+            if (wave == 0) S2STAMP(0, 1);
+            // epilogue: BatchNorm (v_pk_fma_f32 = two v_fma_f32), then the two pooling windows over conv rows (carried, 0, 1) and
+            // (1, 2, 3) with the ReLU folded into the shared row: max(relu a, relu b, relu c) = max3(a, b, max(c, 0))
+            bf16_t* yrow = y + ((size_t)n * PO + 2 * strip) * PO * SC;
+            const bool store = it >= warm;
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) {
+                if (STEM_ABLATE & 32) { asm volatile("" ::"v"(acc[0][fn]), "v"(acc[1][fn]), "v"(acc[2][fn]), "v"(acc[3][fn])); continue; }
+                const int ch = fn * 16 + g * 4;
+                const f32x2 sc0 = *(const f32x2*)(sbn + ch), sc1 = *(const f32x2*)(sbn + ch + 2);
+                const f32x2 sh0 = *(const f32x2*)(sbn + 64 + ch), sh1 = *(const f32x2*)(sbn + 64 + ch + 2);
+                f32x2 v0[4], v1[4];
+#pragma unroll
+                for (int fm = 0; fm < 4; ++fm) {
+                    v0[fm] = __builtin_elementwise_fma(f32x2{acc[fm][fn][0], acc[fm][fn][1]}, sc0, sh0);
+                    v1[fm] = __builtin_elementwise_fma(f32x2{acc[fm][fn][2], acc[fm][fn][3]}, sc1, sh1);
+                }
+                const float t[4] = {fmaxf(v0[1][0], 0.f), fmaxf(v0[1][1], 0.f), fmaxf(v1[1][0], 0.f), fmaxf(v1[1][1], 0.f)};
+                float m[2][4];
+                if (strip > 0) {                             // (the first strip of an image has no conv row above it)
+                    m[0][0] = fmaxf(fmaxf(carry[fn][0][0], v0[0][0]), t[0]); m[0][1] = fmaxf(fmaxf(carry[fn][0][1], v0[0][1]), t[1]);
+                    m[0][2] = fmaxf(fmaxf(carry[fn][1][0], v1[0][0]), t[2]); m[0][3] = fmaxf(fmaxf(carry[fn][1][1], v1[0][1]), t[3]);
+                } else {
+                    m[0][0] = fmaxf(v0[0][0], t[0]); m[0][1] = fmaxf(v0[0][1], t[1]);
+                    m[0][2] = fmaxf(v1[0][0], t[2]); m[0][3] = fmaxf(v1[0][1], t[3]);
+                }
+                m[1][0] = fmaxf(fmaxf(v0[2][0], v0[3][0]), t[0]); m[1][1] = fmaxf(fmaxf(v0[2][1], v0[3][1]), t[1]);
+                m[1][2] = fmaxf(fmaxf(v1[2][0], v1[3][0]), t[2]); m[1][3] = fmaxf(fmaxf(v1[2][1], v1[3][1]), t[3]);
+                carry[fn][0] = v0[3]; carry[fn][1] = v1[3];
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    uint2 o = make_uint2(pack_bf16x2(m[pr][0], m[pr][1]), pack_bf16x2(m[pr][2], m[pr][3]));
+                    // horizontal 3-maximum on the packed values (>= +0: integer order = value order; a missing neighbour -- image
+                    // border, DPP bound -- may enter as 0: the pooling pass's rule, stem_strip_pool)
+                    if (!col_valid) o = make_uint2(0u, 0u);
+                    uint2 h;
+                    h.x = pkmax(pkmax(o.x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o.x, 0x111, 0xf, 0xf, true)),
+                                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o.x, 0x101, 0xf, 0xf, true));
+                    h.y = pkmax(pkmax(o.y, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o.y, 0x111, 0xf, 0xf, true)),
+                                (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o.y, 0x101, 0xf, 0xf, true));
+                    if (centre && store) {
+                        ap_rng_note2(rng, h.x, h.y);
+                        if (STEM_ABLATE & 8) asm volatile("" ::"v"(h)); else
+                        *(uint2*)(yrow + ((size_t)pr * PO + px) * SC + ch) = h;
+                    }
+                }
+            }
+            if (wave == 0) S2STAMP(0, 2);
             __syncthreads();
+            if (wave == 0) S2STAMP(0, 3);
         }
+        ap_rng_flush(range_flag, rng);
     }
 }
 
@@ -1003,7 +1141,8 @@ hipError_t ap_launch_stem_conv_mfma_split(const float* x0, const float* x1, int 
 #endif
 
 hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, const void* w_packed, const float* scale,
-                                const float* shift, void* y_pooled, int n_img, int* range_flag, int form, hipStream_t st) {
+                                const float* shift, void* y_pooled, int n_img, int* range_flag, int form, hipStream_t st,
+                                unsigned long long* dbg) {
     if (form == 2) {                                         // persistent form: one workgroup per CU, contiguous ranges of strips
         static int n_cu_dev[AP_MAX_DEVICES] = {};
         int dev = 0;
@@ -1021,7 +1160,7 @@ hipError_t ap_launch_stem_pool(const float* x0, const float* x1, int n_split, co
         const int per = (total + n_cu_dev[dev] - 1) / n_cu_dev[dev];
         const int grid = (total + per - 1) / per;
         hipLaunchKernelGGL(stem_pool2_kernel, dim3(grid), dim3(S2_NT), S2_LDS, st, x0, x1, n_split, (const bf16_t*)w_packed, scale,
-                           shift, (bf16_t*)y_pooled, range_flag, total, per);
+                           shift, (bf16_t*)y_pooled, range_flag, total, per, dbg);
         return hipGetLastError();
     }
     hipLaunchKernelGGL(stem_pool_kernel, dim3(PO / 2, n_img), dim3(448), 0, st, x0, x1, n_split,
