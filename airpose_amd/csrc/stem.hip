@@ -627,9 +627,10 @@ __global__ void __launch_bounds__(S2_NT) stem_pool2_kernel(const float* __restri
             return __builtin_bit_cast(uint32_t, __builtin_elementwise_max(__builtin_bit_cast(s16x2, a), __builtin_bit_cast(s16x2, b)));
         };
         const int lr = lane & 15, g = lane >> 4;
-        const int xo = 14 * wave - 1 + lr;                   // conv column of this lane (-1: the pool's left border; 112: never used)
+        // conv column of this lane; the pool's left border (column -1, lane 0 of wave 0) computes column 0 a second time -- the
+        // maximum of (c0, c0, c1) is what the padded window gives; column 112 (lane 15 of wave 7) is never used
+        const int xo = wave == 0 && lr == 0 ? 0 : 14 * wave - 1 + lr;
         const bool centre = (lr & 1) && lr < 14;             // lanes 1, 3, .. 13: pooled column 7 w + lr / 2 = conv columns xo - 1 .. xo + 1
-        const bool col_valid = xo >= 0;
         const int px = 7 * wave + (lr >> 1);
         uint32_t rng = 0u;                                   // fp16 range sentinel over the pooled maxima
         f32x2 carry[4][2];                                   // BatchNorm output of the previous strip's last conv row (channels fn * 16 + g * 4 ..)
@@ -680,39 +681,47 @@ __global__ void __launch_bounds__(S2_NT) stem_pool2_kernel(const float* __restri
             });
             if (wave == 0) S2STAMP(0, 1);
             // epilogue: BatchNorm (v_pk_fma_f32 = two v_fma_f32), then the two pooling windows over conv rows (carried, 0, 1) and
-            // (1, 2, 3) with the ReLU folded into the shared row: max(relu a, relu b, relu c) = max3(a, b, max(c, 0))
+            // (1, 2, 3) with the ReLU folded into the shared row: max(relu a, relu b, relu c) = max3(a, b, max(c, 0)).  The first strip
+            // of an image has no row above it: a carried 0 changes no maximum (the shared row's term is >= 0).  Maxima as
+            // instructions: fmaxf() costs a canonicalising v_max_f32 x, x per operand in this mode.
             bf16_t* yrow = y + ((size_t)n * PO + 2 * strip) * PO * SC;
             const bool store = it >= warm;
+            if (strip == 0) {
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) carry[fn][0] = carry[fn][1] = f32x2{0.f, 0.f};
+            }
+            f32x4 bsc[4], bsh[4];                            // BatchNorm scale / shift of this lane's channels: one batch of LDS reads
+#pragma unroll
+            for (int fn = 0; fn < 4; ++fn) {
+                bsc[fn] = *(const f32x4*)(sbn + fn * 16 + g * 4);
+                bsh[fn] = *(const f32x4*)(sbn + 64 + fn * 16 + g * 4);
+            }
 #pragma unroll
             for (int fn = 0; fn < 4; ++fn) {
                 if (STEM_ABLATE & 32) { asm volatile("" ::"v"(acc[0][fn]), "v"(acc[1][fn]), "v"(acc[2][fn]), "v"(acc[3][fn])); continue; }
                 const int ch = fn * 16 + g * 4;
-                const f32x2 sc0 = *(const f32x2*)(sbn + ch), sc1 = *(const f32x2*)(sbn + ch + 2);
-                const f32x2 sh0 = *(const f32x2*)(sbn + 64 + ch), sh1 = *(const f32x2*)(sbn + 64 + ch + 2);
+                const f32x2 sc0 = {bsc[fn][0], bsc[fn][1]}, sc1 = {bsc[fn][2], bsc[fn][3]};
+                const f32x2 sh0 = {bsh[fn][0], bsh[fn][1]}, sh1 = {bsh[fn][2], bsh[fn][3]};
                 f32x2 v0[4], v1[4];
 #pragma unroll
                 for (int fm = 0; fm < 4; ++fm) {
                     v0[fm] = __builtin_elementwise_fma(f32x2{acc[fm][fn][0], acc[fm][fn][1]}, sc0, sh0);
                     v1[fm] = __builtin_elementwise_fma(f32x2{acc[fm][fn][2], acc[fm][fn][3]}, sc1, sh1);
                 }
-                const float t[4] = {fmaxf(v0[1][0], 0.f), fmaxf(v0[1][1], 0.f), fmaxf(v1[1][0], 0.f), fmaxf(v1[1][1], 0.f)};
+                auto relu = [](float a) { float r; asm("v_max_f32 %0, 0, %1" : "=v"(r) : "v"(a)); return r; };
+                auto max3 = [](float a, float b, float c) { float r; asm("v_max3_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c)); return r; };
+                const float t[4] = {relu(v0[1][0]), relu(v0[1][1]), relu(v1[1][0]), relu(v1[1][1])};
                 float m[2][4];
-                if (strip > 0) {                             // (the first strip of an image has no conv row above it)
-                    m[0][0] = fmaxf(fmaxf(carry[fn][0][0], v0[0][0]), t[0]); m[0][1] = fmaxf(fmaxf(carry[fn][0][1], v0[0][1]), t[1]);
-                    m[0][2] = fmaxf(fmaxf(carry[fn][1][0], v1[0][0]), t[2]); m[0][3] = fmaxf(fmaxf(carry[fn][1][1], v1[0][1]), t[3]);
-                } else {
-                    m[0][0] = fmaxf(v0[0][0], t[0]); m[0][1] = fmaxf(v0[0][1], t[1]);
-                    m[0][2] = fmaxf(v1[0][0], t[2]); m[0][3] = fmaxf(v1[0][1], t[3]);
-                }
-                m[1][0] = fmaxf(fmaxf(v0[2][0], v0[3][0]), t[0]); m[1][1] = fmaxf(fmaxf(v0[2][1], v0[3][1]), t[1]);
-                m[1][2] = fmaxf(fmaxf(v1[2][0], v1[3][0]), t[2]); m[1][3] = fmaxf(fmaxf(v1[2][1], v1[3][1]), t[3]);
+                m[0][0] = max3(carry[fn][0][0], v0[0][0], t[0]); m[0][1] = max3(carry[fn][0][1], v0[0][1], t[1]);
+                m[0][2] = max3(carry[fn][1][0], v1[0][0], t[2]); m[0][3] = max3(carry[fn][1][1], v1[0][1], t[3]);
+                m[1][0] = max3(v0[2][0], v0[3][0], t[0]); m[1][1] = max3(v0[2][1], v0[3][1], t[1]);
+                m[1][2] = max3(v1[2][0], v1[3][0], t[2]); m[1][3] = max3(v1[2][1], v1[3][1], t[3]);
                 carry[fn][0] = v0[3]; carry[fn][1] = v1[3];
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
-                    uint2 o = make_uint2(pack_bf16x2(m[pr][0], m[pr][1]), pack_bf16x2(m[pr][2], m[pr][3]));
-                    // horizontal 3-maximum on the packed values (>= +0: integer order = value order; a missing neighbour -- image
-                    // border, DPP bound -- may enter as 0: the pooling pass's rule, stem_strip_pool)
-                    if (!col_valid) o = make_uint2(0u, 0u);
+                    const uint2 o = make_uint2(pack_bf16x2(m[pr][0], m[pr][1]), pack_bf16x2(m[pr][2], m[pr][3]));
+                    // horizontal 3-maximum on the packed values (>= +0: integer order = value order; a neighbour beyond the DPP row
+                    // bound enters as 0: the pooling pass's rule, stem_strip_pool)
                     uint2 h;
                     h.x = pkmax(pkmax(o.x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o.x, 0x111, 0xf, 0xf, true)),
                                 (uint32_t)__builtin_amdgcn_update_dpp(0, (int)o.x, 0x101, 0xf, 0xf, true));

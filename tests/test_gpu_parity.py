@@ -1350,6 +1350,9 @@ def test_fused_stem_pool_is_bit_identical(net16, dev, n):
     gen = torch.Generator(device="cpu").manual_seed(500 + n)
     x = torch.randn(n, 3, 224, 224, generator=gen).to(dev)
     x[0, :, :9, :] = 3.0                                      # a flat top edge: the first strip's missing conv row must not win a maximum
+    x[n - 1, :, -9:, :] = 3.0                                 # ... and the bottom, left and right edges (zero padding of the conv, the pool's
+    x[n // 2, :, :, :7] = 3.0                                 # border columns: the persistent kernel computes conv column 0 twice instead
+    x[n // 2, :, :, -7:] = 3.0                                # of padding, and carries each strip's last conv row into the next strip)
     try:
         net16.set_fuse_stem(0)
         ref = net16.forward_feat_ext(x).clone()
