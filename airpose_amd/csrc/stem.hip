@@ -647,36 +647,37 @@ __global__ void __launch_bounds__(S2_NT) stem_pool2_kernel(const float* __restri
             // kernel row kb reads patch row 2 fm + kb, so within a parity one new row fragment per step (xf rotates)
             f32x4 acc[4][4];
             const unsigned char* xb = pbase + (it & 1) * S2_PBYTES + xoff;
-            u32x4 xf[4];
+            // K loop: kernel rows in the order 0, 2, 4, 6, 1, 3, 5 (stem_kb_of: the summation order of every 16-bit stem); conv row fm at
+            // kernel row kb reads patch row 2 fm + kb, so within a parity a step needs ONE new row fragment (the others move up by one
+            // conv row).  The fragments of step k + 1 are read while the MFMAs of step k run: weights in two register sets, the row
+            // fragments in a ring of five (four in use, the fifth receives the next step's new row)
+            u32x4 xf[5], wf[2][4];
+            auto ldw = [&](int kb, u32x4 (&w)[4]) {
+#pragma unroll
+                for (int fn = 0; fn < 4; ++fn) w[fn] = *(const u32x4*)(wbase + fn * 16 * SWLD + kb * 32);
+            };
+            ldw(stem_kb_of(0), wf[0]);
+#pragma unroll
+            for (int fm = 0; fm < 4; ++fm) xf[fm] = *(const u32x4*)(xb + (2 * fm + stem_kb_of(0)) * FPW * 8);
             stem_sfor<0, SKB>([&](auto ST) {
-                constexpr int step = decltype(ST)::value, kb = stem_kb_of(step);
+                constexpr int step = decltype(ST)::value;
                 constexpr bool first = step == 0 || step == 4;
                 constexpr int rot = first ? 0 : (step < 4 ? step : step - 4);
-                u32x4 wf[4];
-#pragma unroll
-                for (int fn = 0; fn < 4; ++fn) {
-                    if (STEM_ABLATE & 128) wf[fn] = u32x4{0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
-                    else wf[fn] = *(const u32x4*)(wbase + fn * 16 * SWLD + kb * 32);
-                }
-                if constexpr (first) {
-#pragma unroll
-                    for (int fm = 0; fm < 4; ++fm) {
-                        if (STEM_ABLATE & 128) xf[fm] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
-                        else xf[fm] = *(const u32x4*)(xb + (2 * fm + kb) * FPW * 8);
-                    }
-                } else {
-                    if (STEM_ABLATE & 128) xf[(3 + rot) % 4] = u32x4{0x3c003c00u, 0x3c003c00u + kb, 0x3c003c00u, 0x3c003c00u};
-                    else xf[(3 + rot) % 4] = *(const u32x4*)(xb + (6 + kb) * FPW * 8);
+                if constexpr (step + 1 < SKB) {
+                    constexpr int kn = stem_kb_of(step + 1);
+                    ldw(kn, wf[(step + 1) & 1]);
+                    if constexpr (step + 1 != 4) xf[(4 + rot) % 5] = *(const u32x4*)(xb + (6 + kn) * FPW * 8);
                 }
 #pragma unroll
                 for (int fm = 0; fm < 4; ++fm)
 #pragma unroll
-                    for (int fn = 0; fn < 4; ++fn) {
-                        if (STEM_ABLATE & 4) asm volatile("" : "+v"(acc[fm][fn]) : "v"(wf[fn]), "v"(xf[(fm + rot) % 4]));
-                        else acc[fm][fn] = ap_mfma16(
-                            __builtin_bit_cast(bf16x8, wf[fn]), __builtin_bit_cast(bf16x8, xf[(fm + rot) % 4]),
-                            step == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn]);   // (first step: an inline-constant C operand, no zeroing pass)
-                    }
+                    for (int fn = 0; fn < 4; ++fn)
+                        acc[fm][fn] = ap_mfma16(__builtin_bit_cast(bf16x8, wf[step & 1][fn]), __builtin_bit_cast(bf16x8, xf[(fm + rot) % 5]),
+                                                step == 0 ? f32x4{0.f, 0.f, 0.f, 0.f} : acc[fm][fn]);
+                if constexpr (step + 1 == 4) {               // the second parity starts from four fresh rows
+#pragma unroll
+                    for (int fm = 0; fm < 4; ++fm) xf[fm] = *(const u32x4*)(xb + (2 * fm + stem_kb_of(4)) * FPW * 8);
+                }
                 __builtin_amdgcn_sched_barrier(0);
             });
             if (wave == 0) S2STAMP(0, 1);
