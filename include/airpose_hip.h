@@ -366,7 +366,8 @@ int ap_net_set_fuse_ief(ap_net* h, int on);
  * (model_copenet.py:38-45) separately.  Both are parity-tested. */
 int ap_net_set_fuse_ds(ap_net* h, int on);
 /* 16-bit and bf16x2 modes: on = 1 (default) runs conv1+bn1+relu+maxpool as one fused kernel, on = 0 as stem + maxpool
- * kernels (bit-identical results; kept for A/B measurement). */
+ * kernels (bit-identical results; kept for A/B measurement).  16-bit modes: on = 1 is the persistent form (one workgroup per
+ * CU, compute and feeding waves: stem.hip), on = 2 the strip kernel of rounds 2-5 (a workgroup per two pooled rows): same bits. */
 int ap_net_set_fuse_stem(ap_net* h, int on);
 /* 16-bit modes: on = 1 computes AvgPool2d(7) + view (model_copenet.py:173-175) in the epilogue of the last convolution
  * (layer4.2 conv3 + bn3 + identity + ReLU, :38-47): the 7 x 7 x 2048 block output is never written and no pooling kernel runs;
