@@ -16,7 +16,7 @@
 //   * x (401 KB per image) passes through a two-stage LDS ring in K chunks of 64 for conv1 (register-staged, two chunks ahead)
 //     and is read a second time, as the identity, in the accumulator layout of conv3's epilogue;
 //   * conv2 and conv3 run without a single barrier (their B operand is the resident image, their A operand is private).
-// LDS: 258 slots x 512 B (16 zero slots + 1 above, 224 image slots, 16 + 1 below) = 129 KB; XOR swizzle chunk ^ (slot & 15) so the
+// LDS: 258 slots x 512 B (16 zero slots + 1 above, 224 image slots, 16 + 1 below) = 129 KB; chunk c of slot u at position (c + 2 u) mod 16 of its 256-byte half so the
 // 16 pixels of a ds_read_b128 lane group hit 16 different 16-byte bank slots for every tap shift.
 // K order per output element = that of the kernels this one replaces (conv1 / conv3: K steps of 32 in order; conv2: the slab
 // kernel's 64-channel chunk outer, tap inner): the same sums, bit for bit, so the trunk may choose between the two paths by
@@ -131,16 +131,16 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     const uint32_t xs_w = BI_XS + (uint32_t)((xr0 * 16 + xcol) * 128 + ((xpc ^ (xcol & 7)) << 4));
     // B fragments of conv1 out of a staging buffer: slot 16 g + li, piece 4 ks + kq at position piece ^ (slot & 7)
     const uint32_t xs_r = lds0 + BI_XS + (uint32_t)(li * 128 + (((li >> 2) & 1) << 6) + ((kq ^ (li & 3)) << 4));
-    // B fragments out of the image region: physical slot u = 16 R + li + dc + 1 (R = row + 1), chunk 4 ks + kq at position
-    // chunk ^ (u & 15) of its 256-byte half: (base(dc) ^ ((ks & 3) << 6)) + R * 8192 + (ks >> 2) * 256
-    auto tbase = [&](int dc) __attribute__((always_inline)) -> uint32_t {
-        const int m = li + dc + 1;
-        return lds0 + (uint32_t)(m * 512 + (((m >> 2) & 3) << 6) + ((kq ^ (m & 3)) << 4));
-    };
+    // B fragments out of the image region: physical slot u = 16 R + li + dc + 1 (R = row + 1), chunk c = 4 ks + kq at position
+    // (c + 2 u) mod 16 of its 256-byte half: tpos(dc, ks & 3) + R * 8192 + (ks >> 2) * 256.  (Round 5 had c ^ (u & 15): conflict-free if
+    // ds_read_b128 served 16 contiguous lanes per cycle -- its groups are {0-3, 12-15, 20-27}, .. and the XOR form put two lanes of
+    // every group on the same banks, PMC: 31 % of this kernel's LDS cycles; the rotation has none: tools/probes/lds_groups.py.)
+    auto tbase = [&](int dc) __attribute__((always_inline)) -> uint32_t { return lds0 + (uint32_t)((li + dc + 1) * 512); };
+    auto tpos = [&](int dc, int j) __attribute__((always_inline)) -> uint32_t { return (uint32_t)(((4 * j + kq + 2 * (li + dc + 1)) & 15) << 4); };
     // where this lane's 8 channels (chunk index cidx of 32) of pixel (row g, column li) go in the image region
     auto twr = [&](int g, int cidx) __attribute__((always_inline)) -> uint32_t {
         const int u = 16 * (g + 1) + li + 1;
-        return (uint32_t)(u * 512 + (cidx & 16) * 16 + (((cidx ^ u) & 15) << 4));
+        return (uint32_t)(u * 512 + (cidx & 16) * 16 + (((cidx + 2 * u) & 15) << 4));
     };
     using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
@@ -259,7 +259,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             for (int d = 0; d < 3; ++d) {
                 const uint32_t tb = tbase(d - 1) + cp * 256;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) { tl[d][j] = tb ^ ((uint32_t)j << 6); th[d][j] = tl[d][j] + 65536u; }
+                for (int j = 0; j < 4; ++j) { tl[d][j] = tb + tpos(d - 1, j); th[d][j] = tl[d][j] + 65536u; }
             }
             bi_pipe<480, 7>(bf,
                 [&](auto I, u32x4& d) __attribute__((always_inline)) {
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
             const uint32_t tb = tbase(0);
             uint32_t tl[4], th[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { tl[j] = tb ^ ((uint32_t)j << 6); th[j] = tl[j] + 65536u; }
+            for (int j = 0; j < 4; ++j) { tl[j] = tb + tpos(0, j); th[j] = tl[j] + 65536u; }
             // identity / output: this lane's 8 channels of pixel (row g, column li)
             const int pcol = li < BI_HW ? li : BI_HW - 1;
             const uint32_t idoff = (uint32_t)((pcol * BI_C + wave * 32 + kq * 8) * 2);

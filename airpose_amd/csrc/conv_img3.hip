@@ -8,7 +8,8 @@
 //   * pixels in 28 rows of 16 slots: slot S of a row = image column c0 - 1 + S (c0 = 0 or 14); the slot outside the image (S = 0 of
 //     the left half, S = 15 of the right one) holds zeros = the horizontal padding, the other outer slot is the neighbour half's
 //     first column (the halo: fetched, never produced); a zero row above and below: a 3x3 tap is a constant slot shift, no masks;
-//   * 482 slots x 256 B = 120.5 KB, 16-byte chunks at chunk ^ (slot & 15) (conflict-free ds_read_b128 under every tap shift);
+//   * 482 slots x 256 B = 120.5 KB, 16-byte chunk c of slot u at position (c + 2 u) mod 16 (conflict-free ds_read_b128 under every tap
+//     shift for the instruction's real lane groups: see tbase below);
 //   * four waves, one per SIMD, the whole register file each: a wave computes 64 of the 128 output channels for 14 of the 28 rows
 //     (56 accumulators of 16 x 16 in the accumulator half): an LDS operand fragment feeds four MFMAs, a weight fragment fourteen;
 //   * weights never touch the LDS: each wave streams the rows of ITS 64 channels from L2 as MFMA A fragments packed in register and
@@ -116,7 +117,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
     sfor<0, CI_RING>([&](auto S) __attribute__((always_inline)) { refill(S, ar); });
 
     // ---- image DMA: wave w fetches rows w, w + 4, ..; per row four 1-KiB pieces of four slots; lane = (slot of the piece, chunk position p):
-    // LDS position (slot S, p) <- global chunk p ^ S of pixel (row, c0 - 1 + S), or of the zero line where that column is outside the image
+    // LDS position (slot S, p) <- global chunk (p - 2 S) mod 16 of pixel (row, c0 - 1 + S), or of the zero line where that column is outside the image
     const int dslot = lane >> 4, dp = lane & 15;
     auto half_of = [&](int hi, int& img, int& half) __attribute__((always_inline)) {       // both halves of an image on one XCD (block b -> XCD b % 8)
         half = (hi >> 3) & 1;
@@ -132,7 +133,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         for (int j = 0; j < 4; ++j) {
             const int S = 4 * j + dslot, col = c0 - 1 + S;
             const bool ok = live && col >= 0 && col < CI_H;
-            const unsigned char* src = ok ? ximg + ((size_t)col * CI_P * 2 + (uint32_t)((dp ^ S) << 4)) : zg + (dp << 4);
+            const unsigned char* src = ok ? ximg + ((size_t)col * CI_P * 2 + (uint32_t)(((dp - 2 * S) & 15) << 4)) : zg + (dp << 4);
             const uint32_t rstep = ok ? CI_H * CI_P * 2 : 0u;
             src += (size_t)wave * rstep;
 #pragma unroll
@@ -145,18 +146,21 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
         }
     };
 
-    // B fragments out of the image: physical slot u = 16 R + m, m = li + dc + 1 (R = row + 1); chunk 8 c64 + 4 ks + kq at position
-    // chunk ^ (m & 15): (base(dc) ^ ((2 c64 + ks) << 6)) + R * 4096; the wave's row half goes into the base
+    // B fragments out of the image: physical slot u = 16 R + m, m = li + dc + 1 (R = row + 1); chunk c = 8 c64 + 4 ks + kq at position
+    // (c + 2 m) mod 16 of its slot.  (Rounds 5-6 had c ^ (m & 15), conflict-free if ds_read_b128 served 16 CONTIGUOUS lanes per
+    // cycle; its groups are {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, .. (MI355X_MICROARCH.md), i.e. eight pixels of one K quarter
+    // with eight of the next, and the XOR form puts two of them on the same banks under every tap shift: PMC, 25 % of this kernel's
+    // LDS cycles.  The rotation by 2 m is conflict-free for all four groups and the three shifts: tools/probes/lds_groups.py.)
     auto tbase = [&](int dc) __attribute__((always_inline)) -> uint32_t {
         const int m = li + dc + 1;
-        return lds0 + (uint32_t)(rh * CI_HALF * 4096 + m * 256 + (((m >> 2) & 3) << 6) + ((kq ^ (m & 3)) << 4));
+        return lds0 + (uint32_t)(rh * CI_HALF * 4096 + m * 256);
     };
     uint32_t tl[3][4];
 #pragma unroll
     for (int d = 0; d < 3; ++d) {
         const uint32_t tb = tbase(d - 1);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) tl[d][j] = tb ^ ((uint32_t)j << 6);
+        for (int j = 0; j < 4; ++j) tl[d][j] = tb + (uint32_t)(((4 * j + kq + 2 * (li + d)) & 15) << 4);
     }
     using I0 = std::integral_constant<int, 0>;
 
