@@ -37,7 +37,7 @@ NUM_LANDMARKS = 51
 NUM_OUT_JOINTS = NUM_JOINTS + len(EXTRA_JOINT_VERTS) + NUM_LANDMARKS   # 127
 
 
-def make_synthetic_model(seed=4321, num_verts=NUM_VERTS, num_faces=NUM_FACES, max_bones=4):
+def make_synthetic_model(seed=4321, num_verts=NUM_VERTS, num_faces=NUM_FACES, max_bones=4, coherent=False):
     """Seeded SMPL-X-shaped model.  Geometry is body-like only in scale; all that matters for
     parity is the dimensionality, the sparsity pattern (<= max_bones weights per vertex, sparse
     joint regressor) and the real parent table."""
@@ -51,6 +51,11 @@ def make_synthetic_model(seed=4321, num_verts=NUM_VERTS, num_faces=NUM_FACES, ma
         jt[j] = jt[PARENTS[j]] + d * rs.uniform(0.03 if j >= 25 else 0.10, 0.06 if j >= 25 else 0.25)
     # each vertex hangs off a "main" joint
     main = rs.randint(0, J, size=V)
+    if coherent:
+        # vertex ids in the order of their main joint, as in the real SMPL-X mesh (neighbouring ids sit on the same limb and share
+        # their bones): the default draws every vertex's joint independently, which is the WORST case for a skinning kernel that
+        # gathers bone rows from LDS (16 consecutive vertices = ~16 different bones; tools/lbs_bench.py --coherent 1 measures both)
+        main = np.sort(main)
     v_template = (jt[main] + rs.standard_normal((V, 3)) * 0.04).astype(np.float32)
     # skinning weights: main joint + up to 3 relatives (parent / grand-parent / a child)
     children = [[c for c in range(J) if PARENTS[c] == j] for j in range(J)]

@@ -23,9 +23,10 @@ def main():
     ap.add_argument("--bodies", default="512,4096,16384")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--fused", type=int, default=1, help="1: fused contraction + skinning (default); 4: joints stage inside the kernel too; 0: two kernels")
+    ap.add_argument("--coherent", type=int, default=0, help="1: synthetic model with vertex ids ordered by their main joint (the real mesh's locality)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
-    body = smplx.SMPLX(model_data=smplx_model.make_synthetic_model(4321))
+    body = smplx.SMPLX(model_data=smplx_model.make_synthetic_model(4321, coherent=bool(args.coherent)))
     body.set_fused(args.fused)
     rows = []
     for n in [int(v) for v in args.bodies.split(",")]:
