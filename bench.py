@@ -812,7 +812,11 @@ def main():
                          "traffic": pmc_traffic(), "traffic_unit": "HBM bytes per step of %d pairs (FETCH_SIZE x 2 + WRITE_SIZE over the conv-stack kernels)" % 256,
                          "traffic_source": "latest committed rocprofv3 PMC pass (profiles/r*_pmc_traffic.json): counters cannot be collected inside the timed run",
                          "flops_per_launch": conv_flops_step / launches, "launches_per_step": launches,
-                         "avg_launch_ms": (span_ms if span_ms is not None else conv_ms_step) / launches},
+                         "avg_launch_ms": (span_ms if span_ms is not None else conv_ms_step) / launches,
+                         "peak_note": "peak is the guide's dense 16-bit figure; a loop of nothing but v_mfma_f32_16x16x32 in this library's "
+                                      "shape sustains 1.7-1.8 PFLOP/s on all 256 CUs (clock 2.35 -> 1.64-1.79 GHz under that load; "
+                                      "tools/probes/mfma_rate_probe.hip, profiles/r06_mfma_rate_probe.txt): frac %.3f of peak = %.2f-%.2f of that"
+                                      % (path_tf / peak, path_tf / 1800.0, path_tf / 1700.0)},
             "stage_ms_per_step": {"stem_maxpool": ts["stem_ms"] / max(ts["passes"], 1), "conv_stack": conv_ms_step,
                                   "avgpool": ts["avgpool_ms"] / max(ts["passes"], 1),
                                   "regressor": ts["regressor_ms"] / max(ts["passes"], 1),
