@@ -93,6 +93,9 @@ SIGNATURES = {
     "ap_conv_img3_stream_bytes": (_c.c_int64, []),
     "ap_conv_img3_pack": (_i, [_i, _vp, _vp, _vp]),
     "ap_conv_img3_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    "ap_conv_s2p_stream_bytes": (_c.c_int64, []),
+    "ap_conv_s2p_pack": (_i, [_i, _vp, _vp, _vp]),
+    "ap_conv_s2p_nhwc": (_i, [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "ap_conv_pw_stream_bytes": (_c.c_int64, [_i, _i]),
     "ap_conv_pw_pack": (_i, [_i, _vp, _i, _i, _vp, _vp]),
     "ap_conv_pw_nhwc": (_i, [_i] + [_vp] * 6 + [_i] * 3 + [_vp]),
@@ -103,6 +106,7 @@ SIGNATURES = {
     "ap_net_set_even_out": (_i, [_vp, _i]),
     "ap_net_set_img_block": (_i, [_vp, _i]),
     "ap_net_set_img3": (_i, [_vp, _i]),
+    "ap_net_set_s2p": (_i, [_vp, _i]),
     "ap_smplx_create": (_i, [_c.POINTER(_vp), _c.POINTER(SmplxModelStruct), _i]),
     "ap_smplx_destroy": (None, [_vp]),
     "ap_smplx_num_joints_out": (_i, [_vp]),
@@ -125,7 +129,7 @@ SIGNATURES = {
     "ap_perspective_projection": (_i, [_vp, _i, _i, _vp, _vp, _f, _f, _vp, _vp, _vp]),
 }
 
-ABI_VERSION = 8          # include/airpose_hip.h: AP_ABI_VERSION
+ABI_VERSION = 9          # include/airpose_hip.h: AP_ABI_VERSION
 _lib = None
 _lib_lock = threading.Lock()
 

@@ -526,6 +526,10 @@ class copenet(nn.Module):
         """bf16 / f16: pair-kernel-only intermediates in the pair kernel's fragment order (default) or NHWC; same bits."""
         self._set_knob("ap_net_set_tiled", on)
 
+    def set_s2p(self, on):
+        """conv2 of layer2.0 on the polyphase kernel conv_s2p.hip (1) / the generic stride-2 kernels (0, default)."""
+        self._set_knob("ap_net_set_s2p", on)
+
     def set_fuse_stem(self, on):
         self._set_knob("ap_net_set_fuse_stem", on)
 

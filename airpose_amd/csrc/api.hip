@@ -255,7 +255,7 @@ struct ap_net {
     struct Block { Layer c1, c2, c3, down, c3ds; bool has_down = false;
                    DevBuf pair; int pair_p = 0, pair_p2 = 0, pair_c3 = 0, pair_n1 = 0;
                    DevBuf imgw;
-                   DevBuf c2img; };            // layer2 identity blocks: conv2's weights as the fragment streams of conv_img3.hip             // layer3 identity blocks: the three weight matrices as the fragment streams of block_img.hip   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
+                   DevBuf c2img, c2s2; };            // layer2 identity blocks: conv2's weights as the fragment streams of conv_img3.hip             // layer3 identity blocks: the three weight matrices as the fragment streams of block_img.hip   // pair: conv3 of this block + conv1 of the next as one weight stream (conv_pair.hip)
     std::vector<Block> blocks;
     // regressor (fp32)
     Layer fc1_feat, fc1_state, fc2, dec;
@@ -275,6 +275,9 @@ struct ap_net {
     int pw_conv = 1;               // 16-bit modes: conv1 of the layer3 / layer4 bottlenecks that no fused kernel covers on the one-wave-per-SIMD pointwise
                                    // kernel (conv_pw.hip): 0 never; 1 (default) when its tiles fill half the chip or whole rounds of it; 2 whenever
                                    // supported, and conv3 + identity too; 3 conv1 whenever supported
+    int s2p = 0;                   // 16-bit modes: conv2 of layer2.0 (3x3 / stride 2 at 56 x 56) on the polyphase kernel (conv_s2p.hip), at every batch size
+                                   // (its K order is its own).  OFF by default: 12-27 % faster than the ring kernel alone, but it owns its CUs (8 waves x 240
+                                   // registers) and the two free-running passes of the default lose more concurrency than the layer gains: -1.7 % in the bench
     int img3 = 1;                  // 16-bit modes: conv2 of the layer2 identity blocks on the half-image-resident kernel (conv_img3.hip): 0 never, 1 when the
                                    // pass fills whole rounds of the chip with half images (same bits either way), 2 always
     int img_block = 1;             // 16-bit modes: each layer3 identity bottleneck as ONE image-resident kernel (block_img.hip): 0 never,
@@ -621,6 +624,7 @@ void release_blocks(ap_net* h) {
         B.pair.release();
         B.imgw.release();
         B.c2img.release();
+        B.c2s2.release();
     }
     h->blocks.clear();
 }
@@ -719,6 +723,14 @@ int finalize_trunk(ap_net* h) {
             if (!k_bf16::ap_conv_img3_supported(28, 28, L.cin, L.cout, L.k, L.stride, L.pad) || L.wld != 9 * L.cin) continue;
             HIP_TRY(B.c2img.reserve(k_bf16::ap_conv_img3_stream_bytes()));
             HIP_TRY(H16(h->prec, ap_launch_conv_img3_pack)(L.w.p, B.c2img.p, nullptr));
+        }
+    // stride-2 3 x 3 of layer2.0 (56 x 56 -> 28 x 28, 128 channels): weight streams of the polyphase kernel
+    if (h->half())
+        for (auto& B : h->blocks) {
+            const Layer& L = B.c2;
+            if (!k_bf16::ap_conv_s2p_supported(56, 56, L.cin, L.cout, L.k, L.stride, L.pad) || L.wld != 9 * L.cin) continue;
+            HIP_TRY(B.c2s2.reserve(k_bf16::ap_conv_s2p_stream_bytes()));
+            HIP_TRY(H16(h->prec, ap_launch_conv_s2p_pack)(L.w.p, B.c2s2.p, nullptr));
         }
     // pointwise layers of the 14 x 14 and 7 x 7 stages: weight streams of conv_pw.hip (conv1, and conv3 of the identity blocks)
     if (h->half())
@@ -1073,8 +1085,11 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
         // conv2 of a stage's first block on conv_pw.hip (nine taps): it writes NHWC rows, so t2 stays untiled for that block's pair kernel.
         // Automatic rule: only for a pass that has the chip to itself (l4.0.c2 164 -> 149 us, l3.0.c2 168 -> 157: +0.55 % of the whole
         // bench there, -0.45 % beside a concurrent pass, whose workgroups a one-wave-per-SIMD kernel keeps off its CUs; ev_out marks it)
+        // conv2 of layer2.0 on the polyphase kernel (conv_s2p.hip; ap_net_set_s2p, off by default): its K order is its own, so when on it
+        // takes the layer at EVERY batch size
+        const bool c2_s2p = bf && h->s2p && B.c2s2.p && H == 56 && B.c2.stride == 2 && g_conv_mode.load(std::memory_order_relaxed) == -1;
         bool c2_pw = false;
-        if (pw_conv && pw_conv != 4 && !(pw_conv == 1 && ev_out) && B.c2.stride == 2 && g_conv_mode.load(std::memory_order_relaxed) == -1) {
+        if (!c2_s2p && pw_conv && pw_conv != 4 && !(pw_conv == 1 && ev_out) && B.c2.stride == 2 && g_conv_mode.load(std::memory_order_relaxed) == -1) {
             PwArgs p3;
             int err = 0;
             c2_pw = pw_k3_args(B.c2, n, H, H, prec, &p3) && pw_fills(p3.M, B.c2.cout, pw_conv, &err);
@@ -1091,7 +1106,13 @@ int trunk_chunk(ap_net* h, ap_net::TrunkWs& w, const float* x0, int n0, const fl
                 c2_img = units * 8 >= rounds * cus * 7;
             }
         }
-        if (c2_img) {
+        if (c2_s2p) {
+            ConvS2pArgs ca{};
+            ca.x = w.ws_t1.p; ca.y = w.ws_t2.p; ca.wfrag = B.c2s2.p; ca.scale = B.c2.scale.as<float>(); ca.shift = B.c2.shift.as<float>();
+            ca.N = n; ca.y_tiled = t2_tiled; ca.range_flag = w.rflag;
+            HIP_TRY(zero_line(&ca.zero));
+            HIP_TRY(H16(prec, ap_launch_conv_s2p)(ca, st));
+        } else if (c2_img) {
             ConvImg3Args ca{};
             ca.x = w.ws_t1.p; ca.y = w.ws_t2.p; ca.wfrag = B.c2img.p; ca.scale = B.c2.scale.as<float>(); ca.shift = B.c2.shift.as<float>();
             ca.N = n; ca.y_tiled = t2_tiled; ca.range_flag = w.rflag;
@@ -1389,7 +1410,7 @@ int regressor_run(ap_net* h, const RegInputs& in, int B, int iters, int two_view
 // ================================================================================== C ABI
 extern "C" {
 
-const char* ap_version(void) { return "airpose_hip 0.6 (gfx950; abi 8)"; }
+const char* ap_version(void) { return "airpose_hip 0.6 (gfx950; abi 9)"; }
 int ap_abi_version(void) { return AP_ABI_VERSION; }
 const char* ap_last_error(void) { return g_err.c_str(); }
 
@@ -1857,6 +1878,25 @@ int ap_block_img_nhwc(int precision, const void* x, const void* wstream, const f
 
 int64_t ap_conv_img3_stream_bytes(void) { return (int64_t)k_bf16::ap_conv_img3_stream_bytes(); }
 
+int64_t ap_conv_s2p_stream_bytes(void) { return (int64_t)k_bf16::ap_conv_s2p_stream_bytes(); }
+
+int ap_conv_s2p_pack(int precision, const void* w2, void* wstream, void* stream) {
+    if (!prec_half(precision) || !w2 || !wstream) return fail(AP_EINVAL, "ap_conv_s2p_pack: 16-bit precision, w2 [128][3][3][128], stream buffer");
+    HIP_TRY(H16(precision, ap_launch_conv_s2p_pack)(w2, wstream, (hipStream_t)stream));
+    return AP_OK;
+}
+
+int ap_conv_s2p_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, void* y, int N,
+                     int y_tiled, void* stream) {
+    if (!prec_half(precision) || !x || !wstream || !scale || !shift || !y || N <= 0)
+        return fail(AP_EINVAL, "ap_conv_s2p_nhwc: bad argument");
+    ConvS2pArgs a{};
+    a.x = x; a.y = y; a.wfrag = wstream; a.scale = scale; a.shift = shift; a.N = N; a.y_tiled = y_tiled != 0;
+    HIP_TRY(zero_line(&a.zero));
+    HIP_TRY(H16(precision, ap_launch_conv_s2p)(a, (hipStream_t)stream));
+    return AP_OK;
+}
+
 int ap_conv_img3_pack(int precision, const void* w2, void* wstream, void* stream) {
     if (!prec_half(precision) || !w2 || !wstream) return fail(AP_EINVAL, "ap_conv_img3_pack: 16-bit precision, w2 [128][3][3][128], stream buffer");
     HIP_TRY(H16(precision, ap_launch_conv_img3_pack)(w2, wstream, (hipStream_t)stream));
@@ -2027,6 +2067,12 @@ int ap_net_set_fuse_tail(ap_net* h, int on) {
 int ap_net_set_pw_conv(ap_net* h, int on) {
     if (!h) return fail(AP_EINVAL, "null handle");
     h->pw_conv = on < 0 ? 0 : (on > 4 ? 4 : on);               // (3: 1 without the size rule; 4: 1 without the 3 x 3 / stride-2 layers -- A/B aids)
+    return AP_OK;
+}
+
+int ap_net_set_s2p(ap_net* h, int on) {
+    if (!h) return fail(AP_EINVAL, "null handle");
+    h->s2p = on != 0;
     return AP_OK;
 }
 

@@ -99,6 +99,19 @@ struct ConvImg3Args {
     int* range_flag;              // fp16 storage, or NULL
 };
 
+// ---- stride-2 3x3 of layer2.0 in polyphase form, a quarter of an output image per workgroup (conv_s2p.hip); 16-bit storage
+struct ConvS2pArgs {
+    const void* x;                // [N][56][56][128] NHWC
+    void* y;                      // [N][28][28][128] NHWC, or fragment-tiled (y_tiled)
+    const void* wfrag;            // the weights as per-wave MFMA-fragment streams (ap_launch_conv_s2p_pack)
+    const float *scale, *shift;   // BatchNorm
+    const void* zero;             // 256 bytes of zeros (DMA source of the slots outside the image)
+    int N;
+    int y_tiled;
+    int nunits_pad;               // filled by the launcher
+    int* range_flag;              // fp16 storage, or NULL
+};
+
 // ---- pointwise convolution + BN (+ identity) + ReLU on the one-wave-per-SIMD mainloop (conv_pw.hip); 16-bit storage
 struct PwArgs {
     const void* x;                // [M][Cin] NHWC pixel rows

@@ -590,6 +590,8 @@ def main():
         net.set_pw_conv(int(os.environ["AIRPOSE_PW_CONV"]))
     if os.environ.get("AIRPOSE_IMG3"):                      # A/B aid: layer2's 3x3 with half an image resident in LDS (default) / slab kernel
         net.set_img3(int(os.environ["AIRPOSE_IMG3"]))
+    if os.environ.get("AIRPOSE_S2P"):                       # A/B aid: layer2.0's stride-2 3x3 on the polyphase kernel (1) / the ring kernel (0, default)
+        net.set_s2p(int(os.environ["AIRPOSE_S2P"]))
     if os.environ.get("AIRPOSE_STEM"):                      # A/B aid: stem + pool as persistent workgroups (1, default) / a workgroup per strip (2)
         net.set_fuse_stem(int(os.environ["AIRPOSE_STEM"]))
     if os.environ.get("AIRPOSE_IMG_BLOCK"):                 # A/B aid: layer3 identity blocks as image-resident kernels (default) / conv2 + pairs

@@ -53,7 +53,7 @@ typedef struct ap_smplx ap_smplx; /* SMPL-X body model */
  * (8: round 6 -- ap_net_parity_probe, ap_net_range_peek / _mark_next / _slot, ap_regressor_feat_part / _step_local / _step_finish;
  *  7: ap_conv_pw_*, ap_block_img_*; 6: ap_set_pair_groups removed).  A binding built against another number must refuse to load
  * the library (airpose_amd/_native.py does). */
-#define AP_ABI_VERSION 8
+#define AP_ABI_VERSION 9
 const char* ap_version(void);
 int ap_abi_version(void);
 const char* ap_last_error(void);
@@ -272,6 +272,16 @@ int ap_conv_img3_pack(int precision, const void* w2, void* wstream, void* stream
 int ap_conv_img3_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, void* y, int N,
                       int y_tiled, void* stream);
 
+/* Stride-2 3x3 convolution of layer2.0 (128 -> 128 channels, 56 x 56 -> 28 x 28) + bn2 + ReLU in polyphase form, a quarter of an
+ * output image per workgroup (conv_s2p.hip; replaces conv2 of the stage's first Bottleneck, model_copenet.py:32-34 with :18).
+ * x: [N][56][56][128], y: [N][28][28][128] 16-bit NHWC (y_tiled != 0: fragment-tiled); wstream = ap_conv_s2p_pack of the
+ * K-contiguous rows [128][3][3][128] (ap_conv_s2p_stream_bytes bytes, caller-owned).  Its K order (the taps phase by phase) is its
+ * own: the result equals ap_conv2d_nhwc's to fp32 summation order, not bit for bit. */
+int64_t ap_conv_s2p_stream_bytes(void);
+int ap_conv_s2p_pack(int precision, const void* w2, void* wstream, void* stream);
+int ap_conv_s2p_nhwc(int precision, const void* x, const void* wstream, const float* scale, const float* shift, void* y, int N,
+                     int y_tiled, void* stream);
+
 /* Pointwise (1 x 1, stride 1) convolution + BatchNorm (+ identity) + ReLU for the 14 x 14 / 7 x 7 stages (conv1 and conv3 of
  * Bottleneck.forward, model_copenet.py:29-31, 38-45) on the one-wave-per-SIMD mainloop of conv_pw.hip: x [M][Cin], res (or NULL)
  * and y [M][Cout] NHWC pixel rows in the storage type of `precision` (AP_PREC_BF16 or AP_PREC_F16); M a multiple of 196 (whole
@@ -407,6 +417,8 @@ int ap_net_set_even_out(ap_net* h, int on);
  * of conv2 + the fused conv3 -> conv1 pairs: on = 1 (default) when the pass fills whole rounds of the chip (the kernel runs an
  * image per CU: >= 7/8 of ceil(n / CUs) * CUs images), 2 always, 0 never.  Both paths sum in the same order (conv2: the slab
  * kernel's): trunk features are bit-identical, so a pair's result does not depend on the batch it arrives in. */
+int ap_net_set_s2p(ap_net* h, int on);           /* conv2 of layer2.0 on conv_s2p.hip: 1: at every batch size (other fp32 summation order than the generic
+                                                  * kernels); 0 (default): the generic stride-2 kernels -- the polyphase kernel is faster alone and slower in the two-pass schedule */
 int ap_net_set_img3(ap_net* h, int on);          /* conv2 of the layer2 identity blocks on conv_img3.hip: 1 (default) when the pass fills whole rounds of
                                                  * the chip with half images, 2 always, 0 never (slab kernel); same bits */
 int ap_net_set_img_block(ap_net* h, int on);

@@ -2621,3 +2621,105 @@ def test_half_image_resident_layer2_conv2_in_the_trunk_is_bit_identical(net16, d
         net16.set_fuse_pair(1)
     assert torch.isfinite(ref).all()
     assert torch.equal(got, ref) and torch.equal(got_nopair, ref) and torch.equal(auto, ref)
+
+
+def _s2p_case(dev, N, seed, prec):
+    bf = {"bf16": torch.bfloat16, "f16": torch.float16}[prec]
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(N, 56, 56, 128, generator=g).to(bf).to(dev)
+    w = (torch.randn(128, 3, 3, 128, generator=g) * (2.0 / 1152) ** 0.5).to(bf).to(dev)     # [Cout][kh][kw][Cin]: K-contiguous rows
+    sc = (torch.rand(128, generator=g) + 0.5).to(dev)
+    sh = (torch.randn(128, generator=g) * 0.1).to(dev)
+    return x, w, sc, sh
+
+
+@pytest.mark.parametrize("N", [1, 3, 8, 21, 150])
+@pytest.mark.parametrize("prec", ["bf16", "f16"])
+def test_conv_s2p_equals_generic_stride2(dev, prec, N):
+    """conv_s2p.hip (layer2.0's 3x3 / stride 2 in polyphase form, a quarter of an output image per workgroup, waves split into
+    compute and DMA roles) against fp64 on the same operands and against the stand-alone convolution (ap_conv2d_nhwc: the ring
+    kernel).  Its K order is its own (the taps phase by phase), so the comparison with the ring kernel is to fp32 summation order:
+    every output within 2 ulp of the storage type, most of them equal; NHWC and fragment-tiled output; N = 1 / 3 / 21: groups of 32
+    quarter images only partly filled, 150: the persistent loop (600 quarters on 256 workgroups)."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    B = Nn.PRECISIONS[prec]
+    x, w, sc, sh = _s2p_case(dev, N, 90 + N, prec)
+    x[0, :3, :, :] = 2.0                                      # flat borders: the zero padding above / left of the first quarters
+    x[0, :, :3, :] = -2.0
+    x[N - 1, -3:, :, :] = 1.5
+    x[N - 1, :, -3:, :] = -1.5
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    want = torch.empty(N, 28, 28, 128, dtype=x.dtype, device=dev)
+    Nn.check(L.ap_conv2d_nhwc(B, p(x), p(w), p(sc), p(sh), None, p(want), N, 56, 56, 128, 128, 3, 2, 1, 1, st), "conv2d")
+    ws = torch.empty(L.ap_conv_s2p_stream_bytes(), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_s2p_pack(B, p(w), p(ws), st), "pack")
+    got = torch.full_like(want, 7.0)
+    Nn.check(L.ap_conv_s2p_nhwc(B, p(x), p(ws), p(sc), p(sh), p(got), N, 0, st), "s2p")
+    torch.cuda.synchronize()
+    assert torch.isfinite(got.float()).all()
+    ref = F.conv2d(x.double().permute(0, 3, 1, 2).cpu(), w.double().permute(0, 3, 1, 2).cpu(), stride=2, padding=1)
+    ref = torch.relu(ref * sc.double().cpu().view(1, -1, 1, 1) + sh.double().cpu().view(1, -1, 1, 1)).permute(0, 2, 3, 1)
+    e_got, e_ring = rel_err(got.float().cpu().numpy(), ref.numpy()), rel_err(want.float().cpu().numpy(), ref.numpy())
+    print("conv_s2p %s N=%d: rel err vs fp64 %.3e (ring kernel %.3e)" % (prec, N, e_got, e_ring))
+    assert e_got < (2e-2 if prec == "bf16" else 3e-3) and e_got < 1.2 * e_ring + 1e-6
+    d = (got.float() - want.float()).abs()
+    ulp = (2.0 ** -7 if prec == "bf16" else 2.0 ** -10) * torch.clamp(want.float().abs(), min=2.0 ** -6)
+    assert bool((d <= 2.0 * ulp).all()), "max %.3e at %s" % (float(d.max()), (d > 2.0 * ulp).nonzero()[0].tolist())
+    tiled = torch.full_like(want, 7.0)
+    Nn.check(L.ap_conv_s2p_nhwc(B, p(x), p(ws), p(sc), p(sh), p(tiled), N, 1, st), "s2p tiled")
+    again = torch.full_like(want, 7.0)
+    Nn.check(L.ap_conv_s2p_nhwc(B, p(x), p(ws), p(sc), p(sh), p(again), N, 0, st), "s2p again")
+    torch.cuda.synchronize()
+    if (N * 784) % 16 == 0:
+        back = tiled.view(N * 784 // 16, 16, 16, 8).permute(0, 2, 1, 3).reshape(N, 28, 28, 128)
+        assert torch.equal(back.view(torch.int16), got.view(torch.int16))
+    assert torch.equal(again.view(torch.int16), got.view(torch.int16))
+
+
+def test_conv_s2p_soak(dev):
+    """The hand-counted waits of conv_s2p.hip's compute waves and the role split under a second stream that keeps the memory system
+    busy: 40 launches of 256 images, each compared bit for bit with the first result."""
+    from airpose_amd import _native as Nn
+    L = Nn.lib()
+    B = Nn.PRECISIONS["f16"]
+    N = 256
+    x, w, sc, sh = _s2p_case(dev, N, 6, "f16")
+    p = lambda t: ctypes.c_void_p(t.data_ptr()) if t is not None else None
+    st = Nn.stream_ptr(dev)
+    ws = torch.empty(L.ap_conv_s2p_stream_bytes(), dtype=torch.uint8, device=dev)
+    Nn.check(L.ap_conv_s2p_pack(B, p(w), p(ws), st), "pack")
+    first = torch.empty(N, 28, 28, 128, dtype=x.dtype, device=dev)
+    Nn.check(L.ap_conv_s2p_nhwc(B, p(x), p(ws), p(sc), p(sh), p(first), N, 0, st), "s2p")
+    torch.cuda.synchronize()
+    noise = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+    side = torch.cuda.Stream()
+    got = torch.empty_like(first)
+    for rep in range(40):
+        if rep & 1:
+            with torch.cuda.stream(side):
+                noise.normal_()
+        got.fill_(7.0)
+        Nn.check(L.ap_conv_s2p_nhwc(B, p(x), p(ws), p(sc), p(sh), p(got), N, 0, st), "s2p")
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), first.view(torch.int16)), "launch %d differs" % rep
+
+
+def test_trunk_with_polyphase_conv2_is_close_to_the_generic_path(netf16, dev):
+    """layer2.0 conv2 on conv_s2p.hip (ap_net_set_s2p) against the generic stride-2 kernel through the whole trunk: the two K orders differ
+    in fp32 summation order only -- pooled features agree to 1e-3 of the fp16 path's own distance from fp32 scale (2e-4 relative)."""
+    gen = torch.Generator(device="cpu").manual_seed(77)
+    x = torch.randn(5, 3, 224, 224, generator=gen).to(dev)
+    ref = netf16.forward_feat_ext(x).clone()
+    try:
+        netf16.set_s2p(1)                                     # (off by default: faster alone, slower in the two-pass schedule)
+        got = netf16.forward_feat_ext(x).clone()
+        again = netf16.forward_feat_ext(x)
+    finally:
+        netf16.set_s2p(0)
+    assert torch.isfinite(got).all()
+    e = float((got - ref).abs().max() / ref.abs().max())
+    print("trunk, polyphase conv2 vs generic: %.3e" % e)
+    assert 0.0 < e < 2e-3                                     # (0: the knob did nothing)
+    assert torch.equal(again, got)                            # and reproducible
